@@ -1,0 +1,303 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by RUNNING THE REFERENCE on CPU in the build container.
+
+Usage (build container only; /root/reference does not exist on the GPU box):
+    python tests/golden/make_golden.py
+
+What runs reference code unchanged:
+  * utils/similarity.py  (imports with torch only)
+  * utils/pos_embed.py
+  * utils/mim_vit.py     -- needs ``timm`` and ``h5py`` which are absent here; they are
+    replaced by the TEST-ONLY stand-ins below.  The stand-in is this
+    repo's own restatement of timm's published PatchEmbed / Block / param-group
+    semantics, so the Block arithmetic in these goldens is "parity unpinned" third-party
+    arithmetic; everything in mim_vit.py itself (input norm, NaN fill, masking, token
+    assembly, decoder un-shuffle, patchify, loss, init, optimiser wiring) is the
+    reference's own code executing.
+
+Outputs small .npz fixtures next to this file.  Only data is written: no reference
+source or bytecode is copied.
+"""
+import os
+import sys
+import types
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# --------------------------------------------------------------------------
+# test-only stand-ins for absent third-party modules
+# --------------------------------------------------------------------------
+def install_standins():
+    class PatchEmbed(nn.Module):
+        def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
+            super().__init__()
+            self.img_size = (img_size, img_size)
+            self.patch_size = (patch_size, patch_size)
+            self.grid_size = (img_size // patch_size, img_size // patch_size)
+            self.num_patches = self.grid_size[0] * self.grid_size[1]
+            self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size, bias=True)
+
+        def forward(self, x):
+            return self.proj(x).flatten(2).transpose(1, 2)
+
+    class Attention(nn.Module):
+        def __init__(self, dim, num_heads, qkv_bias=True):
+            super().__init__()
+            self.num_heads = num_heads
+            self.head_dim = dim // num_heads
+            self.scale = self.head_dim ** -0.5
+            self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+            self.proj = nn.Linear(dim, dim)
+
+        def forward(self, x):
+            B, N, C = x.shape
+            qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
+            q, k, v = qkv.unbind(0)
+            attn = (q * self.scale) @ k.transpose(-2, -1)
+            attn = attn.softmax(dim=-1)
+            x = (attn @ v).transpose(1, 2).reshape(B, N, C)
+            return self.proj(x)
+
+    class Mlp(nn.Module):
+        def __init__(self, dim, hidden):
+            super().__init__()
+            self.fc1 = nn.Linear(dim, hidden)
+            self.act = nn.GELU()
+            self.fc2 = nn.Linear(hidden, dim)
+
+        def forward(self, x):
+            return self.fc2(self.act(self.fc1(x)))
+
+    class Block(nn.Module):
+        def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, norm_layer=nn.LayerNorm):
+            super().__init__()
+            self.norm1 = norm_layer(dim)
+            self.attn = Attention(dim, num_heads, qkv_bias)
+            self.norm2 = norm_layer(dim)
+            self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+        def forward(self, x):
+            x = x + self.attn(self.norm1(x))
+            return x + self.mlp(self.norm2(x))
+
+    class AttentionPoolLatent(nn.Module):  # placeholder: only built when attn_pool=True
+        def __init__(self, *a, **k):
+            super().__init__()
+            raise NotImplementedError
+
+    def param_groups_weight_decay(model, weight_decay=1e-5, no_weight_decay_list=()):
+        decay, no_decay = [], []
+        for name, p in model.named_parameters():
+            if not p.requires_grad:
+                continue
+            if p.ndim <= 1 or name.endswith(".bias") or name in no_weight_decay_list:
+                no_decay.append(p)
+            else:
+                decay.append(p)
+        return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
+
+    timm = types.ModuleType("timm")
+    optim = types.ModuleType("timm.optim")
+    of = types.ModuleType("timm.optim.optim_factory")
+    of.param_groups_weight_decay = param_groups_weight_decay
+    models = types.ModuleType("timm.models")
+    vt = types.ModuleType("timm.models.vision_transformer")
+    vt.PatchEmbed, vt.Block = PatchEmbed, Block
+    layers = types.ModuleType("timm.layers")
+    layers.AttentionPoolLatent = AttentionPoolLatent
+    timm.optim, optim.optim_factory, timm.models, models.vision_transformer, timm.layers = optim, of, models, vt, layers
+    for n, m in [("timm", timm), ("timm.optim", optim), ("timm.optim.optim_factory", of), ("timm.models", models),
+                 ("timm.models.vision_transformer", vt), ("timm.layers", layers)]:
+        sys.modules[n] = m
+    sys.modules["h5py"] = types.ModuleType("h5py")  # inert: never called on this path
+    return param_groups_weight_decay
+
+
+def sd_np(sd):
+    return {k: v.detach().cpu().numpy().copy() for k, v in sd.items()}
+
+
+def mae_case(mim_vit, pgwd, name, *, img, patch, C=5, D=64, depth=2, heads=4, Dd=32, ddepth=1, dheads=4,
+             norm_pix=True, loss_fn="mse", nan=False, B=4, mask_ratio=0.75, steps=0, seed=0, pixel_mean=0.1,
+             pixel_std=1.3, pmv_rand=False):
+    torch.manual_seed(seed)
+    model = mim_vit.MaskedAutoencoderViT(img_size=img, patch_size=patch, in_chans=C, embed_dim=D, depth=depth,
+                                         num_heads=heads, decoder_embed_dim=Dd, decoder_depth=ddepth,
+                                         decoder_num_heads=dheads, mlp_ratio=4,
+                                         norm_layer=partial(nn.LayerNorm, eps=1e-6), norm_pix_loss=norm_pix,
+                                         loss_fn=loss_fn, pixel_mean=pixel_mean, pixel_std=pixel_std)
+    with torch.no_grad():
+        # make zero-initialised tensors non-trivial so every gradient path is exercised
+        g = torch.Generator().manual_seed(seed + 100)
+        for n, p in model.named_parameters():
+            if n.endswith(".bias") or "norm" in n:
+                p.add_(torch.randn(p.shape, generator=g) * 0.05)
+        if pmv_rand:
+            model.patch_mask_values.copy_(torch.randn(model.patch_mask_values.shape, generator=g) * 0.5)
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(B, C, img, img, generator=g).clamp_(min=-3.0)
+    if nan:
+        x[1, 2] = float("nan")                      # a whole missing band
+        x[2, 0, 3:9, 5:20] = float("nan")           # a NaN blob crossing patch borders
+        x[3, 4, ::7, ::5] = float("nan")            # scattered NaN pixels
+    out = {"imgs": x.numpy().copy(), "mask_ratio": np.float64(mask_ratio),
+           "cfg": np.array([img, patch, C, D, depth, heads, Dd, ddepth, dheads, int(norm_pix)], dtype=np.int64),
+           "loss_fn": np.array(loss_fn), "pixel_mean": np.float64(pixel_mean), "pixel_std": np.float64(pixel_std)}
+    out.update({"state/" + k: v for k, v in sd_np(model.state_dict()).items()})
+
+    L = (img // patch) ** 2
+
+    def fwd(s):
+        # random_masking draws torch.rand(N, L) first thing after the seed (mim_vit.py:363)
+        torch.manual_seed(s)
+        noise = torch.rand(B, L).numpy().copy()
+        torch.manual_seed(s)
+        return model(x, mask_ratio=mask_ratio), noise
+
+    model.train(True)
+    (loss, pred, mask), out["noise"] = fwd(1000)
+    torch.manual_seed(1000)
+    _, _, ids_restore = model.forward_features(x, mask_ratio=mask_ratio)
+    out.update(loss=loss.detach().numpy().copy(), pred=pred.detach().numpy().copy(), mask=mask.numpy().copy(),
+               ids_restore=ids_restore.numpy().copy())
+    # encoder-only path (eval_fns.py:115): mask_ratio=0 keeps all tokens, shuffled
+    torch.manual_seed(1000)
+    latent, _, ids0 = model.forward_features(x, mask_ratio=0, reshape_out=False)
+    out.update(latent_full=latent.detach().numpy().copy(), ids_restore_full=ids0.numpy().copy())
+    loss.backward()
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            out["grad/" + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+    if steps:
+        # run_iter-equivalent: AdamW(param_groups_weight_decay, betas=(0.9,0.95)) + CosineAnnealingLR
+        # (mim_vit.py:126-144, pretrain_fns.py:34-41)
+        model.zero_grad(set_to_none=True)
+        init_lr, wd, total, flf = 1e-3, 0.05, 10, 1e7
+        opt = torch.optim.AdamW(pgwd(model, wd), lr=init_lr, betas=(0.9, 0.95))
+        sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, total, eta_min=init_lr / flf)
+        noises, losses, lrs = [], [], []
+        for it in range(steps):
+            lrs.append(opt.param_groups[0]["lr"])
+            (loss, _, _), nz = fwd(2000 + it)
+            noises.append(nz)
+            loss.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            sched.step()
+            losses.append(float(loss))
+            if it in (0, steps - 1):
+                out.update({f"state_after{it + 1}/" + k: v for k, v in sd_np(model.state_dict()).items()
+                            if k not in ("pos_embed", "decoder_pos_embed")})
+        out.update(step_losses=np.array(losses), step_lrs=np.array(lrs), step_noises=np.stack(noises),
+                   opt_hparams=np.array([init_lr, wd, total, flf]))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name, "loss", float(out["loss"]))
+
+
+def unit_pieces(mim_vit, pos_embed):
+    out = {}
+    for D in (64, 512, 768, 1024):
+        for grid in (4, 8):
+            for rd in (False, True):
+                out[f"sincos/{D}_{grid}_{int(rd)}"] = pos_embed.get_2d_sincos_pos_embed(D, grid, cls_token=True,
+                                                                                       ra_dec=rd).astype(np.float64)
+    model = mim_vit.MaskedAutoencoderViT(img_size=32, patch_size=8, in_chans=3, embed_dim=16, depth=1, num_heads=2,
+                                         decoder_embed_dim=16, decoder_depth=1, decoder_num_heads=2)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 32, 32, generator=g)
+    pt = model.patchify(x)
+    out["patchify/in"] = x.numpy()
+    out["patchify/out"] = pt.numpy()
+    out["patchify/roundtrip"] = model.unpatchify(pt).numpy()
+    xn = pt.clone()
+    xn[0, 3, 5:50] = float("nan")
+    xn[1, 7, ::3] = float("nan")
+    mean, var = mim_vit.patch_mean_and_var(xn)
+    out["pmv/in"], out["pmv/mean"], out["pmv/var"] = xn.numpy(), mean.numpy(), var.numpy()
+    for L in (16, 64):
+        for ratio in (0.0, 0.6, 0.75):
+            torch.manual_seed(77)
+            noise = torch.rand(3, L)
+            torch.manual_seed(77)
+            tok = torch.arange(3 * L * 2, dtype=torch.float32).reshape(3, L, 2)
+            xm, mask, ids = model.random_masking(tok, ratio)
+            key = f"mask/{L}_{ratio}"
+            out[key + "/noise"], out[key + "/x_masked"] = noise.numpy(), xm.numpy()
+            out[key + "/mask"], out[key + "/ids_restore"] = mask.numpy(), ids.numpy()
+    np.savez_compressed(os.path.join(OUT, "unit_pieces.npz"), **out)
+    print("wrote unit_pieces")
+
+
+def similarity_cases(sim):
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    for (T, P, N) in ((130, 1, 512), (65, 16, 128), (65, 64, 64)):
+        D = 96
+        tgt = torch.randn(T, P, D, generator=g) * (0.5 + torch.rand(D, generator=g)) + torch.randn(D, generator=g)
+        tst = torch.randn(N, P, D, generator=g) * 1.1 + 0.2
+        key = f"sim/{T}_{P}_{N}"
+        out[key + "/target"], out[key + "/test"] = tgt.numpy(), tst.numpy()
+        avg, w = sim.determine_target_features(tgt)
+        out[key + "/avg"], out[key + "/w"] = avg.numpy(), w.numpy()
+        for metric in ("cosine", "MSE", "MAE"):
+            for combine in ("min", "mean", "max"):
+                for uw in (True, False):
+                    s = sim.compute_similarity(tgt, tst, metric=metric, combine=combine, use_weights=uw)
+                    out[f"{key}/{metric}_{combine}_{int(uw)}"] = s.numpy()
+    # streaming update_best_scores (similarity.py:18-35) over 8 batches; RA/Dec column 0 carries the sample index
+    N, B, n_save = 512, 64, 50
+    scores = torch.randn(N, generator=g)
+    out["stream/scores"] = scores.numpy()
+    for metric in ("cosine", "MSE"):
+        best_s = torch.full((n_save,), float("-inf") if metric == "cosine" else float("inf"))
+        best_rd = torch.empty((n_save, 2))
+        best_x = torch.empty((n_save, 1))
+        for b in range(N // B):
+            idx = torch.arange(b * B, (b + 1) * B, dtype=torch.float32)
+            rd = torch.stack([idx, idx], dim=1)
+            best_x, best_rd, best_s = sim.update_best_scores(idx[:, None], rd, scores[b * B:(b + 1) * B], best_x,
+                                                             best_rd, best_s, n_save, metric)
+        out[f"stream/{metric}_best_scores"] = best_s.numpy()
+        out[f"stream/{metric}_best_idx"] = best_rd[:, 0].numpy().astype(np.int64)
+    # first-batch standardisation (similarity.py:98-102)
+    lat = torch.randn(32, 4, 96, generator=g) * 3 + 1
+    mu, sd = lat.mean(dim=(0, 1)), lat.std(dim=(0, 1), unbiased=True)
+    out["std/in"], out["std/mu"], out["std/sd"] = lat.numpy(), mu.numpy(), sd.numpy()
+    out["std/out"] = ((lat - mu) / (sd + 1e-8)).numpy()
+    np.savez_compressed(os.path.join(OUT, "similarity.npz"), **out)
+    print("wrote similarity")
+
+
+def main():
+    pgwd = install_standins()
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(REF, "utils"))
+    import importlib
+    mim_vit = importlib.import_module("utils.mim_vit")
+    sim = importlib.import_module("utils.similarity")
+    pos_embed = importlib.import_module("utils.pos_embed")
+    torch.set_num_threads(4)
+    unit_pieces(mim_vit, pos_embed)
+    similarity_cases(sim)
+    # A: BASELINE geometry (64/16, 5 bands), clean input, 3 optimiser steps
+    mae_case(mim_vit, pgwd, "mae_tiny_A", img=64, patch=16, norm_pix=True, loss_fn="mse", steps=3)
+    # B: NaN bands / pixels + non-zero patch_mask_values
+    mae_case(mim_vit, pgwd, "mae_tiny_B_nan", img=32, patch=8, norm_pix=True, loss_fn="mse", nan=True, pmv_rand=True,
+             seed=3)
+    # C: no norm-pix, D: L1 (any loss_fn != 'mse')
+    mae_case(mim_vit, pgwd, "mae_tiny_C_nonorm", img=32, patch=8, norm_pix=False, loss_fn="mse", seed=4)
+    mae_case(mim_vit, pgwd, "mae_tiny_D_l1", img=32, patch=8, norm_pix=True, loss_fn="L1", nan=True, seed=5)
+    # E: reference's usual patch size 8 on 64x64 (L=64, 17 kept) with mask_ratio 0.6
+    mae_case(mim_vit, pgwd, "mae_tiny_E_p8", img=64, patch=8, D=32, Dd=16, heads=2, dheads=2, mask_ratio=0.6, seed=6)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,29 @@
+"""Shared helpers for the parity tests (load goldens into oracle structures)."""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from oracle import mae_oracle as mo
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    img, patch, C, D, depth, heads, Dd, ddepth, dheads, norm_pix = [int(v) for v in z["cfg"]]
+    cfg = mo.MAEConfig(img_size=img, patch_size=patch, in_chans=C, embed_dim=D, depth=depth, num_heads=heads,
+                       decoder_embed_dim=Dd, decoder_depth=ddepth, decoder_num_heads=dheads,
+                       norm_pix_loss=bool(norm_pix), loss_fn=str(z["loss_fn"]), pixel_mean=float(z["pixel_mean"]),
+                       pixel_std=float(z["pixel_std"]))
+    state = OrderedDict()
+    for name_, _shape in mo.state_layout(cfg):
+        state[name_] = torch.from_numpy(z["state/" + name_].copy())
+    return z, cfg, state
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))

@@ -1,0 +1,145 @@
+"""CPU: the oracle (oracle/*.py, oracle/topk_oracle.c) against vectors captured from the reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mae_oracle as mo
+from oracle import similarity_oracle as so
+from tests.helpers import GOLDEN, load_case, rel_err
+
+CASES = ["mae_tiny_A", "mae_tiny_B_nan", "mae_tiny_C_nonorm", "mae_tiny_D_l1", "mae_tiny_E_p8"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_backward_matches_reference(name):
+    z, cfg, st = load_case(name)
+    # state layout == reference state_dict (names, shapes, order)
+    ref_keys = [k[len("state/"):] for k in z.files if k.startswith("state/")]
+    assert ref_keys == [n for n, _ in mo.state_layout(cfg)]
+    imgs, noise = torch.from_numpy(z["imgs"]), torch.from_numpy(z["noise"])
+    loss, pred, mask, ids, latent, grads = mo.loss_and_grads(st, imgs, cfg, float(z["mask_ratio"]), noise)
+    assert np.array_equal(mask.numpy(), z["mask"])
+    assert np.array_equal(ids.numpy(), z["ids_restore"])
+    assert abs(float(loss) - float(z["loss"])) <= 2e-6 * abs(float(z["loss"]))
+    assert rel_err(pred.numpy(), z["pred"]) < 2e-6
+    nan_input = bool(np.isnan(z["imgs"]).any())
+    poisoned = nan_input and cfg.loss_fn == "mse"
+
+    def check(gr):
+        for k, g in gr.items():
+            ref = z["grad/" + k]
+            tol = 2e-5 * max(np.abs(ref).max(), 1e-8) + 1e-9
+            assert np.abs(g.numpy() - ref).max() <= tol, k
+
+    if poisoned:
+        # reference behaviour pinned: with MSE, NaN targets poison the whole backward
+        # (forward_loss docstring); L1's backward is sign-based and stays finite.
+        for k, g in grads.items():
+            assert np.array_equal(np.isnan(g.numpy()), np.isnan(z["grad/" + k])), k
+        assert np.isnan(z["grad/cls_token"]).all() and np.isnan(z["grad/blocks.0.mlp.fc1.weight"]).all()
+    else:
+        check(grads)
+    if nan_input:
+        loss2, pred2, _, _, _, g2 = mo.loss_and_grads(st, imgs, cfg, float(z["mask_ratio"]), noise, nan_safe=True)
+        assert float(loss2) == float(loss) and np.array_equal(pred2.numpy(), pred.numpy())
+        assert all(bool(torch.isfinite(v).all()) for v in g2.values())
+        if not poisoned:
+            check(g2)  # nan_safe == the reference wherever the reference is finite
+    # encoder-only path (mask_ratio=0 keeps every token, shuffled)
+    lat, _, ids0 = mo.forward_features(st, imgs, cfg, 0.0, noise, reshape_out=False)
+    assert np.array_equal(ids0.numpy(), z["ids_restore_full"])
+    assert rel_err(lat.numpy(), z["latent_full"]) < 2e-6
+
+
+def test_adamw_cosine_steps_match_reference():
+    z, cfg, st = load_case("mae_tiny_A")
+    init_lr, wd, total, flf = [float(v) for v in z["opt_hparams"]]
+    tr = mo.Trainer(cfg, st, init_lr=init_lr, weight_decay=wd, total_iters=int(total), final_lr_factor=flf)
+    imgs = torch.from_numpy(z["imgs"])
+    for it in range(3):
+        assert abs(tr.lr() - float(z["step_lrs"][it])) <= 1e-12 * init_lr + 1e-18
+        loss, *_ = tr.step(imgs, float(z["mask_ratio"]), torch.from_numpy(z["step_noises"][it]))
+        assert abs(float(loss) - float(z["step_losses"][it])) <= 5e-6 * abs(float(z["step_losses"][it]))
+        if it in (0, 2):
+            for k in tr.decay + tr.no_decay:
+                ref = z[f"state_after{it + 1}/{k}"]
+                # Adam turns rounding noise on ~zero gradients (e.g. the key bias, to which softmax is
+                # invariant) into +-lr-sized moves, so allow a small fraction of lr absolute.
+                tol = 3e-6 * max(np.abs(ref).max(), 1e-3) + (0 if it == 0 else 5e-3 * init_lr)
+                assert np.abs(st[k].numpy() - ref).max() <= tol, (it, k)
+    # timm param_groups_weight_decay split (86 / 167 for MAE-B per SURVEY §8a a11)
+    d, nd = mo.weight_decay_split(mo.config_for("base", patch_size=16, in_chans=5))
+    assert (len(d), len(nd)) == (86, 167)
+
+
+def test_unit_pieces():
+    z = np.load(f"{GOLDEN}/unit_pieces.npz")
+    for D in (64, 512, 768, 1024):
+        for grid in (4, 8):
+            for rd in (False, True):
+                got = mo.sincos_pos_embed(D, grid, True, rd)
+                assert np.array_equal(got, z[f"sincos/{D}_{grid}_{int(rd)}"])
+    cfg = mo.MAEConfig(img_size=32, patch_size=8, in_chans=3)
+    x = torch.from_numpy(z["patchify/in"])
+    pt = mo.patchify(x, cfg)
+    assert np.array_equal(pt.numpy(), z["patchify/out"])
+    assert np.array_equal(mo.unpatchify(pt, cfg).numpy(), z["patchify/roundtrip"])
+    mean, var = mo.patch_mean_and_var(torch.from_numpy(z["pmv/in"]))
+    assert np.array_equal(mean.numpy(), z["pmv/mean"]) and np.array_equal(var.numpy(), z["pmv/var"])
+    for L in (16, 64):
+        for ratio in (0.0, 0.6, 0.75):
+            key = f"mask/{L}_{ratio}"
+            tok = torch.arange(3 * L * 2, dtype=torch.float32).reshape(3, L, 2)
+            xm, mask, ids = mo.random_masking_from_noise(tok, ratio, torch.from_numpy(z[key + "/noise"]))
+            assert np.array_equal(xm.numpy(), z[key + "/x_masked"])
+            assert np.array_equal(mask.numpy(), z[key + "/mask"])
+            assert np.array_equal(ids.numpy(), z[key + "/ids_restore"])
+
+
+def test_similarity_matches_reference():
+    z = np.load(f"{GOLDEN}/similarity.npz")
+    for (T, P, N) in ((130, 1, 512), (65, 16, 128), (65, 64, 64)):
+        key = f"sim/{T}_{P}_{N}"
+        tgt, tst = torch.from_numpy(z[key + "/target"]), torch.from_numpy(z[key + "/test"])
+        avg, w = so.determine_target_features(tgt)
+        assert np.array_equal(avg.numpy(), z[key + "/avg"]) and np.array_equal(w.numpy(), z[key + "/w"])
+        for metric in ("cosine", "MSE", "MAE"):
+            for combine in ("min", "mean", "max"):
+                for uw in (True, False):
+                    s = so.compute_similarity(tgt, tst, metric=metric, combine=combine, use_weights=uw)
+                    assert np.array_equal(s.numpy(), z[f"{key}/{metric}_{combine}_{int(uw)}"])
+    # streaming best-n == reference's streaming result (scores and sample tags)
+    scores = torch.from_numpy(z["stream/scores"])
+    for metric in ("cosine", "MSE"):
+        bs = torch.full((50,), float("-inf") if metric == "cosine" else float("inf"))
+        bt = torch.full((50,), -1, dtype=torch.int64)
+        for b in range(8):
+            sl = slice(b * 64, (b + 1) * 64)
+            bs, bt = so.update_best_scores(scores[sl], torch.arange(b * 64, (b + 1) * 64), bs, bt, 50, metric)
+        assert np.array_equal(bs.numpy(), z[f"stream/{metric}_best_scores"])
+        assert np.array_equal(bt.numpy(), z[f"stream/{metric}_best_idx"])
+    mu, sd = so.standardise_first_batch(torch.from_numpy(z["std/in"]))
+    assert np.array_equal(mu.numpy(), z["std/mu"]) and np.array_equal(sd.numpy(), z["std/sd"])
+    got = so.standardise_np(z["std/in"].reshape(-1, 96), z["std/mu"], z["std/sd"])
+    assert np.array_equal(got, z["std/out"].reshape(-1, 96))
+
+
+def test_c_topk_oracle_against_reference_formula():
+    """The fixed-order C contract stays within fp32 rounding of the reference's torch formula and
+    its top-k equals a stable sort of its own scores."""
+    z = np.load(f"{GOLDEN}/similarity.npz")
+    tgt, tst = torch.from_numpy(z["sim/130_1_512/target"]), torch.from_numpy(z["sim/130_1_512/test"])
+    avg, w = so.determine_target_features(tgt)
+    ref = z["sim/130_1_512/cosine_min_1"]  # P == 1 so 'min' is the identity
+    sc = so.cosine_scores_np(avg[None].numpy(), tst[:, 0].numpy(), w.numpy())
+    assert np.abs(sc[0] - ref).max() < 5e-7
+    s, i = so.cosine_topk_np(avg[None].numpy(), tst[:, 0].numpy(), 20, w.numpy())
+    order = np.argsort(-sc[0], kind="stable")[:20]
+    assert np.array_equal(i[0], order) and np.array_equal(s[0], sc[0][order])
+    # exact ties -> lower index first; k > N pads with (-inf, -1)
+    q = np.ones((1, 8), np.float32)
+    bank = np.ones((5, 8), np.float32)
+    bank[3] = -1
+    s, i = so.cosine_topk_np(q, bank, 7)
+    assert i[0].tolist() == [0, 1, 2, 4, 3, -1, -1]
+    assert np.isneginf(s[0][5:]).all()
