@@ -1,0 +1,197 @@
+/*
+ * skyemb.h -- C ABI of libskyemb (MI355X / gfx950 hot path of sky_embeddings).
+ *
+ * The reference (teaghan/sky_embeddings) has no FFI layer: its hot path is Python
+ * (torch + timm).  This header is the lower drop-in boundary the build inserts beneath
+ * the reference's module API: every entry point below names the
+ * reference lines (paths relative to the reference root) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - plain C, raw DEVICE pointers + sizes, no torch types; caller owns every buffer
+ *     (workspaces included); nothing is allocated or freed inside the library;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, no host
+ *     synchronisation, safe under stream capture (hipGraph);
+ *   - return 0 on success, non-zero on error with the text in skyemb_last_error()
+ *     (thread-local);
+ *   - `dtype` selects the ACTIVATION element type of the call: SKYEMB_BF16 (throughput
+ *     mode: bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulate) or SKYEMB_F32
+ *     (parity mode: exact-fp32 v_mfma_f32_16x16x4_f32).  Statistics, losses, the
+ *     residual stream, gradients of parameters and optimiser state are always fp32.
+ */
+#ifndef SKYEMB_H
+#define SKYEMB_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SKYEMB_BF16 0
+#define SKYEMB_F32 1
+
+/* operand layouts of skyemb_gemm (logical A[M,K], B[N,K]; C = A * B^T) */
+#define SKYEMB_KC 0 /* k contiguous:   X(r,k) at X[r*ld + k] */
+#define SKYEMB_RC 1 /* row contiguous: X(r,k) at X[k*ld + r] */
+
+/* epilogue activations */
+#define SKYEMB_ACT_NONE 0
+#define SKYEMB_ACT_GELU 1  /* out = gelu(v) (exact erf); out2 = v (pre-activation)  */
+#define SKYEMB_ACT_DGELU 2 /* out = v * gelu'(aux)                                  */
+
+const char *skyemb_last_error(void);
+int skyemb_version(void);
+
+/* ---------------------------------------------------------------- GEMM ----
+ * Replaces every nn.Linear / Conv2d(k=s=p) contraction of timm PatchEmbed / Block /
+ * the MAE decoder (utils/mim_vit.py:206,231-233,269,276-281) and their autograd
+ * backward (dgrad, wgrad) (utils/pretrain_fns.py:34).
+ *
+ *   v[m,n]   = alpha * sum_k A(m,k) * B(n,k)  + bias[n] + table[tab_row[m], n] + resid[orow, n]
+ *   orow     = dst_row ? dst_row[m] : m        (orow < 0: row is not stored)
+ *   out_f32[orow, n] / out[orow, n] / out2[orow, n] per `act` (see above).
+ * A, B, aux, out, out2 have element type `dtype`; bias/table/resid/out_f32 are fp32.
+ * Constraint: the contiguous extent of A and of B (K for KC, rows for RC) is a
+ * multiple of 8 (bf16) / 4 (f32) elements and 16-byte aligned.
+ */
+typedef struct skyemb_gemm_args {
+    const void *A;
+    const void *B;
+    int64_t lda, ldb;
+    int32_t a_layout, b_layout; /* SKYEMB_KC / SKYEMB_RC */
+    int32_t M, N, K;
+    int32_t dtype;
+    float alpha;
+    const float *bias;          /* [N] or NULL */
+    const float *table;         /* fp32 rows added by index, or NULL */
+    const int32_t *tab_row;     /* [M] */
+    int64_t ldt;
+    const int32_t *dst_row;     /* [M] or NULL */
+    const float *resid;         /* fp32 [*, ldr] or NULL (indexed by orow) */
+    int64_t ldr;
+    const void *aux;            /* dtype [M, ldaux] (ACT_DGELU), indexed by m */
+    int64_t ldaux;
+    int32_t act;
+    float *out_f32;             /* or NULL */
+    int64_t ldo32;
+    void *out;                  /* dtype, or NULL */
+    int64_t ldo;
+    void *out2;                 /* dtype, or NULL (ACT_GELU pre-activation) */
+    int64_t ldo2;
+    int32_t tile;               /* 0 = auto, 64 or 128 */
+} skyemb_gemm_args;
+
+int skyemb_gemm(const skyemb_gemm_args *args, void *stream);
+
+/* column sums: out[n] = sum_m X[m,n]; X is `dtype` (bias gradients) or fp32 partials
+ * (LayerNorm dgamma/dbeta second stage).  Replaces autograd's bias-gradient reductions. */
+int skyemb_colsum(const void *X, int dtype, int64_t ldx, int M, int N, float *out, void *stream);
+
+/* ----------------------------------------------------------- front end ----
+ * utils/mim_vit.py:354-379 random_masking with the noise supplied by the caller
+ * (ties -> lower index).  noise [B,L] -> ids_restore i64 [B,L], mask f32 [B,L]
+ * (1 = removed), ids_keep i32 [B,keep] (first `keep` of the shuffle, in shuffle order).
+ * Optional (NULL to skip) decoder un-shuffle maps for utils/mim_vit.py:446-453, one entry per
+ * encoder token (cls first): dec_dst i32 [B,1+keep] = row of the [B,1+L] decoder sequence the token
+ * lands on, dec_tab i32 [B,1+keep] = its decoder_pos_embed row. */
+int skyemb_random_mask_from_noise(const float *noise, int B, int L, int keep, int64_t *ids_restore, float *mask,
+                                  int32_t *ids_keep, int32_t *dec_dst, int32_t *dec_tab, void *stream);
+
+/* utils/mim_vit.py:385-392 + the im2row half of timm PatchEmbed (:206,402): for every kept
+ * patch (b, ids_keep[b,j]) write the row  out[b*keep + j, c*p*p + py*p + px] =
+ * isnan(x) ? pmv[c,py,px] : (x - mean)/std   in `dtype`.  ids_keep == NULL: all L patches in order. */
+int skyemb_patch_gather(const float *imgs, const float *pmv, const int32_t *ids_keep, void *out, int dtype, int B,
+                        int C, int H, int W, int p, int keep, float pixel_mean, float pixel_std, void *stream);
+
+/* gradient of patch_mask_values: dpmv[c,py,px] = sum over gathered NaN pixels of drows (fp32
+ * [B*keep, C*p*p]); deterministic two-stage reduction, `partial` is fp32 [B, C*p*p]. */
+int skyemb_patch_gather_bwd_pmv(const float *imgs, const int32_t *ids_keep, const float *drows, float *partial,
+                                float *dpmv, int B, int C, int H, int W, int p, int keep, void *stream);
+
+/* -------------------------------------------------------- LayerNorm -------
+ * nn.LayerNorm(eps=1e-6) of timm Block.norm1/norm2 and the final norms
+ * (utils/mim_vit.py:236,280,429,458).  x fp32 [M,D] -> y dtype [M,D] (+ y32 fp32 copy if
+ * non-NULL), mean/rstd fp32 [M]. */
+int skyemb_layernorm_fwd(const float *x, const float *gamma, const float *beta, void *y, float *y32, int dtype,
+                         float *mean, float *rstd, int M, int D, float eps, void *stream);
+
+/* dx = LN'(dy); g_out = (g_in ? g_in : 0) + dx (fp32; g_out may alias g_in); g_lp = dtype copy
+ * of g_out (or NULL).  dy is `dtype` (or fp32 when dy_is_f32).  dgamma/dbeta partial sums are
+ * written to part[2, nblk, D] (nblk = skyemb_layernorm_bwd_blocks(M)); reduce with skyemb_colsum. */
+int skyemb_layernorm_bwd_blocks(int M);
+int skyemb_layernorm_bwd(const void *dy, int dy_is_f32, int dtype, const float *x, const float *gamma,
+                         const float *mean, const float *rstd, const float *g_in, float *g_out, void *g_lp,
+                         float *part, int M, int D, void *stream);
+
+/* -------------------------------------------------------- attention -------
+ * timm Attention core / F.scaled_dot_product_attention on tiny sequences (N = 5, 17, 65, 66):
+ * qkv dtype [B, N, 3, H, hd] -> out dtype [B, N, H*hd];  softmax(q k^T hd^-0.5) v in fp32.
+ * Backward recomputes the probabilities from q, k. */
+int skyemb_mha_fwd(const void *qkv, void *out, int dtype, int B, int N, int H, int hd, void *stream);
+int skyemb_mha_bwd(const void *qkv, const void *dout, void *dqkv, int dtype, int B, int N, int H, int hd,
+                   void *stream);
+
+/* -------------------------------------------------------- decoder glue ----
+ * utils/mim_vit.py:446-453: rows of the decoder sequence that hold a mask token:
+ * x[b, 1+l, :] = mask_token + dec_pos[1+l] for every l with mask[b,l]==1 (x fp32 [B, 1+L, Dd]). */
+int skyemb_fill_mask_tokens(float *x, const float *mask, const float *mask_token, const float *dec_pos, int B,
+                            int L, int Dd, void *stream);
+/* gather fp32 rows: out[i, :] = src[idx[i], :] (also emits a dtype copy when out_lp != NULL) */
+int skyemb_gather_rows(const float *src, const int32_t *idx, float *out, void *out_lp, int dtype, int n_rows,
+                       int D, void *stream);
+/* selected row sum (d mask_token, d cls_token): out[d] = sum_i [sel == NULL || sel[i] != 0] src[r(i)*ld + d],
+ * r(i) = row0 + (i / inner) * outer_stride + (i % inner), i in [0, n_rows); `partial` fp32 [64, D]. */
+int skyemb_rowsum_select(const float *src, int64_t ld, const float *sel, int row0, int inner, int outer_stride,
+                         int n_rows, int D, float *partial, float *out, void *stream);
+
+/* ------------------------------------------------------------- loss -------
+ * utils/mim_vit.py:326-338,473-521,614-627: patchify + NaN-aware per-patch mean / biased
+ * variance normalisation + masked MSE (loss_l1 == 0) or L1 + NaN exclusion.
+ * pred fp32 [B, Nd, pv] with the first `extra` rows of each sample ignored (cls / ra_dec).
+ * Outputs: loss (fp32 scalar, device), dpred dtype/fp32 [B, Nd, pv] (extra + unmasked rows
+ * zero) = d loss / d pred.  NaN target elements contribute zero gradient (DESIGN.md deviation).
+ * `ws` fp32 workspace of 4*B*L + 4 floats. */
+int skyemb_masked_patch_loss(const float *imgs, const float *pred, const float *mask, float *loss, void *dpred,
+                             float *dpred32, int dtype, float *ws, int B, int C, int H, int W, int p, int extra,
+                             float pixel_mean, float pixel_std, int norm_pix, int loss_l1, void *stream);
+
+/* ----------------------------------------------------------- optimiser ----
+ * torch.optim.AdamW single-tensor update order (utils/mim_vit.py:126-129,
+ * utils/pretrain_fns.py:36-41) over one flat fp32 parameter buffer:
+ * elements [0, n_decay) use weight decay `wd`, the rest 0.  hyper (device, fp32[4]) =
+ * {lr, 1-beta1^t, 1-beta2^t, unused}.  Also refreshes the dtype shadow copy `p_lp` used by
+ * the GEMMs (NULL to skip) and optionally zeroes g. */
+int skyemb_adamw(float *p, float *g, float *m, float *v, void *p_lp, int dtype, int64_t n, int64_t n_decay,
+                 const float *hyper, float beta1, float beta2, float eps, float wd, float grad_scale, int zero_grad,
+                 void *stream);
+int skyemb_cast(const float *src, void *dst, int dtype, int64_t n, void *stream);
+
+/* ------------------------------------------------------ similarity search -
+ * utils/similarity.py:98-102: standardise bank rows in place or to `out`:
+ * (x - mu) / (sigma + 1e-8). */
+int skyemb_standardise(const float *x, const float *mu, const float *sigma, float *out, int64_t N, int D,
+                       void *stream);
+/* utils/similarity.py:166-167: weighted norms sqrt(sum_d w x^2) in the oracle's fixed fma order:
+ * rows[n] (bank) ; for queries also tw = w * t (utils/similarity.py:163). w == NULL -> ones. */
+int skyemb_weighted_norms(const float *x, const float *w, float *norms, float *xw_out, int64_t N, int D,
+                          void *stream);
+/* utils/similarity.py:149-172 + 18-35 fused: per-(query tile, bank chunk) exact partial top-k.
+ *   tw [Q,D] (= w*t), qn [Q], bank [N,D], xn [N]  ->  part_s f32 / part_i i64 [Q, nchunks, k]
+ * sorted by (score desc, index asc); idx = idx_offset + local row.  Then skyemb_topk_merge. */
+int skyemb_cosine_topk_chunks(int64_t N, int Q, int k);
+int skyemb_cosine_topk(const float *tw, const float *qn, const float *bank, const float *xn, int Q, int64_t N,
+                       int D, int k, float eps, int64_t idx_offset, int nchunks, float *part_s, int64_t *part_i,
+                       void *stream);
+/* merge `nlists` sorted length-k lists per query (bank chunks, or per-rank results after the
+ * RCCL all-gather): in [Q, nlists, k] -> out [Q, k]. */
+int skyemb_topk_merge(const float *in_s, const int64_t *in_i, int Q, int nlists, int k, float *out_s,
+                      int64_t *out_i, void *stream);
+/* plain score matrix for the reference-shaped path with P>1 patches per sample
+ * (utils/similarity.py:262-267 combine over patches happens on these): scores [Q, N]. */
+int skyemb_cosine_scores(const float *tw, const float *qn, const float *bank, const float *xn, int Q, int64_t N,
+                         int D, float eps, float *scores, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SKYEMB_H */

@@ -1,0 +1,63 @@
+// Fused flat-buffer AdamW (torch.optim.AdamW single-tensor op order; utils/mim_vit.py:126-129,
+// utils/pretrain_fns.py:36-41).  One launch updates every parameter: the model keeps all
+// trainable tensors in ONE flat fp32 buffer laid out [decayed | not decayed], so the only
+// per-element state is the position relative to n_decay.  HBM-bound: reads p,g,m,v, writes
+// p,m,v (+ the bf16/fp32 shadow copy the GEMMs read, + optional gradient zeroing).
+#include "common.h"
+
+namespace {
+
+template <typename T, bool LP>
+__global__ __launch_bounds__(256) void adamw_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
+                                                    float *__restrict__ v, T *__restrict__ p_lp, int64_t n4,
+                                                    int64_t n_decay, const float *__restrict__ hyper, float beta1,
+                                                    float beta2, float eps, float wd, float grad_scale, int zero_grad) {
+    const float lr = hyper[0], bc1 = hyper[1], bc2 = hyper[2];
+    const float step_size = lr / bc1;
+    const float bc2_sqrt = sqrtf(bc2);
+    const float decay = 1.0f - lr * wd;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 pv = *(float4 *)(p + 4 * i), gv = *(float4 *)(g + 4 * i);
+        float4 mv = *(float4 *)(m + 4 * i), vv = *(float4 *)(v + 4 * i);
+        float pa[4] = {pv.x, pv.y, pv.z, pv.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w};
+        float ma[4] = {mv.x, mv.y, mv.z, mv.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gj = ga[j] * grad_scale;
+            if (4 * i + j < n_decay) pa[j] *= decay;                   // p.mul_(1 - lr*wd)
+            ma[j] = ma[j] * beta1 + gj * (1.0f - beta1);                // exp_avg.lerp_(grad, 1-beta1)
+            va[j] = va[j] * beta2 + gj * gj * (1.0f - beta2);           // exp_avg_sq.mul_().addcmul_()
+            const float denom = sqrtf(va[j]) / bc2_sqrt + eps;
+            pa[j] -= step_size * (ma[j] / denom);                      // p.addcdiv_(m, denom, -step_size)
+        }
+        *(float4 *)(p + 4 * i) = make_float4(pa[0], pa[1], pa[2], pa[3]);
+        *(float4 *)(m + 4 * i) = make_float4(ma[0], ma[1], ma[2], ma[3]);
+        *(float4 *)(v + 4 * i) = make_float4(va[0], va[1], va[2], va[3]);
+        if (LP) store4<T>(p_lp + 4 * i, pa[0], pa[1], pa[2], pa[3]);
+        if (zero_grad) *(float4 *)(g + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+}  // namespace
+
+extern "C" int skyemb_adamw(float *p, float *g, float *m, float *v, void *p_lp, int dtype, int64_t n, int64_t n_decay,
+                            const float *hyper, float beta1, float beta2, float eps, float wd, float grad_scale,
+                            int zero_grad, void *stream) {
+    SKY_CHECK_ARG(n > 0 && n % 4 == 0 && n_decay >= 0 && n_decay <= n, "skyemb_adamw: n must be a positive multiple of 4");
+    SKY_CHECK_ARG(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), "skyemb_adamw: unaligned buffers");
+    int64_t blocks = ceil_div64(n / 4, 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)blocks), block(256);
+    if (!p_lp)
+        hipLaunchKernelGGL((adamw_kernel<float, false>), grid, block, 0, st, p, g, m, v, (float *)nullptr, n / 4, n_decay,
+                           hyper, beta1, beta2, eps, wd, grad_scale, zero_grad);
+    else if (dtype == SKYEMB_BF16)
+        hipLaunchKernelGGL((adamw_kernel<bf16_t, true>), grid, block, 0, st, p, g, m, v, (bf16_t *)p_lp, n / 4, n_decay,
+                           hyper, beta1, beta2, eps, wd, grad_scale, zero_grad);
+    else
+        hipLaunchKernelGGL((adamw_kernel<float, true>), grid, block, 0, st, p, g, m, v, (float *)p_lp, n / 4, n_decay, hyper,
+                           beta1, beta2, eps, wd, grad_scale, zero_grad);
+    SKY_LAUNCH_CHECK("skyemb_adamw");
+    return 0;
+}

@@ -1,0 +1,85 @@
+// Shared device/host helpers for libskyemb (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/skyemb.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define SKYEMB_WAVE 64
+
+void skyemb_set_error(const char *fmt, ...);
+
+#define SKY_CHECK_ARG(cond, ...)            \
+    do {                                    \
+        if (!(cond)) {                      \
+            skyemb_set_error(__VA_ARGS__);  \
+            return 1;                       \
+        }                                   \
+    } while (0)
+
+#define SKY_LAUNCH_CHECK(name)                                                        \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) {                                                       \
+            skyemb_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));   \
+            return 2;                                                                 \
+        }                                                                             \
+    } while (0)
+
+template <typename T>
+__device__ __forceinline__ float to_f32(T v);
+template <>
+__device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+
+template <typename T>
+__device__ __forceinline__ T from_f32(float v);
+template <>
+__device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+
+template <typename T>
+__device__ __forceinline__ void store4(T *p, float a, float b, float c, float d);
+template <>
+__device__ __forceinline__ void store4<float>(float *p, float a, float b, float c, float d) {
+    *(float4 *)p = make_float4(a, b, c, d);
+}
+template <>
+__device__ __forceinline__ void store4<bf16_t>(bf16_t *p, float a, float b, float c, float d) {
+    bf16x4 v;
+    v[0] = (bf16_t)a; v[1] = (bf16_t)b; v[2] = (bf16_t)c; v[3] = (bf16_t)d;
+    *(bf16x4 *)p = v;
+}
+template <typename T>
+__device__ __forceinline__ float4 load4(const T *p);
+template <>
+__device__ __forceinline__ float4 load4<float>(const float *p) { return *(const float4 *)p; }
+template <>
+__device__ __forceinline__ float4 load4<bf16_t>(const bf16_t *p) {
+    bf16x4 v = *(const bf16x4 *)p;
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }

@@ -1,0 +1,246 @@
+// Front-end / glue kernels of the MIM path: random masking from supplied noise, fused
+// normalise + NaN-fill + patch gather (im2row of the kept patches only), decoder mask-token fill,
+// row gathers, small deterministic reductions.  All HBM-bound, coalesced 16-byte accesses.
+#include "common.h"
+
+namespace {
+
+// ---- utils/mim_vit.py:354-379 ---------------------------------------------------------------
+// one wave per sample: rank[i] = #{j : noise[j] < noise[i] or (== and j < i)}  (stable argsort)
+__global__ __launch_bounds__(256) void mask_kernel(const float *__restrict__ noise, int B, int L, int keep,
+                                                   int64_t *__restrict__ ids_restore, float *__restrict__ mask,
+                                                   int32_t *__restrict__ ids_keep, int32_t *__restrict__ dec_dst,
+                                                   int32_t *__restrict__ dec_tab) {
+    extern __shared__ float sn[];  // [4][L]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    float *row = sn + wave * L;
+    for (int i = lane; i < L; i += 64) row[i] = noise[(int64_t)b * L + i];
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < L; i += 64) {
+        const float v = row[i];
+        int rank = 0;
+        for (int j = 0; j < L; ++j) {
+            const float u = row[j];
+            rank += (u < v || (u == v && j < i)) ? 1 : 0;
+        }
+        ids_restore[(int64_t)b * L + i] = rank;
+        mask[(int64_t)b * L + i] = rank >= keep ? 1.0f : 0.0f;
+        if (rank < keep) {
+            ids_keep[(int64_t)b * keep + rank] = i;
+            if (dec_dst) {  // encoder token 1+rank of sample b lands on decoder row 1+i (mim_vit.py:448-450)
+                dec_dst[(int64_t)b * (keep + 1) + 1 + rank] = b * (L + 1) + 1 + i;
+                dec_tab[(int64_t)b * (keep + 1) + 1 + rank] = 1 + i;
+            }
+        }
+    }
+    if (dec_dst && lane == 0) {
+        dec_dst[(int64_t)b * (keep + 1)] = b * (L + 1);
+        dec_tab[(int64_t)b * (keep + 1)] = 0;
+    }
+}
+
+// ---- utils/mim_vit.py:385-392 + im2row for Conv2d(k=s=p) --------------------------------------
+// grid = B*keep rows; each thread moves 4 consecutive px of one (c, py)
+template <typename T>
+__global__ __launch_bounds__(256) void patch_gather_kernel(const float *__restrict__ imgs, const float *__restrict__ pmv,
+                                                           const int32_t *__restrict__ ids_keep, T *__restrict__ out,
+                                                           int C, int H, int W, int p, int keep, float mean, float stdv) {
+    const int row = blockIdx.x;
+    const int b = row / keep;
+    const int l = ids_keep ? ids_keep[row] : (row - b * keep);
+    const int gw = W / p;
+    const int y0 = (l / gw) * p, x0 = (l % gw) * p;
+    const int pv4 = C * p * p / 4, p4 = p / 4;
+    for (int e = threadIdx.x; e < pv4; e += 256) {
+        const int px4 = e % p4, py = (e / p4) % p, c = e / (p4 * p);
+        const float4 x = *(const float4 *)(imgs + (((int64_t)b * C + c) * H + y0 + py) * W + x0 + 4 * px4);
+        const float4 m = *(const float4 *)(pmv + (c * p + py) * p + 4 * px4);
+        float4 o;
+        // (x - mean) / std exactly as the reference; NaN -> learned fill value
+        o.x = x.x != x.x ? m.x : (x.x - mean) / stdv;
+        o.y = x.y != x.y ? m.y : (x.y - mean) / stdv;
+        o.z = x.z != x.z ? m.z : (x.z - mean) / stdv;
+        o.w = x.w != x.w ? m.w : (x.w - mean) / stdv;
+        store4<T>(out + (int64_t)row * (C * p * p) + 4 * e, o.x, o.y, o.z, o.w);
+    }
+}
+
+// partial[b][e] = sum_j isnan(pixel) ? drows[b*keep+j][e] : 0
+__global__ __launch_bounds__(256) void pmv_partial_kernel(const float *__restrict__ imgs, const int32_t *__restrict__ ids_keep,
+                                                          const float *__restrict__ drows, float *__restrict__ partial,
+                                                          int C, int H, int W, int p, int keep) {
+    const int b = blockIdx.x;
+    const int gw = W / p, pv = C * p * p;
+    for (int e = threadIdx.x; e < pv; e += 256) {
+        const int px = e % p, py = (e / p) % p, c = e / (p * p);
+        float acc = 0.f;
+        for (int j = 0; j < keep; ++j) {
+            const int l = ids_keep ? ids_keep[b * keep + j] : j;
+            const int y = (l / gw) * p + py, x = (l % gw) * p + px;
+            const float v = imgs[(((int64_t)b * C + c) * H + y) * W + x];
+            if (v != v) acc += drows[((int64_t)b * keep + j) * pv + e];
+        }
+        partial[(int64_t)b * pv + e] = acc;
+    }
+}
+
+// ---- column sums: out[n] = sum_m X[m][n]; block = 64 columns x 4 row groups -------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ X, int64_t ldx, int M, int N,
+                                                     float *__restrict__ out) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    float acc = 0.f;
+    if (n < N)
+        for (int m = wave; m < M; m += 4) acc += to_f32<T>(X[(int64_t)m * ldx + n]);
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && n < N) out[n] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// ---- utils/mim_vit.py:446-453: rows holding a mask token ----------------------------------------
+__global__ __launch_bounds__(256) void fill_mask_tokens_kernel(float *__restrict__ x, const float *__restrict__ mask,
+                                                               const float *__restrict__ mask_token,
+                                                               const float *__restrict__ dec_pos, int L, int Dd) {
+    const int b = blockIdx.x / L, l = blockIdx.x % L;
+    if (mask[(int64_t)b * L + l] == 0.0f) return;
+    float *dst = x + ((int64_t)b * (L + 1) + 1 + l) * Dd;
+    const float *pos = dec_pos + (int64_t)(1 + l) * Dd;
+    for (int d = threadIdx.x * 4; d < Dd; d += 1024) {
+        const float4 t = *(const float4 *)(mask_token + d), q = *(const float4 *)(pos + d);
+        *(float4 *)(dst + d) = make_float4(t.x + q.x, t.y + q.y, t.z + q.z, t.w + q.w);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src, const int32_t *__restrict__ idx,
+                                                          float *__restrict__ out, T *__restrict__ out_lp, int D) {
+    const int r = blockIdx.x;
+    const float *s = src + (int64_t)idx[r] * D;
+    for (int d = threadIdx.x * 4; d < D; d += 1024) {
+        const float4 v = *(const float4 *)(s + d);
+        if (out) *(float4 *)(out + (int64_t)r * D + d) = v;
+        if (out_lp) store4<T>(out_lp + (int64_t)r * D + d, v.x, v.y, v.z, v.w);
+    }
+}
+
+// partial[blk][d] = sum over this block's selected rows
+__global__ __launch_bounds__(256) void rowsum_select_kernel(const float *__restrict__ src, int64_t ld,
+                                                            const float *__restrict__ sel, int row0, int inner,
+                                                            int outer_stride, int n_rows, int D,
+                                                            float *__restrict__ partial) {
+    const int nblk = gridDim.x;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float acc = 0.f;
+        for (int i = blockIdx.x; i < n_rows; i += nblk) {
+            if (sel && sel[i] == 0.0f) continue;
+            const int64_t r = (int64_t)row0 + (int64_t)(i / inner) * outer_stride + (i % inner);
+            acc += src[r * ld + d];
+        }
+        partial[(int64_t)blockIdx.x * D + d] = acc;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_kernel(const float *__restrict__ src, T *__restrict__ dst, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = *(const float4 *)(src + 4 * i);
+        store4<T>(dst + 4 * i, v.x, v.y, v.z, v.w);
+    }
+}
+
+}  // namespace
+
+extern "C" int skyemb_random_mask_from_noise(const float *noise, int B, int L, int keep, int64_t *ids_restore,
+                                             float *mask, int32_t *ids_keep, int32_t *dec_dst, int32_t *dec_tab,
+                                             void *stream) {
+    SKY_CHECK_ARG(B > 0 && L > 0 && keep >= 0 && keep <= L && L <= 4096, "skyemb_random_mask_from_noise: bad shape B=%d L=%d keep=%d", B, L, keep);
+    hipLaunchKernelGGL(mask_kernel, dim3((B + 3) / 4), dim3(256), (size_t)4 * L * sizeof(float), (hipStream_t)stream, noise,
+                       B, L, keep, ids_restore, mask, ids_keep, dec_dst, dec_tab);
+    SKY_LAUNCH_CHECK("skyemb_random_mask_from_noise");
+    return 0;
+}
+
+extern "C" int skyemb_patch_gather(const float *imgs, const float *pmv, const int32_t *ids_keep, void *out, int dtype,
+                                   int B, int C, int H, int W, int p, int keep, float pixel_mean, float pixel_std,
+                                   void *stream) {
+    SKY_CHECK_ARG(B > 0 && C > 0 && p > 0 && p % 4 == 0 && H % p == 0 && W % p == 0 && keep > 0,
+                  "skyemb_patch_gather: bad geometry C=%d H=%d W=%d p=%d keep=%d", C, H, W, p, keep);
+    SKY_CHECK_ARG(ids_keep || keep == (H / p) * (W / p), "skyemb_patch_gather: ids_keep == NULL needs keep == L");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SKYEMB_BF16)
+        hipLaunchKernelGGL(patch_gather_kernel<bf16_t>, dim3(B * keep), dim3(256), 0, st, imgs, pmv, ids_keep, (bf16_t *)out,
+                           C, H, W, p, keep, pixel_mean, pixel_std);
+    else
+        hipLaunchKernelGGL(patch_gather_kernel<float>, dim3(B * keep), dim3(256), 0, st, imgs, pmv, ids_keep, (float *)out, C,
+                           H, W, p, keep, pixel_mean, pixel_std);
+    SKY_LAUNCH_CHECK("skyemb_patch_gather");
+    return 0;
+}
+
+extern "C" int skyemb_colsum(const void *X, int dtype, int64_t ldx, int M, int N, float *out, void *stream) {
+    SKY_CHECK_ARG(M > 0 && N > 0, "skyemb_colsum: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SKYEMB_BF16)
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((N + 63) / 64), dim3(256), 0, st, (const bf16_t *)X, ldx, M, N, out);
+    else
+        hipLaunchKernelGGL(colsum_kernel<float>, dim3((N + 63) / 64), dim3(256), 0, st, (const float *)X, ldx, M, N, out);
+    SKY_LAUNCH_CHECK("skyemb_colsum");
+    return 0;
+}
+
+extern "C" int skyemb_patch_gather_bwd_pmv(const float *imgs, const int32_t *ids_keep, const float *drows, float *partial,
+                                           float *dpmv, int B, int C, int H, int W, int p, int keep, void *stream) {
+    SKY_CHECK_ARG(B > 0 && C > 0 && p > 0 && keep > 0, "skyemb_patch_gather_bwd_pmv: bad geometry");
+    hipLaunchKernelGGL(pmv_partial_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, imgs, ids_keep, drows, partial, C, H,
+                       W, p, keep);
+    SKY_LAUNCH_CHECK("skyemb_patch_gather_bwd_pmv");
+    return skyemb_colsum(partial, SKYEMB_F32, (int64_t)C * p * p, B, C * p * p, dpmv, stream);
+}
+
+extern "C" int skyemb_fill_mask_tokens(float *x, const float *mask, const float *mask_token, const float *dec_pos, int B,
+                                       int L, int Dd, void *stream) {
+    SKY_CHECK_ARG(B > 0 && L > 0 && Dd % 4 == 0, "skyemb_fill_mask_tokens: bad shape");
+    hipLaunchKernelGGL(fill_mask_tokens_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, x, mask, mask_token, dec_pos,
+                       L, Dd);
+    SKY_LAUNCH_CHECK("skyemb_fill_mask_tokens");
+    return 0;
+}
+
+extern "C" int skyemb_gather_rows(const float *src, const int32_t *idx, float *out, void *out_lp, int dtype, int n_rows,
+                                  int D, void *stream) {
+    SKY_CHECK_ARG(n_rows > 0 && D % 4 == 0, "skyemb_gather_rows: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SKYEMB_BF16)
+        hipLaunchKernelGGL(gather_rows_kernel<bf16_t>, dim3(n_rows), dim3(256), 0, st, src, idx, out, (bf16_t *)out_lp, D);
+    else
+        hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(n_rows), dim3(256), 0, st, src, idx, out, (float *)out_lp, D);
+    SKY_LAUNCH_CHECK("skyemb_gather_rows");
+    return 0;
+}
+
+extern "C" int skyemb_rowsum_select(const float *src, int64_t ld, const float *sel, int row0, int inner, int outer_stride,
+                                    int n_rows, int D, float *partial, float *out, void *stream) {
+    SKY_CHECK_ARG(n_rows > 0 && D > 0 && inner > 0, "skyemb_rowsum_select: bad shape");
+    const int nblk = 64;
+    hipLaunchKernelGGL(rowsum_select_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, src, ld, sel, row0, inner,
+                       outer_stride, n_rows, D, partial);
+    SKY_LAUNCH_CHECK("skyemb_rowsum_select");
+    return skyemb_colsum(partial, SKYEMB_F32, D, nblk, D, out, stream);
+}
+
+extern "C" int skyemb_cast(const float *src, void *dst, int dtype, int64_t n, void *stream) {
+    SKY_CHECK_ARG(n > 0 && n % 4 == 0, "skyemb_cast: n must be a positive multiple of 4");
+    int64_t blocks = ceil_div64(n / 4, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SKYEMB_BF16)
+        hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, src, (bf16_t *)dst, n / 4);
+    else
+        hipLaunchKernelGGL(cast_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, src, (float *)dst, n / 4);
+    SKY_LAUNCH_CHECK("skyemb_cast");
+    return 0;
+}

@@ -1,0 +1,207 @@
+// LayerNorm forward / backward (fp32 statistics, wavefront-shuffle reductions).
+// One 64-lane wave per token row; a row of D <= 2048 floats lives in registers as float4s.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXV = 8;  // float4 per lane -> D <= 2048 (kernels are instantiated per NV = ceil(D/256))
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                     const float *__restrict__ beta, T *__restrict__ y,
+                                                     float *__restrict__ y32, float *__restrict__ mean_o,
+                                                     float *__restrict__ rstd_o, int M, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = D >> 2;
+    const float *xr = x + (int64_t)row * D;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            v[i] = *(const float4 *)(xr + 4 * c);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) {
+        mean_o[row] = mean;
+        rstd_o[row] = rstd;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const float4 g = *(const float4 *)(gamma + 4 * c), b = *(const float4 *)(beta + 4 * c);
+            const float o0 = (v[i].x - mean) * rstd * g.x + b.x, o1 = (v[i].y - mean) * rstd * g.y + b.y;
+            const float o2 = (v[i].z - mean) * rstd * g.z + b.z, o3 = (v[i].w - mean) * rstd * g.w + b.w;
+            if (y) store4<T>(y + (int64_t)row * D + 4 * c, o0, o1, o2, o3);
+            if (y32) *(float4 *)(y32 + (int64_t)row * D + 4 * c) = make_float4(o0, o1, o2, o3);
+        }
+    }
+}
+
+// dy element type TD (T or float), low-precision copy type T.
+template <typename TD, typename T, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TD *__restrict__ dy, const float *__restrict__ x,
+                                                     const float *__restrict__ gamma, const float *__restrict__ mean,
+                                                     const float *__restrict__ rstd, const float *g_in, float *g_out,
+                                                     T *__restrict__ g_lp, float *__restrict__ part, int M, int D,
+                                                     int nblk) {
+    __shared__ float red[4][64 * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = D >> 2;
+    float4 dgam[NV], dbet[NV], gam[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        dgam[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dbet[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c = lane + i * 64;
+        gam[i] = c < nv ? *(const float4 *)(gamma + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int row = blockIdx.x * 4 + wave; row < M; row += nblk * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float4 xh[NV], dyv[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nv) {
+                const float4 xv = *(const float4 *)(x + (int64_t)row * D + 4 * c);
+                dyv[i] = load4<TD>(dy + (int64_t)row * D + 4 * c);
+                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                const float a0 = dyv[i].x * gam[i].x, a1 = dyv[i].y * gam[i].y, a2 = dyv[i].z * gam[i].z,
+                            a3 = dyv[i].w * gam[i].w;
+                s1 += (a0 + a1) + (a2 + a3);
+                s2 += (a0 * xh[i].x + a1 * xh[i].y) + (a2 * xh[i].z + a3 * xh[i].w);
+                dgam[i].x += dyv[i].x * xh[i].x; dgam[i].y += dyv[i].y * xh[i].y;
+                dgam[i].z += dyv[i].z * xh[i].z; dgam[i].w += dyv[i].w * xh[i].w;
+                dbet[i].x += dyv[i].x; dbet[i].y += dyv[i].y; dbet[i].z += dyv[i].z; dbet[i].w += dyv[i].w;
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nv) {
+                float4 o;
+                o.x = rs * (dyv[i].x * gam[i].x - m1 - xh[i].x * m2);
+                o.y = rs * (dyv[i].y * gam[i].y - m1 - xh[i].y * m2);
+                o.z = rs * (dyv[i].z * gam[i].z - m1 - xh[i].z * m2);
+                o.w = rs * (dyv[i].w * gam[i].w - m1 - xh[i].w * m2);
+                const int64_t off = (int64_t)row * D + 4 * c;
+                if (g_in) {
+                    const float4 gi = *(const float4 *)(g_in + off);
+                    o.x += gi.x; o.y += gi.y; o.z += gi.z; o.w += gi.w;
+                }
+                *(float4 *)(g_out + off) = o;
+                if (g_lp) store4<T>(g_lp + off, o.x, o.y, o.z, o.w);
+            }
+        }
+    }
+    // reduce the 4 waves' column partials through LDS, one float4 slot at a time
+    float *pg = part + (int64_t)blockIdx.x * D;
+    float *pb = part + (int64_t)nblk * D + (int64_t)blockIdx.x * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const float4 val = pass == 0 ? dgam[i] : dbet[i];
+            __syncthreads();
+            *(float4 *)&red[wave][lane * 4] = val;
+            __syncthreads();
+            if (wave == 0 && c < nv) {
+                float4 a = *(float4 *)&red[0][lane * 4];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) {
+                    const float4 b = *(float4 *)&red[w][lane * 4];
+                    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+                }
+                *(float4 *)((pass == 0 ? pg : pb) + 4 * c) = a;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int skyemb_layernorm_fwd(const float *x, const float *gamma, const float *beta, void *y, float *y32,
+                                    int dtype, float *mean, float *rstd, int M, int D, float eps, void *stream) {
+    SKY_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= MAXV * 256, "skyemb_layernorm_fwd: bad shape M=%d D=%d", M, D);
+    SKY_CHECK_ARG(aligned16(x) && aligned16(gamma) && aligned16(beta), "skyemb_layernorm_fwd: unaligned input");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((M + 3) / 4), block(256);
+#define LN_FWD(NV)                                                                                                   \
+    if (dtype == SKYEMB_BF16)                                                                                        \
+        hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, NV>), grid, block, 0, st, x, gamma, beta, (bf16_t *)y, y32, mean,   \
+                           rstd, M, D, eps);                                                                         \
+    else                                                                                                             \
+        hipLaunchKernelGGL((ln_fwd_kernel<float, NV>), grid, block, 0, st, x, gamma, beta, (float *)y, y32, mean,     \
+                           rstd, M, D, eps);
+    switch ((D + 255) / 256) {
+        case 1: LN_FWD(1) break;
+        case 2: LN_FWD(2) break;
+        case 3: LN_FWD(3) break;
+        case 4: LN_FWD(4) break;
+        case 5: LN_FWD(5) break;
+        case 6: LN_FWD(6) break;
+        case 7: LN_FWD(7) break;
+        default: LN_FWD(8) break;
+    }
+#undef LN_FWD
+    SKY_LAUNCH_CHECK("skyemb_layernorm_fwd");
+    return 0;
+}
+
+extern "C" int skyemb_layernorm_bwd_blocks(int M) {
+    int nb = (M + 3) / 4;
+    return nb < 256 ? (nb < 1 ? 1 : nb) : 256;
+}
+
+extern "C" int skyemb_layernorm_bwd(const void *dy, int dy_is_f32, int dtype, const float *x, const float *gamma,
+                                    const float *mean, const float *rstd, const float *g_in, float *g_out, void *g_lp,
+                                    float *part, int M, int D, void *stream) {
+    SKY_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= MAXV * 256, "skyemb_layernorm_bwd: bad shape M=%d D=%d", M, D);
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = skyemb_layernorm_bwd_blocks(M);
+    dim3 grid(nblk), block(256);
+#define LN_BWD(NV)                                                                                                   \
+    if (dtype == SKYEMB_BF16) {                                                                                      \
+        if (dy_is_f32)                                                                                               \
+            hipLaunchKernelGGL((ln_bwd_kernel<float, bf16_t, NV>), grid, block, 0, st, (const float *)dy, x, gamma,   \
+                               mean, rstd, g_in, g_out, (bf16_t *)g_lp, part, M, D, nblk);                           \
+        else                                                                                                         \
+            hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, bf16_t, NV>), grid, block, 0, st, (const bf16_t *)dy, x, gamma, \
+                               mean, rstd, g_in, g_out, (bf16_t *)g_lp, part, M, D, nblk);                           \
+    } else {                                                                                                         \
+        hipLaunchKernelGGL((ln_bwd_kernel<float, float, NV>), grid, block, 0, st, (const float *)dy, x, gamma, mean,  \
+                           rstd, g_in, g_out, (float *)g_lp, part, M, D, nblk);                                      \
+    }
+    switch ((D + 255) / 256) {
+        case 1: LN_BWD(1) break;
+        case 2: LN_BWD(2) break;
+        case 3: LN_BWD(3) break;
+        case 4: LN_BWD(4) break;
+        case 5: LN_BWD(5) break;
+        case 6: LN_BWD(6) break;
+        case 7: LN_BWD(7) break;
+        default: LN_BWD(8) break;
+    }
+#undef LN_BWD
+    SKY_LAUNCH_CHECK("skyemb_layernorm_bwd");
+    return 0;
+}

@@ -1,0 +1,416 @@
+// Weighted-cosine scoring + exact top-k over an embedding bank (utils/similarity.py:18-35,98-102,
+// 149-172), bit-exact against oracle/topk_oracle.c:
+//   dot(q,n) is ONE fp32 fma chain over d = 0..D-1 -- v_mfma_f32_16x16x4_f32 is a k-ordered fmaf
+//   chain on its C input, and consecutive MFMAs take consecutive 4-wide k groups;
+//   score = dot / (qn*xn + eps) with explicit round-to-nearest mul / add / IEEE divide.
+// Never materialises the Q x N score matrix: every block keeps, per query of its tile, a sorted
+// top-k list in LDS for its bank chunk (threshold-filtered insertion); the per-chunk lists are
+// merged by skyemb_topk_merge (also used after the RCCL all-gather of per-rank results).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 16;           // k-tile (floats)
+constexpr int PITCH = BK + 4;    // LDS row pitch of a staged operand tile
+
+// ------------------------------------------------------------------------------------------------
+// standardise: (x - mu) / (sigma + 1e-8)   (utils/similarity.py:101-102)
+__global__ __launch_bounds__(256) void standardise_kernel(const float *__restrict__ x, const float *__restrict__ mu,
+                                                          const float *__restrict__ sigma, float *__restrict__ out,
+                                                          int64_t total4, int D4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int d = (int)(i % D4) * 4;
+        const float4 v = *(const float4 *)(x + 4 * i);
+        const float4 m = *(const float4 *)(mu + d), s = *(const float4 *)(sigma + d);
+        float4 o;
+        o.x = __fdiv_rn(__fsub_rn(v.x, m.x), __fadd_rn(s.x, 1e-8f));
+        o.y = __fdiv_rn(__fsub_rn(v.y, m.y), __fadd_rn(s.y, 1e-8f));
+        o.z = __fdiv_rn(__fsub_rn(v.z, m.z), __fadd_rn(s.z, 1e-8f));
+        o.w = __fdiv_rn(__fsub_rn(v.w, m.w), __fadd_rn(s.w, 1e-8f));
+        *(float4 *)(out + 4 * i) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// norms[n] = sqrt( chain_d fma(w[d]*x[n][d], x[n][d], acc) ), optional xw_out = w*x.
+// Block = 256 rows; 32-wide d chunks are staged coalesced through LDS, each thread walks its own
+// row in order (the chain is serial by definition).
+__global__ __launch_bounds__(256) void wnorm_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                    float *__restrict__ norms, float *__restrict__ xw_out, int64_t N,
+                                                    int D) {
+    __shared__ float tile[256][33];
+    const int tid = threadIdx.x;
+    const int64_t n0 = (int64_t)blockIdx.x * 256;
+    float acc = 0.f;
+    for (int d0 = 0; d0 < D; d0 += 32) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int v = tid + i * 256, r = v >> 3, c = (v & 7) * 4;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n0 + r < N && d0 + c < D) val = *(const float4 *)(x + (n0 + r) * D + d0 + c);
+            tile[r][c] = val.x; tile[r][c + 1] = val.y; tile[r][c + 2] = val.z; tile[r][c + 3] = val.w;
+        }
+        __syncthreads();
+        const int dn = (D - d0) < 32 ? (D - d0) : 32;
+        for (int dd = 0; dd < dn; ++dd) {
+            const float xv = tile[tid][dd];
+            const float xw = w ? __fmul_rn(w[d0 + dd], xv) : xv;
+            acc = fmaf(xw, xv, acc);
+            if (xw_out) tile[tid][dd] = xw;
+        }
+        if (xw_out) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int v = tid + i * 256, r = v >> 3, c = (v & 7) * 4;
+                if (n0 + r < N && d0 + c < D)
+                    *(float4 *)(xw_out + (n0 + r) * D + d0 + c) =
+                        make_float4(tile[r][c], tile[r][c + 1], tile[r][c + 2], tile[r][c + 3]);
+            }
+        }
+    }
+    if (n0 + tid < N) norms[n0 + tid] = __fsqrt_rn(acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float finish_score(float dot, float qn, float xn, float eps) {
+    const float den = __fadd_rn(__fmul_rn(qn, xn), eps);
+    const float s = __fdiv_rn(dot, den);
+    return s == s ? s : -INFINITY;
+}
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int R>
+__device__ __forceinline__ void load_rows(const float *__restrict__ X, int64_t r0, int64_t rows, int D, int k0, int tid,
+                                          float4 (&reg)[(R * BK / 4 + 255) / 256]) {
+    constexpr int NV = (R * BK / 4 + 255) / 256;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * 256;
+        const int r = v >> 2, k = (v & 3) * 4;
+        const bool ok = (R * BK / 4 >= 256 || v < R * BK / 4) && r0 + r < rows && k0 + k < D;
+        reg[i] = ok ? *(const float4 *)(X + (r0 + r) * D + k0 + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+template <int R>
+__device__ __forceinline__ void store_rows(float *s, int tid, const float4 (&reg)[(R * BK / 4 + 255) / 256]) {
+    constexpr int NV = (R * BK / 4 + 255) / 256;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * 256;
+        if (R * BK / 4 >= 256 || v < R * BK / 4) *(float4 *)&s[(v >> 2) * PITCH + (v & 3) * 4] = reg[i];
+    }
+}
+
+// QT queries x BT bank rows per tile; 4 waves as WM x WN.
+template <int QT, int BT, bool SCORES_ONLY>
+__global__ __launch_bounds__(256) void cosine_topk_kernel(const float *__restrict__ tw, const float *__restrict__ qn,
+                                                          const float *__restrict__ bank, const float *__restrict__ xn,
+                                                          int Q, int64_t N, int D, int k, float eps, int64_t idx_offset,
+                                                          int nchunks, int64_t rows_per_chunk, float *__restrict__ part_s,
+                                                          int64_t *__restrict__ part_i, float *__restrict__ scores) {
+    constexpr int WM = QT >= 64 ? 2 : 1, WN = 4 / WM;
+    constexpr int TM = QT / WM / 16, TN = BT / WN / 16;
+    constexpr int SCP = BT + 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *sA0 = lds, *sA1 = sA0 + QT * PITCH, *sB0 = sA1 + QT * PITCH, *sB1 = sB0 + BT * PITCH;
+    float *sc = sB1 + BT * PITCH;            // [QT][SCP]
+    float *ls = sc + QT * SCP;               // [QT][k]
+    int *li = (int *)(ls + (SCORES_ONLY ? 0 : QT * k));  // [QT][k]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int qt = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
+    const int q0 = qt * QT;
+    const int64_t c_begin = (int64_t)chunk * rows_per_chunk;
+    int64_t c_end = c_begin + rows_per_chunk;
+    if (c_end > N) c_end = N;
+    const int KT = (D + BK - 1) / BK;
+
+    int cnt[QT / 4];  // per-wave list sizes for its queries (static indexing below)
+#pragma unroll
+    for (int i = 0; i < QT / 4; ++i) cnt[i] = 0;
+
+    for (int64_t nb = c_begin; nb < c_end; nb += BT) {
+        f32x4 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float4 ra[(QT * BK / 4 + 255) / 256], rb[(BT * BK / 4 + 255) / 256];
+        load_rows<QT>(tw, q0, Q, D, 0, tid, ra);
+        load_rows<BT>(bank, nb, c_end, D, 0, tid, rb);
+        __syncthreads();  // previous tile's epilogue is done with LDS
+        store_rows<QT>(sA0, tid, ra);
+        store_rows<BT>(sB0, tid, rb);
+        __syncthreads();
+        for (int kt = 0; kt < KT; ++kt) {
+            const bool more = kt + 1 < KT;
+            if (more) {
+                load_rows<QT>(tw, q0, Q, D, (kt + 1) * BK, tid, ra);
+                load_rows<BT>(bank, nb, c_end, D, (kt + 1) * BK, tid, rb);
+            }
+            const float *cA = (kt & 1) ? sA1 : sA0;
+            const float *cB = (kt & 1) ? sB1 : sB0;
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                float fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[i] = cA[(wm * (QT / WM) + i * 16 + (lane & 15)) * PITCH + kk * 4 + (lane >> 4)];
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fb[j] = cB[(wn * (BT / WN) + j * 16 + (lane & 15)) * PITCH + kk * 4 + (lane >> 4)];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+            if (more) {
+                store_rows<QT>((kt & 1) ? sA0 : sA1, tid, ra);
+                store_rows<BT>((kt & 1) ? sB0 : sB1, tid, rb);
+            }
+            __syncthreads();
+        }
+        // ---- finish scores into the LDS score tile (C/D: col = lane&15 -> bank row, row -> query) ----
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qr = wm * (QT / WM) + i * 16 + 4 * (lane >> 4) + r;
+                const bool qok = q0 + qr < Q;
+                const float qnv = qok ? qn[q0 + qr] : 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int c = wn * (BT / WN) + j * 16 + (lane & 15);
+                    const bool ok = qok && nb + c < c_end;
+                    sc[qr * SCP + c] = ok ? finish_score(acc[i][j][r], qnv, xn[nb + c], eps) : -INFINITY;
+                }
+            }
+        __syncthreads();
+        if (SCORES_ONLY) {
+            for (int e = tid; e < QT * BT; e += 256) {
+                const int qr = e / BT, c = e % BT;
+                if (q0 + qr < Q && nb + c < c_end) scores[(int64_t)(q0 + qr) * N + nb + c] = sc[qr * SCP + c];
+            }
+        } else {
+            // ---- per-query threshold-filtered sorted insertion; wave w owns queries w*(QT/4).. ----
+#pragma unroll
+            for (int qi = 0; qi < QT / 4; ++qi) {
+                const int qq = wave * (QT / 4) + qi;
+                if (q0 + qq >= Q) continue;
+                float *lsq = ls + qq * k;
+                int *liq = li + qq * k;
+                int n_in = cnt[qi];
+                float thr = n_in == k ? lsq[k - 1] : -INFINITY;
+                for (int t = 0; t < BT / 64; ++t) {
+                    const float v = sc[qq * SCP + t * 64 + lane];
+                    unsigned long long m = __ballot(v > thr);
+                    while (m) {
+                        const int src = __builtin_ctzll(m);
+                        m &= m - 1;
+                        const float cv = __shfl(v, src, 64);
+                        if (!(cv > thr)) continue;  // threshold rose during this batch
+                        int pos = 0;
+                        for (int e = lane; e < n_in; e += 64) pos += lsq[e] >= cv ? 1 : 0;
+                        pos = wave_sum_i(pos);
+                        const int new_n = n_in < k ? n_in + 1 : k;
+                        // shift [pos, new_n-1) down by one, highest 64-chunk first (read-then-write per chunk)
+                        for (int e0 = ((new_n - 1) / 64) * 64; e0 >= 0; e0 -= 64) {
+                            const int e = e0 + lane;
+                            const bool mv = e >= pos && e < new_n - 1;
+                            float sv = 0.f;
+                            int iv = 0;
+                            if (mv) { sv = lsq[e]; iv = liq[e]; }
+                            __builtin_amdgcn_wave_barrier();
+                            if (mv) { lsq[e + 1] = sv; liq[e + 1] = iv; }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                        if (lane == 0) {
+                            lsq[pos] = cv;
+                            liq[pos] = (int)(nb - 0 + t * 64 + src);  // row index local to this bank shard
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        n_in = new_n;
+                        thr = n_in == k ? lsq[k - 1] : -INFINITY;
+                    }
+                }
+                cnt[qi] = n_in;
+            }
+        }
+    }
+    if (!SCORES_ONLY) {
+        __syncthreads();
+#pragma unroll
+        for (int qi = 0; qi < QT / 4; ++qi) {
+            const int qq = wave * (QT / 4) + qi;
+            if (q0 + qq >= Q) continue;
+            const int64_t o = ((int64_t)(q0 + qq) * nchunks + chunk) * k;
+            for (int e = lane; e < k; e += 64) {
+                const bool have = e < cnt[qi];
+                part_s[o + e] = have ? ls[qq * k + e] : -INFINITY;
+                part_i[o + e] = have ? idx_offset + (int64_t)li[qq * k + e] : -1;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// merge: one wave per query, `nlists` sorted lists of length k -> best k by (score desc, idx asc).
+// Heads live in LDS; each round every lane proposes the best head among its lists, a butterfly
+// picks the winner, the owning lane advances that list.
+__global__ __launch_bounds__(64) void topk_merge_kernel(const float *__restrict__ in_s, const int64_t *__restrict__ in_i,
+                                                        int nlists, int k, float *__restrict__ out_s,
+                                                        int64_t *__restrict__ out_i) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *hs = (float *)smem;                       // [nlists] head score
+    int64_t *hi = (int64_t *)(smem + ((nlists * 4 + 15) & ~15));  // [nlists] head idx
+    int *hp = (int *)(hi + nlists);                  // [nlists] head position
+    const int lane = threadIdx.x, q = blockIdx.x;
+    const float *ps = in_s + (int64_t)q * nlists * k;
+    const int64_t *pi = in_i + (int64_t)q * nlists * k;
+    for (int l = lane; l < nlists; l += 64) {
+        hs[l] = ps[(int64_t)l * k];
+        hi[l] = pi[(int64_t)l * k];
+        hp[l] = 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int r = 0; r < k; ++r) {
+        float bs = -INFINITY;
+        int64_t bi = INT64_MAX;
+        int bl = -1;
+        for (int l = lane; l < nlists; l += 64) {
+            const float s = hs[l];
+            const int64_t ix = hi[l];
+            if (ix >= 0 && (s > bs || (s == bs && ix < bi))) { bs = s; bi = ix; bl = l; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float s2 = __shfl_xor(bs, o, 64);
+            const int lo2 = __shfl_xor((int)(bi & 0xffffffffll), o, 64), hi2 = __shfl_xor((int)(bi >> 32), o, 64);
+            const int l2 = __shfl_xor(bl, o, 64);
+            const int64_t i2 = ((int64_t)hi2 << 32) | (unsigned int)lo2;
+            if (l2 >= 0 && (bl < 0 || s2 > bs || (s2 == bs && i2 < bi))) { bs = s2; bi = i2; bl = l2; }
+        }
+        if (lane == 0) {
+            out_s[(int64_t)q * k + r] = bl >= 0 ? bs : -INFINITY;
+            out_i[(int64_t)q * k + r] = bl >= 0 ? bi : -1;
+        }
+        if (bl >= 0 && (bl & 63) == lane) {  // owner advances the winning list
+            const int np = hp[bl] + 1;
+            hp[bl] = np;
+            if (np < k) { hs[bl] = ps[(int64_t)bl * k + np]; hi[bl] = pi[(int64_t)bl * k + np]; }
+            else { hs[bl] = -INFINITY; hi[bl] = -1; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int QT, int BT, bool SO>
+int launch_topk(const float *tw, const float *qn, const float *bank, const float *xn, int Q, int64_t N, int D, int k,
+                float eps, int64_t idx_offset, int nchunks, float *part_s, int64_t *part_i, float *scores, hipStream_t st,
+                const char *name) {
+    const size_t smem = sizeof(float) * (2 * QT * PITCH + 2 * BT * PITCH + QT * (BT + 1) + (SO ? 0 : 2 * (size_t)QT * k));
+    if (smem > 160 * 1024) {
+        skyemb_set_error("%s: k=%d needs %zu B of LDS (max 160 KiB)", name, k, smem);
+        return 1;
+    }
+    auto kern = cosine_topk_kernel<QT, BT, SO>;
+    if (smem > 65536) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) {
+            skyemb_set_error("%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
+            return 2;
+        }
+    }
+    int64_t rows_per_chunk = ceil_div64(ceil_div64(N, nchunks), BT) * BT;
+    const int qtiles = (Q + QT - 1) / QT;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(qtiles * nchunks)), dim3(256), smem, st, tw, qn, bank, xn, Q, N, D, k, eps,
+                       idx_offset, nchunks, rows_per_chunk, part_s, part_i, scores);
+    hipError_t e_ = hipGetLastError();
+    if (e_ != hipSuccess) {
+        skyemb_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));
+        return 2;
+    }
+    return 0;
+}
+
+inline bool small_tile(int Q, int k) { return Q <= 16 || k > 128; }
+
+}  // namespace
+
+extern "C" int skyemb_standardise(const float *x, const float *mu, const float *sigma, float *out, int64_t N, int D,
+                                  void *stream) {
+    SKY_CHECK_ARG(N > 0 && D > 0 && D % 4 == 0, "skyemb_standardise: bad shape");
+    const int64_t total4 = N * D / 4;
+    int64_t blocks = ceil_div64(total4, 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(standardise_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, mu, sigma, out,
+                       total4, D / 4);
+    SKY_LAUNCH_CHECK("skyemb_standardise");
+    return 0;
+}
+
+extern "C" int skyemb_weighted_norms(const float *x, const float *w, float *norms, float *xw_out, int64_t N, int D,
+                                     void *stream) {
+    SKY_CHECK_ARG(N > 0 && D > 0 && D % 4 == 0, "skyemb_weighted_norms: bad shape");
+    hipLaunchKernelGGL(wnorm_kernel, dim3((unsigned)ceil_div64(N, 256)), dim3(256), 0, (hipStream_t)stream, x, w, norms,
+                       xw_out, N, D);
+    SKY_LAUNCH_CHECK("skyemb_weighted_norms");
+    return 0;
+}
+
+extern "C" int skyemb_cosine_topk_chunks(int64_t N, int Q, int k) {
+    const bool small = small_tile(Q, k);
+    const int QT = small ? 16 : 64, BT = small ? 256 : 128;
+    const int qtiles = (Q + QT - 1) / QT;
+    int64_t want = 1024 / qtiles;
+    if (want < 1) want = 1;
+    // keep chunks long enough that the top-k fill (k inserts) is amortised
+    const int64_t max_by_rows = ceil_div64(N, (int64_t)BT * 8);
+    if (want > max_by_rows) want = max_by_rows;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+extern "C" int skyemb_cosine_topk(const float *tw, const float *qn, const float *bank, const float *xn, int Q, int64_t N,
+                                  int D, int k, float eps, int64_t idx_offset, int nchunks, float *part_s, int64_t *part_i,
+                                  void *stream) {
+    SKY_CHECK_ARG(Q > 0 && N > 0 && D > 0 && D % 4 == 0 && k > 0 && nchunks > 0, "skyemb_cosine_topk: bad shape");
+    SKY_CHECK_ARG(N < (1ll << 31), "skyemb_cosine_topk: shard too large (N < 2^31 rows per call)");
+    hipStream_t st = (hipStream_t)stream;
+    if (small_tile(Q, k))
+        return launch_topk<16, 256, false>(tw, qn, bank, xn, Q, N, D, k, eps, idx_offset, nchunks, part_s, part_i, nullptr,
+                                           st, "skyemb_cosine_topk");
+    return launch_topk<64, 128, false>(tw, qn, bank, xn, Q, N, D, k, eps, idx_offset, nchunks, part_s, part_i, nullptr, st,
+                                       "skyemb_cosine_topk");
+}
+
+extern "C" int skyemb_cosine_scores(const float *tw, const float *qn, const float *bank, const float *xn, int Q, int64_t N,
+                                    int D, float eps, float *scores, void *stream) {
+    SKY_CHECK_ARG(Q > 0 && N > 0 && D > 0 && D % 4 == 0, "skyemb_cosine_scores: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunks = (int)ceil_div64(N, 128 * 8) < 1 ? 1 : (int)ceil_div64(N, 128 * 8);
+    if (Q <= 16)
+        return launch_topk<16, 256, true>(tw, qn, bank, xn, Q, N, D, 1, eps, 0, (int)ceil_div64(N, 256 * 4), nullptr,
+                                          nullptr, scores, st, "skyemb_cosine_scores");
+    return launch_topk<64, 128, true>(tw, qn, bank, xn, Q, N, D, 1, eps, 0, nchunks, nullptr, nullptr, scores, st,
+                                      "skyemb_cosine_scores");
+}
+
+extern "C" int skyemb_topk_merge(const float *in_s, const int64_t *in_i, int Q, int nlists, int k, float *out_s,
+                                 int64_t *out_i, void *stream) {
+    SKY_CHECK_ARG(Q > 0 && nlists > 0 && k > 0, "skyemb_topk_merge: bad shape");
+    const size_t smem = ((nlists * 4 + 15) & ~15) + (size_t)nlists * 8 + (size_t)nlists * 4;
+    SKY_CHECK_ARG(smem <= 65536, "skyemb_topk_merge: too many lists (%d)", nlists);
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(Q), dim3(64), smem, (hipStream_t)stream, in_s, in_i, nlists, k, out_s, out_i);
+    SKY_LAUNCH_CHECK("skyemb_topk_merge");
+    return 0;
+}

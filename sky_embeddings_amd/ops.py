@@ -1,0 +1,169 @@
+"""Thin torch-tensor front end of the C ABI (pointers + sizes in, nothing allocated inside).
+
+PyTorch is used only for device memory and streams; every op below runs a hand-written gfx950
+kernel from libskyemb.so on torch's current stream and raises if the library is missing.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_DGELU, ACT_GELU, ACT_NONE, BF16, F32, KC, RC, GemmArgs, check, lib
+
+TORCH_DTYPE = {BF16: torch.bfloat16, F32: torch.float32}
+
+
+def dtype_code(t: torch.dtype) -> int:
+    if t == torch.bfloat16:
+        return BF16
+    if t == torch.float32:
+        return F32
+    raise TypeError(f"unsupported activation dtype {t}")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "libskyemb ops need device tensors (there is no CPU fallback)"
+    return t.data_ptr()
+
+
+def gemm(A, B, *, M, N, K, a_layout=KC, b_layout=KC, lda=None, ldb=None, alpha=1.0, bias=None, table=None,
+         tab_row=None, ldt=0, dst_row=None, resid=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, out_f32=None, ldo32=0,
+         out=None, ldo=0, out2=None, ldo2=0, tile=0):
+    """C[M,N] = alpha * A[M,K] B[N,K]^T with fused epilogue (see include/skyemb.h)."""
+    g = GemmArgs()
+    g.A, g.B = _p(A), _p(B)
+    g.lda = lda if lda is not None else (K if a_layout == KC else M)
+    g.ldb = ldb if ldb is not None else (K if b_layout == KC else N)
+    g.a_layout, g.b_layout = a_layout, b_layout
+    g.M, g.N, g.K = M, N, K
+    g.dtype = dtype_code(A.dtype)
+    assert B.dtype == A.dtype
+    g.alpha = alpha
+    g.bias, g.table, g.tab_row, g.ldt, g.dst_row = _p(bias), _p(table), _p(tab_row), ldt, _p(dst_row)
+    g.resid, g.ldr, g.aux, g.ldaux, g.act = _p(resid), ldr, _p(aux), ldaux, act
+    g.out_f32, g.ldo32, g.out, g.ldo, g.out2, g.ldo2 = _p(out_f32), ldo32 or N, _p(out), ldo or N, _p(out2), ldo2 or N
+    g.tile = tile
+    check(lib().skyemb_gemm(ctypes.byref(g), _stream()), "skyemb_gemm")
+
+
+def colsum(X, M, N, out, ldx=None):
+    code = F32 if X.dtype == torch.float32 else BF16
+    check(lib().skyemb_colsum(_p(X), code, ldx if ldx is not None else N, M, N, _p(out), _stream()), "skyemb_colsum")
+
+
+def random_mask_from_noise(noise, keep, ids_restore, mask, ids_keep, dec_dst=None, dec_tab=None):
+    B, L = noise.shape
+    check(lib().skyemb_random_mask_from_noise(_p(noise), B, L, keep, _p(ids_restore), _p(mask), _p(ids_keep),
+                                              _p(dec_dst), _p(dec_tab), _stream()), "skyemb_random_mask_from_noise")
+
+
+def patch_gather(imgs, pmv, ids_keep, out, p, keep, pixel_mean, pixel_std):
+    B, C, H, W = imgs.shape
+    check(lib().skyemb_patch_gather(_p(imgs), _p(pmv), _p(ids_keep), _p(out), dtype_code(out.dtype), B, C, H, W, p,
+                                    keep, pixel_mean, pixel_std, _stream()), "skyemb_patch_gather")
+
+
+def patch_gather_bwd_pmv(imgs, ids_keep, drows, partial, dpmv, p, keep):
+    B, C, H, W = imgs.shape
+    check(lib().skyemb_patch_gather_bwd_pmv(_p(imgs), _p(ids_keep), _p(drows), _p(partial), _p(dpmv), B, C, H, W, p,
+                                            keep, _stream()), "skyemb_patch_gather_bwd_pmv")
+
+
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, M, D, eps, y32=None, dtype=None):
+    code = dtype if dtype is not None else dtype_code(y.dtype)
+    check(lib().skyemb_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(y32), code, _p(mean), _p(rstd), M, D, eps,
+                                     _stream()), "skyemb_layernorm_fwd")
+
+
+def layernorm_bwd_blocks(M):
+    return lib().skyemb_layernorm_bwd_blocks(M)
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, g_in, g_out, g_lp, part, M, D, dtype):
+    dy_f32 = 1 if (dy.dtype == torch.float32 and dtype == BF16) else 0
+    check(lib().skyemb_layernorm_bwd(_p(dy), dy_f32, dtype, _p(x), _p(gamma), _p(mean), _p(rstd), _p(g_in), _p(g_out),
+                                     _p(g_lp), _p(part), M, D, _stream()), "skyemb_layernorm_bwd")
+
+
+def mha_fwd(qkv, out, B, N, H, hd):
+    check(lib().skyemb_mha_fwd(_p(qkv), _p(out), dtype_code(qkv.dtype), B, N, H, hd, _stream()), "skyemb_mha_fwd")
+
+
+def mha_bwd(qkv, dout, dqkv, B, N, H, hd):
+    check(lib().skyemb_mha_bwd(_p(qkv), _p(dout), _p(dqkv), dtype_code(qkv.dtype), B, N, H, hd, _stream()),
+          "skyemb_mha_bwd")
+
+
+def fill_mask_tokens(x, mask, mask_token, dec_pos, B, L, Dd):
+    check(lib().skyemb_fill_mask_tokens(_p(x), _p(mask), _p(mask_token), _p(dec_pos), B, L, Dd, _stream()),
+          "skyemb_fill_mask_tokens")
+
+
+def gather_rows(src, idx, out, out_lp, n_rows, D):
+    code = dtype_code(out_lp.dtype) if out_lp is not None else F32
+    check(lib().skyemb_gather_rows(_p(src), _p(idx), _p(out), _p(out_lp), code, n_rows, D, _stream()),
+          "skyemb_gather_rows")
+
+
+def rowsum_select(src, ld, sel, row0, inner, outer_stride, n_rows, D, partial, out):
+    check(lib().skyemb_rowsum_select(_p(src), ld, _p(sel), row0, inner, outer_stride, n_rows, D, _p(partial), _p(out),
+                                     _stream()), "skyemb_rowsum_select")
+
+
+def masked_patch_loss(imgs, pred, mask, loss, dpred, dpred32, dtype, ws, p, extra, pixel_mean, pixel_std, norm_pix,
+                      loss_l1):
+    B, C, H, W = imgs.shape
+    check(lib().skyemb_masked_patch_loss(_p(imgs), _p(pred), _p(mask), _p(loss), _p(dpred), _p(dpred32), dtype, _p(ws),
+                                         B, C, H, W, p, extra, pixel_mean, pixel_std, int(norm_pix), int(loss_l1),
+                                         _stream()), "skyemb_masked_patch_loss")
+
+
+def adamw(p, g, m, v, p_lp, n, n_decay, hyper, beta1, beta2, eps, wd, grad_scale=1.0, zero_grad=False):
+    code = dtype_code(p_lp.dtype) if p_lp is not None else F32
+    check(lib().skyemb_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_lp), code, n, n_decay, _p(hyper), beta1, beta2, eps, wd,
+                             grad_scale, int(zero_grad), _stream()), "skyemb_adamw")
+
+
+def cast(src, dst, n):
+    check(lib().skyemb_cast(_p(src), _p(dst), dtype_code(dst.dtype), n, _stream()), "skyemb_cast")
+
+
+def standardise(x, mu, sigma, out):
+    N, D = x.shape
+    check(lib().skyemb_standardise(_p(x), _p(mu), _p(sigma), _p(out), N, D, _stream()), "skyemb_standardise")
+
+
+def weighted_norms(x, w, norms, xw_out=None):
+    N, D = x.shape
+    check(lib().skyemb_weighted_norms(_p(x), _p(w), _p(norms), _p(xw_out), N, D, _stream()), "skyemb_weighted_norms")
+
+
+def cosine_topk_chunks(N, Q, k):
+    return lib().skyemb_cosine_topk_chunks(N, Q, k)
+
+
+def cosine_topk(tw, qn, bank, xn, k, eps, idx_offset, nchunks, part_s, part_i):
+    Q, D = tw.shape
+    N = bank.shape[0]
+    check(lib().skyemb_cosine_topk(_p(tw), _p(qn), _p(bank), _p(xn), Q, N, D, k, eps, idx_offset, nchunks, _p(part_s),
+                                   _p(part_i), _stream()), "skyemb_cosine_topk")
+
+
+def topk_merge(in_s, in_i, Q, nlists, k, out_s, out_i):
+    check(lib().skyemb_topk_merge(_p(in_s), _p(in_i), Q, nlists, k, _p(out_s), _p(out_i), _stream()),
+          "skyemb_topk_merge")
+
+
+def cosine_scores(tw, qn, bank, xn, eps, scores):
+    Q, D = tw.shape
+    N = bank.shape[0]
+    check(lib().skyemb_cosine_scores(_p(tw), _p(qn), _p(bank), _p(xn), Q, N, D, eps, _p(scores), _stream()),
+          "skyemb_cosine_scores")

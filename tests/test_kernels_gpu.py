@@ -1,0 +1,362 @@
+"""GPU parity tests, one HIP kernel family at a time, through the C ABI (libskyemb.so via ctypes).
+
+Each kernel is compared with the CPU oracle piece it replaces (oracle/mae_oracle.py,
+oracle/topk_oracle.c) or, for the floating-point building blocks the oracle delegates to torch
+(LayerNorm, attention core, GEMM), with a plain torch fp32 CPU statement of the same op.
+Tolerances: bit-exact for index / mask / top-k work; fp32 kernels 1e-5..1e-4 relative; bf16 mode
+is compared against the fp32 result of the bf16-rounded operands (accumulation is fp32).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mae_oracle as mo
+from oracle import similarity_oracle as so
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    from sky_embeddings_amd import ops as _ops
+    _ops.lib()  # fail loudly if libskyemb.so is missing
+    return _ops
+
+
+DEV = "cuda"
+
+
+def dev(t, dtype=None):
+    t = t.to(DEV)
+    return t.to(dtype) if dtype is not None else t
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+# ------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("layouts", [(0, 0), (0, 1), (1, 1), (1, 0)])
+@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("shape", [(20, 72, 40), (68, 96, 256), (200, 136, 72), (128, 128, 64), (257, 520, 264)])
+def test_gemm_layouts(ops, dtype, layouts, tile, shape):
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g)
+    # asymmetric integer-ish content catches transposed fragments exactly
+    A[: min(M, 16), : min(K, 16)] = torch.arange(min(M, 16) * min(K, 16)).reshape(min(M, 16), -1).float() % 7 - 3
+    Ar, Br = A.to(dtype).float(), B.to(dtype).float()
+    ref = Ar.double() @ Br.double().T
+    a_l, b_l = layouts
+    Ad = dev(A.T.contiguous() if a_l else A, dtype)
+    Bd = dev(B.T.contiguous() if b_l else B, dtype)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(Ad, Bd, M=M, N=N, K=K, a_layout=a_l, b_layout=b_l, out_f32=out, tile=tile)
+    torch.cuda.synchronize()
+    scale = float((Ar.abs().double() @ Br.abs().double().T).max())
+    assert float((out.cpu().double() - ref).abs().max()) <= 2e-6 * scale, (dtype, layouts, tile, shape)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogues(ops, dtype):
+    M, N, K = 70, 136, 96
+    g = torch.Generator().manual_seed(11)
+    A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.2
+    bias, table = torch.randn(N, generator=g), torch.randn(9, N, generator=g)
+    tab_row = torch.randint(0, 9, (M,), generator=g, dtype=torch.int32)
+    perm = torch.randperm(M + 5, generator=g)[:M].to(torch.int32)
+    perm[3] = -1  # skipped row
+    resid = torch.randn(M + 5, N, generator=g)
+    Ar, Br = A.to(dtype).float(), B.to(dtype).float()
+    base = Ar @ Br.T * 0.5 + bias + table[tab_row.long()]
+    tol = 3e-2 if dtype == torch.bfloat16 else 1e-4
+    # scatter + table + resid, fp32 out and low-precision out
+    out32 = torch.zeros(M + 5, N, device=DEV)
+    outlp = torch.zeros(M + 5, N, device=DEV, dtype=dtype)
+    ops.gemm(dev(A, dtype), dev(B, dtype), M=M, N=N, K=K, alpha=0.5, bias=dev(bias), table=dev(table), tab_row=dev(tab_row),
+             ldt=N, dst_row=dev(perm), resid=dev(resid), ldr=N, out_f32=out32, out=outlp)
+    ref = torch.zeros(M + 5, N)
+    for m in range(M):
+        if perm[m] >= 0:
+            ref[perm[m]] = base[m] + resid[perm[m]]
+    assert float((out32.cpu() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+    assert float((outlp.float().cpu() - ref).abs().max()) < tol * max(1.0, float(ref.abs().max()))
+    # GELU: out = gelu(v), out2 = v
+    act = torch.zeros(M, N, device=DEV, dtype=dtype)
+    pre = torch.zeros(M, N, device=DEV, dtype=dtype)
+    ops.gemm(dev(A, dtype), dev(B, dtype), M=M, N=N, K=K, bias=dev(bias), act=ops.ACT_GELU, out=act, out2=pre)
+    v = Ar @ Br.T + bias
+    assert float((pre.float().cpu() - v).abs().max()) < tol * float(v.abs().max())
+    assert float((act.float().cpu() - torch.nn.functional.gelu(v)).abs().max()) < tol * float(v.abs().max())
+    # dGELU: out = v * gelu'(aux)
+    aux = torch.randn(M, N, generator=g)
+    auxr = aux.to(dtype).float().requires_grad_(True)
+    torch.nn.functional.gelu(auxr).sum().backward()
+    dg = torch.zeros(M, N, device=DEV, dtype=dtype)
+    ops.gemm(dev(A, dtype), dev(B, dtype), M=M, N=N, K=K, aux=dev(aux, dtype), ldaux=N, act=ops.ACT_DGELU, out=dg)
+    refd = (Ar @ Br.T) * auxr.grad
+    assert float((dg.float().cpu() - refd).abs().max()) < tol * float(refd.abs().max())
+
+
+# ------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(20, 64), (1280, 768), (37, 512), (9, 1280), (5, 192)])
+def test_layernorm(ops, dtype, shape):
+    M, D = shape
+    g = torch.Generator().manual_seed(D)
+    x = torch.randn(M, D, generator=g) * 2 + 0.3
+    gamma, beta = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6)
+    dy = torch.randn(M, D, generator=g)
+    dyr = dy.to(dtype).float()
+    y.backward(dyr)
+    yd = torch.empty(M, D, device=DEV, dtype=dtype)
+    y32 = torch.empty(M, D, device=DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    ops.layernorm_fwd(dev(x), dev(gamma), dev(beta), yd, mean, rstd, M, D, 1e-6, y32=y32)
+    assert relerr(y32, y.detach()) < 2e-6
+    assert relerr(yd.float(), y.detach()) < (5e-3 if dtype == torch.bfloat16 else 2e-6)
+    nblk = ops.layernorm_bwd_blocks(M)
+    part = torch.empty(2, nblk, D, device=DEV)
+    g_in = torch.randn(M, D, generator=g)
+    g_out = dev(g_in.clone())
+    g_lp = torch.empty(M, D, device=DEV, dtype=dtype)
+    code = ops.dtype_code(dtype)
+    ops.layernorm_bwd(dev(dy, dtype), dev(x), dev(gamma), mean, rstd, g_out, g_out, g_lp, part, M, D, code)
+    dgam, dbet = torch.empty(D, device=DEV), torch.empty(D, device=DEV)
+    ops.colsum(part[0], nblk, D, dgam)
+    ops.colsum(part[1], nblk, D, dbet)
+    assert relerr(g_out, g_in + xr.grad) < 5e-6
+    assert relerr(g_lp.float(), g_in + xr.grad) < (5e-3 if dtype == torch.bfloat16 else 5e-6)
+    assert relerr(dgam, gr.grad) < 1e-5 and relerr(dbet, br.grad) < 1e-5
+
+
+# ------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(3, 5, 12, 64), (2, 17, 16, 32), (2, 66, 2, 64), (4, 5, 4, 16), (1, 65, 3, 8)])
+def test_attention(ops, dtype, cfg):
+    B, N, H, hd = cfg
+    D = H * hd
+    g = torch.Generator().manual_seed(N * 100 + hd)
+    qkv = torch.randn(B, N, 3 * D, generator=g)
+    dout = torch.randn(B, N, D, generator=g)
+    q_r = qkv.to(dtype).float().requires_grad_(True)
+    t = q_r.reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    att = ((t[0] * hd ** -0.5) @ t[1].transpose(-2, -1)).softmax(-1)
+    o = (att @ t[2]).transpose(1, 2).reshape(B, N, D)
+    o.backward(dout.to(dtype).float())
+    out = torch.empty(B, N, D, device=DEV, dtype=dtype)
+    dqkv = torch.empty(B, N, 3 * D, device=DEV, dtype=dtype)
+    ops.mha_fwd(dev(qkv, dtype), out, B, N, H, hd)
+    ops.mha_bwd(dev(qkv, dtype), dev(dout, dtype), dqkv, B, N, H, hd)
+    tol = 6e-3 if dtype == torch.bfloat16 else 3e-6
+    assert relerr(out.float(), o.detach()) < tol
+    assert relerr(dqkv.float(), q_r.grad) < tol
+
+
+# ------------------------------------------------------------------------------------ front end
+@pytest.mark.parametrize("L,ratio", [(16, 0.75), (64, 0.6), (16, 0.0), (256, 0.9)])
+def test_random_mask_from_noise(ops, L, ratio):
+    B = 7
+    g = torch.Generator().manual_seed(L)
+    noise = torch.rand(B, L, generator=g)
+    noise[2, 3] = noise[2, 1]  # exact tie -> lower index first
+    keep = int(L * (1 - ratio))
+    tok = torch.arange(B * L, dtype=torch.float32).reshape(B, L, 1)
+    xm, mask_ref, ids_ref = mo.random_masking_from_noise(tok, ratio, noise)
+    ids = torch.empty(B, L, dtype=torch.int64, device=DEV)
+    mask = torch.empty(B, L, device=DEV)
+    ids_keep = torch.empty(B, keep, dtype=torch.int32, device=DEV)
+    dd = torch.empty(B, keep + 1, dtype=torch.int32, device=DEV)
+    dt = torch.empty(B, keep + 1, dtype=torch.int32, device=DEV)
+    ops.random_mask_from_noise(dev(noise), keep, ids, mask, ids_keep, dd, dt)
+    assert torch.equal(ids.cpu(), ids_ref) and torch.equal(mask.cpu(), mask_ref)
+    assert torch.equal(ids_keep.cpu().long(), (xm[:, :, 0] - torch.arange(B)[:, None] * L).long())
+    assert torch.equal(dt.cpu()[:, 1:].long(), ids_keep.cpu().long() + 1) and bool((dt.cpu()[:, 0] == 0).all())
+    assert torch.equal(dd.cpu().long(), dt.cpu().long() + torch.arange(B)[:, None] * (L + 1))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("geom", [(5, 64, 16), (9, 64, 8), (3, 32, 4)])
+def test_patch_gather_and_pmv_grad(ops, dtype, geom):
+    C, H, p = geom
+    B, L = 3, (H // p) ** 2
+    keep = max(1, L // 4)
+    cfg = mo.MAEConfig(img_size=H, patch_size=p, in_chans=C, pixel_mean=0.2, pixel_std=1.7)
+    g = torch.Generator().manual_seed(C + p)
+    x = torch.randn(B, C, H, H, generator=g)
+    x[0, 1] = float("nan")
+    x[1, 0, 3:9, 2:30] = float("nan")
+    pmv = torch.randn(C, p, p, generator=g)
+    ids_keep = torch.stack([torch.randperm(L, generator=g)[:keep] for _ in range(B)]).to(torch.int32)
+    xn = mo.norm_inputs(x, cfg)
+    xn = torch.where(torch.isnan(xn), pmv.repeat(1, H // p, H // p).expand(B, -1, -1, -1), xn)
+    # conv-weight order (c, py, px)
+    pat = xn.reshape(B, C, H // p, p, H // p, p).permute(0, 2, 4, 1, 3, 5).reshape(B, L, C * p * p)
+    ref = torch.gather(pat, 1, ids_keep.long()[:, :, None].expand(-1, -1, C * p * p)).reshape(B * keep, -1)
+    out = torch.empty(B * keep, C * p * p, device=DEV, dtype=dtype)
+    ops.patch_gather(dev(x), dev(pmv), dev(ids_keep), out, p, keep, 0.2, 1.7)
+    assert torch.equal(out.float().cpu(), ref.to(dtype).float())
+    # all patches in order
+    out_all = torch.empty(B * L, C * p * p, device=DEV, dtype=dtype)
+    ops.patch_gather(dev(x), dev(pmv), None, out_all, p, L, 0.2, 1.7)
+    assert torch.equal(out_all.float().cpu(), pat.reshape(B * L, -1).to(dtype).float())
+    # d patch_mask_values = sum of row-gradients at NaN pixels
+    drows = torch.randn(B * keep, C * p * p, generator=g)
+    nanpat = torch.isnan(x).float().reshape(B, C, H // p, p, H // p, p).permute(0, 2, 4, 1, 3, 5).reshape(B, L, -1)
+    nansel = torch.gather(nanpat, 1, ids_keep.long()[:, :, None].expand(-1, -1, C * p * p)).reshape(B * keep, -1)
+    ref_d = (drows * nansel).sum(0).reshape(C, p, p)
+    part = torch.empty(B, C * p * p, device=DEV)
+    dpmv = torch.empty(C, p, p, device=DEV)
+    ops.patch_gather_bwd_pmv(dev(x), dev(ids_keep), dev(drows), part, dpmv, p, keep)
+    assert float((dpmv.cpu() - ref_d).abs().max()) < 1e-5 * max(1.0, float(ref_d.abs().max()))
+
+
+def test_glue_kernels(ops):
+    g = torch.Generator().manual_seed(3)
+    B, L, Dd = 5, 16, 32
+    x = torch.randn(B, L + 1, Dd, generator=g)
+    mask = (torch.rand(B, L, generator=g) > 0.4).float()
+    mt, pos = torch.randn(Dd, generator=g), torch.randn(L + 1, Dd, generator=g)
+    xd = dev(x.clone())
+    ops.fill_mask_tokens(xd, dev(mask), dev(mt), dev(pos), B, L, Dd)
+    ref = x.clone()
+    ref[:, 1:][mask.bool()] = (mt + pos[1:]).expand(B, -1, -1)[mask.bool()]
+    assert torch.equal(xd.cpu(), ref)
+    idx = torch.randint(0, B * (L + 1), (23,), generator=g, dtype=torch.int32)
+    o32, olp = torch.empty(23, Dd, device=DEV), torch.empty(23, Dd, device=DEV, dtype=torch.bfloat16)
+    ops.gather_rows(dev(x.reshape(-1, Dd)), dev(idx), o32, olp, 23, Dd)
+    assert torch.equal(o32.cpu(), x.reshape(-1, Dd)[idx.long()])
+    assert torch.equal(olp.cpu(), x.reshape(-1, Dd)[idx.long()].bfloat16())
+    part, out = torch.empty(64, Dd, device=DEV), torch.empty(Dd, device=DEV)
+    ops.rowsum_select(dev(x.reshape(-1, Dd)), Dd, dev(mask.reshape(-1)), 1, L, L + 1, B * L, Dd, part, out)
+    assert float((out.cpu() - (x[:, 1:] * mask[:, :, None]).sum((0, 1))).abs().max()) < 1e-5
+    ops.rowsum_select(dev(x.reshape(-1, Dd)), Dd, None, 0, 1, L + 1, B, Dd, part, out)
+    assert float((out.cpu() - x[:, 0].sum(0)).abs().max()) < 1e-5
+    X = torch.randn(301, 200, generator=g)
+    cs = torch.empty(200, device=DEV)
+    ops.colsum(dev(X), 301, 200, cs)
+    assert float((cs.cpu() - X.sum(0)).abs().max()) < 1e-4
+    ops.colsum(dev(X, torch.bfloat16), 301, 200, cs)
+    assert float((cs.cpu() - X.bfloat16().float().sum(0)).abs().max()) < 1e-4
+    dst = torch.empty(301 * 200, device=DEV, dtype=torch.bfloat16)
+    ops.cast(dev(X.reshape(-1)), dst, 301 * 200)
+    assert torch.equal(dst.cpu(), X.reshape(-1).bfloat16())
+
+
+# ------------------------------------------------------------------------------------ loss
+@pytest.mark.parametrize("norm_pix,loss_fn", [(True, "mse"), (False, "mse"), (True, "L1")])
+@pytest.mark.parametrize("geom", [(5, 64, 16), (9, 32, 8)])
+def test_masked_patch_loss(ops, norm_pix, loss_fn, geom):
+    C, H, p = geom
+    B, L, pv = 4, (H // p) ** 2, C * p * p
+    cfg = mo.MAEConfig(img_size=H, patch_size=p, in_chans=C, pixel_mean=0.1, pixel_std=1.3, norm_pix_loss=norm_pix,
+                       loss_fn=loss_fn)
+    g = torch.Generator().manual_seed(H + C)
+    x = torch.randn(B, C, H, H, generator=g)
+    x[1, 2] = float("nan")
+    x[2, 0, 3:9, 5:20] = float("nan")
+    mask = (torch.rand(B, L, generator=g) < 0.7).float()
+    pred_full = torch.randn(B, L + 1, pv, generator=g)
+    pr = pred_full[:, 1:].clone().requires_grad_(True)
+    loss_ref = mo.forward_loss(mo.norm_inputs(x, cfg), pr, mask, cfg, nan_safe=True)
+    loss_ref.backward()
+    # faithful (not nan-safe) forward value is identical
+    assert float(mo.forward_loss(mo.norm_inputs(x, cfg), pr.detach(), mask, cfg)) == float(loss_ref)
+    loss = torch.empty(1, device=DEV)
+    ws = torch.empty(4 * B * L + 4, device=DEV)
+    d32 = torch.full((B, L + 1, pv), float("nan"), device=DEV)
+    dlp = torch.empty(B, L + 1, pv, device=DEV, dtype=torch.bfloat16)
+    ops.masked_patch_loss(dev(x), dev(pred_full), dev(mask), loss, dlp, d32, ops.BF16, ws, p, 1, 0.1, 1.3, norm_pix,
+                          loss_fn != "mse")
+    assert abs(float(loss) - float(loss_ref)) < 2e-6 * abs(float(loss_ref))
+    assert bool((d32[:, 0] == 0).all())
+    assert float((d32[:, 1:].cpu() - pr.grad).abs().max()) < 1e-5 * float(pr.grad.abs().max())
+    assert relerr(dlp[:, 1:].float(), pr.grad) < 5e-3
+
+
+# ------------------------------------------------------------------------------------ optimiser
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_adamw(ops, dtype):
+    n, n_decay = 4096 + 8, 1000
+    g = torch.Generator().manual_seed(5)
+    p, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 0.1
+    m, v = torch.randn(n, generator=g) * 0.01, torch.rand(n, generator=g) * 0.01
+    pd, gd, md, vd = dev(p.clone()), dev(gr.clone()), dev(m.clone()), dev(v.clone())
+    plp = torch.empty(n, device=DEV, dtype=dtype)
+    step, lr, wd = 3, 1e-3, 0.05
+    hyper = dev(torch.tensor([lr, 1 - 0.9 ** step, 1 - 0.95 ** step, 0.0]))
+    ops.adamw(pd, gd, md, vd, plp, n, n_decay, hyper, 0.9, 0.95, 1e-8, wd, grad_scale=0.5, zero_grad=True)
+    pr, mr, vr = p.clone(), m.clone(), v.clone()
+    mo.adamw_step(pr[:n_decay], gr[:n_decay] * 0.5, mr[:n_decay], vr[:n_decay], step, lr, wd)
+    mo.adamw_step(pr[n_decay:], gr[n_decay:] * 0.5, mr[n_decay:], vr[n_decay:], step, lr, 0.0)
+    assert float((pd.cpu() - pr).abs().max()) < 2e-7 and float((md.cpu() - mr).abs().max()) < 1e-8
+    assert float((vd.cpu() - vr).abs().max()) < 1e-9
+    assert torch.equal(plp.cpu(), pd.cpu().to(dtype)) and bool((gd == 0).all())
+
+
+# ------------------------------------------------------------------------------------ similarity search
+def _run_topk(ops, q, x, w, k):
+    Q, D = q.shape
+    N = x.shape[0]
+    qd, xd = dev(torch.from_numpy(q)), dev(torch.from_numpy(x))
+    wd = dev(torch.from_numpy(w)) if w is not None else None
+    tw, qn, xn = torch.empty(Q, D, device=DEV), torch.empty(Q, device=DEV), torch.empty(N, device=DEV)
+    ops.weighted_norms(qd, wd, qn, tw)
+    ops.weighted_norms(xd, wd, xn)
+    nch = ops.cosine_topk_chunks(N, Q, k)
+    ps = torch.empty(Q, nch, k, device=DEV)
+    pi = torch.empty(Q, nch, k, device=DEV, dtype=torch.int64)
+    ops.cosine_topk(tw, qn, xd, xn, k, 1e-6, 0, nch, ps, pi)
+    os_, oi = torch.empty(Q, k, device=DEV), torch.empty(Q, k, device=DEV, dtype=torch.int64)
+    ops.topk_merge(ps, pi, Q, nch, k, os_, oi)
+    sc = torch.empty(Q, N, device=DEV)
+    ops.cosine_scores(tw, qn, xd, xn, 1e-6, sc)
+    torch.cuda.synchronize()
+    return os_.cpu().numpy(), oi.cpu().numpy(), sc.cpu().numpy()
+
+
+@pytest.mark.parametrize("Q,N,D,k,weighted", [(1, 5000, 768, 100, True), (5, 3001, 96, 10, False), (16, 4097, 768, 300, True),
+                                              (70, 9000, 768, 100, True), (130, 2500, 64, 17, False), (3, 50, 32, 64, True)])
+def test_cosine_topk_bit_exact(ops, Q, N, D, k, weighted):
+    rng = np.random.default_rng(Q * 1000 + N)
+    q = rng.standard_normal((Q, D), dtype=np.float32)
+    x = rng.standard_normal((N, D), dtype=np.float32)
+    x[7] = x[3]            # exact ties across rows
+    x[N - 1] = x[3]
+    if N > 2000:
+        x[1999] = x[3]
+    w = None
+    if weighted:
+        w = rng.random(D, dtype=np.float32) + 0.1
+        w /= w.sum()
+    ref_s, ref_i = so.cosine_topk_np(q, x, k, w)
+    ref_sc = so.cosine_scores_np(q, x, w)
+    s, i, sc = _run_topk(ops, q, x, w, k)
+    assert np.array_equal(sc, ref_sc), "scores must be bit-identical to the fixed-order oracle"
+    assert np.array_equal(i, ref_i)
+    assert np.array_equal(s, ref_s)
+
+
+def test_standardise_exact(ops):
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((1000, 96), dtype=np.float32) * 3 + 1
+    mu, sd = x.mean(0), x.std(0, ddof=1)
+    out = torch.empty(1000, 96, device=DEV)
+    ops.standardise(dev(torch.from_numpy(x)), dev(torch.from_numpy(mu)), dev(torch.from_numpy(sd)), out)
+    assert np.array_equal(out.cpu().numpy(), so.standardise_np(x, mu, sd))
+
+
+def test_errors_are_reported(ops):
+    a = torch.zeros(8, 12, device=DEV, dtype=torch.bfloat16)  # K=12 is not a multiple of 8
+    with pytest.raises(Exception) as e:
+        ops.gemm(a, a, M=8, N=8, K=12, out_f32=torch.zeros(8, 8, device=DEV))
+    assert "multiples" in str(e.value)
