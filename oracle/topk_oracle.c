@@ -15,7 +15,7 @@
  *   dot    = fma-chain over d = 0..D-1, acc0 = 0: acc = fmaf(tw[d], x[n][d], acc)
  *   qn2    = fma-chain: acc = fmaf(tw[d], t[q][d], acc)
  *   xn2    = fma-chain: acc = fmaf(w[d]*x[n][d], x[n][d], acc)
- *   score  = dot / (sqrtf(qn2) * sqrtf(xn2) + eps)   (mul, add, IEEE divide; no contraction)
+ *   score  = dot / fmaf(sqrtf(qn2), sqrtf(xn2), eps)   (fused multiply-add, IEEE sqrt and divide)
  *   NaN scores compare as -inf.
  *   order  = score descending, then index ascending (reference argsort is not
  *            stable: utils/similarity.py:24).
@@ -68,8 +68,7 @@ static inline float chain_wnorm2(const float *w, const float *x, int64_t D) {
 }
 
 static inline float finish(float dot, float qn, float xn, float eps) {
-    float den = qn * xn;
-    den = den + eps;
+    float den = fmaf(qn, xn, eps); /* one rounding: what the GPU compiler emits for qn*xn+eps anyway */
     float s = dot / den;
     if (!(s == s)) s = -INFINITY;
     return s;
@@ -174,5 +173,38 @@ int skyemb_oracle_standardise(const float *X, const float *mu, const float *sigm
             float den = sigma[d] + 1e-8f;
             out[n * D + d] = (X[n * D + d] - mu[d]) / den;
         }
+    return 0;
+}
+
+/* ---- diagnostics (used once to pin the MFMA accumulation order; kept for the parity tests) ----
+ * variants of a D-long dot product, D % 4 == 0:
+ *  0: sequential fma chain d = 0..D-1 (the contract)
+ *  1: per group of 4, reversed order inside the group
+ *  2: per group of 4: t = fma(a1,b1, a0*b0); u = fma(a3,b3, a2*b2); acc = acc + (t + u)
+ *  3: per group of 4: exact (double) sum of the 4 products added to acc with one rounding
+ *  4: unfused: acc = acc + (float)(a*b) sequential
+ */
+int skyemb_oracle_dot_variants(const float *a, const float *b, int64_t D, float *out) {
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+    for (int64_t d = 0; d < D; ++d) v0 = fmaf(a[d], b[d], v0);
+    for (int64_t g = 0; g < D; g += 4) {
+        for (int j = 3; j >= 0; --j) v1 = fmaf(a[g + j], b[g + j], v1);
+        float t = fmaf(a[g + 1], b[g + 1], a[g] * b[g]);
+        float u = fmaf(a[g + 3], b[g + 3], a[g + 2] * b[g + 2]);
+        v2 = v2 + (t + u);
+        double s = (double)a[g] * b[g] + (double)a[g + 1] * b[g + 1] + (double)a[g + 2] * b[g + 2] +
+                   (double)a[g + 3] * b[g + 3];
+        v3 = (float)((double)v3 + s);
+    }
+    for (int64_t d = 0; d < D; ++d) {
+        float p = a[d] * b[d];
+        v4 = v4 + p;
+    }
+    out[0] = v0; out[1] = v1; out[2] = v2; out[3] = v3; out[4] = v4;
+    return 0;
+}
+
+int skyemb_oracle_wnorms(const float *X, const float *w, int64_t N, int64_t D, float *out) {
+    for (int64_t n = 0; n < N; ++n) out[n] = sqrtf(chain_wnorm2(w, X + n * D, D));
     return 0;
 }

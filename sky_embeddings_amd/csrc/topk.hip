@@ -2,7 +2,7 @@
 // 149-172), bit-exact against oracle/topk_oracle.c:
 //   dot(q,n) is ONE fp32 fma chain over d = 0..D-1 -- v_mfma_f32_16x16x4_f32 is a k-ordered fmaf
 //   chain on its C input, and consecutive MFMAs take consecutive 4-wide k groups;
-//   score = dot / (qn*xn + eps) with explicit round-to-nearest mul / add / IEEE divide.
+//   score = dot / fmaf(qn, xn, eps) with IEEE sqrt / divide.
 // Never materialises the Q x N score matrix: every block keeps, per query of its tile, a sorted
 // top-k list in LDS for its bank chunk (threshold-filtered insertion); the per-chunk lists are
 // merged by skyemb_topk_merge (also used after the RCCL all-gather of per-rank results).
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void wnorm_kernel(const float *__restrict__ x,
 
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float finish_score(float dot, float qn, float xn, float eps) {
-    const float den = __fadd_rn(__fmul_rn(qn, xn), eps);
+    const float den = fmaf(qn, xn, eps);
     const float s = __fdiv_rn(dot, den);
     return s == s ? s : -INFINITY;
 }
