@@ -79,6 +79,8 @@ typedef struct skyemb_gemm_args {
     void *out2;                 /* dtype, or NULL (ACT_GELU pre-activation) */
     int64_t ldo2;
     int32_t tile;               /* 0 = auto, 64 or 128 */
+    float *colsum_a;            /* optional, A must be RC: colsum_a[m] = sum_k A(m,k)  (bias gradient fused
+                                   into the wgrad launch: A = dy, so this is sum over tokens of dy[:, m]) */
 } skyemb_gemm_args;
 
 int skyemb_gemm(const skyemb_gemm_args *args, void *stream);
@@ -116,12 +118,12 @@ int skyemb_layernorm_fwd(const float *x, const float *gamma, const float *beta, 
                          float *mean, float *rstd, int M, int D, float eps, void *stream);
 
 /* dx = LN'(dy); g_out = (g_in ? g_in : 0) + dx (fp32; g_out may alias g_in); g_lp = dtype copy
- * of g_out (or NULL).  dy is `dtype` (or fp32 when dy_is_f32).  dgamma/dbeta partial sums are
- * written to part[2, nblk, D] (nblk = skyemb_layernorm_bwd_blocks(M)); reduce with skyemb_colsum. */
+ * of g_out (or NULL).  dy is `dtype` (or fp32 when dy_is_f32).  dgamma/dbeta: deterministic two-stage
+ * reduction through part[2, nblk, D] (fp32 workspace, nblk = skyemb_layernorm_bwd_blocks(M)). */
 int skyemb_layernorm_bwd_blocks(int M);
 int skyemb_layernorm_bwd(const void *dy, int dy_is_f32, int dtype, const float *x, const float *gamma,
                          const float *mean, const float *rstd, const float *g_in, float *g_out, void *g_lp,
-                         float *part, int M, int D, void *stream);
+                         float *part, float *dgamma, float *dbeta, int M, int D, void *stream);
 
 /* -------------------------------------------------------- attention -------
  * timm Attention core / F.scaled_dot_product_attention on tiny sequences (N = 5, 17, 65, 66):
@@ -158,12 +160,13 @@ int skyemb_masked_patch_loss(const float *imgs, const float *pred, const float *
 /* ----------------------------------------------------------- optimiser ----
  * torch.optim.AdamW single-tensor update order (utils/mim_vit.py:126-129,
  * utils/pretrain_fns.py:36-41) over one flat fp32 parameter buffer:
- * elements [0, n_decay) use weight decay `wd`, the rest 0.  hyper (device, fp32[4]) =
- * {lr, 1-beta1^t, 1-beta2^t, unused}.  Also refreshes the dtype shadow copy `p_lp` used by
- * the GEMMs (NULL to skip) and optionally zeroes g. */
+ * elements [0, n_decay) use weight decay `wd`, the rest 0.  Step scalars {lr, 1-beta1^t, 1-beta2^t}
+ * come from `hyper` (device fp32[4], for launches captured in a HIP graph) when non-NULL, else
+ * from the lr/bc1/bc2 arguments.  Also refreshes the dtype shadow copy `p_lp` used by the GEMMs
+ * (NULL to skip), scales gradients by grad_scale (DDP averaging) and optionally zeroes g. */
 int skyemb_adamw(float *p, float *g, float *m, float *v, void *p_lp, int dtype, int64_t n, int64_t n_decay,
-                 const float *hyper, float beta1, float beta2, float eps, float wd, float grad_scale, int zero_grad,
-                 void *stream);
+                 const float *hyper, float lr, float bc1, float bc2, float beta1, float beta2, float eps, float wd,
+                 float grad_scale, int zero_grad, void *stream);
 int skyemb_cast(const float *src, void *dst, int dtype, int64_t n, void *stream);
 
 /* ------------------------------------------------------ similarity search -

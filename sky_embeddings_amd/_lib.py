@@ -9,6 +9,11 @@ import ctypes
 import os
 import subprocess
 
+# torch bundles its own HIP runtime (torch/lib/libamdhip64.so).  It must be in the process BEFORE
+# libskyemb.so is dlopen'ed so that both resolve to ONE runtime (otherwise kernels launched on
+# torch's streams fail with "no ROCm-capable device is detected").
+import torch  # noqa: F401  (import order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libskyemb.so")
 CSRC = os.path.join(_HERE, "csrc")
@@ -36,7 +41,7 @@ class GemmArgs(ctypes.Structure):
         ("bias", c_vp), ("table", c_vp), ("tab_row", c_vp), ("ldt", c_i64), ("dst_row", c_vp),
         ("resid", c_vp), ("ldr", c_i64), ("aux", c_vp), ("ldaux", c_i64), ("act", c_i32),
         ("out_f32", c_vp), ("ldo32", c_i64), ("out", c_vp), ("ldo", c_i64), ("out2", c_vp), ("ldo2", c_i64),
-        ("tile", c_i32),
+        ("tile", c_i32), ("colsum_a", c_vp),
     ]
 
 
@@ -53,8 +58,8 @@ PROTOTYPES = {
                                             c_vp]),
     "skyemb_layernorm_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp]),
     "skyemb_layernorm_bwd_blocks": (c_i32, [c_i32]),
-    "skyemb_layernorm_bwd": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
-                                     c_vp]),
+    "skyemb_layernorm_bwd": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                     c_i32, c_i32, c_vp]),
     "skyemb_mha_fwd": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "skyemb_mha_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "skyemb_fill_mask_tokens": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
@@ -63,7 +68,7 @@ PROTOTYPES = {
     "skyemb_masked_patch_loss": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32,
                                          c_i32, c_i32, c_f32, c_f32, c_i32, c_i32, c_vp]),
     "skyemb_adamw": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_vp, c_f32, c_f32, c_f32, c_f32,
-                             c_f32, c_i32, c_vp]),
+                             c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
     "skyemb_cast": (c_i32, [c_vp, c_vp, c_i32, c_i64, c_vp]),
     "skyemb_standardise": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
     "skyemb_weighted_norms": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),

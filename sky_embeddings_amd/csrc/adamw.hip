@@ -10,9 +10,11 @@ namespace {
 template <typename T, bool LP>
 __global__ __launch_bounds__(256) void adamw_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
                                                     float *__restrict__ v, T *__restrict__ p_lp, int64_t n4,
-                                                    int64_t n_decay, const float *__restrict__ hyper, float beta1,
-                                                    float beta2, float eps, float wd, float grad_scale, int zero_grad) {
-    const float lr = hyper[0], bc1 = hyper[1], bc2 = hyper[2];
+                                                    int64_t n_decay, const float *__restrict__ hyper, float lr_arg,
+                                                    float bc1_arg, float bc2_arg, float beta1, float beta2, float eps,
+                                                    float wd, float grad_scale, int zero_grad) {
+    // hyper (device) wins when given: kernel arguments are frozen inside a captured HIP graph
+    const float lr = hyper ? hyper[0] : lr_arg, bc1 = hyper ? hyper[1] : bc1_arg, bc2 = hyper ? hyper[2] : bc2_arg;
     const float step_size = lr / bc1;
     const float bc2_sqrt = sqrtf(bc2);
     const float decay = 1.0f - lr * wd;
@@ -41,8 +43,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float *__restrict__ p, float
 }  // namespace
 
 extern "C" int skyemb_adamw(float *p, float *g, float *m, float *v, void *p_lp, int dtype, int64_t n, int64_t n_decay,
-                            const float *hyper, float beta1, float beta2, float eps, float wd, float grad_scale,
-                            int zero_grad, void *stream) {
+                            const float *hyper, float lr, float bc1, float bc2, float beta1, float beta2, float eps,
+                            float wd, float grad_scale, int zero_grad, void *stream) {
     SKY_CHECK_ARG(n > 0 && n % 4 == 0 && n_decay >= 0 && n_decay <= n, "skyemb_adamw: n must be a positive multiple of 4");
     SKY_CHECK_ARG(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), "skyemb_adamw: unaligned buffers");
     int64_t blocks = ceil_div64(n / 4, 256);
@@ -51,13 +53,13 @@ extern "C" int skyemb_adamw(float *p, float *g, float *m, float *v, void *p_lp, 
     dim3 grid((unsigned)blocks), block(256);
     if (!p_lp)
         hipLaunchKernelGGL((adamw_kernel<float, false>), grid, block, 0, st, p, g, m, v, (float *)nullptr, n / 4, n_decay,
-                           hyper, beta1, beta2, eps, wd, grad_scale, zero_grad);
+                           hyper, lr, bc1, bc2, beta1, beta2, eps, wd, grad_scale, zero_grad);
     else if (dtype == SKYEMB_BF16)
         hipLaunchKernelGGL((adamw_kernel<bf16_t, true>), grid, block, 0, st, p, g, m, v, (bf16_t *)p_lp, n / 4, n_decay,
-                           hyper, beta1, beta2, eps, wd, grad_scale, zero_grad);
+                           hyper, lr, bc1, bc2, beta1, beta2, eps, wd, grad_scale, zero_grad);
     else
         hipLaunchKernelGGL((adamw_kernel<float, true>), grid, block, 0, st, p, g, m, v, (float *)p_lp, n / 4, n_decay, hyper,
-                           beta1, beta2, eps, wd, grad_scale, zero_grad);
+                           lr, bc1, bc2, beta1, beta2, eps, wd, grad_scale, zero_grad);
     SKY_LAUNCH_CHECK("skyemb_adamw");
     return 0;
 }

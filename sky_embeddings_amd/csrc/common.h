@@ -17,8 +17,12 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 void skyemb_set_error(const char *fmt, ...);
 
+// Also drops any stale sticky HIP error left by other code in this thread (e.g. a device probe),
+// so that SKY_LAUNCH_CHECK reports only this call's launches.  Every launching entry point starts
+// with a SKY_CHECK_ARG.
 #define SKY_CHECK_ARG(cond, ...)            \
     do {                                    \
+        (void)hipGetLastError();            \
         if (!(cond)) {                      \
             skyemb_set_error(__VA_ARGS__);  \
             return 1;                       \

@@ -172,6 +172,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const skyemb_gemm_args g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // fused column sum of an RC A operand (bias gradient of the wgrad launch): only the first
+    // column of tiles does it, thread t owns logical row m0 + t, summing the staged [k][rows] tile
+    const bool do_colsum = !A_KC && g.colsum_a != nullptr && (blockIdx.x % tiles_n) == 0 && tid < BM;
+    float csum = 0.f;
+
     uint4 ra[SA::NVEC], rb[SB::NVEC];
     load_tile<T, A_KC, BM>(A, g.lda, m0, g.M, 0, g.K, tid, ra);
     load_tile<T, B_KC, BN>(B, g.ldb, n0, g.N, 0, g.K, tid, rb);
@@ -187,6 +192,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const skyemb_gemm_args g) {
         }
         const T *cA = (kt & 1) ? sA1 : sA0;
         const T *cB = (kt & 1) ? sB1 : sB0;
+        if (!A_KC && do_colsum) {
+#pragma unroll 8
+            for (int k = 0; k < BK; ++k) csum += to_f32<T>(cA[k * SA::PITCH + tid]);
+        }
 #pragma unroll
         for (int kk = 0; kk < BK / C::KSTEP; ++kk) {
             typename C::Frag fa[TM], fb[TN];
@@ -206,6 +215,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const skyemb_gemm_args g) {
         __syncthreads();
     }
 
+    if (!A_KC && do_colsum && m0 + tid < g.M) g.colsum_a[m0 + tid] = csum;
     // ---- epilogue: C/D layout col = lane&15, row = 4*(lane>>4) + r -------------------------
     T *out = (T *)g.out;
     T *out2 = (T *)g.out2;
@@ -287,6 +297,7 @@ extern "C" int skyemb_gemm(const skyemb_gemm_args *args, void *stream) {
     SKY_CHECK_ARG(g.out || g.out_f32, "skyemb_gemm: no output");
     SKY_CHECK_ARG(g.act != SKYEMB_ACT_DGELU || g.aux, "skyemb_gemm: ACT_DGELU needs aux");
     SKY_CHECK_ARG(!g.table || g.tab_row, "skyemb_gemm: table without tab_row");
+    SKY_CHECK_ARG(!g.colsum_a || g.a_layout == SKYEMB_RC, "skyemb_gemm: colsum_a needs an RC A operand");
     hipStream_t st = (hipStream_t)stream;
     int tile = g.tile;
     if (tile == 0) tile = (ceil_div64(g.M, 128) * ceil_div64(g.N, 128) >= 200) ? 128 : 64;

@@ -1,0 +1,407 @@
+"""MAE pretraining engine: explicit forward / backward / optimiser schedule over libskyemb.
+
+This replaces the reference's autograd graph (utils/mim_vit.py:552-559 forward,
+utils/pretrain_fns.py:26-41 backward + AdamW) with a fixed launch sequence of hand-written
+gfx950 kernels.  Python only sequences the launches and owns the buffers (torch tensors);
+no torch op touches activations on the hot path, so a whole step can be captured in a HIP graph.
+
+Memory layout (HBM, per process):
+  * parameters: ONE flat fp32 buffer ``p`` laid out [decayed tensors | non-decayed tensors],
+    every tensor padded to a multiple of 8 elements; ``g`` (grads), ``m``, ``v`` (Adam state)
+    mirror it; ``p_lp`` is the bf16 (or fp32) shadow the GEMMs read, refreshed by the AdamW kernel.
+    DDP all-reduces contiguous slices of ``g``.
+  * activations: residual stream fp32 [tokens, D]; GEMM operands in the compute dtype;
+    per-block tensors saved for backward (LN inputs + stats, qkv, attention out, MLP pre/post).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import ACT_DGELU, ACT_GELU, BF16, F32, KC, RC
+from .model_config import FROZEN, MAEConfig, sincos_pos_embed, state_layout, weight_decay_split, xavier_bound
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+class ParamStore:
+    """Flat parameter / gradient / optimiser-state buffers with named views."""
+
+    def __init__(self, cfg: MAEConfig, device, lp_dtype):
+        self.cfg = cfg
+        shapes = dict(state_layout(cfg))
+        decay, no_decay = weight_decay_split(cfg)
+        self.decay, self.no_decay = decay, no_decay
+        self.order = decay + no_decay
+        self.offsets = {}
+        off = 0
+        for name in decay:
+            self.offsets[name] = off
+            off += _pad8(int(np.prod(shapes[name])))
+        self.n_decay = off
+        for name in no_decay:
+            self.offsets[name] = off
+            off += _pad8(int(np.prod(shapes[name])))
+        self.n = off
+        self.shapes = shapes
+        self.p = torch.zeros(self.n, device=device, dtype=torch.float32)
+        self.g = torch.zeros(self.n, device=device, dtype=torch.float32)
+        self.m = torch.zeros(self.n, device=device, dtype=torch.float32)
+        self.v = torch.zeros(self.n, device=device, dtype=torch.float32)
+        self.p_lp = torch.zeros(self.n, device=device, dtype=lp_dtype)
+        self.frozen = {k: torch.zeros(shapes[k], device=device, dtype=torch.float32) for k in FROZEN}
+
+    def _view(self, buf, name):
+        o = self.offsets[name]
+        return buf[o:o + int(np.prod(self.shapes[name]))].view(self.shapes[name])
+
+    def param(self, name):
+        return self.frozen[name] if name in FROZEN else self._view(self.p, name)
+
+    def grad(self, name):
+        return self._view(self.g, name)
+
+    def lp(self, name):
+        return self._view(self.p_lp, name)
+
+    def refresh_lp(self):
+        ops.cast(self.p, self.p_lp, self.n)
+
+
+class MAEEngine:
+    def __init__(self, cfg: MAEConfig, device="cuda", compute_dtype=torch.bfloat16, seed=None):
+        if cfg.simmim or cfg.ra_dec or cfg.attn_pool:
+            raise NotImplementedError(
+                "SimMIM head / ra_dec token / attn_pool are 'next' rows (SURVEY.md §8f); this round builds the MAE path")
+        assert cfg.embed_dim % cfg.num_heads == 0 and cfg.decoder_embed_dim % cfg.decoder_num_heads == 0
+        assert cfg.embed_dim % 8 == 0 and cfg.decoder_embed_dim % 8 == 0 and cfg.patch_size % 4 == 0
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.dtype = compute_dtype
+        self.code = ops.dtype_code(compute_dtype)
+        self.store = ParamStore(cfg, self.device, compute_dtype)
+        self._ws = {}
+        self._last = None
+        self.initialize_weights(seed)
+
+    # ------------------------------------------------------------------ parameters
+    def initialize_weights(self, seed=None):
+        """utils/mim_vit.py:290-324: sincos tables, xavier_uniform on every Linear and on the conv
+        weight viewed [D,-1], N(0,0.02) cls/mask tokens, LayerNorm 1/0, zero Linear biases,
+        patch_mask_values zeros; the conv bias keeps nn.Conv2d's default U(+-1/sqrt(fan_in))."""
+        cfg, st = self.cfg, self.store
+        gen = torch.Generator().manual_seed(seed if seed is not None else int(torch.initial_seed() % (2 ** 31)))
+        for name in st.order:
+            shape = st.shapes[name]
+            if name in ("cls_token", "mask_token"):
+                t = torch.randn(shape, generator=gen) * 0.02
+            elif name == "patch_mask_values":
+                t = torch.zeros(shape)
+            elif name == "patch_embed.proj.bias":
+                b = 1.0 / math.sqrt(cfg.patch_dim)
+                t = (torch.rand(shape, generator=gen) * 2 - 1) * b
+            elif name.endswith("norm1.weight") or name.endswith("norm2.weight") or name.endswith("norm.weight"):
+                t = torch.ones(shape)
+            elif name.endswith(".bias"):
+                t = torch.zeros(shape)
+            else:
+                t = (torch.rand(shape, generator=gen) * 2 - 1) * xavier_bound(shape)
+            st.param(name).copy_(t)
+        for k in FROZEN:
+            tab = sincos_pos_embed(st.shapes[k][-1], cfg.grid, True, cfg.ra_dec)
+            st.frozen[k].copy_(torch.from_numpy(tab).float().unsqueeze(0))
+        st.refresh_lp()
+
+    def state_dict(self):
+        out = OrderedDict()
+        for name, _ in state_layout(self.cfg):
+            out[name] = self.store.param(name)
+        return out
+
+    def load_state_dict(self, sd, strict=True):
+        names = [n for n, _ in state_layout(self.cfg)]
+        missing = [n for n in names if n not in sd]
+        unexpected = [k for k in sd if k not in names]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
+        for n in names:
+            if n in sd:
+                self.store.param(n).copy_(torch.as_tensor(sd[n]).to(torch.float32).reshape(self.store.shapes[n]))
+        self.store.refresh_lp()
+
+    # ------------------------------------------------------------------ workspaces
+    def _workspace(self, B, keep, train):
+        key = (B, keep, train)
+        if key in self._ws:
+            return self._ws[key]
+        cfg, dev, T = self.cfg, self.device, self.dtype
+        L, D, Dd, pv = cfg.num_patches, cfg.embed_dim, cfg.decoder_embed_dim, cfg.patch_dim
+        Ne, Nd = 1 + keep, 1 + L
+        Me, Md = B * Ne, B * Nd
+        f32 = dict(device=dev, dtype=torch.float32)
+        lp = dict(device=dev, dtype=T)
+        i32 = dict(device=dev, dtype=torch.int32)
+        w = {}
+        w["ids_restore"] = torch.empty(B, L, device=dev, dtype=torch.int64)
+        w["mask"] = torch.empty(B, L, **f32)
+        w["ids_keep"] = torch.empty(B, keep, **i32)
+        w["dec_dst"] = torch.empty(B, Ne, **i32)
+        w["dec_tab"] = torch.empty(B, Ne, **i32)
+        w["pe_dst"] = (torch.arange(B, device=dev)[:, None] * Ne + 1 + torch.arange(keep, device=dev)[None, :]).to(torch.int32).contiguous()
+        w["patches"] = torch.empty(B * keep, pv, **lp)
+        w["latent32"] = torch.empty(Me, D, **f32)
+
+        def block_bufs(M, dim):
+            return dict(ln1=torch.empty(M, dim, **lp), mean1=torch.empty(M, **f32), rstd1=torch.empty(M, **f32),
+                        qkv=torch.empty(M, 3 * dim, **lp), att=torch.empty(M, dim, **lp), xmid=torch.empty(M, dim, **f32),
+                        ln2=torch.empty(M, dim, **lp), mean2=torch.empty(M, **f32), rstd2=torch.empty(M, **f32),
+                        hpre=torch.empty(M, int(dim * cfg.mlp_ratio), **lp), hact=torch.empty(M, int(dim * cfg.mlp_ratio), **lp))
+
+        n_enc_sets = cfg.depth if train else 1
+        w["enc"] = [block_bufs(Me, D) for _ in range(n_enc_sets)]
+        w["xs"] = [torch.empty(Me, D, **f32) for _ in range((cfg.depth + 1) if train else 2)]
+        w["lat_lp"] = torch.empty(Me, D, **lp)
+        w["lat_mean"], w["lat_rstd"] = torch.empty(Me, **f32), torch.empty(Me, **f32)
+        if train:
+            w["dec"] = [block_bufs(Md, Dd) for _ in range(cfg.decoder_depth)]
+            w["xd"] = [torch.empty(Md, Dd, **f32) for _ in range(cfg.decoder_depth + 1)]
+            w["dlat_lp"] = torch.empty(Md, Dd, **lp)
+            w["dlat_mean"], w["dlat_rstd"] = torch.empty(Md, **f32), torch.empty(Md, **f32)
+            w["pred"] = torch.empty(B, Nd, pv, **f32)
+            w["loss"] = torch.zeros(1, **f32)
+            w["loss_ws"] = torch.empty(4 * B * L + 4, **f32)
+            w["dpred"] = torch.empty(Md, pv, **lp)
+            # backward temporaries (sized for the larger of encoder / decoder)
+            Mx = max(Me, Md)
+            Dx = max(D, Dd)
+            Hx = max(Me * int(D * cfg.mlp_ratio), Md * int(Dd * cfg.mlp_ratio))
+            w["g"] = torch.empty(Mx * Dx, **f32)
+            w["g_lp"] = torch.empty(Mx * Dx, **lp)
+            w["dln"] = torch.empty(Mx * Dx, **lp)
+            w["datt"] = torch.empty(Mx * Dx, **lp)
+            w["dh"] = torch.empty(Hx, **lp)
+            w["dqkv"] = torch.empty(3 * Mx * Dx, **lp)
+            nblk = ops.layernorm_bwd_blocks(Mx)
+            w["ln_part"] = torch.empty(2 * nblk * Dx, **f32)
+            w["dE"] = torch.empty(Me, Dd, **lp)
+            w["dT"] = torch.empty(B * keep, D, **lp)
+            w["drows"] = torch.empty(B * keep, pv, **f32)
+            w["pmv_part"] = torch.empty(B, pv, **f32)
+            w["rs_part"] = torch.empty(64, max(D, Dd), **f32)
+        self._ws[key] = w
+        return w
+
+    # ------------------------------------------------------------------ forward pieces
+    def _embed(self, imgs, noise, keep, w):
+        """a3-a6: mask from noise, fused normalise/NaN-fill/gather of the kept patches, patch-embed
+        GEMM with bias + positional rows scattered into the token sequence, cls row."""
+        cfg, st = self.cfg, self.store
+        B = imgs.shape[0]
+        L, D, pv = cfg.num_patches, cfg.embed_dim, cfg.patch_dim
+        Ne = 1 + keep
+        ops.random_mask_from_noise(noise, keep, w["ids_restore"], w["mask"], w["ids_keep"], w["dec_dst"], w["dec_tab"])
+        ops.patch_gather(imgs, st.param("patch_mask_values"), w["ids_keep"], w["patches"], cfg.patch_size, keep,
+                         cfg.pixel_mean, cfg.pixel_std)
+        x0 = w["xs"][0]
+        pos = st.frozen["pos_embed"].view(-1, D)
+        ops.gemm(w["patches"], st.lp("patch_embed.proj.weight"), M=B * keep, N=D, K=pv,
+                 bias=st.param("patch_embed.proj.bias"), table=pos[1:], tab_row=w["ids_keep"], ldt=D,
+                 dst_row=w["pe_dst"], out_f32=x0, ldo32=D)
+        # cls_token + pos_embed[:, :1] (utils/mim_vit.py:417-419): B tiny row copies (host glue)
+        x0.view(B, Ne, D)[:, 0, :] = st.param("cls_token").view(D) + pos[0]
+        return x0
+
+    def _block_fwd(self, x_in, x_out, bufs, prefix, M, dim, heads, Bsz, N):
+        st, eps = self.store, self.cfg.ln_eps
+        hd = dim // heads
+        hidden = bufs["hpre"].shape[1]
+        P, LP = st.param, st.lp
+        ops.layernorm_fwd(x_in, P(f"{prefix}.norm1.weight"), P(f"{prefix}.norm1.bias"), bufs["ln1"], bufs["mean1"],
+                          bufs["rstd1"], M, dim, eps)
+        ops.gemm(bufs["ln1"], LP(f"{prefix}.attn.qkv.weight"), M=M, N=3 * dim, K=dim, bias=P(f"{prefix}.attn.qkv.bias"),
+                 out=bufs["qkv"])
+        ops.mha_fwd(bufs["qkv"], bufs["att"], Bsz, N, heads, hd)
+        ops.gemm(bufs["att"], LP(f"{prefix}.attn.proj.weight"), M=M, N=dim, K=dim, bias=P(f"{prefix}.attn.proj.bias"),
+                 resid=x_in, ldr=dim, out_f32=bufs["xmid"])
+        ops.layernorm_fwd(bufs["xmid"], P(f"{prefix}.norm2.weight"), P(f"{prefix}.norm2.bias"), bufs["ln2"],
+                          bufs["mean2"], bufs["rstd2"], M, dim, eps)
+        ops.gemm(bufs["ln2"], LP(f"{prefix}.mlp.fc1.weight"), M=M, N=hidden, K=dim, bias=P(f"{prefix}.mlp.fc1.bias"),
+                 act=ACT_GELU, out=bufs["hact"], out2=bufs["hpre"])
+        ops.gemm(bufs["hact"], LP(f"{prefix}.mlp.fc2.weight"), M=M, N=dim, K=hidden, bias=P(f"{prefix}.mlp.fc2.bias"),
+                 resid=bufs["xmid"], ldr=dim, out_f32=x_out)
+
+    def _encoder_fwd(self, imgs, noise, keep, w, train):
+        cfg, st = self.cfg, self.store
+        B = imgs.shape[0]
+        D, Ne = cfg.embed_dim, 1 + keep
+        Me = B * Ne
+        self._embed(imgs, noise, keep, w)
+        xs = w["xs"]
+        for i in range(cfg.depth):
+            if train:
+                self._block_fwd(xs[i], xs[i + 1], w["enc"][i], f"blocks.{i}", Me, D, cfg.num_heads, B, Ne)
+            else:
+                self._block_fwd(xs[i % 2], xs[(i + 1) % 2], w["enc"][0], f"blocks.{i}", Me, D, cfg.num_heads, B, Ne)
+        x_last = xs[cfg.depth] if train else xs[cfg.depth % 2]
+        ops.layernorm_fwd(x_last, st.param("norm.weight"), st.param("norm.bias"), w["lat_lp"], w["lat_mean"],
+                          w["lat_rstd"], Me, D, cfg.ln_eps, y32=w["latent32"])
+        return x_last
+
+    # ------------------------------------------------------------------ public forward paths
+    def _check_inputs(self, imgs, noise):
+        cfg = self.cfg
+        assert imgs.is_cuda and imgs.dtype == torch.float32 and imgs.is_contiguous()
+        B, C, H, W = imgs.shape
+        assert (C, H, W) == (cfg.in_chans, cfg.img_size, cfg.img_size), f"bad cutout shape {tuple(imgs.shape)}"
+        if noise is None:
+            noise = torch.rand(B, cfg.num_patches, device=imgs.device)  # utils/mim_vit.py:363
+        assert noise.shape == (B, cfg.num_patches) and noise.is_cuda and noise.dtype == torch.float32
+        return noise.contiguous()
+
+    def forward_features(self, imgs, mask_ratio=0.0, noise=None):
+        """utils/mim_vit.py:381-438 (MAE mode): -> (latent fp32 [B, 1+keep, D], mask [B,L], ids_restore [B,L])."""
+        cfg = self.cfg
+        noise = self._check_inputs(imgs, noise)
+        B = imgs.shape[0]
+        keep = int(cfg.num_patches * (1 - mask_ratio))
+        w = self._workspace(B, keep, False)
+        self._encoder_fwd(imgs, noise, keep, w, False)
+        return w["latent32"].view(B, 1 + keep, cfg.embed_dim), w["mask"], w["ids_restore"]
+
+    def forward_train(self, imgs, mask_ratio=0.75, noise=None):
+        """utils/mim_vit.py:552-559: -> (loss [1] device tensor, pred fp32 view [B, L, pv], mask [B, L]).
+        Activations are saved for :meth:`backward`."""
+        cfg, st = self.cfg, self.store
+        noise = self._check_inputs(imgs, noise)
+        B = imgs.shape[0]
+        L, D, Dd, pv = cfg.num_patches, cfg.embed_dim, cfg.decoder_embed_dim, cfg.patch_dim
+        keep = int(L * (1 - mask_ratio))
+        assert keep >= 1, "mask_ratio leaves no visible patch"
+        Ne, Nd = 1 + keep, 1 + L
+        Me, Md = B * Ne, B * Nd
+        w = self._workspace(B, keep, True)
+        self._encoder_fwd(imgs, noise, keep, w, True)
+        # ---- decoder (utils/mim_vit.py:440-467)
+        xd = w["xd"]
+        dpos = st.frozen["decoder_pos_embed"].view(-1, Dd)
+        ops.gemm(w["lat_lp"], st.lp("decoder_embed.weight"), M=Me, N=Dd, K=D, bias=st.param("decoder_embed.bias"),
+                 table=dpos, tab_row=w["dec_tab"], ldt=Dd, dst_row=w["dec_dst"], out_f32=xd[0], ldo32=Dd)
+        ops.fill_mask_tokens(xd[0], w["mask"], st.param("mask_token"), dpos, B, L, Dd)
+        for i in range(cfg.decoder_depth):
+            self._block_fwd(xd[i], xd[i + 1], w["dec"][i], f"decoder_blocks.{i}", Md, Dd, cfg.decoder_num_heads, B, Nd)
+        ops.layernorm_fwd(xd[-1], st.param("decoder_norm.weight"), st.param("decoder_norm.bias"), w["dlat_lp"],
+                          w["dlat_mean"], w["dlat_rstd"], Md, Dd, cfg.ln_eps)
+        ops.gemm(w["dlat_lp"], st.lp("decoder_pred.weight"), M=Md, N=pv, K=Dd, bias=st.param("decoder_pred.bias"),
+                 out_f32=w["pred"])
+        # ---- loss + d loss / d pred (utils/mim_vit.py:473-521)
+        ops.masked_patch_loss(imgs, w["pred"], w["mask"], w["loss"], w["dpred"], None, self.code, w["loss_ws"],
+                              cfg.patch_size, 1, cfg.pixel_mean, cfg.pixel_std, cfg.norm_pix_loss, cfg.loss_fn != "mse")
+        self._last = (imgs, B, keep)
+        return w["loss"], w["pred"][:, 1:, :], w["mask"]
+
+    # ------------------------------------------------------------------ backward
+    def _linear_bwd(self, dy, x_in, wname, bname, M, N, K, w, dx_out=None, dx_act=0, dx_aux=None):
+        """dy [M,N] (lp), x_in [M,K] (lp): dW[N,K] = dy^T x, db = colsum(dy), optional dx = dy W."""
+        st = self.store
+        # wgrad; the bias gradient (column sums of dy) rides along in the same launch
+        ops.gemm(dy, x_in, M=N, N=K, K=M, a_layout=RC, b_layout=RC, lda=N, ldb=K, out_f32=st.grad(wname),
+                 colsum_a=st.grad(bname))
+        if dx_out is not None:
+            ops.gemm(dy, st.lp(wname), M=M, N=K, K=N, a_layout=KC, b_layout=RC, lda=N, ldb=K, act=dx_act, aux=dx_aux,
+                     ldaux=K, out=dx_out)
+
+    def _ln_bwd(self, dy, x, prefix, mean, rstd, g_in, g, g_lp, M, dim, w):
+        st = self.store
+        nblk = ops.layernorm_bwd_blocks(M)
+        part = w["ln_part"][:2 * nblk * dim].view(2, nblk, dim)
+        ops.layernorm_bwd(dy, x, st.param(f"{prefix}.weight"), mean, rstd, g_in, g, g_lp, part,
+                          st.grad(f"{prefix}.weight"), st.grad(f"{prefix}.bias"), M, dim, self.code)
+
+    def _block_bwd(self, x_in, bufs, prefix, M, dim, heads, Bsz, N, g, g_lp, w):
+        """g / g_lp hold d(block output) on entry and d(block input) on exit."""
+        hd = dim // heads
+        hidden = bufs["hpre"].shape[1]
+        dh = w["dh"][:M * hidden].view(M, hidden)
+        dln = w["dln"][:M * dim].view(M, dim)
+        datt = w["datt"][:M * dim].view(M, dim)
+        dqkv = w["dqkv"][:3 * M * dim].view(M, 3 * dim)
+        # MLP: x_out = xmid + fc2(gelu(fc1(ln2(xmid))))
+        self._linear_bwd(g_lp, bufs["hact"], f"{prefix}.mlp.fc2.weight", f"{prefix}.mlp.fc2.bias", M, dim, hidden, w,
+                         dx_out=dh, dx_act=ACT_DGELU, dx_aux=bufs["hpre"])
+        self._linear_bwd(dh, bufs["ln2"], f"{prefix}.mlp.fc1.weight", f"{prefix}.mlp.fc1.bias", M, hidden, dim, w,
+                         dx_out=dln)
+        self._ln_bwd(dln, bufs["xmid"], f"{prefix}.norm2", bufs["mean2"], bufs["rstd2"], g, g, g_lp, M, dim, w)
+        # attention: xmid = x_in + proj(mha(qkv(ln1(x_in))))
+        self._linear_bwd(g_lp, bufs["att"], f"{prefix}.attn.proj.weight", f"{prefix}.attn.proj.bias", M, dim, dim, w,
+                         dx_out=datt)
+        ops.mha_bwd(bufs["qkv"], datt, dqkv, Bsz, N, heads, hd)
+        self._linear_bwd(dqkv, bufs["ln1"], f"{prefix}.attn.qkv.weight", f"{prefix}.attn.qkv.bias", M, 3 * dim, dim, w,
+                         dx_out=dln)
+        self._ln_bwd(dln, x_in, f"{prefix}.norm1", bufs["mean1"], bufs["rstd1"], g, g, g_lp, M, dim, w)
+
+    def backward(self):
+        """Gradients of the last :meth:`forward_train` loss into the flat ``g`` buffer (every
+        trainable tensor is written exactly once, so no zeroing pass is needed)."""
+        assert self._last is not None, "backward() without forward_train()"
+        imgs, B, keep = self._last
+        cfg, st = self.cfg, self.store
+        L, D, Dd, pv = cfg.num_patches, cfg.embed_dim, cfg.decoder_embed_dim, cfg.patch_dim
+        Ne, Nd = 1 + keep, 1 + L
+        Me, Md = B * Ne, B * Nd
+        w = self._ws[(B, keep, True)]
+        # ---- decoder_pred, decoder_norm
+        dln = w["dln"][:Md * Dd].view(Md, Dd)
+        self._linear_bwd(w["dpred"], w["dlat_lp"], "decoder_pred.weight", "decoder_pred.bias", Md, pv, Dd, w, dx_out=dln)
+        g = w["g"][:Md * Dd].view(Md, Dd)
+        g_lp = w["g_lp"][:Md * Dd].view(Md, Dd)
+        self._ln_bwd(dln, w["xd"][-1], "decoder_norm", w["dlat_mean"], w["dlat_rstd"], None, g, g_lp, Md, Dd, w)
+        for i in reversed(range(cfg.decoder_depth)):
+            self._block_bwd(w["xd"][i], w["dec"][i], f"decoder_blocks.{i}", Md, Dd, cfg.decoder_num_heads, B, Nd, g,
+                            g_lp, w)
+        # ---- mask token, decoder_embed (g = d xd[0])
+        ops.rowsum_select(g, Dd, w["mask"], 1, L, Nd, B * L, Dd, w["rs_part"], st.grad("mask_token").view(Dd))
+        ops.gather_rows(g, w["dec_dst"], None, w["dE"], Me, Dd)
+        dln_e = w["dln"][:Me * D].view(Me, D)
+        self._linear_bwd(w["dE"], w["lat_lp"], "decoder_embed.weight", "decoder_embed.bias", Me, Dd, D, w, dx_out=dln_e)
+        # ---- encoder
+        g = w["g"][:Me * D].view(Me, D)
+        g_lp = w["g_lp"][:Me * D].view(Me, D)
+        self._ln_bwd(dln_e, w["xs"][cfg.depth], "norm", w["lat_mean"], w["lat_rstd"], None, g, g_lp, Me, D, w)
+        for i in reversed(range(cfg.depth)):
+            self._block_bwd(w["xs"][i], w["enc"][i], f"blocks.{i}", Me, D, cfg.num_heads, B, Ne, g, g_lp, w)
+        # ---- cls token, patch embedding, patch_mask_values (g = d xs[0])
+        ops.rowsum_select(g, D, None, 0, 1, Ne, B, D, w["rs_part"], st.grad("cls_token").view(D))
+        ops.gather_rows(g, w["pe_dst"], None, w["dT"], B * keep, D)
+        ops.gemm(w["dT"], w["patches"], M=D, N=pv, K=B * keep, a_layout=RC, b_layout=RC, lda=D, ldb=pv,
+                 out_f32=st.grad("patch_embed.proj.weight"), colsum_a=st.grad("patch_embed.proj.bias"))
+        ops.gemm(w["dT"], st.lp("patch_embed.proj.weight"), M=B * keep, N=pv, K=D, a_layout=KC, b_layout=RC, lda=D,
+                 ldb=pv, out_f32=w["drows"])
+        ops.patch_gather_bwd_pmv(imgs, w["ids_keep"], w["drows"], w["pmv_part"], st.grad("patch_mask_values"),
+                                 cfg.patch_size, keep)
+
+    # ------------------------------------------------------------------ accounting
+    def flops_per_image(self, mask_ratio=0.75):
+        """(executed, reference-algorithmic) forward+backward FLOPs per image, 3x-forward
+        convention of SURVEY.md §8: the reference embeds all L patches before masking, the
+        build only the kept ones (identical results)."""
+        cfg = self.cfg
+        L, D, Dd, pv = cfg.num_patches, cfg.embed_dim, cfg.decoder_embed_dim, cfg.patch_dim
+        keep = int(L * (1 - mask_ratio))
+        Ne, Nd = 1 + keep, 1 + L
+        r = cfg.mlp_ratio
+
+        def blocks(n, d, depth, heads):
+            lin = 2 * n * d * (3 * d + d + 2 * r * d)
+            att = 2 * 2 * n * n * d
+            return depth * (lin + att)
+        common = blocks(Ne, D, cfg.depth, cfg.num_heads) + 2 * Ne * D * Dd + blocks(Nd, Dd, cfg.decoder_depth,
+                                                                                  cfg.decoder_num_heads) + 2 * Nd * Dd * pv
+        executed = 3 * (common + 2 * keep * pv * D)
+        algorithmic = 3 * (common + 2 * L * pv * D)
+        return executed, algorithmic

@@ -36,7 +36,7 @@ def _p(t):
 
 def gemm(A, B, *, M, N, K, a_layout=KC, b_layout=KC, lda=None, ldb=None, alpha=1.0, bias=None, table=None,
          tab_row=None, ldt=0, dst_row=None, resid=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, out_f32=None, ldo32=0,
-         out=None, ldo=0, out2=None, ldo2=0, tile=0):
+         out=None, ldo=0, out2=None, ldo2=0, tile=0, colsum_a=None):
     """C[M,N] = alpha * A[M,K] B[N,K]^T with fused epilogue (see include/skyemb.h)."""
     g = GemmArgs()
     g.A, g.B = _p(A), _p(B)
@@ -51,6 +51,7 @@ def gemm(A, B, *, M, N, K, a_layout=KC, b_layout=KC, lda=None, ldb=None, alpha=1
     g.resid, g.ldr, g.aux, g.ldaux, g.act = _p(resid), ldr, _p(aux), ldaux, act
     g.out_f32, g.ldo32, g.out, g.ldo, g.out2, g.ldo2 = _p(out_f32), ldo32 or N, _p(out), ldo or N, _p(out2), ldo2 or N
     g.tile = tile
+    g.colsum_a = _p(colsum_a)
     check(lib().skyemb_gemm(ctypes.byref(g), _stream()), "skyemb_gemm")
 
 
@@ -87,10 +88,10 @@ def layernorm_bwd_blocks(M):
     return lib().skyemb_layernorm_bwd_blocks(M)
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, g_in, g_out, g_lp, part, M, D, dtype):
+def layernorm_bwd(dy, x, gamma, mean, rstd, g_in, g_out, g_lp, part, dgamma, dbeta, M, D, dtype):
     dy_f32 = 1 if (dy.dtype == torch.float32 and dtype == BF16) else 0
     check(lib().skyemb_layernorm_bwd(_p(dy), dy_f32, dtype, _p(x), _p(gamma), _p(mean), _p(rstd), _p(g_in), _p(g_out),
-                                     _p(g_lp), _p(part), M, D, _stream()), "skyemb_layernorm_bwd")
+                                     _p(g_lp), _p(part), _p(dgamma), _p(dbeta), M, D, _stream()), "skyemb_layernorm_bwd")
 
 
 def mha_fwd(qkv, out, B, N, H, hd):
@@ -126,10 +127,12 @@ def masked_patch_loss(imgs, pred, mask, loss, dpred, dpred32, dtype, ws, p, extr
                                          _stream()), "skyemb_masked_patch_loss")
 
 
-def adamw(p, g, m, v, p_lp, n, n_decay, hyper, beta1, beta2, eps, wd, grad_scale=1.0, zero_grad=False):
+def adamw(p, g, m, v, p_lp, n, n_decay, hyper, beta1, beta2, eps, wd, grad_scale=1.0, zero_grad=False, lr=0.0, bc1=1.0,
+          bc2=1.0):
+    """hyper: device fp32[4] {lr, 1-b1^t, 1-b2^t} (graph-safe) or None to pass lr/bc1/bc2 by value."""
     code = dtype_code(p_lp.dtype) if p_lp is not None else F32
-    check(lib().skyemb_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_lp), code, n, n_decay, _p(hyper), beta1, beta2, eps, wd,
-                             grad_scale, int(zero_grad), _stream()), "skyemb_adamw")
+    check(lib().skyemb_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_lp), code, n, n_decay, _p(hyper), lr, bc1, bc2, beta1,
+                             beta2, eps, wd, grad_scale, int(zero_grad), _stream()), "skyemb_adamw")
 
 
 def cast(src, dst, n):

@@ -1,0 +1,141 @@
+"""Optimiser + schedule of the pretraining path (utils/mim_vit.py:119-144) on the flat buffers.
+
+``FusedAdamW`` = torch.optim.AdamW(param_groups_weight_decay(model, wd), lr, betas=(0.9, 0.95))
+as ONE kernel launch over the engine's flat parameter buffer; ``CosineLR`` =
+torch.optim.lr_scheduler.CosineAnnealingLR(T_max, eta_min) in closed form.  Both expose
+``step / zero_grad / state_dict / load_state_dict`` with torch-compatible state layouts so that
+checkpoints written by either implementation load in the other.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+class FusedAdamW:
+    def __init__(self, engine, lr=1e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05, process_group=None):
+        self.engine = engine
+        self.store = engine.store
+        self.defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
+        # group order == timm param_groups_weight_decay: [no_decay (wd 0), decay (wd)]
+        self.param_groups = [dict(lr=lr, initial_lr=lr, betas=tuple(betas), eps=eps, weight_decay=0.0),
+                             dict(lr=lr, initial_lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)]
+        self.step_count = 0
+        self.grad_scale = 1.0
+        # graph mode: step scalars live in device memory (kernel arguments are frozen in a HIP graph)
+        self.hyper_device = None
+        self.process_group = process_group
+
+    @property
+    def lr(self):
+        return self.param_groups[0]["lr"]
+
+    def set_lr(self, lr):
+        for g in self.param_groups:
+            g["lr"] = lr
+
+    def zero_grad(self, set_to_none=True):
+        # every gradient is overwritten by the next backward(); nothing to clear
+        return None
+
+    def step(self):
+        self.step_count += 1
+        b1, b2 = self.defaults["betas"]
+        t = self.step_count
+        st = self.store
+        ops.adamw(st.p, st.g, st.m, st.v, st.p_lp, st.n, st.n_decay, self.hyper_device, b1, b2, self.defaults["eps"],
+                  self.param_groups[1]["weight_decay"], grad_scale=self.grad_scale, zero_grad=False, lr=self.lr,
+                  bc1=1.0 - b1 ** t, bc2=1.0 - b2 ** t)
+
+    def step_scalars(self, t=None):
+        """(lr, 1-b1^t, 1-b2^t) of optimiser step t (default: the next one) for graph-mode callers."""
+        b1, b2 = self.defaults["betas"]
+        t = self.step_count + 1 if t is None else t
+        return self.lr, 1.0 - b1 ** t, 1.0 - b2 ** t
+
+    # ---- torch.optim.AdamW-compatible (de)serialisation --------------------------------------
+    def _index(self):
+        st = self.store
+        return list(st.no_decay) + list(st.decay)
+
+    def state_dict(self):
+        st = self.store
+        names = self._index()
+        state = {}
+        if self.step_count > 0:
+            for i, n in enumerate(names):
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": st._view(st.m, n).detach().clone(),
+                            "exp_avg_sq": st._view(st.v, n).detach().clone()}
+        nd = len(st.no_decay)
+        groups = []
+        for gi, ids in enumerate((list(range(nd)), list(range(nd, len(names))))):
+            g = dict(self.param_groups[gi])
+            g.update(amsgrad=False, foreach=None, maximize=False, capturable=False, differentiable=False, fused=None,
+                     params=ids)
+            groups.append(g)
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        st = self.store
+        names = self._index()
+        groups = sd["param_groups"]
+        assert sum(len(g["params"]) for g in groups) == len(names), "optimizer state does not match this model"
+        for g_new, g_old in zip(self.param_groups, groups):
+            for k in ("lr", "initial_lr", "weight_decay", "eps"):
+                if k in g_old:
+                    g_new[k] = g_old[k]
+            if "betas" in g_old:
+                g_new["betas"] = tuple(g_old["betas"])
+        self.defaults["betas"] = self.param_groups[0]["betas"]
+        steps = set()
+        for i, n in enumerate(names):
+            s = sd["state"].get(i)
+            if s is None:
+                continue
+            st._view(st.m, n).copy_(s["exp_avg"].to(torch.float32))
+            st._view(st.v, n).copy_(s["exp_avg_sq"].to(torch.float32))
+            steps.add(int(float(s["step"])))
+        assert len(steps) <= 1, "per-parameter step counts differ; unsupported"
+        self.step_count = steps.pop() if steps else 0
+
+
+class CosineLR:
+    """CosineAnnealingLR(optimizer, T_max, eta_min) (utils/mim_vit.py:142-144)."""
+
+    def __init__(self, optimizer, T_max, eta_min=0.0):
+        self.optimizer = optimizer
+        self.T_max = int(T_max)
+        self.eta_min = float(eta_min)
+        self.base_lr = float(optimizer.param_groups[0].get("initial_lr", optimizer.lr))
+        self.last_epoch = 0
+        self._apply()
+
+    def _lr_at(self, t):
+        return self.eta_min + (self.base_lr - self.eta_min) * (1 + math.cos(math.pi * t / self.T_max)) / 2
+
+    def _apply(self):
+        self.optimizer.set_lr(self._lr_at(self.last_epoch))
+
+    def step(self):
+        self.last_epoch += 1
+        self._apply()
+
+    def get_last_lr(self):
+        return [self.optimizer.lr for _ in self.optimizer.param_groups]
+
+    def state_dict(self):
+        return {"T_max": self.T_max, "eta_min": self.eta_min, "base_lrs": [self.base_lr] * 2,
+                "last_epoch": self.last_epoch, "_step_count": self.last_epoch + 1, "_last_lr": self.get_last_lr()}
+
+    def load_state_dict(self, sd):
+        self.T_max = int(sd.get("T_max", self.T_max))
+        self.eta_min = float(sd.get("eta_min", self.eta_min))
+        if "base_lrs" in sd:
+            self.base_lr = float(sd["base_lrs"][0])
+        self.last_epoch = int(sd["last_epoch"])
+        self._apply()

@@ -1,0 +1,82 @@
+"""Batched weighted-cosine top-k over an embedding bank resident in HBM.
+
+Build-level formulation of the reference search (utils/similarity.py: one mean target vector +
+inverse-variance weights scored against streamed batches, best ``n_save`` kept by cat+argsort):
+``cosine_topk(queries[Q,D], bank[N,D], k, weights)`` returns the exact top-k (score desc, index
+asc) per query; Q = 1 with ``weights`` reproduces ``compute_similarity(metric='cosine')`` +
+``update_best_scores``.  Multi-GPU: the bank is sharded by rows (one process per GPU), every rank
+scores its shard, the per-rank [Q,k] results are all-gathered over RCCL and merged with the same
+order, so the result is identical to the single-GPU one.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class PreparedBank:
+    """Bank rows + their weighted norms (recomputed only when the weights change)."""
+
+    def __init__(self, bank: torch.Tensor, weights: torch.Tensor | None = None, idx_offset: int = 0):
+        assert bank.is_cuda and bank.dtype == torch.float32 and bank.is_contiguous() and bank.dim() == 2
+        self.bank, self.idx_offset = bank, int(idx_offset)
+        self.norms = torch.empty(bank.shape[0], device=bank.device)
+        self.set_weights(weights)
+
+    def set_weights(self, weights):
+        self.weights = None if weights is None else weights.to(self.bank.device, torch.float32).contiguous()
+        ops.weighted_norms(self.bank, self.weights, self.norms)
+
+
+def standardise_(bank: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, out: torch.Tensor | None = None):
+    """(x - mean) / (std + 1e-8) row-wise (utils/similarity.py:101-102); in place by default."""
+    out = bank if out is None else out
+    ops.standardise(bank, mean.contiguous(), std.contiguous(), out)
+    return out
+
+
+def prepare_queries(queries: torch.Tensor, weights: torch.Tensor | None):
+    Q, D = queries.shape
+    tw = torch.empty(Q, D, device=queries.device)
+    qn = torch.empty(Q, device=queries.device)
+    ops.weighted_norms(queries.contiguous(), weights, qn, tw)
+    return tw, qn
+
+
+def cosine_topk(queries: torch.Tensor, bank, k: int, weights: torch.Tensor | None = None, eps: float = 1e-6,
+                process_group=None, world_size: int = 1):
+    """-> (scores f32 [Q,k], indices i64 [Q,k]).  ``bank`` is a [N,D] tensor or a PreparedBank
+    (this rank's shard; ``idx_offset`` = first global row of the shard)."""
+    pb = bank if isinstance(bank, PreparedBank) else PreparedBank(bank, weights)
+    q = queries.to(pb.bank.device, torch.float32).contiguous()
+    Q, D = q.shape
+    N = pb.bank.shape[0]
+    assert D == pb.bank.shape[1]
+    tw, qn = prepare_queries(q, pb.weights)
+    nch = ops.cosine_topk_chunks(N, Q, k)
+    dev = q.device
+    ps = torch.empty(Q, nch, k, device=dev)
+    pi = torch.empty(Q, nch, k, device=dev, dtype=torch.int64)
+    ops.cosine_topk(tw, qn, pb.bank, pb.norms, k, eps, pb.idx_offset, nch, ps, pi)
+    out_s = torch.empty(Q, k, device=dev)
+    out_i = torch.empty(Q, k, device=dev, dtype=torch.int64)
+    ops.topk_merge(ps, pi, Q, nch, k, out_s, out_i)
+    if world_size > 1:
+        gs = torch.empty(world_size, Q, k, device=dev)
+        gi = torch.empty(world_size, Q, k, device=dev, dtype=torch.int64)
+        torch.distributed.all_gather_into_tensor(gs, out_s, group=process_group)
+        torch.distributed.all_gather_into_tensor(gi, out_i, group=process_group)
+        gs, gi = gs.permute(1, 0, 2).contiguous(), gi.permute(1, 0, 2).contiguous()
+        ops.topk_merge(gs, gi, Q, world_size, k, out_s, out_i)
+    return out_s, out_i
+
+
+def cosine_scores(queries: torch.Tensor, bank, weights: torch.Tensor | None = None, eps: float = 1e-6):
+    """Plain [Q,N] score matrix (reference-shaped path with several patches per sample)."""
+    pb = bank if isinstance(bank, PreparedBank) else PreparedBank(bank, weights)
+    q = queries.to(pb.bank.device, torch.float32).contiguous()
+    tw, qn = prepare_queries(q, pb.weights)
+    out = torch.empty(q.shape[0], pb.bank.shape[0], device=q.device)
+    ops.cosine_scores(tw, qn, pb.bank, pb.norms, eps, out)
+    return out

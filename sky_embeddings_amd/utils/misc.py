@@ -1,0 +1,49 @@
+"""utils/misc.py mirror (only what the hot path uses: SURVEY.md §2 row 8)."""
+import argparse
+
+import numpy as np
+
+
+def str2bool(v):
+    """utils/misc.py:6-7."""
+    return str(v).lower() in ("yes", "true", "t", "1")
+
+
+def parseArguments():
+    """utils/misc.py:9-33: ``model_name [-v N] [-ct MIN] [-dd DIR]``."""
+    parser = argparse.ArgumentParser('Training for Masked Image Modelling', add_help=False)
+    parser.add_argument("model_name", help="Name of model.", type=str)
+    parser.add_argument("-v", "--verbose_iters",
+                        help="Number of batch  iters after which to evaluate val set and display output.",
+                        type=int, default=10000)
+    parser.add_argument("-ct", "--cp_time", help="Number of minutes after which to save a checkpoint.",
+                        type=float, default=15)
+    parser.add_argument("-dd", "--data_dir", help="Data directory if different from sky_embeddings/data/",
+                        type=str, default=None)
+    return parser
+
+
+def calculate_snr(images, n_central_pix):
+    """utils/misc.py:138-163: mean of the central n x n region over the std of the rest, per channel."""
+    batch_size, n_channels, img_size, _ = images.shape
+    start = (img_size - n_central_pix) // 2
+    end = start + n_central_pix
+    central = images[:, :, start:end, start:end]
+    mask = np.ones((img_size, img_size), dtype=bool)
+    mask[start:end, start:end] = False
+    surround = images[:, :, mask].reshape(batch_size, n_channels, -1)
+    return np.mean(central, axis=(2, 3)) / (np.std(surround, axis=2) + 1e-8)
+
+
+def h5_snr(h5_path, n_central_pix=8, batch_size=5000, num_samples=None):
+    """utils/misc.py:165-180, reading through this package's HDF5 access layer."""
+    from .dataloaders import open_h5
+    snr_vals = []
+    with open_h5(h5_path) as f:
+        cut = f['cutouts']
+        if num_samples is None:
+            num_samples = len(cut)
+        for i in range(0, num_samples, batch_size):
+            end = min(num_samples, i + batch_size)
+            snr_vals.append(calculate_snr(np.asarray(cut[i:end]), n_central_pix))
+    return np.concatenate(snr_vals)

@@ -61,8 +61,11 @@ def test_gemm_layouts(ops, dtype, layouts, tile, shape):
     Ad = dev(A.T.contiguous() if a_l else A, dtype)
     Bd = dev(B.T.contiguous() if b_l else B, dtype)
     out = torch.full((M, N), float("nan"), device=DEV)
-    ops.gemm(Ad, Bd, M=M, N=N, K=K, a_layout=a_l, b_layout=b_l, out_f32=out, tile=tile)
+    cs = torch.full((M,), float("nan"), device=DEV) if a_l else None  # fused bias-gradient column sum
+    ops.gemm(Ad, Bd, M=M, N=N, K=K, a_layout=a_l, b_layout=b_l, out_f32=out, tile=tile, colsum_a=cs)
     torch.cuda.synchronize()
+    if cs is not None:
+        assert float((cs.cpu().double() - Ar.double().sum(1)).abs().max()) <= 1e-5 * float(Ar.abs().sum(1).max())
     scale = float((Ar.abs().double() @ Br.abs().double().T).max())
     assert float((out.cpu().double() - ref).abs().max()) <= 2e-6 * scale, (dtype, layouts, tile, shape)
 
@@ -134,10 +137,8 @@ def test_layernorm(ops, dtype, shape):
     g_out = dev(g_in.clone())
     g_lp = torch.empty(M, D, device=DEV, dtype=dtype)
     code = ops.dtype_code(dtype)
-    ops.layernorm_bwd(dev(dy, dtype), dev(x), dev(gamma), mean, rstd, g_out, g_out, g_lp, part, M, D, code)
     dgam, dbet = torch.empty(D, device=DEV), torch.empty(D, device=DEV)
-    ops.colsum(part[0], nblk, D, dgam)
-    ops.colsum(part[1], nblk, D, dbet)
+    ops.layernorm_bwd(dev(dy, dtype), dev(x), dev(gamma), mean, rstd, g_out, g_out, g_lp, part, dgam, dbet, M, D, code)
     assert relerr(g_out, g_in + xr.grad) < 5e-6
     assert relerr(g_lp.float(), g_in + xr.grad) < (5e-3 if dtype == torch.bfloat16 else 5e-6)
     assert relerr(dgam, gr.grad) < 1e-5 and relerr(dbet, br.grad) < 1e-5
@@ -297,8 +298,12 @@ def test_adamw(ops, dtype):
     pd, gd, md, vd = dev(p.clone()), dev(gr.clone()), dev(m.clone()), dev(v.clone())
     plp = torch.empty(n, device=DEV, dtype=dtype)
     step, lr, wd = 3, 1e-3, 0.05
-    hyper = dev(torch.tensor([lr, 1 - 0.9 ** step, 1 - 0.95 ** step, 0.0]))
-    ops.adamw(pd, gd, md, vd, plp, n, n_decay, hyper, 0.9, 0.95, 1e-8, wd, grad_scale=0.5, zero_grad=True)
+    if dtype == torch.float32:  # step scalars from device memory (graph mode) ...
+        hyper = dev(torch.tensor([lr, 1 - 0.9 ** step, 1 - 0.95 ** step, 0.0]))
+        ops.adamw(pd, gd, md, vd, plp, n, n_decay, hyper, 0.9, 0.95, 1e-8, wd, grad_scale=0.5, zero_grad=True)
+    else:  # ... or by value
+        ops.adamw(pd, gd, md, vd, plp, n, n_decay, None, 0.9, 0.95, 1e-8, wd, grad_scale=0.5, zero_grad=True, lr=lr,
+                  bc1=1 - 0.9 ** step, bc2=1 - 0.95 ** step)
     pr, mr, vr = p.clone(), m.clone(), v.clone()
     mo.adamw_step(pr[:n_decay], gr[:n_decay] * 0.5, mr[:n_decay], vr[:n_decay], step, lr, wd)
     mo.adamw_step(pr[n_decay:], gr[n_decay:] * 0.5, mr[n_decay:], vr[n_decay:], step, lr, 0.0)

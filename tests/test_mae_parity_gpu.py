@@ -1,0 +1,158 @@
+"""GPU: end-to-end MAE forward / backward / optimiser parity of the HIP path (through the C ABI)
+against (i) the golden vectors captured from the reference and (ii) the CPU oracle.
+
+Tolerances (north_star: loss and reconstructed pixels within 1e-3 relative fp32):
+  * f32 parity mode (exact-fp32 MFMA): loss 2e-5 rel, pred 2e-5 rel-L2, gradients 2e-4 of the
+    tensor's max -- i.e. well inside 1e-3;
+  * bf16 throughput mode: loss 1e-2 rel, pred 3e-2 rel-L2 (bf16 operands, fp32 accumulation).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mae_oracle as mo
+from tests.helpers import load_case, rel_err
+
+CASES = ["mae_tiny_A", "mae_tiny_B_nan", "mae_tiny_C_nonorm", "mae_tiny_D_l1", "mae_tiny_E_p8"]
+
+
+def make_engine(cfg, state, dtype):
+    from sky_embeddings_amd.engine import MAEEngine
+    from sky_embeddings_amd.model_config import MAEConfig
+    c = MAEConfig(img_size=cfg.img_size, patch_size=cfg.patch_size, in_chans=cfg.in_chans, embed_dim=cfg.embed_dim,
+                  depth=cfg.depth, num_heads=cfg.num_heads, decoder_embed_dim=cfg.decoder_embed_dim,
+                  decoder_depth=cfg.decoder_depth, decoder_num_heads=cfg.decoder_num_heads, norm_pix_loss=cfg.norm_pix_loss,
+                  loss_fn=cfg.loss_fn, pixel_mean=cfg.pixel_mean, pixel_std=cfg.pixel_std)
+    eng = MAEEngine(c, device="cuda", compute_dtype=dtype, seed=0)
+    eng.load_state_dict(state)
+    return eng
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_forward_backward_vs_reference_goldens(name, dtype):
+    z, cfg, st = load_case(name)
+    eng = make_engine(cfg, st, dtype)
+    imgs = torch.from_numpy(z["imgs"]).cuda()
+    noise = torch.from_numpy(z["noise"]).cuda()
+    ratio = float(z["mask_ratio"])
+    loss, pred, mask = eng.forward_train(imgs, ratio, noise)
+    eng.backward()
+    torch.cuda.synchronize()
+    # integer / index work: bit exact
+    assert np.array_equal(mask.cpu().numpy(), z["mask"])
+    assert np.array_equal(eng._ws[(imgs.shape[0], int(cfg.num_patches * (1 - ratio)), True)]["ids_restore"].cpu().numpy(),
+                          z["ids_restore"])
+    f32 = dtype == torch.float32
+    assert abs(float(loss) - float(z["loss"])) <= (2e-5 if f32 else 1e-2) * abs(float(z["loss"]))
+    assert rel_err(pred.cpu().numpy(), z["pred"]) < (2e-5 if f32 else 3e-2)
+    # gradients: reference goldens where they are finite, else the oracle's nan-safe gradients
+    nan_in = bool(np.isnan(z["imgs"]).any())
+    if nan_in:
+        _, _, _, _, _, ref = mo.loss_and_grads(st, torch.from_numpy(z["imgs"]), cfg, ratio, torch.from_numpy(z["noise"]),
+                                               nan_safe=True)
+        ref = {k: v.numpy() for k, v in ref.items()}
+    else:
+        ref = {k[len("grad/"):]: z[k] for k in z.files if k.startswith("grad/")}
+    for k, r in ref.items():
+        g = eng.store.grad(k).cpu().numpy()
+        assert np.isfinite(g).all(), k
+        scale = max(float(np.abs(r).max()), 1e-6)
+        tol = (2e-4 if f32 else 6e-2) * scale
+        if not f32:  # bf16: judge by relative L2 of the tensor (elementwise bf16 noise is expected)
+            assert rel_err(g, r) < 8e-2 or float(np.abs(g - r).max()) < tol, k
+        else:
+            assert float(np.abs(g - r).max()) <= tol, (k, float(np.abs(g - r).max()), scale)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_encoder_only_path(dtype):
+    z, cfg, st = load_case("mae_tiny_A")
+    eng = make_engine(cfg, st, dtype)
+    imgs, noise = torch.from_numpy(z["imgs"]).cuda(), torch.from_numpy(z["noise"]).cuda()
+    lat, mask, ids = eng.forward_features(imgs, 0.0, noise)
+    assert np.array_equal(ids.cpu().numpy(), z["ids_restore_full"])
+    assert rel_err(lat.cpu().numpy(), z["latent_full"]) < (2e-5 if dtype == torch.float32 else 2e-2)
+
+
+def test_adamw_cosine_training_steps_match_reference():
+    """Three run_iter steps (forward, backward, AdamW, cosine LR) through the public mirror API."""
+    from sky_embeddings_amd.optim import CosineLR, FusedAdamW
+    from sky_embeddings_amd.utils.pretrain_fns import run_iter
+    z, cfg, st = load_case("mae_tiny_A")
+    init_lr, wd, total, flf = [float(v) for v in z["opt_hparams"]]
+    from sky_embeddings_amd.utils.mim_vit import MaskedAutoencoderViT, _DataParallelShim
+    m = MaskedAutoencoderViT(img_size=cfg.img_size, patch_size=cfg.patch_size, in_chans=cfg.in_chans,
+                             embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads,
+                             decoder_embed_dim=cfg.decoder_embed_dim, decoder_depth=cfg.decoder_depth,
+                             decoder_num_heads=cfg.decoder_num_heads, norm_pix_loss=cfg.norm_pix_loss, loss_fn=cfg.loss_fn,
+                             pixel_mean=cfg.pixel_mean, pixel_std=cfg.pixel_std, compute_dtype=torch.float32)
+    m.load_state_dict(st)
+    model = _DataParallelShim(m)
+    opt = FusedAdamW(m.engine, lr=init_lr, betas=(0.9, 0.95), weight_decay=wd)
+    sched = CosineLR(opt, int(total), eta_min=init_lr / flf)
+    imgs = torch.from_numpy(z["imgs"]).cuda()
+    from collections import defaultdict
+    losses = defaultdict(list)
+    for it in range(3):
+        assert abs(opt.lr - float(z["step_lrs"][it])) <= 1e-12 * init_lr
+        noise = torch.from_numpy(z["step_noises"][it]).cuda()
+        # run_iter has no noise argument (reference signature): inject through the engine hook
+        m.forward_noise = noise
+        loss, _, _ = model(imgs, mask_ratio=float(z["mask_ratio"]), noise=noise)
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        sched.step()
+        assert abs(float(loss) - float(z["step_losses"][it])) <= 2e-5 * abs(float(z["step_losses"][it])), it
+        if it in (0, 2):
+            sd = m.state_dict()
+            for k in opt.store.order:
+                ref = z[f"state_after{it + 1}/{k}"]
+                # Adam's first steps move every element by ~lr * sign(g): elements whose gradient is rounding
+                # noise may differ by a fraction of lr (see tests/test_oracle_golden.py)
+                tol = 5e-6 * max(float(np.abs(ref).max()), 1e-3) + 2e-2 * init_lr
+                assert float(np.abs(sd[k].cpu().numpy() - ref).max()) <= tol, (it, k)
+    # run_iter itself (random noise): loss decreases and the bookkeeping matches the reference's
+    model2, opt2, sched2, losses = run_iter(model, imgs, None, None, float(z["mask_ratio"]), opt, sched, losses, 'train')
+    assert len(losses['train_loss']) == 1 and opt.step_count == 4 and sched.last_epoch == 4
+    run_iter(model, imgs, None, None, float(z["mask_ratio"]), opt, sched, losses, 'val')
+    assert len(losses['val_loss']) == 1 and opt.step_count == 4
+    # optimizer / scheduler state round trip in torch's layout
+    sd = opt.state_dict()
+    assert len(sd["state"]) == len(opt.store.order) and len(sd["param_groups"]) == 2
+    assert sd["param_groups"][0]["weight_decay"] == 0.0 and sd["param_groups"][1]["weight_decay"] == wd
+    opt3 = FusedAdamW(m.engine, lr=init_lr, weight_decay=wd)
+    m_before = opt.store.m.clone()
+    opt.store.m.zero_()
+    opt3.load_state_dict(sd)
+    assert opt3.step_count == 4 and torch.equal(opt.store.m, m_before)
+
+
+def test_full_size_config_a_against_oracle():
+    """BASELINE config A (MAE ViT-B/16, 5x64x64, mask 0.75) at B=8: f32 mode vs the CPU oracle."""
+    from sky_embeddings_amd.engine import MAEEngine
+    from sky_embeddings_amd.model_config import config_for
+    cfg_o = mo.config_for("base", patch_size=16, in_chans=5, img_size=64, embed_dim=768)
+    st = mo.init_state(cfg_o, seed=0)
+    g = torch.Generator().manual_seed(1234)
+    B = 8
+    imgs = torch.randn(B, 5, 64, 64, generator=g).clamp_(min=-3.0)
+    noise = torch.rand(B, 16, generator=g)
+    loss_o, pred_o, mask_o, _, _, grads_o = mo.loss_and_grads(st, imgs, cfg_o, 0.75, noise)
+    for dtype, ltol, ptol in ((torch.float32, 2e-5, 5e-5), (torch.bfloat16, 1e-2, 4e-2)):
+        eng = MAEEngine(config_for("base", patch_size=16, in_chans=5, img_size=64, embed_dim=768), compute_dtype=dtype, seed=0)
+        eng.load_state_dict(st)
+        loss, pred, mask = eng.forward_train(imgs.cuda(), 0.75, noise.cuda())
+        eng.backward()
+        assert torch.equal(mask.cpu(), mask_o)
+        assert abs(float(loss) - float(loss_o)) <= ltol * float(loss_o), (dtype, float(loss), float(loss_o))
+        assert rel_err(pred.cpu().numpy(), pred_o.numpy()) < ptol
+        for k in ("decoder_pred.weight", "blocks.0.attn.qkv.weight", "blocks.11.mlp.fc1.weight", "patch_embed.proj.weight",
+                  "cls_token", "mask_token", "norm.weight", "decoder_blocks.3.norm1.bias", "decoder_embed.weight"):
+            r = rel_err(eng.store.grad(k).cpu().numpy(), grads_o[k].numpy())
+            assert r < (3e-4 if dtype == torch.float32 else 1e-1), (dtype, k, r)
+        del eng
+        torch.cuda.empty_cache()
