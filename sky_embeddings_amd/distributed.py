@@ -1,0 +1,100 @@
+"""One process per GPU over RCCL/xGMI (torch.distributed backend "nccl" is RCCL on ROCm).
+
+Replaces the reference's single-process ``nn.DataParallel`` (utils/mim_vit.py:117): weights are
+replicated, each rank trains on its own shard of the minibatch stream, gradients are averaged with
+an all-reduce of the engine's flat gradient buffer (bucketed contiguous slices), AdamW runs
+replicated.  With equal shard sizes this equals DataParallel's mean of per-replica losses
+(SURVEY.md §8e).  The host logic here is backend-agnostic so it is covered by gloo tests on CPU.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str | None = None):
+    """-> (rank, world, local_rank).  No-op single process when WORLD_SIZE is unset / 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    return rank, world, local
+
+
+def bucket_bounds(n: int, bucket_elems: int):
+    """Contiguous [start, end) slices of a flat buffer, each a multiple of 8 elements except the last."""
+    bucket_elems = max(8, bucket_elems // 8 * 8)
+    return [(s, min(n, s + bucket_elems)) for s in range(0, n, bucket_elems)]
+
+
+def allreduce_flat_gradients(g: torch.Tensor, world: int, bucket_elems: int = 16 * 1024 * 1024, group=None,
+                             async_op: bool = False):
+    """Sum-all-reduce the flat gradient buffer in buckets (64 MB fp32 by default: xGMI is
+    point-to-point, large buckets amortise the per-collective latency).  Averaging (1/world) is
+    folded into the AdamW kernel's ``grad_scale``.  Returns the work handles when async."""
+    if world <= 1:
+        return []
+    works = []
+    for s, e in bucket_bounds(g.numel(), bucket_elems):
+        w = dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        if async_op:
+            works.append(w)
+    return works
+
+
+def shard_rows(n_rows: int, rank: int, world: int):
+    """Contiguous row shard [lo, hi) of a bank / dataset for this rank (last shards may be shorter)."""
+    per = (n_rows + world - 1) // world
+    lo = min(n_rows, rank * per)
+    return lo, min(n_rows, lo + per)
+
+
+def gather_topk(scores: torch.Tensor, idx: torch.Tensor, world: int, group=None):
+    """All-gather per-rank [Q,k] results into [Q, world, k] lists ready for the k-way merge."""
+    if world <= 1:
+        return scores.unsqueeze(1), idx.unsqueeze(1)
+    Q, k = scores.shape
+    gs = torch.empty(world, Q, k, dtype=scores.dtype, device=scores.device)
+    gi = torch.empty(world, Q, k, dtype=idx.dtype, device=idx.device)
+    if dist.get_backend(group) == "gloo":
+        ls = [gs[r] for r in range(world)]
+        li = [gi[r] for r in range(world)]
+        dist.all_gather(ls, scores.contiguous(), group=group)
+        dist.all_gather(li, idx.contiguous(), group=group)
+    else:
+        dist.all_gather_into_tensor(gs, scores.contiguous(), group=group)
+        dist.all_gather_into_tensor(gi, idx.contiguous(), group=group)
+    return gs.permute(1, 0, 2).contiguous(), gi.permute(1, 0, 2).contiguous()
+
+
+class DistributedIndexSampler(torch.utils.data.Sampler):
+    """Disjoint per-rank index shards of a dataset, reshuffled per epoch with a shared seed."""
+
+    def __init__(self, n: int, rank: int, world: int, shuffle: bool = True, seed: int = 0):
+        self.n, self.rank, self.world, self.shuffle, self.seed, self.epoch = n, rank, world, shuffle, seed, 0
+        self.per = n // world  # drop the remainder so every rank sees equally many samples
+
+    def set_epoch(self, epoch: int):
+        self.epoch = epoch
+
+    def __len__(self):
+        return self.per
+
+    def __iter__(self):
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            order = torch.randperm(self.n, generator=g)
+        else:
+            order = torch.arange(self.n)
+        return iter(order[self.rank * self.per:(self.rank + 1) * self.per].tolist())

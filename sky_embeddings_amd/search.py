@@ -63,11 +63,8 @@ def cosine_topk(queries: torch.Tensor, bank, k: int, weights: torch.Tensor | Non
     out_i = torch.empty(Q, k, device=dev, dtype=torch.int64)
     ops.topk_merge(ps, pi, Q, nch, k, out_s, out_i)
     if world_size > 1:
-        gs = torch.empty(world_size, Q, k, device=dev)
-        gi = torch.empty(world_size, Q, k, device=dev, dtype=torch.int64)
-        torch.distributed.all_gather_into_tensor(gs, out_s, group=process_group)
-        torch.distributed.all_gather_into_tensor(gi, out_i, group=process_group)
-        gs, gi = gs.permute(1, 0, 2).contiguous(), gi.permute(1, 0, 2).contiguous()
+        from .distributed import gather_topk
+        gs, gi = gather_topk(out_s, out_i, world_size, process_group)   # RCCL all-gather -> [Q, world, k]
         ops.topk_merge(gs, gi, Q, world_size, k, out_s, out_i)
     return out_s, out_i
 

@@ -59,7 +59,8 @@ class TrainStep:
         else:
             self._fwd_bwd()
         if self.world_size > 1:
-            torch.distributed.all_reduce(self.engine.store.g, group=self.process_group)
+            from .distributed import allreduce_flat_gradients
+            allreduce_flat_gradients(self.engine.store.g, self.world_size, group=self.process_group)
         self.optimizer.step()
         self.scheduler.step()
         return self.loss

@@ -1,0 +1,145 @@
+"""GPU: the drop-in module API (utils.mim_vit / utils.similarity / entry points) end to end."""
+import configparser
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def test_similarity_module_matches_reference_goldens():
+    """utils.similarity.compute_similarity (cosine through the HIP kernel) vs vectors captured from the
+    reference; cosine within fp32 rounding of torch's unspecified summation order, MSE/MAE exact."""
+    from sky_embeddings_amd.utils import similarity as sim
+    z = np.load(os.path.join(GOLDEN, "similarity.npz"))
+    for (T, P, N) in ((130, 1, 512), (65, 16, 128), (65, 64, 64)):
+        key = f"sim/{T}_{P}_{N}"
+        tgt, tst = torch.from_numpy(z[key + "/target"]).cuda(), torch.from_numpy(z[key + "/test"]).cuda()
+        avg, w = sim.determine_target_features(tgt)
+        assert np.allclose(avg.cpu().numpy(), z[key + "/avg"], rtol=1e-5, atol=1e-6)
+        for metric in ("cosine", "MSE", "MAE"):
+            for combine in ("min", "mean", "max"):
+                for uw in (True, False):
+                    s = sim.compute_similarity(tgt, tst, metric=metric, combine=combine, use_weights=uw).cpu().numpy()
+                    ref = z[f"{key}/{metric}_{combine}_{int(uw)}"]
+                    assert np.abs(s - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (key, metric, combine, uw)
+    # streaming best-n (scores + which samples) == the reference's streaming result
+    scores = torch.from_numpy(z["stream/scores"]).cuda()
+    for metric in ("cosine", "MSE"):
+        bs = torch.full((50,), float("-inf") if metric == "cosine" else float("inf"), device="cuda")
+        bx, brd = torch.empty(50, 1, device="cuda"), torch.empty(50, 2, device="cuda")
+        for b in range(8):
+            idx = torch.arange(b * 64, (b + 1) * 64, dtype=torch.float32, device="cuda")
+            bx, brd, bs = sim.update_best_scores(idx[:, None], torch.stack([idx, idx], 1), scores[b * 64:(b + 1) * 64], bx,
+                                                 brd, bs, 50, metric)
+        assert np.array_equal(bs.cpu().numpy(), z[f"stream/{metric}_best_scores"])
+        assert np.array_equal(brd[:, 0].cpu().numpy().astype(np.int64), z[f"stream/{metric}_best_idx"])
+
+
+def _tiny_ini(tmp_path, total_iters=6, bs=8):
+    cfg = configparser.ConfigParser()
+    cfg.read(os.path.join(ROOT, "configs", "mim_1.ini"))
+    cfg["TRAINING"]["total_batch_iters"] = str(total_iters)
+    cfg["TRAINING"]["batch_size"] = str(bs)
+    return cfg
+
+
+def test_build_model_train_checkpoint_resume_and_search(tmp_path):
+    from sky_embeddings_amd import hdf5_lite, search
+    from sky_embeddings_amd.utils.dataloaders import build_h5_dataloader
+    from sky_embeddings_amd.utils.eval_fns import build_embedding_bank, mae_latent, mae_predict
+    from sky_embeddings_amd.utils.mim_vit import build_model
+    from sky_embeddings_amd.utils.pretrain_fns import run_iter
+    from sky_embeddings_amd.utils.similarity import determine_target_features, mae_simsearch
+    cfg = _tiny_ini(tmp_path)
+    # fp32 parity mode: the two search paths below encode the test set in separate passes whose random
+    # token shuffles differ (reference behaviour); in bf16 that alone moves scores by ~1e-3
+    cfg["TRAINING"]["compute_dtype"] = "f32"
+    data = hdf5_lite.make_synthetic_cutouts(str(tmp_path / "d.h5"), n=96, seed=1, nan_fraction=0.02)
+    fn = str(tmp_path / "m.pth.tar")
+    torch.manual_seed(0)
+    model, losses, cur_iter, opt, sched = build_model(cfg, fn, torch.device("cuda"), build_optimizer=True)
+    assert cur_iter == 1 and model.module.patch_embed.num_patches == 16 and model.module.num_extra_tokens == 1
+    dl = build_h5_dataloader(data, batch_size=8, num_workers=0, patch_size=16, num_channels=5, img_size=64, shuffle=False)
+    from collections import defaultdict
+    cp = defaultdict(list)
+    for i, (x, m, rd) in enumerate(dl):
+        model, opt, sched, cp = run_iter(model, x.cuda(), rd, m, 0.75, opt, sched, cp, 'train')
+        if i == 5:
+            break
+    tl = [float(v) for v in cp['train_loss']]
+    assert len(tl) == 6 and all(np.isfinite(tl)) and opt.step_count == 6
+    # checkpoint in the reference's format, resume restores everything
+    torch.save({'batch_iters': 6, 'losses': dict(losses), 'optimizer': opt.state_dict(), 'lr_scheduler': sched.state_dict(),
+                'model': {k: v.cpu() for k, v in model.module.state_dict().items()}}, fn)
+    model2, losses2, cur2, opt2, sched2 = build_model(cfg, fn, torch.device("cuda"), build_optimizer=True)
+    assert cur2 == 7 and opt2.step_count == 6 and sched2.last_epoch == 6 and abs(opt2.lr - opt.lr) < 1e-18
+    for k, v in model.module.state_dict().items():
+        assert torch.equal(v, model2.module.state_dict()[k]), k
+    assert torch.equal(opt.store.m, opt2.store.m) and torch.equal(opt.store.v, opt2.store.v)
+    # same next step on both
+    x, m, rd = next(iter(dl))
+    noise = torch.rand(8, 16, device="cuda")
+    l1, _, _ = model.module.forward(x.cuda(), noise=noise)
+    l2, _, _ = model2.module.forward(x.cuda(), noise=noise)
+    assert float(l1) == float(l2)
+    # predictions / latents through the eval mirrors
+    pred, masked, orig = mae_predict(model, dl, torch.device("cuda"), 0.75)
+    assert pred.shape == (8, 64, 64, 5) and np.isfinite(pred[~np.isnan(orig)]).all()
+    lat = mae_latent(model, dl, torch.device("cuda"), n_batches=2, remove_cls=False, verbose=0)
+    assert lat.shape == (16, 17, 192)
+    # reference-shaped streaming search == encode-once bank + fused top-k kernel
+    tgt = lat[:5]
+    imgs, blat, brd, bsc = mae_simsearch(model, tgt, dl, torch.device("cuda"), metric='cosine', combine='min',
+                                         use_weights=True, max_pool=True, cls_token=False, nested_batches=False, n_save=10,
+                                         verbose=1000)
+    assert imgs.shape == (10, 5, 64, 64) and bsc.shape == (10,) and bool((bsc[:-1] >= bsc[1:]).all())
+    bank = build_embedding_bank(model, dl, torch.device("cuda"), pool='max')
+    assert bank.shape == (96, 192)
+    first = bank[:8]
+    mu, sd = first.mean(0), first.std(0, unbiased=True)
+    t = tgt.cuda()[:, 1:].max(dim=1, keepdim=True).values
+    t = (t - mu) / (sd + 1e-8)
+    search.standardise_(bank, mu, sd)
+    avg, w = determine_target_features(t)
+    s, i = search.cosine_topk(avg.reshape(1, -1), bank, 10, weights=w)
+    assert np.allclose(s[0].cpu().numpy(), bsc.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    ds = dl.dataset
+    for rank_, j in enumerate(i[0].cpu().tolist()):
+        ref_img = ds[j][0]
+        got = imgs[rank_].cpu()
+        assert torch.equal(torch.nan_to_num(got), torch.nan_to_num(ref_img)), rank_
+
+
+def test_pretrain_entry_point_runs(tmp_path):
+    """python pretrain_mim.py mim_1 on a synthetic HDF5 (BASELINE configs[0] plumbing)."""
+    from sky_embeddings_amd import hdf5_lite
+    dd = tmp_path / "data"
+    dd.mkdir()
+    hdf5_lite.make_synthetic_cutouts(str(dd / "synthetic_cutouts_GRIZY_64_train.h5"), n=64, seed=1234)
+    hdf5_lite.make_synthetic_cutouts(str(dd / "synthetic_cutouts_GRIZY_64_val.h5"), n=16, seed=4321)
+    # a private copy of the ini with a short schedule, in a scratch checkout layout
+    work = tmp_path / "work"
+    (work / "configs").mkdir(parents=True)
+    cfg = _tiny_ini(tmp_path, total_iters=5)
+    with open(work / "configs" / "mim_t.ini", "w") as fh:
+        cfg.write(fh)
+    for name in ("pretrain_mim.py",):
+        os.symlink(os.path.join(ROOT, name), work / name)
+    for name in ("utils", "sky_embeddings_amd"):
+        os.symlink(os.path.join(ROOT, name), work / name)
+    env = dict(os.environ, PYTHONPATH=str(work))
+    out = subprocess.run([sys.executable, str(work / "pretrain_mim.py"), "mim_t", "-v", "2", "-ct", "0.001", "-dd", str(dd)],
+                         cwd=str(work), env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "Training complete." in out.stdout and "Total Loss" in out.stdout
+    ck = torch.load(str(work / "models" / "mim_t.pth.tar"), map_location="cpu", weights_only=False)
+    assert set(ck) == {"batch_iters", "losses", "optimizer", "lr_scheduler", "model"}
+    assert len(ck["model"]) == 255 - 0 and ck["batch_iters"] >= 5 and len(ck["losses"]["val_loss"]) >= 1

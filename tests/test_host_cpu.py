@@ -1,0 +1,189 @@
+"""CPU: host-side logic of the product (no GPU compute): config / layout, HDF5 access + dataset
+semantics, optimiser-state and schedule bookkeeping, and the N>1 paths under gloo (world_size 2)."""
+import configparser
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from sky_embeddings_amd import distributed as sdist
+from sky_embeddings_amd import hdf5_lite, model_config as mc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_model_layout_matches_reference_checkpoint_schema():
+    cfg = mc.config_for("base", img_size=64, patch_size=16, in_chans=5, embed_dim=768)
+    layout = mc.state_layout(cfg)
+    assert len(layout) == 255                       # 255 tensors for MAE-B
+    decay, no_decay = mc.weight_decay_split(cfg)
+    assert (len(decay), len(no_decay)) == (86, 167)  # timm param_groups_weight_decay split
+    n_train = sum(int(np.prod(s)) for n, s in layout if n not in mc.FROZEN)
+    assert abs(n_train - 112.31e6) < 0.01e6         # 112.31 M trainable parameters
+    # same names / shapes / order as the state dict captured from the reference (tiny geometry)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "mae_tiny_A.npz"))
+    img, patch, C, D, depth, heads, Dd, ddepth, dheads, _ = [int(v) for v in z["cfg"]]
+    tiny = mc.MAEConfig(img_size=img, patch_size=patch, in_chans=C, embed_dim=D, depth=depth, num_heads=heads,
+                        decoder_embed_dim=Dd, decoder_depth=ddepth, decoder_num_heads=dheads)
+    ref = [(k[len("state/"):], z[k].shape) for k in z.files if k.startswith("state/")]
+    assert ref == [(n, tuple(s)) for n, s in mc.state_layout(tiny)]
+    assert np.array_equal(mc.sincos_pos_embed(D, img // patch).astype(np.float32), z["state/pos_embed"][0])
+
+
+def test_hdf5_lite_roundtrip_and_dataset_semantics(tmp_path):
+    from sky_embeddings_amd.utils.dataloaders import H5Dataset, build_h5_dataloader
+    path = str(tmp_path / "cut.h5")
+    rng = np.random.default_rng(0)
+    cut = rng.standard_normal((20, 5, 72, 72)).astype(np.float32) * 3
+    cut[3, 1] = np.nan
+    ra, dec = rng.uniform(0, 360, 20).astype(np.float32), rng.uniform(-90, 90, 20).astype(np.float32)
+    hdf5_lite.write_datasets(path, {"cutouts": cut, "ra": ra, "dec": dec, "class": np.arange(20, dtype=np.int64)})
+    with hdf5_lite.File(path) as f:
+        assert sorted(f.keys()) == ["class", "cutouts", "dec", "ra"]
+        assert f["cutouts"].shape == (20, 5, 72, 72) and f["cutouts"].dtype == np.float32
+        assert np.array_equal(f["cutouts"][7], cut[7]) and np.array_equal(f["class"][:], np.arange(20))
+        assert np.array_equal(np.asarray(f["ra"]), ra)
+    ds = H5Dataset(path, img_size=64, patch_size=16, num_channels=5, max_mask_ratio=None, indices=[3, 7, 11])
+    assert len(ds) == 3
+    x, mask, rd = ds[0]                                  # utils/dataloaders.py:285-328 semantics
+    assert x.shape == (5, 64, 64) and x.dtype == torch.float32 and mask.shape == x.shape and float(mask.sum()) == 0
+    ref = cut[3].copy()
+    ref[ref < -3.0] = -3.0
+    ref = ref[:, 4:68, 4:68]
+    assert np.array_equal(np.isnan(x.numpy()), np.isnan(ref)) and np.array_equal(np.nan_to_num(x.numpy()), np.nan_to_num(ref))
+    assert torch.equal(rd, torch.tensor([ra[3], dec[3]]))
+    dl = build_h5_dataloader(path, batch_size=4, num_workers=0, patch_size=16, num_channels=5, img_size=64, shuffle=False)
+    xb, mb, rb = next(iter(dl))
+    assert xb.shape == (4, 5, 64, 64) and rb.shape == (4, 2)
+    ds2 = H5Dataset(path, img_size=64, patch_size=16, num_channels=5, max_mask_ratio=0.9)
+    torch.manual_seed(0)
+    _, m2, _ = ds2[0]
+    assert m2.shape == (5, 64, 64) and set(m2.unique().tolist()) <= {0, 1}
+    per_chan = m2.reshape(5, 4, 16, 4, 16)[:, :, 0, :, 0].reshape(5, -1).sum(1)
+    assert len(set(per_chan.tolist())) == 1               # same count, different patches per channel
+    # synthetic generator follows the schema
+    p2 = hdf5_lite.make_synthetic_cutouts(str(tmp_path / "syn.h5"), n=16, nan_fraction=0.2, with_labels=True)
+    with hdf5_lite.File(p2) as f:
+        c = np.asarray(f["cutouts"])
+        assert c.shape == (16, 5, 64, 64) and np.nanmin(c) >= -3.0 and np.isnan(c).any()
+    with pytest.raises(hdf5_lite.H5LiteError):
+        open(str(tmp_path / "bad.h5"), "wb").write(b"not hdf5 at all")
+        hdf5_lite.File(str(tmp_path / "bad.h5"))
+
+
+def test_product_refuses_cpu_and_never_imports_oracle():
+    from sky_embeddings_amd.utils.mim_vit import build_model
+    cfg = configparser.ConfigParser()
+    cfg.read(os.path.join(ROOT, "configs", "mim_1.ini"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        build_model(cfg, "/nonexistent.pth.tar", torch.device("cpu"))
+    # no product module imports the oracle package
+    import re
+    for base, _, files in os.walk(os.path.join(ROOT, "sky_embeddings_amd")):
+        for fn in files:
+            if fn.endswith(".py"):
+                src = open(os.path.join(base, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
+    for fn in ("pretrain_mim.py", "similarity_search.py"):
+        assert not re.search(r"^\s*(from|import)\s+oracle", open(os.path.join(ROOT, fn)).read(), flags=re.M)
+
+
+def test_cosine_schedule_and_ini_surface():
+    from sky_embeddings_amd.optim import CosineLR
+
+    class FakeOpt:
+        def __init__(self):
+            self.param_groups = [{"lr": 1e-3, "initial_lr": 1e-3}, {"lr": 1e-3, "initial_lr": 1e-3}]
+            self.lr = 1e-3
+
+        def set_lr(self, lr):
+            self.lr = lr
+    o = FakeOpt()
+    s = CosineLR(o, 10, eta_min=1e-3 / 1e7)
+    p = torch.nn.Parameter(torch.zeros(1))
+    topt = torch.optim.AdamW([p], lr=1e-3)
+    ts = torch.optim.lr_scheduler.CosineAnnealingLR(topt, 10, eta_min=1e-3 / 1e7)
+    for _ in range(12):
+        assert abs(o.lr - topt.param_groups[0]["lr"]) < 1e-15
+        topt.step()
+        ts.step()
+        s.step()
+    sd = s.state_dict()
+    s2 = CosineLR(FakeOpt(), 10, eta_min=1e-10)
+    s2.load_state_dict(sd)
+    assert s2.last_epoch == 12 and abs(s2.optimizer.lr - o.lr) < 1e-18
+    for name in ("mim_1", "mim_32"):
+        cfg = configparser.ConfigParser()
+        assert cfg.read(os.path.join(ROOT, "configs", name + ".ini"))
+        for sec, keys in (("TRAINING", ["batch_size", "total_batch_iters", "mask_ratio", "norm_pix_loss", "weight_decay",
+                                        "init_lr", "final_lr_factor", "loss_fn"]),
+                          ("ARCHITECTURE", ["img_size", "num_channels", "pixel_mean", "pixel_std", "embed_dim", "patch_size",
+                                            "model_type", "attn_pool", "ra_dec"]),
+                          ("DATA", ["train_data_file", "val_data_file"])):
+            for k in keys:
+                assert k in cfg[sec], (name, sec, k)
+        assert cfg["ARCHITECTURE"]["model_type"] in mc.MODEL_TYPES
+
+
+# ------------------------------------------------------------------------------------ gloo, world_size 2
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    r, w, _ = sdist.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    from oracle import similarity_oracle as so
+    # (1) DDP gradient averaging over the flat buffer in buckets == mean of per-rank gradients
+    g = torch.Generator().manual_seed(100 + rank)
+    n = 10_000 + 8
+    grad = torch.randn(n, generator=g)
+    mine = grad.clone()
+    sdist.allreduce_flat_gradients(grad, world, bucket_elems=4096)
+    other = torch.randn(n, generator=torch.Generator().manual_seed(100 + (1 - rank)))
+    assert torch.allclose(grad * (1.0 / world), (mine + other) / 2, atol=1e-6)
+    # (2) sharded bank: per-rank exact top-k on the shard + all-gather + merge == single-process top-k
+    rng = np.random.default_rng(5)
+    Q, N, D, k = 6, 1501, 48, 20
+    q = rng.standard_normal((Q, D), dtype=np.float32)
+    x = rng.standard_normal((N, D), dtype=np.float32)
+    x[1400] = x[10]                                   # tie across shards -> lower global index first
+    w8 = rng.random(D, dtype=np.float32) + 0.1
+    lo, hi = sdist.shard_rows(N, rank, world)
+    s_loc, i_loc = so.cosine_topk_np(q, x[lo:hi], k, w8)
+    i_loc = np.where(i_loc >= 0, i_loc + lo, -1)
+    gs, gi = sdist.gather_topk(torch.from_numpy(s_loc), torch.from_numpy(i_loc), world)
+    assert gs.shape == (Q, world, k)
+    cs, ci = gs.reshape(Q, -1).numpy(), gi.reshape(Q, -1).numpy()
+    order = np.lexsort((ci, -cs), axis=1)[:, :k]
+    ms, mi = np.take_along_axis(cs, order, 1), np.take_along_axis(ci, order, 1)
+    rs, ri = so.cosine_topk_np(q, x, k, w8)
+    assert np.array_equal(mi, ri) and np.array_equal(ms, rs)
+    # (3) disjoint, equally sized index shards
+    samp = sdist.DistributedIndexSampler(101, rank, world, shuffle=True, seed=3)
+    mine_idx = torch.tensor(list(samp))
+    both = [torch.zeros_like(mine_idx) for _ in range(world)]
+    dist.all_gather(both, mine_idx)
+    allidx = torch.cat(both)
+    assert len(mine_idx) == 50 and len(set(allidx.tolist())) == 100
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+
+
+def test_two_process_gloo_paths(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+    assert sdist.bucket_bounds(20, 8) == [(0, 8), (8, 16), (16, 20)]
+    assert sdist.shard_rows(10, 3, 4) == (9, 10) and sdist.shard_rows(10, 0, 4) == (0, 3)
