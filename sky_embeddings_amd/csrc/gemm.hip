@@ -13,6 +13,7 @@
 // Block = 256 threads = 4 waves (2x2), tile BM x BN in {128x128, 64x64}, BK = 64 (bf16) / 16 (f32),
 // register-staged global->LDS double buffer (one barrier per k-tile).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -161,7 +162,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const skyemb_gemm_args g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (g.N + BN - 1) / BN;
-    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+    // XCD-aware tile order (speed only): workgroups are dealt round-robin over the 8 XCDs, each with
+    // a private 4 MiB L2.  Give every XCD a CONTIGUOUS run of tiles (a few tile-rows x all tile-
+    // columns) so that its A rows stay L2-resident while it sweeps B.  Bijective for any grid size.
+    int wg;
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
     const T *A = (const T *)g.A;
     const T *B = (const T *)g.B;
     const int KT = (g.K + BK - 1) / BK;
@@ -174,7 +184,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const skyemb_gemm_args g) {
 
     // fused column sum of an RC A operand (bias gradient of the wgrad launch): only the first
     // column of tiles does it, thread t owns logical row m0 + t, summing the staged [k][rows] tile
-    const bool do_colsum = !A_KC && g.colsum_a != nullptr && (blockIdx.x % tiles_n) == 0 && tid < BM;
+    const bool do_colsum = !A_KC && g.colsum_a != nullptr && (wg % tiles_n) == 0 && tid < BM;
     float csum = 0.f;
 
     uint4 ra[SA::NVEC], rb[SB::NVEC];
@@ -282,6 +292,8 @@ int dispatch_layout(const skyemb_gemm_args &g, hipStream_t st) {
 
 }  // namespace
 
+int skyemb_gemm_pipe_try(const skyemb_gemm_args &g, hipStream_t st);  // gemm_pipe.hip (-1: not applicable)
+
 extern "C" int skyemb_gemm(const skyemb_gemm_args *args, void *stream) {
     SKY_CHECK_ARG(args != nullptr, "skyemb_gemm: null args");
     const skyemb_gemm_args &g = *args;
@@ -299,6 +311,11 @@ extern "C" int skyemb_gemm(const skyemb_gemm_args *args, void *stream) {
     SKY_CHECK_ARG(!g.table || g.tab_row, "skyemb_gemm: table without tab_row");
     SKY_CHECK_ARG(!g.colsum_a || g.a_layout == SKYEMB_RC, "skyemb_gemm: colsum_a needs an RC A operand");
     hipStream_t st = (hipStream_t)stream;
+    static const bool use_pipe = []() { const char *e = getenv("SKYEMB_GEMM_PIPE"); return !(e && e[0] == '0'); }();
+    if (use_pipe) {
+        const int rc = skyemb_gemm_pipe_try(g, st);
+        if (rc >= 0) return rc;
+    }
     int tile = g.tile;
     if (tile == 0) tile = (ceil_div64(g.M, 128) * ceil_div64(g.N, 128) >= 200) ? 128 : 64;
     if (g.dtype == SKYEMB_BF16) {

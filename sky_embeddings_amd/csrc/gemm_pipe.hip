@@ -1,0 +1,331 @@
+// Pipelined bf16 MFMA GEMM: LDS-DMA (global_load_lds_dwordx4) staging, 3-stage ring, counted
+// vmcnt + raw s_barrier (one barrier per k-tile), XOR-swizzled LDS images, vectorised epilogue.
+//
+// Same contract as gemm.hip (skyemb_gemm_args) for the fast-path subset:
+//   bf16, K % 64 == 0, N % 4 == 0, M >= 8 (k-contiguous rows) -- everything the ViT layers need.
+// Operand tiles (BK = 64):
+//   KC operand  [rows][64 k]  : 128-byte rows; 16-byte chunk c of row r is stored at chunk c ^ (r & 7)
+//                               (the swizzle is applied to the per-lane SOURCE address: the LDS-DMA
+//                               destination is always wave-base + lane*16); fragments by ds_read_b128.
+//   RC operand  [64 k][rows]  : rows*2-byte k-rows; chunk ch of k-row k is stored at chunk
+//                               ch ^ rc_swz(k); fragments by ds_read_b64_tr_b16 (transposed read).
+// The MFMA is issued with operands swapped (D = B_frag x A_frag) so that every lane owns 4
+// consecutive output COLUMNS of one row: 16-byte fp32 / 8-byte bf16 stores, float4 bias loads.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
+
+constexpr int BK = 64;
+constexpr int NSTAGE = 3;
+
+__device__ __forceinline__ void glds16(const void *src, char *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gvoid_t *)src, (lvoid_t *)lds_wave_base, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// ---- stage issue -----------------------------------------------------------------------------
+// KC operand: R rows x 64 k.  One wave-instruction = 8 rows x 128 B.
+template <int R>
+__device__ __forceinline__ void issue_kc(const bf16_t *__restrict__ X, int64_t ld, int r0, int rows, int k0, char *sbase,
+                                         int wave, int lane) {
+    constexpr int PER_WAVE = R / 32;
+    const int rr = lane >> 3, cs = (lane & 7) ^ rr;   // source chunk for LDS chunk lane&7 of row rr (rows8 % 8 == 0)
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) {
+        const int rows8 = (wave * PER_WAVE + j) * 8;
+        int gr = r0 + rows8 + rr;
+        gr = gr < rows ? gr : rows - 1;            // rows past the edge feed outputs that are never stored
+        glds16(X + (int64_t)gr * ld + k0 + cs * 8, sbase + rows8 * 128);
+    }
+}
+// XOR applied to the 16-byte chunk index of k-row k in an RC image [64 k][R rows]: makes the 8 k-rows
+// that one half-wave of a ds_read_b64_tr_b16 touches land on disjoint bank ranges (checked
+// exhaustively with the bank rules of MI355X_MICROARCH.md: conflict-free for R = 128 and R = 64).
+template <int R>
+__device__ __forceinline__ int rc_swz(int k) {
+    return R == 128 ? (((k & 3) << 1) | (((k >> 3) & 1) << 3)) : ((((k >> 1) & 1) << 1) | (((k >> 3) & 1) << 2));
+}
+// RC operand: 64 k-rows x R rows (R*2 bytes per k-row).  One wave-instruction = 1 KiB = 512/R k-rows.
+template <int R>
+__device__ __forceinline__ void issue_rc(const bf16_t *__restrict__ X, int64_t ld, int r0, int rows, int k0, char *sbase,
+                                         int wave, int lane) {
+    constexpr int CH = R / 8;                 // 16-byte chunks per k-row
+    constexpr int KROWS = 64 / CH;            // k-rows per wave-instruction (4 for R=128, 8 for R=64)
+    constexpr int PER_WAVE = 64 / KROWS / 4;  // instructions per wave
+    const int kr = lane / CH, ch = lane % CH;
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) {
+        const int kbase = (wave * PER_WAVE + j) * KROWS;
+        const int k = kbase + kr;
+        const int sch = ch ^ rc_swz<R>(k);                          // source chunk for LDS chunk `ch`
+        int gr = r0 + sch * 8;
+        gr = gr + 8 <= rows ? gr : rows - 8;   // clamp whole chunk (rows % 8 == 0)
+        glds16(X + (int64_t)(k0 + k) * ld + gr, sbase + kbase * (R * 2));
+    }
+}
+
+// byte offset of 16-byte chunk `ch` of k-row `k` in an RC stage image
+template <int R>
+__device__ __forceinline__ int rc_off(int k, int ch) {
+    return k * (R * 2) + ((ch ^ rc_swz<R>(k)) << 4);
+}
+
+// ---- fragment reads --------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8 frag_kc(const char *sbase, int rbase, int kk, int lane) {
+    const int r = rbase + (lane & 15);
+    const int c = (4 * kk + (lane >> 4)) ^ (lane & 7);
+    return *(const bf16x8 *)(sbase + r * 128 + (c << 4));
+}
+template <int R>
+__device__ __forceinline__ bf16x8 frag_rc(const char *sbase, int rbase, int kk, int lane) {
+    const int i = lane & 15, q = i >> 2, p = i & 3;
+    const int kb = kk * 32 + 8 * (lane >> 4);
+    const int ch = (rbase >> 3) + (p >> 1);
+    const char *a0 = sbase + rc_off<R>(kb + q, ch) + 8 * (p & 1);
+    const char *a1 = sbase + rc_off<R>(kb + 4 + q, ch) + 8 * (p & 1);
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)a0);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)a1);
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_pipe_kernel(const skyemb_gemm_args g) {
+    constexpr int TM = BM / 32, TN = BN / 32;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int NI = (A_KC ? BM / 32 : (BM == 128 ? 4 : 2)) + (B_KC ? BN / 32 : (BN == 128 ? 4 : 2));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int S = g.split_k > 1 ? g.split_k : 1;           // split-K factor (host-resolved)
+    const int ntiles = gridDim.x / S;
+    const int split = blockIdx.x / ntiles, tb = blockIdx.x - split * ntiles;
+    int wg;
+    {   // XCD-aware tile order (see gemm.hip)
+        const int nwg = ntiles, xcd = tb & 7, local = tb >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+    const bf16_t *A = (const bf16_t *)g.A;
+    const bf16_t *B = (const bf16_t *)g.B;
+    const int KT_all = g.K / BK;
+    const int kt_begin = (int)((int64_t)KT_all * split / S), KT = (int)((int64_t)KT_all * (split + 1) / S) - kt_begin;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto issue = [&](int kt, int buf) {
+        char *sa = smem + buf * STAGE, *sb = sa + A_BYTES;
+        const int k0 = (kt_begin + kt) * BK;
+        if (A_KC) issue_kc<BM>(A, g.lda, m0, g.M, k0, sa, wave, lane);
+        else issue_rc<BM>(A, g.lda, m0, g.M, k0, sa, wave, lane);
+        if (B_KC) issue_kc<BN>(B, g.ldb, n0, g.N, k0, sb, wave, lane);
+        else issue_rc<BN>(B, g.ldb, n0, g.N, k0, sb, wave, lane);
+    };
+
+    const bool do_colsum = !A_KC && g.colsum_a != nullptr && (wg % tiles_n) == 0 && tid < BM;
+    float csum = 0.f;
+
+    issue(0, 0);
+    if (KT > 1) issue(1, 1);
+    int buf = 0;
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) wait_vmcnt<NI>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < KT) issue(kt + 2, buf >= 1 ? buf - 1 : NSTAGE - 1);   // (kt+2) % 3 == (buf+2) % 3
+        const char *sa = smem + buf * STAGE, *sb = sa + A_BYTES;
+        if (!A_KC && do_colsum) {
+            // column sum of the staged [k][rows] A tile (bias gradient): thread t owns row t
+            const int ch = tid >> 3, e = tid & 7;
+#pragma unroll 8
+            for (int k = 0; k < BK; ++k) csum += (float)*(const bf16_t *)(sa + rc_off<BM>(k, ch) + e * 2);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[i] = A_KC ? frag_kc(sa, wm * (BM / 2) + i * 16, kk, lane) : frag_rc<BM>(sa, wm * (BM / 2) + i * 16, kk, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[j] = B_KC ? frag_kc(sb, wn * (BN / 2) + j * 16, kk, lane) : frag_rc<BN>(sb, wn * (BN / 2) + j * 16, kk, lane);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D[n][m]
+        }
+        buf = buf + 1 < NSTAGE ? buf + 1 : 0;
+    }
+    if (S > 1) {
+        // split-K: raw partial tile (and partial column sums) to the workspace; splitk_reduce finishes
+        float *slab = (float *)g.ws + (int64_t)split * g.M * g.N;
+        float *cs = (float *)g.ws + (int64_t)S * g.M * g.N + (int64_t)split * g.M;
+        if (!A_KC && do_colsum && m0 + tid < g.M) cs[m0 + tid] = csum;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 16 + 4 * (lane >> 4);
+                if (n >= g.N) continue;
+                *(float4 *)(slab + (int64_t)m * g.N + n) =
+                    make_float4(acc[i][j][0] * g.alpha, acc[i][j][1] * g.alpha, acc[i][j][2] * g.alpha, acc[i][j][3] * g.alpha);
+            }
+        }
+        return;
+    }
+    if (!A_KC && do_colsum && m0 + tid < g.M) g.colsum_a[m0 + tid] = csum;
+
+    // ---- epilogue: lane owns row m = ... + (lane&15) and 4 consecutive columns n4 + (0..3) -------
+    bf16_t *out = (bf16_t *)g.out;
+    bf16_t *out2 = (bf16_t *)g.out2;
+    const bf16_t *aux = (const bf16_t *)g.aux;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
+        if (m >= g.M) continue;
+        const int orow = g.dst_row ? g.dst_row[m] : m;
+        if (orow < 0) continue;
+        const float *trow = g.table ? g.table + (int64_t)g.tab_row[m] * g.ldt : nullptr;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 16 + 4 * (lane >> 4);
+            if (n >= g.N) continue;
+            float v[4] = {acc[i][j][0] * g.alpha, acc[i][j][1] * g.alpha, acc[i][j][2] * g.alpha, acc[i][j][3] * g.alpha};
+            if (g.bias) {
+                const float4 b = *(const float4 *)(g.bias + n);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            }
+            if (trow) {
+                const float4 t = *(const float4 *)(trow + n);
+                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+            }
+            if (g.resid) {
+                const float4 t = *(const float4 *)(g.resid + (int64_t)orow * g.ldr + n);
+                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+            }
+            if (g.act == SKYEMB_ACT_GELU) {
+                if (out2) store4<bf16_t>(out2 + (int64_t)orow * g.ldo2 + n, v[0], v[1], v[2], v[3]);
+                v[0] = gelu_f(v[0]); v[1] = gelu_f(v[1]); v[2] = gelu_f(v[2]); v[3] = gelu_f(v[3]);
+            } else if (g.act == SKYEMB_ACT_DGELU) {
+                const float4 a = load4<bf16_t>(aux + (int64_t)m * g.ldaux + n);
+                v[0] *= dgelu_f(a.x); v[1] *= dgelu_f(a.y); v[2] *= dgelu_f(a.z); v[3] *= dgelu_f(a.w);
+            }
+            if (g.out_f32) *(float4 *)(g.out_f32 + (int64_t)orow * g.ldo32 + n) = make_float4(v[0], v[1], v[2], v[3]);
+            if (out) store4<bf16_t>(out + (int64_t)orow * g.ldo + n, v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// out[m][n] = sum_s slab[s][m][n] (fixed order), colsum[m] = sum_s cs[s][m]
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ ws, int S, int M, int N,
+                                                            float *__restrict__ out, int64_t ldo, float *__restrict__ colsum) {
+    const int64_t mn4 = (int64_t)M * N / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < mn4; i += (int64_t)gridDim.x * 256) {
+        float4 a = *(const float4 *)(ws + 4 * i);
+        for (int s = 1; s < S; ++s) {
+            const float4 b = *(const float4 *)(ws + (int64_t)s * M * N + 4 * i);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        const int64_t e = 4 * i;
+        *(float4 *)(out + (e / N) * ldo + (e % N)) = a;
+    }
+    if (colsum && blockIdx.x == 0) {
+        const float *cs = ws + (int64_t)S * M * N;
+        for (int m = threadIdx.x; m < M; m += 256) {
+            float a = cs[m];
+            for (int s = 1; s < S; ++s) a += cs[(int64_t)s * M + m];
+            colsum[m] = a;
+        }
+    }
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC>
+int launch(const skyemb_gemm_args &g, hipStream_t st) {
+    constexpr size_t smem = (size_t)NSTAGE * (BM + BN) * BK * 2;
+    static bool attr_set = false;
+    auto kern = gemm_pipe_kernel<BM, BN, A_KC, B_KC>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) {
+            skyemb_set_error("skyemb_gemm(pipe): hipFuncSetAttribute(%zu B LDS): %s", smem, hipGetErrorString(e));
+            return 2;
+        }
+        attr_set = true;
+    }
+    const int64_t tiles = ceil_div64(g.M, BM) * ceil_div64(g.N, BN);
+    const int S = g.split_k > 1 ? g.split_k : 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * S)), dim3(256), smem, st, g);
+    if (S > 1) {
+        int64_t blocks = ceil_div64((int64_t)g.M * g.N / 4, 256);
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)g.ws, S, g.M, g.N,
+                           g.out_f32, g.ldo32, g.a_layout == SKYEMB_RC ? g.colsum_a : nullptr);
+    }
+    SKY_LAUNCH_CHECK("skyemb_gemm(pipe)");
+    return 0;
+}
+
+template <int BT>
+int dispatch(const skyemb_gemm_args &g, hipStream_t st) {
+    const bool a = g.a_layout == SKYEMB_KC, b = g.b_layout == SKYEMB_KC;
+    if (a && b) return launch<BT, BT, true, true>(g, st);
+    if (a && !b) return launch<BT, BT, true, false>(g, st);
+    if (!a && !b) return launch<BT, BT, false, false>(g, st);
+    return launch<BT, BT, false, true>(g, st);
+}
+
+}  // namespace
+
+// returns -1 when the problem is outside the fast-path subset (caller falls back to gemm.hip)
+int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
+    skyemb_gemm_args g = g_in;
+    if (g.dtype != SKYEMB_BF16 || g.K % BK != 0 || g.N % 4 != 0) return -1;
+    // alignment of the vectorised epilogue operands
+    if ((g.ldo32 % 4) || (g.ldo % 4) || (g.ldo2 % 4) || (g.ldr % 4) || (g.ldt % 4) || (g.ldaux % 4)) return -1;
+    if (g.a_layout == SKYEMB_KC ? g.M < 1 : (g.M % 8 != 0 || g.M < 8)) return -1;
+    if (g.b_layout == SKYEMB_KC ? g.N < 1 : (g.N % 8 != 0 || g.N < 8)) return -1;
+    int tile = g.tile;
+    if (tile == 0) tile = 64;   // measured: the 64x64 tile (3 workgroups per CU) beats 128x128 on every ViT-B shape
+    // split-K (deterministic slabs) for launches with too few tiles to fill the chip (the wgrads)
+    const bool plain = g.out_f32 && !g.out && !g.out2 && !g.bias && !g.table && !g.resid && !g.dst_row &&
+                       g.act == SKYEMB_ACT_NONE && g.ldo32 % 4 == 0;
+    int S = 1;
+    if (plain && g.ws && g.split_k != 1) {
+        const int64_t tiles = ceil_div64(g.M, tile) * ceil_div64(g.N, tile);
+        const int KT = g.K / BK;
+        S = g.split_k > 1 ? g.split_k : (int)(768 / tiles);
+        if (S > 8) S = 8;
+        if (S > KT / 4) S = KT / 4;
+        while (S > 1 && (int64_t)S * ((int64_t)g.M * g.N + g.M) * 4 > g.ws_bytes) --S;
+        if (S < 1) S = 1;
+    }
+    g.split_k = S;
+    return tile == 128 ? dispatch<128>(g, st) : dispatch<64>(g, st);
+}

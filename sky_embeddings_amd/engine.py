@@ -194,6 +194,7 @@ class MAEEngine:
             w["drows"] = torch.empty(B * keep, pv, **f32)
             w["pmv_part"] = torch.empty(B, pv, **f32)
             w["rs_part"] = torch.empty(64, max(D, Dd), **f32)
+            w["splitk_ws"] = torch.empty(8 * 1024 * 1024, **f32)   # 32 MB: split-K slabs of the wgrad launches
         self._ws[key] = w
         return w
 
@@ -311,7 +312,7 @@ class MAEEngine:
         st = self.store
         # wgrad; the bias gradient (column sums of dy) rides along in the same launch
         ops.gemm(dy, x_in, M=N, N=K, K=M, a_layout=RC, b_layout=RC, lda=N, ldb=K, out_f32=st.grad(wname),
-                 colsum_a=st.grad(bname))
+                 colsum_a=st.grad(bname), ws=w["splitk_ws"])
         if dx_out is not None:
             ops.gemm(dy, st.lp(wname), M=M, N=K, K=N, a_layout=KC, b_layout=RC, lda=N, ldb=K, act=dx_act, aux=dx_aux,
                      ldaux=K, out=dx_out)
@@ -379,7 +380,8 @@ class MAEEngine:
         ops.rowsum_select(g, D, None, 0, 1, Ne, B, D, w["rs_part"], st.grad("cls_token").view(D))
         ops.gather_rows(g, w["pe_dst"], None, w["dT"], B * keep, D)
         ops.gemm(w["dT"], w["patches"], M=D, N=pv, K=B * keep, a_layout=RC, b_layout=RC, lda=D, ldb=pv,
-                 out_f32=st.grad("patch_embed.proj.weight"), colsum_a=st.grad("patch_embed.proj.bias"))
+                 out_f32=st.grad("patch_embed.proj.weight"), colsum_a=st.grad("patch_embed.proj.bias"),
+                 ws=w["splitk_ws"])
         ops.gemm(w["dT"], st.lp("patch_embed.proj.weight"), M=B * keep, N=pv, K=D, a_layout=KC, b_layout=RC, lda=D,
                  ldb=pv, out_f32=w["drows"])
         ops.patch_gather_bwd_pmv(imgs, w["ids_keep"], w["drows"], w["pmv_part"], st.grad("patch_mask_values"),

@@ -369,3 +369,25 @@ def test_errors_are_reported(ops):
     with pytest.raises(Exception) as e:
         ops.gemm(a, a, M=8, N=8, K=12, out_f32=torch.zeros(8, 8, device=DEV))
     assert "multiples" in str(e.value)
+
+
+@pytest.mark.parametrize("split", [0, 2, 5])
+def test_gemm_split_k_wgrad(ops, split):
+    """wgrad-shaped launch (contraction over tokens) through the deterministic split-K path + fused bias gradient."""
+    tokens, N, K = 1280, 136, 72          # dW[N,K] = dy[tokens,N]^T x[tokens,K]
+    g = torch.Generator().manual_seed(split)
+    dy, x = torch.randn(tokens, N, generator=g), torch.randn(tokens, K, generator=g)
+    dyr, xr = dy.bfloat16().float(), x.bfloat16().float()
+    ws = torch.empty(4 * 1024 * 1024, device=DEV)
+    outs = []
+    for _ in range(2):
+        dw = torch.full((N, K), float("nan"), device=DEV)
+        db = torch.full((N,), float("nan"), device=DEV)
+        ops.gemm(dev(dy, torch.bfloat16), dev(x, torch.bfloat16), M=N, N=K, K=tokens, a_layout=ops.RC, b_layout=ops.RC,
+                 lda=N, ldb=K, out_f32=dw, colsum_a=db, ws=ws, split_k=split)
+        outs.append((dw.cpu(), db.cpu()))
+    ref = dyr.double().T @ xr.double()
+    scale = float((dyr.abs().double().T @ xr.abs().double()).max())
+    assert float((outs[0][0].double() - ref).abs().max()) <= 2e-6 * scale
+    assert float((outs[0][1].double() - dyr.double().sum(0)).abs().max()) <= 1e-5 * float(dyr.abs().sum(0).max())
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])   # run-to-run deterministic
