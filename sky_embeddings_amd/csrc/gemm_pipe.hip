@@ -12,6 +12,7 @@
 // The MFMA is issued with operands swapped (D = B_frag x A_frag) so that every lane owns 4
 // consecutive output COLUMNS of one row: 16-byte fp32 / 8-byte bf16 stores, float4 bias loads.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -20,7 +21,6 @@ typedef __attribute__((address_space(3))) void lvoid_t;
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
 
 constexpr int BK = 64;
-constexpr int NSTAGE = 3;
 
 __device__ __forceinline__ void glds16(const void *src, char *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gvoid_t *)src, (lvoid_t *)lds_wave_base, 16, 0, 0);
@@ -40,10 +40,10 @@ __device__ __forceinline__ float dgelu_f(float x) {
 
 // ---- stage issue -----------------------------------------------------------------------------
 // KC operand: R rows x 64 k.  One wave-instruction = 8 rows x 128 B.
-template <int R>
+template <int R, int NW>
 __device__ __forceinline__ void issue_kc(const bf16_t *__restrict__ X, int64_t ld, int r0, int rows, int k0, char *sbase,
                                          int wave, int lane) {
-    constexpr int PER_WAVE = R / 32;
+    constexpr int PER_WAVE = R / 8 / NW;
     const int rr = lane >> 3, cs = (lane & 7) ^ rr;   // source chunk for LDS chunk lane&7 of row rr (rows8 % 8 == 0)
 #pragma unroll
     for (int j = 0; j < PER_WAVE; ++j) {
@@ -61,12 +61,12 @@ __device__ __forceinline__ int rc_swz(int k) {
     return R == 128 ? (((k & 3) << 1) | (((k >> 3) & 1) << 3)) : ((((k >> 1) & 1) << 1) | (((k >> 3) & 1) << 2));
 }
 // RC operand: 64 k-rows x R rows (R*2 bytes per k-row).  One wave-instruction = 1 KiB = 512/R k-rows.
-template <int R>
+template <int R, int NW>
 __device__ __forceinline__ void issue_rc(const bf16_t *__restrict__ X, int64_t ld, int r0, int rows, int k0, char *sbase,
                                          int wave, int lane) {
     constexpr int CH = R / 8;                 // 16-byte chunks per k-row
     constexpr int KROWS = 64 / CH;            // k-rows per wave-instruction (4 for R=128, 8 for R=64)
-    constexpr int PER_WAVE = 64 / KROWS / 4;  // instructions per wave
+    constexpr int PER_WAVE = 64 / KROWS / NW; // instructions per wave
     const int kr = lane / CH, ch = lane % CH;
 #pragma unroll
     for (int j = 0; j < PER_WAVE; ++j) {
@@ -106,11 +106,28 @@ __device__ __forceinline__ bf16x8 frag_rc(const char *sbase, int rbase, int kk, 
     return r;
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_pipe_kernel(const skyemb_gemm_args g) {
-    constexpr int TM = BM / 32, TN = BN / 32;
+// wait until at most `rem` younger stages (NI LDS-DMA instructions each) are still in flight
+template <int NI, int MAXREM>
+__device__ __forceinline__ void wait_stages(int rem) {
+    if constexpr (MAXREM == 0) {
+        wait_vmcnt<0>();
+    } else {
+        if (rem >= MAXREM) wait_vmcnt<MAXREM * NI>();
+        else wait_stages<NI, MAXREM - 1>(rem);
+    }
+}
+
+// NSTAGE-deep LDS ring: NSTAGE-1 k-tiles are in flight ahead of the one being consumed.  3 stages
+// when several workgroups share a CU, 6 when the launch has about one workgroup per CU (its loads
+// must cover the L2 latency alone).
+// NW waves per workgroup: 4 (2x2, 64x64 tiles) or 8 (4x2, 128x128 tiles: 64 FLOP/byte and two waves
+// per SIMD even when the launch has a single workgroup per CU).
+template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_pipe_kernel(const skyemb_gemm_args g) {
+    constexpr int WGM = NW / 2;                         // waves along M (x 2 along N)
+    constexpr int TM = BM / WGM / 16, TN = BN / 2 / 16;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-    constexpr int NI = (A_KC ? BM / 32 : (BM == 128 ? 4 : 2)) + (B_KC ? BN / 32 : (BN == 128 ? 4 : 2));
+    constexpr int NI = (BM + BN) / 8 / NW;              // LDS-DMA instructions per wave per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -141,22 +158,24 @@ __global__ __launch_bounds__(256) void gemm_pipe_kernel(const skyemb_gemm_args g
     auto issue = [&](int kt, int buf) {
         char *sa = smem + buf * STAGE, *sb = sa + A_BYTES;
         const int k0 = (kt_begin + kt) * BK;
-        if (A_KC) issue_kc<BM>(A, g.lda, m0, g.M, k0, sa, wave, lane);
-        else issue_rc<BM>(A, g.lda, m0, g.M, k0, sa, wave, lane);
-        if (B_KC) issue_kc<BN>(B, g.ldb, n0, g.N, k0, sb, wave, lane);
-        else issue_rc<BN>(B, g.ldb, n0, g.N, k0, sb, wave, lane);
+        if (A_KC) issue_kc<BM, NW>(A, g.lda, m0, g.M, k0, sa, wave, lane);
+        else issue_rc<BM, NW>(A, g.lda, m0, g.M, k0, sa, wave, lane);
+        if (B_KC) issue_kc<BN, NW>(B, g.ldb, n0, g.N, k0, sb, wave, lane);
+        else issue_rc<BN, NW>(B, g.ldb, n0, g.N, k0, sb, wave, lane);
     };
 
     const bool do_colsum = !A_KC && g.colsum_a != nullptr && (wg % tiles_n) == 0 && tid < BM;
     float csum = 0.f;
 
-    issue(0, 0);
-    if (KT > 1) issue(1, 1);
+    constexpr int AHEAD = NSTAGE - 1;
+#pragma unroll
+    for (int p = 0; p < AHEAD; ++p)
+        if (p < KT) issue(p, p);
     int buf = 0;
     for (int kt = 0; kt < KT; ++kt) {
-        if (kt + 1 < KT) wait_vmcnt<NI>(); else wait_vmcnt<0>();
+        wait_stages<NI, AHEAD - 1>(KT - 1 - kt);   // stage kt has landed; up to AHEAD-1 younger ones stay in flight
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < KT) issue(kt + 2, buf >= 1 ? buf - 1 : NSTAGE - 1);   // (kt+2) % 3 == (buf+2) % 3
+        if (kt + AHEAD < KT) issue(kt + AHEAD, buf >= 1 ? buf - 1 : NSTAGE - 1);   // (kt+AHEAD) % NSTAGE == (buf-1) mod NSTAGE
         const char *sa = smem + buf * STAGE, *sb = sa + A_BYTES;
         if (!A_KC && do_colsum) {
             // column sum of the staged [k][rows] A tile (bias gradient): thread t owns row t
@@ -164,12 +183,16 @@ __global__ __launch_bounds__(256) void gemm_pipe_kernel(const skyemb_gemm_args g
 #pragma unroll 8
             for (int k = 0; k < BK; ++k) csum += (float)*(const bf16_t *)(sa + rc_off<BM>(k, ch) + e * 2);
         }
+#ifdef SKY_NOMATH   // experiment build: LDS-DMA stream + barriers only
+        buf = buf + 1 < NSTAGE ? buf + 1 : 0;
+        continue;
+#endif
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                fa[i] = A_KC ? frag_kc(sa, wm * (BM / 2) + i * 16, kk, lane) : frag_rc<BM>(sa, wm * (BM / 2) + i * 16, kk, lane);
+                fa[i] = A_KC ? frag_kc(sa, wm * (BM / WGM) + i * 16, kk, lane) : frag_rc<BM>(sa, wm * (BM / WGM) + i * 16, kk, lane);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 fb[j] = B_KC ? frag_kc(sb, wn * (BN / 2) + j * 16, kk, lane) : frag_rc<BN>(sb, wn * (BN / 2) + j * 16, kk, lane);
@@ -188,7 +211,7 @@ __global__ __launch_bounds__(256) void gemm_pipe_kernel(const skyemb_gemm_args g
         if (!A_KC && do_colsum && m0 + tid < g.M) cs[m0 + tid] = csum;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
+            const int m = m0 + wm * (BM / WGM) + i * 16 + (lane & 15);
             if (m >= g.M) continue;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -208,7 +231,7 @@ __global__ __launch_bounds__(256) void gemm_pipe_kernel(const skyemb_gemm_args g
     const bf16_t *aux = (const bf16_t *)g.aux;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
+        const int m = m0 + wm * (BM / WGM) + i * 16 + (lane & 15);
         if (m >= g.M) continue;
         const int orow = g.dst_row ? g.dst_row[m] : m;
         if (orow < 0) continue;
@@ -243,34 +266,63 @@ __global__ __launch_bounds__(256) void gemm_pipe_kernel(const skyemb_gemm_args g
     }
 }
 
-// out[m][n] = sum_s slab[s][m][n] (fixed order), colsum[m] = sum_s cs[s][m]
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ ws, int S, int M, int N,
-                                                            float *__restrict__ out, int64_t ldo, float *__restrict__ colsum) {
+// second launch of a split-K GEMM: v = sum_s slab[s][m][n] (fixed order, alpha already applied), then
+// the full epilogue of the contract; colsum[m] = sum_s cs[s][m].
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const skyemb_gemm_args g, int S) {
+    const float *ws = (const float *)g.ws;
+    const int M = g.M, N = g.N;
     const int64_t mn4 = (int64_t)M * N / 4;
+    bf16_t *out = (bf16_t *)g.out;
+    bf16_t *out2 = (bf16_t *)g.out2;
+    const bf16_t *aux = (const bf16_t *)g.aux;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < mn4; i += (int64_t)gridDim.x * 256) {
         float4 a = *(const float4 *)(ws + 4 * i);
         for (int s = 1; s < S; ++s) {
             const float4 b = *(const float4 *)(ws + (int64_t)s * M * N + 4 * i);
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
         }
-        const int64_t e = 4 * i;
-        *(float4 *)(out + (e / N) * ldo + (e % N)) = a;
+        const int m = (int)((4 * i) / N), n = (int)((4 * i) % N);
+        const int orow = g.dst_row ? g.dst_row[m] : m;
+        if (orow < 0) continue;
+        float v[4] = {a.x, a.y, a.z, a.w};
+        if (g.bias) {
+            const float4 t = *(const float4 *)(g.bias + n);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        }
+        if (g.table) {
+            const float4 t = *(const float4 *)(g.table + (int64_t)g.tab_row[m] * g.ldt + n);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        }
+        if (g.resid) {
+            const float4 t = *(const float4 *)(g.resid + (int64_t)orow * g.ldr + n);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        }
+        if (g.act == SKYEMB_ACT_GELU) {
+            if (out2) store4<bf16_t>(out2 + (int64_t)orow * g.ldo2 + n, v[0], v[1], v[2], v[3]);
+            v[0] = gelu_f(v[0]); v[1] = gelu_f(v[1]); v[2] = gelu_f(v[2]); v[3] = gelu_f(v[3]);
+        } else if (g.act == SKYEMB_ACT_DGELU) {
+            const float4 t = load4<bf16_t>(aux + (int64_t)m * g.ldaux + n);
+            v[0] *= dgelu_f(t.x); v[1] *= dgelu_f(t.y); v[2] *= dgelu_f(t.z); v[3] *= dgelu_f(t.w);
+        }
+        if (g.out_f32) *(float4 *)(g.out_f32 + (int64_t)orow * g.ldo32 + n) = make_float4(v[0], v[1], v[2], v[3]);
+        if (out) store4<bf16_t>(out + (int64_t)orow * g.ldo + n, v[0], v[1], v[2], v[3]);
     }
-    if (colsum && blockIdx.x == 0) {
+    if (g.colsum_a && g.a_layout == SKYEMB_RC && blockIdx.x == 0) {
         const float *cs = ws + (int64_t)S * M * N;
         for (int m = threadIdx.x; m < M; m += 256) {
-            float a = cs[m];
-            for (int s = 1; s < S; ++s) a += cs[(int64_t)s * M + m];
-            colsum[m] = a;
+            float t = cs[m];
+            for (int s = 1; s < S; ++s) t += cs[(int64_t)s * M + m];
+            g.colsum_a[m] = t;
         }
     }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC>
-int launch(const skyemb_gemm_args &g, hipStream_t st) {
+template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE>
+int launch_n(const skyemb_gemm_args &g, hipStream_t st) {
     constexpr size_t smem = (size_t)NSTAGE * (BM + BN) * BK * 2;
+    constexpr int NW = BM == 128 ? 8 : 4;
     static bool attr_set = false;
-    auto kern = gemm_pipe_kernel<BM, BN, A_KC, B_KC>;
+    auto kern = gemm_pipe_kernel<BM, BN, A_KC, B_KC, NSTAGE, NW>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) {
@@ -281,15 +333,24 @@ int launch(const skyemb_gemm_args &g, hipStream_t st) {
     }
     const int64_t tiles = ceil_div64(g.M, BM) * ceil_div64(g.N, BN);
     const int S = g.split_k > 1 ? g.split_k : 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * S)), dim3(256), smem, st, g);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * S)), dim3(NW * 64), smem, st, g);
     if (S > 1) {
         int64_t blocks = ceil_div64((int64_t)g.M * g.N / 4, 256);
         if (blocks > 1024) blocks = 1024;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)g.ws, S, g.M, g.N,
-                           g.out_f32, g.ldo32, g.a_layout == SKYEMB_RC ? g.colsum_a : nullptr);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, S);
     }
     SKY_LAUNCH_CHECK("skyemb_gemm(pipe)");
     return 0;
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC>
+int launch(const skyemb_gemm_args &g, hipStream_t st) {
+    // (a 6-deep ring for launches with ~1 workgroup per CU was measured: no gain -- those launches are
+    // bound by the per-wave issue chain, not by loads in flight)
+    static const int stages = []() { const char *e = getenv("SKYEMB_GEMM_STAGES"); return e ? atoi(e) : 3; }();
+    if (stages == 2) return launch_n<BM, BN, A_KC, B_KC, 2>(g, st);
+    if (stages == 4) return launch_n<BM, BN, A_KC, B_KC, 4>(g, st);
+    return launch_n<BM, BN, A_KC, B_KC, 3>(g, st);
 }
 
 template <int BT>
@@ -313,11 +374,10 @@ int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
     if (g.b_layout == SKYEMB_KC ? g.N < 1 : (g.N % 8 != 0 || g.N < 8)) return -1;
     int tile = g.tile;
     if (tile == 0) tile = 64;   // measured: the 64x64 tile (3 workgroups per CU) beats 128x128 on every ViT-B shape
-    // split-K (deterministic slabs) for launches with too few tiles to fill the chip (the wgrads)
-    const bool plain = g.out_f32 && !g.out && !g.out2 && !g.bias && !g.table && !g.resid && !g.dst_row &&
-                       g.act == SKYEMB_ACT_NONE && g.ldo32 % 4 == 0;
+    // split-K (deterministic slabs + a reduce launch that applies the epilogue) for launches with too
+    // few tiles to fill the chip: the wgrads, and every GEMM whose output is [1280 tokens, <= 768]
     int S = 1;
-    if (plain && g.ws && g.split_k != 1) {
+    if (g.ws && g.split_k != 1) {
         const int64_t tiles = ceil_div64(g.M, tile) * ceil_div64(g.N, tile);
         const int KT = g.K / BK;
         S = g.split_k > 1 ? g.split_k : (int)(768 / tiles);

@@ -137,22 +137,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD *__restrict__ dy, 
     }
 }
 
-// second stage: out[which][d] = sum_b part[which][b][d]; block = 32 columns x 8 row groups, grid = (D/32, 2)
-__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float *__restrict__ part, float *__restrict__ dgamma,
-                                                            float *__restrict__ dbeta, int nblk, int D) {
-    __shared__ float red[8][33];
+// second stage: out[which][d] = sum_b part[which][b][d]; block = 32 columns x 32 row groups, grid = (D/32, 2)
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float *__restrict__ part, float *__restrict__ dgamma,
+                                                             float *__restrict__ dbeta, int nblk, int D) {
+    __shared__ float red[32][33];
     const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int d = blockIdx.x * 32 + col;
     const float *src = part + (int64_t)blockIdx.y * nblk * D;
     float acc = 0.f;
     if (d < D)
-        for (int b = rg; b < nblk; b += 8) acc += src[(int64_t)b * D + d];
+        for (int b = rg; b < nblk; b += 32) acc += src[(int64_t)b * D + d];
     red[rg][col] = acc;
     __syncthreads();
     if (rg == 0 && d < D) {
         float t = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) t += red[r][col];
+        for (int r = 0; r < 32; ++r) t += red[r][col];
         (blockIdx.y == 0 ? dgamma : dbeta)[d] = t;
     }
 }
@@ -189,7 +189,7 @@ extern "C" int skyemb_layernorm_fwd(const float *x, const float *gamma, const fl
 
 extern "C" int skyemb_layernorm_bwd_blocks(int M) {
     int nb = (M + 3) / 4;
-    return nb < 128 ? (nb < 1 ? 1 : nb) : 128;
+    return nb < 512 ? (nb < 1 ? 1 : nb) : 512;   // 2 waves per SIMD at M >= 2048 rows
 }
 
 extern "C" int skyemb_layernorm_bwd(const void *dy, int dy_is_f32, int dtype, const float *x, const float *gamma,
@@ -223,7 +223,7 @@ extern "C" int skyemb_layernorm_bwd(const void *dy, int dy_is_f32, int dtype, co
     }
 #undef LN_BWD
     if (dgamma && dbeta)
-        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((D + 31) / 32, 2), dim3(256), 0, st, part, dgamma, dbeta, nblk, D);
+        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((D + 31) / 32, 2), dim3(1024), 0, st, part, dgamma, dbeta, nblk, D);
     SKY_LAUNCH_CHECK("skyemb_layernorm_bwd");
     return 0;
 }

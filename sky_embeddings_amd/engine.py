@@ -88,6 +88,8 @@ class MAEEngine:
         self.store = ParamStore(cfg, self.device, compute_dtype)
         self._ws = {}
         self._last = None
+        # fp32 scratch for split-K GEMM launches (partial slabs; every launch on the stream reuses it)
+        self._splitk_ws = torch.empty(8 * 1024 * 1024, device=self.device, dtype=torch.float32)
         self.initialize_weights(seed)
 
     # ------------------------------------------------------------------ parameters
@@ -194,7 +196,7 @@ class MAEEngine:
             w["drows"] = torch.empty(B * keep, pv, **f32)
             w["pmv_part"] = torch.empty(B, pv, **f32)
             w["rs_part"] = torch.empty(64, max(D, Dd), **f32)
-            w["splitk_ws"] = torch.empty(8 * 1024 * 1024, **f32)   # 32 MB: split-K slabs of the wgrad launches
+            w["splitk_ws"] = self._splitk_ws
         self._ws[key] = w
         return w
 
@@ -229,13 +231,13 @@ class MAEEngine:
                  out=bufs["qkv"])
         ops.mha_fwd(bufs["qkv"], bufs["att"], Bsz, N, heads, hd)
         ops.gemm(bufs["att"], LP(f"{prefix}.attn.proj.weight"), M=M, N=dim, K=dim, bias=P(f"{prefix}.attn.proj.bias"),
-                 resid=x_in, ldr=dim, out_f32=bufs["xmid"])
+                 resid=x_in, ldr=dim, out_f32=bufs["xmid"], ws=self._splitk_ws)
         ops.layernorm_fwd(bufs["xmid"], P(f"{prefix}.norm2.weight"), P(f"{prefix}.norm2.bias"), bufs["ln2"],
                           bufs["mean2"], bufs["rstd2"], M, dim, eps)
         ops.gemm(bufs["ln2"], LP(f"{prefix}.mlp.fc1.weight"), M=M, N=hidden, K=dim, bias=P(f"{prefix}.mlp.fc1.bias"),
                  act=ACT_GELU, out=bufs["hact"], out2=bufs["hpre"])
         ops.gemm(bufs["hact"], LP(f"{prefix}.mlp.fc2.weight"), M=M, N=dim, K=hidden, bias=P(f"{prefix}.mlp.fc2.bias"),
-                 resid=bufs["xmid"], ldr=dim, out_f32=x_out)
+                 resid=bufs["xmid"], ldr=dim, out_f32=x_out, ws=self._splitk_ws)
 
     def _encoder_fwd(self, imgs, noise, keep, w, train):
         cfg, st = self.cfg, self.store
@@ -315,7 +317,7 @@ class MAEEngine:
                  colsum_a=st.grad(bname), ws=w["splitk_ws"])
         if dx_out is not None:
             ops.gemm(dy, st.lp(wname), M=M, N=K, K=N, a_layout=KC, b_layout=RC, lda=N, ldb=K, act=dx_act, aux=dx_aux,
-                     ldaux=K, out=dx_out)
+                     ldaux=K, out=dx_out, ws=w["splitk_ws"])
 
     def _ln_bwd(self, dy, x, prefix, mean, rstd, g_in, g, g_lp, M, dim, w):
         st = self.store

@@ -60,14 +60,14 @@ for name, M, N, K, cnt, epi in layers:
     if epi == "gelu":
         fwd = lambda: ops.gemm(x, w, M=M, N=N, K=K, bias=bias, act=ops.ACT_GELU, out=y, out2=y2, tile=args.tile)
     elif epi == "resid":
-        fwd = lambda: ops.gemm(x, w, M=M, N=N, K=K, bias=bias, resid=res, ldr=N, out_f32=y32, tile=args.tile)
+        fwd = lambda: ops.gemm(x, w, M=M, N=N, K=K, bias=bias, resid=res, ldr=N, out_f32=y32, tile=args.tile, ws=ws)
     else:
         fwd = lambda: ops.gemm(x, w, M=M, N=N, K=K, bias=bias, out=y, tile=args.tile)
     if name.endswith("fc2"):
         dgrad = lambda: ops.gemm(dy, w, M=M, N=K, K=N, a_layout=ops.KC, b_layout=ops.RC, lda=N, ldb=K, act=ops.ACT_DGELU,
-                                 aux=aux, ldaux=K, out=dx, tile=args.tile)
+                                 aux=aux, ldaux=K, out=dx, tile=args.tile, ws=ws)
     else:
-        dgrad = lambda: ops.gemm(dy, w, M=M, N=K, K=N, a_layout=ops.KC, b_layout=ops.RC, lda=N, ldb=K, out=dx, tile=args.tile)
+        dgrad = lambda: ops.gemm(dy, w, M=M, N=K, K=N, a_layout=ops.KC, b_layout=ops.RC, lda=N, ldb=K, out=dx, tile=args.tile, ws=ws)
     wgrad = lambda: ops.gemm(dy, x, M=N, N=K, K=M, a_layout=ops.RC, b_layout=ops.RC, lda=N, ldb=K, out_f32=dw, colsum_a=db,
                              tile=args.tile, ws=ws)
     fl = 2.0 * M * N * K
