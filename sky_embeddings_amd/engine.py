@@ -74,6 +74,25 @@ class ParamStore:
         ops.cast(self.p, self.p_lp, self.n)
 
 
+def stage_gradient_ranges(store: ParamStore, cfg: MAEConfig, n_encoder_groups: int = 3):
+    """Slices of the flat gradient buffer that are FINAL after each backward stage
+    [decoder, encoder block groups (top first) ..., embedding].  Decayed weights sit in layout order, so
+    every stage owns one contiguous run of them; the small non-decayed tail (biases, LayerNorm) and
+    the front tensors (cls, patch_mask_values, mask_token, patch embedding) go with the last stage.
+    Returns (encoder groups [(hi, lo), ...], ranges per stage)."""
+    off = store.offsets
+    dec0 = off["decoder_embed.weight"]
+    ranges = [[(dec0, store.n_decay)]]
+    bounds = sorted({round(cfg.depth * k / n_encoder_groups) for k in range(n_encoder_groups + 1)}, reverse=True)
+    groups = []
+    for hi, lo in zip(bounds[:-1], bounds[1:]):
+        groups.append((hi, lo))
+        end = dec0 if hi == cfg.depth else off[f"blocks.{hi}.attn.qkv.weight"]
+        ranges.append([(off[f"blocks.{lo}.attn.qkv.weight"], end)])
+    ranges.append([(0, off["blocks.0.attn.qkv.weight"]), (store.n_decay, store.n)])
+    return groups, ranges
+
+
 class MAEEngine:
     def __init__(self, cfg: MAEConfig, device="cuda", compute_dtype=torch.bfloat16, seed=None):
         if cfg.simmim or cfg.ra_dec or cfg.attn_pool:
@@ -348,17 +367,19 @@ class MAEEngine:
                          dx_out=dln)
         self._ln_bwd(dln, x_in, f"{prefix}.norm1", bufs["mean1"], bufs["rstd1"], g, g, g_lp, M, dim, w)
 
-    def backward(self):
-        """Gradients of the last :meth:`forward_train` loss into the flat ``g`` buffer (every
-        trainable tensor is written exactly once, so no zeroing pass is needed)."""
+    def _bwd_ctx(self):
         assert self._last is not None, "backward() without forward_train()"
         imgs, B, keep = self._last
+        cfg = self.cfg
+        L = cfg.num_patches
+        return imgs, B, keep, 1 + keep, 1 + L, self._ws[(B, keep, True)]
+
+    def backward_decoder(self):
+        """Stage 0 of backward: decoder_pred ... decoder_embed (+ mask_token); leaves d latent in w['dln']."""
+        imgs, B, keep, Ne, Nd, w = self._bwd_ctx()
         cfg, st = self.cfg, self.store
         L, D, Dd, pv = cfg.num_patches, cfg.embed_dim, cfg.decoder_embed_dim, cfg.patch_dim
-        Ne, Nd = 1 + keep, 1 + L
         Me, Md = B * Ne, B * Nd
-        w = self._ws[(B, keep, True)]
-        # ---- decoder_pred, decoder_norm
         dln = w["dln"][:Md * Dd].view(Md, Dd)
         self._linear_bwd(w["dpred"], w["dlat_lp"], "decoder_pred.weight", "decoder_pred.bias", Md, pv, Dd, w, dx_out=dln)
         g = w["g"][:Md * Dd].view(Md, Dd)
@@ -367,18 +388,34 @@ class MAEEngine:
         for i in reversed(range(cfg.decoder_depth)):
             self._block_bwd(w["xd"][i], w["dec"][i], f"decoder_blocks.{i}", Md, Dd, cfg.decoder_num_heads, B, Nd, g,
                             g_lp, w)
-        # ---- mask token, decoder_embed (g = d xd[0])
+        # mask token, decoder_embed (g = d xd[0])
         ops.rowsum_select(g, Dd, w["mask"], 1, L, Nd, B * L, Dd, w["rs_part"], st.grad("mask_token").view(Dd))
         ops.gather_rows(g, w["dec_dst"], None, w["dE"], Me, Dd)
         dln_e = w["dln"][:Me * D].view(Me, D)
         self._linear_bwd(w["dE"], w["lat_lp"], "decoder_embed.weight", "decoder_embed.bias", Me, Dd, D, w, dx_out=dln_e)
-        # ---- encoder
+
+    def backward_encoder(self, hi=None, lo=0):
+        """Encoder blocks hi-1 ... lo (hi=None: from the top, including the final norm)."""
+        imgs, B, keep, Ne, Nd, w = self._bwd_ctx()
+        cfg = self.cfg
+        D = cfg.embed_dim
+        Me = B * Ne
         g = w["g"][:Me * D].view(Me, D)
         g_lp = w["g_lp"][:Me * D].view(Me, D)
-        self._ln_bwd(dln_e, w["xs"][cfg.depth], "norm", w["lat_mean"], w["lat_rstd"], None, g, g_lp, Me, D, w)
-        for i in reversed(range(cfg.depth)):
+        if hi is None:
+            hi = cfg.depth
+            dln_e = w["dln"][:Me * D].view(Me, D)
+            self._ln_bwd(dln_e, w["xs"][cfg.depth], "norm", w["lat_mean"], w["lat_rstd"], None, g, g_lp, Me, D, w)
+        for i in reversed(range(lo, hi)):
             self._block_bwd(w["xs"][i], w["enc"][i], f"blocks.{i}", Me, D, cfg.num_heads, B, Ne, g, g_lp, w)
-        # ---- cls token, patch embedding, patch_mask_values (g = d xs[0])
+
+    def backward_embed(self):
+        """Last stage: cls token, patch embedding, patch_mask_values (g = d xs[0])."""
+        imgs, B, keep, Ne, Nd, w = self._bwd_ctx()
+        cfg, st = self.cfg, self.store
+        D, pv = cfg.embed_dim, cfg.patch_dim
+        Me = B * Ne
+        g = w["g"][:Me * D].view(Me, D)
         ops.rowsum_select(g, D, None, 0, 1, Ne, B, D, w["rs_part"], st.grad("cls_token").view(D))
         ops.gather_rows(g, w["pe_dst"], None, w["dT"], B * keep, D)
         ops.gemm(w["dT"], w["patches"], M=D, N=pv, K=B * keep, a_layout=RC, b_layout=RC, lda=D, ldb=pv,
@@ -388,6 +425,24 @@ class MAEEngine:
                  ldb=pv, out_f32=w["drows"])
         ops.patch_gather_bwd_pmv(imgs, w["ids_keep"], w["drows"], w["pmv_part"], st.grad("patch_mask_values"),
                                  cfg.patch_size, keep)
+
+    def backward(self):
+        """Gradients of the last :meth:`forward_train` loss into the flat ``g`` buffer (every
+        trainable tensor is written exactly once, so no zeroing pass is needed)."""
+        self.backward_decoder()
+        self.backward_encoder()
+        self.backward_embed()
+
+    def backward_stages(self, n_encoder_groups=3):
+        """Backward cut into stages for gradient all-reduce overlap (one process per GPU): a list of
+        (callable, [(start, end), ...]) -- see :func:`stage_gradient_ranges`."""
+        cfg = self.cfg
+        groups, ranges = stage_gradient_ranges(self.store, cfg, n_encoder_groups)
+        stages = [(self.backward_decoder, ranges[0])]
+        for k, (hi, lo) in enumerate(groups):
+            stages.append(((lambda h=hi, l=lo, top=(k == 0): self.backward_encoder(None if top else h, l)), ranges[1 + k]))
+        stages.append((self.backward_embed, ranges[-1]))
+        return stages
 
     # ------------------------------------------------------------------ accounting
     def flops_per_image(self, mask_ratio=0.75):

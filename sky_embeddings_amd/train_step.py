@@ -1,51 +1,73 @@
-"""One optimiser step of MAE pretraining as a replayable HIP graph.
+"""One optimiser step of MAE pretraining as replayable HIP graphs.
 
-A step at BASELINE config A is ~500 short kernels (1.36 TFLOP in total): eager launches are
-host-bound, so forward + backward are captured ONCE into a HIP graph (through torch's stream
+A step at BASELINE config A is ~500 short kernels (1.34 TFLOP in total): eager launches are
+host-bound, so the launch schedule is captured ONCE into HIP graphs (through torch's stream
 capture; the kernels are this package's, launched via the C ABI on the capture stream) and
-replayed per step.  The gradient all-reduce (RCCL, one process per GPU) and the single fused
-AdamW launch follow the replay on the same stream.
+replayed per step.
+
+* 1 GPU: one graph = noise draw + forward + backward; then the single fused AdamW launch.
+* N GPUs (one process each): backward is cut into stages (decoder, encoder block groups, patch
+  embedding).  After each stage's graph is enqueued, the slices of the flat gradient buffer it has
+  finalised are all-reduced asynchronously (RCCL runs on its own stream, ordered after that stage),
+  so communication overlaps the remaining backward stages; AdamW (grad_scale = 1/N) follows the
+  last collective.  No other collective is used.
 """
 from __future__ import annotations
 
 import torch
 
+from .distributed import bucket_bounds
 from .optim import CosineLR, FusedAdamW
 
 
 class TrainStep:
     def __init__(self, engine, optimizer: FusedAdamW, scheduler: CosineLR, batch_size: int, mask_ratio: float = 0.75,
-                 use_graph: bool = True, process_group=None, world_size: int = 1, warmup_iters: int = 2):
+                 use_graph: bool = True, process_group=None, world_size: int = 1, warmup_iters: int = 2,
+                 staged: bool | None = None, n_encoder_groups: int = 3, bucket_elems: int = 32 * 1024 * 1024):
         self.engine, self.optimizer, self.scheduler = engine, optimizer, scheduler
         self.mask_ratio = mask_ratio
         self.world_size = world_size
         self.process_group = process_group
+        self.bucket_elems = bucket_elems
         cfg = engine.cfg
         dev = engine.device
         self.imgs = torch.zeros(batch_size, cfg.in_chans, cfg.img_size, cfg.img_size, device=dev)
         self.noise = torch.zeros(batch_size, cfg.num_patches, device=dev)
-        self.graph = None
         self.loss = None
+        self.staged = (world_size > 1) if staged is None else staged
         if world_size > 1:
             optimizer.grad_scale = 1.0 / world_size  # DDP mean of per-rank gradients
+        # stage list: [(callable, [(start, end) slices of the flat gradient buffer final after it])]
+        if self.staged:
+            stages = engine.backward_stages(n_encoder_groups)
+            first_fn, first_ranges = stages[0]
+            self.stages = [((lambda: (self._forward(), first_fn())), first_ranges)] + stages[1:]
+        else:
+            self.stages = [((lambda: (self._forward(), engine.backward())), [(0, engine.store.n)])]
+        self.graphs = None
         if use_graph:
             # warm up on a side stream (lazy hipFuncSetAttribute calls, workspace allocation), then capture
             s = torch.cuda.Stream(device=dev)
             s.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(s):
                 for _ in range(warmup_iters):
-                    self._fwd_bwd()
+                    for fn, _ in self.stages:
+                        fn()
             torch.cuda.current_stream(dev).wait_stream(s)
             torch.cuda.synchronize(dev)
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self._fwd_bwd()
+            self.graphs = []
+            pool = None
+            for fn, _ in self.stages:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    fn()
+                pool = g.pool()
+                self.graphs.append(g)
 
-    def _fwd_bwd(self):
+    def _forward(self):
         # utils/mim_vit.py:363 draws the masking noise inside forward; keep it inside the step
         self.noise.uniform_()
         self.loss, self.pred, self.mask = self.engine.forward_train(self.imgs, self.mask_ratio, self.noise)
-        self.engine.backward()
 
     def load_batch(self, imgs):
         """Stage the next minibatch (device or pinned host tensor) into the static input buffer."""
@@ -54,13 +76,20 @@ class TrainStep:
     def __call__(self, imgs=None):
         if imgs is not None:
             self.load_batch(imgs)
-        if self.graph is not None:
-            self.graph.replay()
-        else:
-            self._fwd_bwd()
-        if self.world_size > 1:
-            from .distributed import allreduce_flat_gradients
-            allreduce_flat_gradients(self.engine.store.g, self.world_size, group=self.process_group)
+        works = []
+        g = self.engine.store.g
+        for k, (fn, ranges) in enumerate(self.stages):
+            if self.graphs is not None:
+                self.graphs[k].replay()
+            else:
+                fn()
+            if self.world_size > 1:
+                for (s, e) in ranges:
+                    for (bs, be) in bucket_bounds(e - s, self.bucket_elems):
+                        works.append(torch.distributed.all_reduce(g[s + bs:s + be], group=self.process_group,
+                                                                  async_op=True))
+        for w in works:
+            w.wait()   # makes the compute stream wait for the collectives (no host block with NCCL/RCCL)
         self.optimizer.step()
         self.scheduler.step()
         return self.loss

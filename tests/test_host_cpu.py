@@ -187,3 +187,21 @@ def test_two_process_gloo_paths(tmp_path):
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
     assert sdist.bucket_bounds(20, 8) == [(0, 8), (8, 16), (16, 20)]
     assert sdist.shard_rows(10, 3, 4) == (9, 10) and sdist.shard_rows(10, 0, 4) == (0, 3)
+
+
+def test_backward_stage_ranges_tile_the_gradient_buffer():
+    """DDP overlap: the per-stage all-reduce slices cover the flat gradient buffer exactly once."""
+    from sky_embeddings_amd.engine import ParamStore, stage_gradient_ranges
+    for mt, groups in (("base", 3), ("tiny", 4), ("large", 5), ("base", 1)):
+        cfg = mc.config_for(mt, img_size=64, patch_size=16, in_chans=5, embed_dim=192 if mt == "tiny" else 768)
+        st = ParamStore(cfg, "cpu", torch.bfloat16)
+        enc_groups, ranges = stage_gradient_ranges(st, cfg, groups)
+        assert enc_groups[0][0] == cfg.depth and enc_groups[-1][1] == 0
+        flat = sorted(r for stage in ranges for r in stage)
+        assert flat[0][0] == 0 and flat[-1][1] == st.n
+        for (a0, a1), (b0, b1) in zip(flat[:-1], flat[1:]):
+            assert a1 == b0 and a0 < a1
+        # a stage's slice holds exactly the weights of its own blocks
+        hi, lo = enc_groups[0]
+        s, e = ranges[1][0]
+        assert s == st.offsets[f"blocks.{lo}.attn.qkv.weight"] and e == st.offsets["decoder_embed.weight"]
