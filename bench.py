@@ -155,10 +155,12 @@ def bench_search(args, rank, world, dev):
         tw = torch.empty(Q, D, device=dev)
         qn = torch.empty(Q, device=dev)
         ops.weighted_norms(q.contiguous(), w, qn, tw)
-        nch = ops.cosine_topk_chunks(hi - lo, Q, k)
+        nch = ops.cosine_topk_chunks(hi - lo, Q, D, k)
         ps = torch.empty(Q, nch, k, device=dev)
         pi = torch.empty(Q, nch, k, device=dev, dtype=torch.int64)
-        kms = ev_time_ms(lambda: ops.cosine_topk(tw, qn, bank, pb.norms, k, 1e-6, lo, nch, ps, pi), iters)
+        from sky_embeddings_amd.search import pruning_floor
+        thr0 = pruning_floor(tw, qn, pb, k, 1e-6)
+        kms = ev_time_ms(lambda: ops.cosine_topk(tw, qn, bank, pb.norms, k, 1e-6, lo, nch, ps, pi, thr0), iters)
         bank_bytes = (hi - lo) * D * 4
         res[label] = dict(Q=Q, sec=dt, queries_per_sec=Q / dt, kernel_ms=kms,
                           kernel_hbm_gbs=(bank_bytes + Q * D * 4 + Q * nch * k * 12) / kms / 1e6,

@@ -185,11 +185,16 @@ int skyemb_weighted_norms(const float *x, const float *w, float *norms, float *x
                           void *stream);
 /* utils/similarity.py:149-172 + 18-35 fused: per-(query tile, bank chunk) exact partial top-k.
  *   tw [Q,D] (= w*t), qn [Q], bank [N,D], xn [N]  ->  part_s f32 / part_i i64 [Q, nchunks, k]
+ * (nchunks = skyemb_cosine_topk_chunks(N, Q, D, k): bank chunks of the tiled kernel, or one list per
+ * wavefront of the bank-streaming kernel used when Q <= 16).
+ * thr0 (optional, [Q]): a pruning floor per query -- only rows scoring STRICTLY above it are kept.  Any value
+ * below the true k-th best score is valid (e.g. nextafter(k-th best of a row sample, -inf)) and leaves
+ * the result unchanged while removing most list insertions.
  * sorted by (score desc, index asc); idx = idx_offset + local row.  Then skyemb_topk_merge. */
-int skyemb_cosine_topk_chunks(int64_t N, int Q, int k);
+int skyemb_cosine_topk_chunks(int64_t N, int Q, int D, int k);
 int skyemb_cosine_topk(const float *tw, const float *qn, const float *bank, const float *xn, int Q, int64_t N,
-                       int D, int k, float eps, int64_t idx_offset, int nchunks, float *part_s, int64_t *part_i,
-                       void *stream);
+                       int D, int k, float eps, int64_t idx_offset, int nchunks, const float *thr0, float *part_s,
+                       int64_t *part_i, void *stream);
 /* merge `nlists` sorted length-k lists per query (bank chunks, or per-rank results after the
  * RCCL all-gather): in [Q, nlists, k] -> out [Q, k]. */
 int skyemb_topk_merge(const float *in_s, const int64_t *in_i, int Q, int nlists, int k, float *out_s,

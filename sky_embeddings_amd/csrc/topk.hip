@@ -7,6 +7,7 @@
 // top-k list in LDS for its bank chunk (threshold-filtered insertion); the per-chunk lists are
 // merged by skyemb_topk_merge (also used after the RCCL all-gather of per-rank results).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -114,7 +115,8 @@ __global__ __launch_bounds__(256) void cosine_topk_kernel(const float *__restric
                                                           const float *__restrict__ bank, const float *__restrict__ xn,
                                                           int Q, int64_t N, int D, int k, float eps, int64_t idx_offset,
                                                           int nchunks, int64_t rows_per_chunk, float *__restrict__ part_s,
-                                                          int64_t *__restrict__ part_i, float *__restrict__ scores) {
+                                                          int64_t *__restrict__ part_i, float *__restrict__ scores,
+                                                          const float *__restrict__ thr0) {
     constexpr int WM = QT >= 64 ? 2 : 1, WN = 4 / WM;
     constexpr int TM = QT / WM / 16, TN = BT / WN / 16;
     constexpr int SCP = BT + 1;
@@ -209,7 +211,8 @@ __global__ __launch_bounds__(256) void cosine_topk_kernel(const float *__restric
                 float *lsq = ls + qq * k;
                 int *liq = li + qq * k;
                 int n_in = cnt[qi];
-                float thr = n_in == k ? lsq[k - 1] : -INFINITY;
+                const float floor_thr = thr0 ? thr0[q0 + qq] : -INFINITY;   // valid lower bound of the global k-th best
+                float thr = n_in == k ? lsq[k - 1] : floor_thr;
                 for (int t = 0; t < BT / 64; ++t) {
                     const float v = sc[qq * SCP + t * 64 + lane];
                     unsigned long long m = __ballot(v > thr);
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(256) void cosine_topk_kernel(const float *__restric
                         }
                         __builtin_amdgcn_wave_barrier();
                         n_in = new_n;
-                        thr = n_in == k ? lsq[k - 1] : -INFINITY;
+                        thr = n_in == k ? lsq[k - 1] : floor_thr;
                     }
                 }
                 cnt[qi] = n_in;
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(64) void topk_merge_kernel(const float *__restrict_
 template <int QT, int BT, bool SO>
 int launch_topk(const float *tw, const float *qn, const float *bank, const float *xn, int Q, int64_t N, int D, int k,
                 float eps, int64_t idx_offset, int nchunks, float *part_s, int64_t *part_i, float *scores, hipStream_t st,
-                const char *name) {
+                const char *name, const float *thr0 = nullptr) {
     const size_t smem = sizeof(float) * (2 * QT * PITCH + 2 * BT * PITCH + QT * (BT + 1) + (SO ? 0 : 2 * (size_t)QT * k));
     if (smem > 160 * 1024) {
         skyemb_set_error("%s: k=%d needs %zu B of LDS (max 160 KiB)", name, k, smem);
@@ -333,7 +336,7 @@ int launch_topk(const float *tw, const float *qn, const float *bank, const float
     int64_t rows_per_chunk = ceil_div64(ceil_div64(N, nchunks), BT) * BT;
     const int qtiles = (Q + QT - 1) / QT;
     hipLaunchKernelGGL(kern, dim3((unsigned)(qtiles * nchunks)), dim3(256), smem, st, tw, qn, bank, xn, Q, N, D, k, eps,
-                       idx_offset, nchunks, rows_per_chunk, part_s, part_i, scores);
+                       idx_offset, nchunks, rows_per_chunk, part_s, part_i, scores, thr0);
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) {
         skyemb_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));
@@ -367,7 +370,19 @@ extern "C" int skyemb_weighted_norms(const float *x, const float *w, float *norm
     return 0;
 }
 
-extern "C" int skyemb_cosine_topk_chunks(int64_t N, int Q, int k) {
+// topk_stream.hip: bank-streaming variant for Q <= 16
+bool skyemb_topk_stream_applicable(int Q, int D, int k);
+int skyemb_topk_stream_lists(int64_t N);
+int skyemb_topk_stream_launch(const float *tw, const float *qn, const float *bank, const float *xn, int Q, int64_t N, int D,
+                              int k, float eps, int64_t idx_offset, int nlists, float *part_s, int64_t *part_i,
+                              const float *thr0, hipStream_t st);
+static bool use_stream(int Q, int D, int k) {
+    static const bool on = []() { const char *e = getenv("SKYEMB_TOPK_STREAM"); return !(e && e[0] == '0'); }();
+    return on && skyemb_topk_stream_applicable(Q, D, k);
+}
+
+extern "C" int skyemb_cosine_topk_chunks(int64_t N, int Q, int D, int k) {
+    if (use_stream(Q, D, k)) return skyemb_topk_stream_lists(N);
     const bool small = small_tile(Q, k);
     const int QT = small ? 16 : 64, BT = small ? 256 : 128;
     const int qtiles = (Q + QT - 1) / QT;
@@ -381,16 +396,20 @@ extern "C" int skyemb_cosine_topk_chunks(int64_t N, int Q, int k) {
 }
 
 extern "C" int skyemb_cosine_topk(const float *tw, const float *qn, const float *bank, const float *xn, int Q, int64_t N,
-                                  int D, int k, float eps, int64_t idx_offset, int nchunks, float *part_s, int64_t *part_i,
-                                  void *stream) {
+                                  int D, int k, float eps, int64_t idx_offset, int nchunks, const float *thr0, float *part_s,
+                                  int64_t *part_i, void *stream) {
     SKY_CHECK_ARG(Q > 0 && N > 0 && D > 0 && D % 4 == 0 && k > 0 && nchunks > 0, "skyemb_cosine_topk: bad shape");
     SKY_CHECK_ARG(N < (1ll << 31), "skyemb_cosine_topk: shard too large (N < 2^31 rows per call)");
     hipStream_t st = (hipStream_t)stream;
+    if (use_stream(Q, D, k)) {
+        SKY_CHECK_ARG(nchunks == skyemb_topk_stream_lists(N), "skyemb_cosine_topk: nchunks must come from skyemb_cosine_topk_chunks");
+        return skyemb_topk_stream_launch(tw, qn, bank, xn, Q, N, D, k, eps, idx_offset, nchunks, part_s, part_i, thr0, st);
+    }
     if (small_tile(Q, k))
         return launch_topk<16, 256, false>(tw, qn, bank, xn, Q, N, D, k, eps, idx_offset, nchunks, part_s, part_i, nullptr,
-                                           st, "skyemb_cosine_topk");
+                                           st, "skyemb_cosine_topk", thr0);
     return launch_topk<64, 128, false>(tw, qn, bank, xn, Q, N, D, k, eps, idx_offset, nchunks, part_s, part_i, nullptr, st,
-                                       "skyemb_cosine_topk");
+                                       "skyemb_cosine_topk", thr0);
 }
 
 extern "C" int skyemb_cosine_scores(const float *tw, const float *qn, const float *bank, const float *xn, int Q, int64_t N,

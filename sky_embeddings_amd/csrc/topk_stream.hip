@@ -1,0 +1,231 @@
+// Bank-streaming cosine top-k for Q <= 16 queries (the HBM-bound regime, e.g. the reference's one
+// target vector): every wavefront streams its own slice of the bank straight from HBM into
+// registers (16-byte loads, no LDS staging, no barriers), feeds v_mfma_f32_16x16x4_f32 and keeps
+// private sorted top-k lists for the 16 queries in LDS.  Bit-identical to the tiled kernel and to
+// oracle/topk_oracle.c: the fma chain runs over d = 0,1,2,... in order.
+//
+// Lane (n = lane&15, g = lane>>4) loads bank[row0+n][16c + 4g .. 4g+3]; the MFMA B operand of k-step m
+// must hold bank[row0+n][16c + 4m + g], i.e. the 4x4 transpose of (lane group g) x (element s):
+// two v_permlane32_swap (lanes +-32) and two v_permlane16_swap (lanes +-16) per float4.
+#include "common.h"
+
+namespace {
+
+constexpr int WAVES = 4;
+constexpr int UNROLL = 4;   // float4 loads per register set (2 sets: up to 8 KiB per wave in flight)
+
+__device__ __forceinline__ float finish_score(float dot, float qn, float xn, float eps) {
+    const float den = fmaf(qn, xn, eps);
+    const float s = __fdiv_rn(dot, den);
+    return s == s ? s : -INFINITY;
+}
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ void swap32(float &lo_half_src, float &hi_half_dst) {
+    // lanes 32-63 of `hi_half_dst` <-> lanes 0-31 of `lo_half_src`
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(hi_half_dst), __float_as_uint(lo_half_src), false, false);
+    hi_half_dst = __uint_as_float(r[0]);
+    lo_half_src = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap16(float &even_src, float &odd_dst) {
+    // odd 16-lane rows of `odd_dst` <-> even 16-lane rows of `even_src`
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(odd_dst), __float_as_uint(even_src), false, false);
+    odd_dst = __uint_as_float(r[0]);
+    even_src = __uint_as_float(r[1]);
+}
+
+// v[s] of lane group g  ->  v[g'] ... transpose so that afterwards v[m] (group g) == old v[g] of group m
+__device__ __forceinline__ void transpose4(float4 &v) {
+    swap32(v.z, v.x);   // upper half's x <-> lower half's z
+    swap32(v.w, v.y);   // upper half's y <-> lower half's w
+    swap16(v.y, v.x);   // odd rows' x <-> even rows' y
+    swap16(v.w, v.z);   // odd rows' z <-> even rows' w
+}
+
+__global__ __launch_bounds__(256) void cosine_topk_stream_kernel(const float *__restrict__ tw, const float *__restrict__ qn,
+                                                                 const float *__restrict__ bank, const float *__restrict__ xn,
+                                                                 int Q, int64_t N, int D, int k, float eps, int64_t idx_offset,
+                                                                 int64_t rows_per_wave, float *__restrict__ part_s,
+                                                                 int64_t *__restrict__ part_i, const float *__restrict__ thr0) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nchunk = D >> 4;
+    float4 *imgA = (float4 *)lds;                                   // [nchunk][64]: A fragments of every k-step
+    float *ls_all = lds + (size_t)nchunk * 64 * 4;                  // [WAVES][16][k]
+    int *li_all = (int *)(ls_all + (size_t)WAVES * 16 * k);        // [WAVES][16][k]
+    // A operand image: lane (q = l&15, g = l>>4), element m: tw[q][16c + 4m + g]
+    for (int e = tid; e < nchunk * 64; e += 256) {
+        const int c = e >> 6, l = e & 63, q = l & 15, g = l >> 4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < Q) {
+            const float *src = tw + (int64_t)q * D + 16 * c + g;
+            a = make_float4(src[0], src[4], src[8], src[12]);
+        }
+        imgA[e] = a;
+    }
+    __syncthreads();
+    float *ls = ls_all + (size_t)wave * 16 * k;
+    int *li = li_all + (size_t)wave * 16 * k;
+    const int wid = blockIdx.x * WAVES + wave;
+    const int64_t r_begin = (int64_t)wid * rows_per_wave;
+    int64_t r_end = r_begin + rows_per_wave;
+    if (r_end > N) r_end = N;
+    const int n_lane = lane & 15, g = lane >> 4;
+    // per-query list sizes / thresholds live in registers of ALL lanes (wave-uniform arrays of 16)
+    int n_in[16];
+    float thr[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { n_in[q] = 0; thr[q] = (thr0 && q < Q) ? thr0[q] : -INFINITY; }
+    float floor_thr[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) floor_thr[q] = thr[q];   // valid lower bound of the global k-th best (or -inf)
+    float qn4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) qn4[r] = (4 * g + r) < Q ? qn[4 * g + r] : 0.f;
+
+    for (int64_t n0 = r_begin; n0 < r_end; n0 += 16) {
+        int64_t row = n0 + n_lane;
+        const bool row_ok = row < r_end;
+        if (!row_ok) row = r_end - 1;                                // clamp: masked below
+        const float *src = bank + row * D + 4 * g;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // two register sets (nchunk % UNROLL == 0 is checked on the host): the next group's loads are in
+        // flight while the current group feeds the MFMAs
+        float4 b0[UNROLL], b1[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) b0[u] = *(const float4 *)(src + 16 * u);
+        for (int c0 = 0; c0 < nchunk; c0 += 2 * UNROLL) {
+            const bool more1 = c0 + UNROLL < nchunk, more2 = c0 + 2 * UNROLL < nchunk;
+            if (more1) {
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) b1[u] = *(const float4 *)(src + 16 * (c0 + UNROLL + u));
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                transpose4(b0[u]);
+                const float4 a = imgA[(c0 + u) * 64 + lane];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0[u].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0[u].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0[u].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0[u].w, acc, 0, 0, 0);
+            }
+            if (more2) {
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) b0[u] = *(const float4 *)(src + 16 * (c0 + 2 * UNROLL + u));
+            }
+            if (more1) {
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    transpose4(b1[u]);
+                    const float4 a = imgA[(c0 + UNROLL + u) * 64 + lane];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1[u].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1[u].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1[u].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1[u].w, acc, 0, 0, 0);
+                }
+            }
+        }
+        // C/D: col = lane&15 -> bank row n0 + n_lane, row = 4g + r -> query
+        const float xnv = xn[row];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q_mine = 4 * g + r;
+            const float s = (row_ok && q_mine < Q) ? finish_score(acc[r], qn4[r], xnv, eps) : -INFINITY;
+            // candidates of the 4 queries {r, 4+r, 8+r, 12+r} (one per lane group), rows ascending within a group
+            float my_thr = -INFINITY;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) my_thr = (g == gg) ? thr[4 * gg + r] : my_thr;
+            unsigned long long m = __ballot(s > my_thr);
+            while (m) {
+                const int srcl = __builtin_ctzll(m);
+                m &= m - 1;
+                const float cv = __shfl(s, srcl, 64);
+                const int q = 4 * (srcl >> 4) + r;
+                float *lsq = ls + q * k;
+                int *liq = li + q * k;
+                // wave-uniform per-query state (static indexing through the unrolled select)
+                int nq = 0;
+                float tq = -INFINITY;
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg)
+                    if (q == 4 * gg + r) { nq = n_in[4 * gg + r]; tq = thr[4 * gg + r]; }
+                if (!(cv > tq)) continue;
+                int pos = 0;
+                for (int e = lane; e < nq; e += 64) pos += lsq[e] >= cv ? 1 : 0;
+                pos = wave_sum_i(pos);
+                const int new_n = nq < k ? nq + 1 : k;
+                for (int e0 = ((new_n - 1) / 64) * 64; e0 >= 0; e0 -= 64) {
+                    const int e = e0 + lane;
+                    const bool mv = e >= pos && e < new_n - 1;
+                    float sv = 0.f;
+                    int iv = 0;
+                    if (mv) { sv = lsq[e]; iv = liq[e]; }
+                    __builtin_amdgcn_wave_barrier();
+                    if (mv) { lsq[e + 1] = sv; liq[e + 1] = iv; }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (lane == 0) {
+                    lsq[pos] = cv;
+                    liq[pos] = (int)(n0 + (srcl & 15));
+                }
+                __builtin_amdgcn_wave_barrier();
+                const float kth = new_n == k ? lsq[k - 1] : -INFINITY;
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg)
+                    if (q == 4 * gg + r) {
+                        n_in[4 * gg + r] = new_n;
+                        thr[4 * gg + r] = new_n == k ? kth : floor_thr[4 * gg + r];
+                    }
+            }
+        }
+    }
+    // write this wave's lists: part[q][wid][k]
+    const int nlists = gridDim.x * WAVES;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        if (q >= Q) continue;
+        const int64_t o = ((int64_t)q * nlists + wid) * k;
+        for (int e = lane; e < k; e += 64) {
+            const bool have = e < n_in[q];
+            part_s[o + e] = have ? ls[q * k + e] : -INFINITY;
+            part_i[o + e] = have ? idx_offset + (int64_t)li[q * k + e] : -1;
+        }
+    }
+}
+
+}  // namespace
+
+bool skyemb_topk_stream_applicable(int Q, int D, int k) { return Q <= 16 && k <= 128 && D % (16 * UNROLL) == 0 && D <= 1024; }
+
+int skyemb_topk_stream_lists(int64_t N) {
+    int64_t blocks = 256;
+    while (blocks > 1 && blocks * WAVES * 64 > N) blocks >>= 1;   // at least 64 rows per wave
+    return (int)(blocks * WAVES);
+}
+
+int skyemb_topk_stream_launch(const float *tw, const float *qn, const float *bank, const float *xn, int Q, int64_t N, int D,
+                              int k, float eps, int64_t idx_offset, int nlists, float *part_s, int64_t *part_i,
+                              const float *thr0, hipStream_t st) {
+    const int blocks = nlists / WAVES;
+    const size_t smem = sizeof(float) * ((size_t)(D >> 4) * 64 * 4 + 2 * (size_t)WAVES * 16 * k);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)cosine_topk_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024);
+        if (e != hipSuccess) {
+            skyemb_set_error("skyemb_cosine_topk(stream): hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return 2;
+        }
+        attr_set = true;
+    }
+    int64_t rows_per_wave = ceil_div64(ceil_div64(N, nlists), 16) * 16;
+    hipLaunchKernelGGL(cosine_topk_stream_kernel, dim3(blocks), dim3(256), smem, st, tw, qn, bank, xn, Q, N, D, k, eps,
+                       idx_offset, rows_per_wave, part_s, part_i, thr0);
+    SKY_LAUNCH_CHECK("skyemb_cosine_topk(stream)");
+    return 0;
+}

@@ -150,15 +150,15 @@ def weighted_norms(x, w, norms, xw_out=None):
     check(lib().skyemb_weighted_norms(_p(x), _p(w), _p(norms), _p(xw_out), N, D, _stream()), "skyemb_weighted_norms")
 
 
-def cosine_topk_chunks(N, Q, k):
-    return lib().skyemb_cosine_topk_chunks(N, Q, k)
+def cosine_topk_chunks(N, Q, D, k):
+    return lib().skyemb_cosine_topk_chunks(N, Q, D, k)
 
 
-def cosine_topk(tw, qn, bank, xn, k, eps, idx_offset, nchunks, part_s, part_i):
+def cosine_topk(tw, qn, bank, xn, k, eps, idx_offset, nchunks, part_s, part_i, thr0=None):
     Q, D = tw.shape
     N = bank.shape[0]
-    check(lib().skyemb_cosine_topk(_p(tw), _p(qn), _p(bank), _p(xn), Q, N, D, k, eps, idx_offset, nchunks, _p(part_s),
-                                   _p(part_i), _stream()), "skyemb_cosine_topk")
+    check(lib().skyemb_cosine_topk(_p(tw), _p(qn), _p(bank), _p(xn), Q, N, D, k, eps, idx_offset, nchunks, _p(thr0),
+                                   _p(part_s), _p(part_i), _stream()), "skyemb_cosine_topk")
 
 
 def topk_merge(in_s, in_i, Q, nlists, k, out_s, out_i):

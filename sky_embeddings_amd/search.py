@@ -22,11 +22,22 @@ class PreparedBank:
         assert bank.is_cuda and bank.dtype == torch.float32 and bank.is_contiguous() and bank.dim() == 2
         self.bank, self.idx_offset = bank, int(idx_offset)
         self.norms = torch.empty(bank.shape[0], device=bank.device)
+        self._sample = None
         self.set_weights(weights)
 
     def set_weights(self, weights):
         self.weights = None if weights is None else weights.to(self.bank.device, torch.float32).contiguous()
         ops.weighted_norms(self.bank, self.weights, self.norms)
+        self._sample = None
+
+    def sample(self, rows: int):
+        """A strided row sample (bank rows + norms) used to derive the pruning floor of a search."""
+        N = self.bank.shape[0]
+        rows = min(rows, N)
+        if self._sample is None or self._sample[0].shape[0] != rows:
+            idx = torch.arange(rows, device=self.bank.device) * (N // rows)
+            self._sample = (self.bank.index_select(0, idx).contiguous(), self.norms.index_select(0, idx).contiguous())
+        return self._sample
 
 
 def standardise_(bank: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, out: torch.Tensor | None = None):
@@ -44,8 +55,38 @@ def prepare_queries(queries: torch.Tensor, weights: torch.Tensor | None):
     return tw, qn
 
 
+def _local_topk(tw, qn, bank, norms, k, eps, idx_offset, thr0=None):
+    Q, D = tw.shape
+    N = bank.shape[0]
+    dev = tw.device
+    nch = ops.cosine_topk_chunks(N, Q, D, k)
+    ps = torch.empty(Q, nch, k, device=dev)
+    pi = torch.empty(Q, nch, k, device=dev, dtype=torch.int64)
+    ops.cosine_topk(tw, qn, bank, norms, k, eps, idx_offset, nch, ps, pi, thr0)
+    out_s = torch.empty(Q, k, device=dev)
+    out_i = torch.empty(Q, k, device=dev, dtype=torch.int64)
+    ops.topk_merge(ps, pi, Q, nch, k, out_s, out_i)
+    return out_s, out_i
+
+
+def pruning_floor(tw, qn, pb: "PreparedBank", k: int, eps: float, sample_rows: int | None = None):
+    """Per-query score floor for the main pass: the k-th best score over a row SAMPLE is a lower
+    bound of the k-th best over the whole bank, so rows scoring below it can never enter the
+    result.  Returned one ulp lower (the kernels keep rows STRICTLY above the floor, ties included
+    this way).  None when the bank is too small for the extra pass to pay."""
+    N = pb.bank.shape[0]
+    if sample_rows is None:
+        sample_rows = 128 * k
+    if N < 8 * sample_rows:
+        return None
+    sb, sn = pb.sample(sample_rows)
+    s, _ = _local_topk(tw, qn, sb, sn, k, eps, 0)
+    tau = s[:, k - 1].contiguous()
+    return torch.nextafter(tau, torch.full_like(tau, float("-inf")))
+
+
 def cosine_topk(queries: torch.Tensor, bank, k: int, weights: torch.Tensor | None = None, eps: float = 1e-6,
-                process_group=None, world_size: int = 1):
+                process_group=None, world_size: int = 1, prune: bool = True):
     """-> (scores f32 [Q,k], indices i64 [Q,k]).  ``bank`` is a [N,D] tensor or a PreparedBank
     (this rank's shard; ``idx_offset`` = first global row of the shard)."""
     pb = bank if isinstance(bank, PreparedBank) else PreparedBank(bank, weights)
@@ -54,14 +95,8 @@ def cosine_topk(queries: torch.Tensor, bank, k: int, weights: torch.Tensor | Non
     N = pb.bank.shape[0]
     assert D == pb.bank.shape[1]
     tw, qn = prepare_queries(q, pb.weights)
-    nch = ops.cosine_topk_chunks(N, Q, k)
-    dev = q.device
-    ps = torch.empty(Q, nch, k, device=dev)
-    pi = torch.empty(Q, nch, k, device=dev, dtype=torch.int64)
-    ops.cosine_topk(tw, qn, pb.bank, pb.norms, k, eps, pb.idx_offset, nch, ps, pi)
-    out_s = torch.empty(Q, k, device=dev)
-    out_i = torch.empty(Q, k, device=dev, dtype=torch.int64)
-    ops.topk_merge(ps, pi, Q, nch, k, out_s, out_i)
+    thr0 = pruning_floor(tw, qn, pb, k, eps) if prune else None
+    out_s, out_i = _local_topk(tw, qn, pb.bank, pb.norms, k, eps, pb.idx_offset, thr0)
     if world_size > 1:
         from .distributed import gather_topk
         gs, gi = gather_topk(out_s, out_i, world_size, process_group)   # RCCL all-gather -> [Q, world, k]

@@ -33,7 +33,7 @@ def test_loader_and_error_channel():
     g = _lib.GemmArgs()
     rc = L.skyemb_gemm(ctypes.byref(g), None)
     assert rc != 0 and b"empty problem" in L.skyemb_last_error()
-    rc = L.skyemb_cosine_topk(None, None, None, None, 0, 0, 0, 0, 0.0, 0, 0, None, None, None)
+    rc = L.skyemb_cosine_topk(None, None, None, None, 0, 0, 0, 0, 0.0, 0, 0, None, None, None, None)
     assert rc != 0 and b"bad shape" in L.skyemb_last_error()
 
 

@@ -321,7 +321,7 @@ def _run_topk(ops, q, x, w, k):
     tw, qn, xn = torch.empty(Q, D, device=DEV), torch.empty(Q, device=DEV), torch.empty(N, device=DEV)
     ops.weighted_norms(qd, wd, qn, tw)
     ops.weighted_norms(xd, wd, xn)
-    nch = ops.cosine_topk_chunks(N, Q, k)
+    nch = ops.cosine_topk_chunks(N, Q, D, k)
     ps = torch.empty(Q, nch, k, device=DEV)
     pi = torch.empty(Q, nch, k, device=DEV, dtype=torch.int64)
     ops.cosine_topk(tw, qn, xd, xn, k, 1e-6, 0, nch, ps, pi)
