@@ -196,9 +196,10 @@ int skyemb_cosine_topk(const float *tw, const float *qn, const float *bank, cons
                        int D, int k, float eps, int64_t idx_offset, int nchunks, const float *thr0, float *part_s,
                        int64_t *part_i, void *stream);
 /* merge `nlists` sorted length-k lists per query (bank chunks, or per-rank results after the
- * RCCL all-gather): in [Q, nlists, k] -> out [Q, k]. */
+ * RCCL all-gather): in [Q, nlists, k] -> out [Q, k].  `ws` (optional, Q ints) enables the gather + block-sort
+ * path used for the many short lists of the bank-streaming kernel (per-query fallback to the tournament). */
 int skyemb_topk_merge(const float *in_s, const int64_t *in_i, int Q, int nlists, int k, float *out_s,
-                      int64_t *out_i, void *stream);
+                      int64_t *out_i, void *ws, void *stream);
 /* plain score matrix for the reference-shaped path with P>1 patches per sample
  * (utils/similarity.py:262-267 combine over patches happens on these): scores [Q, N]. */
 int skyemb_cosine_scores(const float *tw, const float *qn, const float *bank, const float *xn, int Q, int64_t N,

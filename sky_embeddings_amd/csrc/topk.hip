@@ -269,10 +269,9 @@ __global__ __launch_bounds__(256) void cosine_topk_kernel(const float *__restric
 // merge: one wave per query, `nlists` sorted lists of length k -> best k by (score desc, idx asc).
 // Heads live in LDS; each round every lane proposes the best head among its lists, a butterfly
 // picks the winner, the owning lane advances that list.
-__global__ __launch_bounds__(64) void topk_merge_kernel(const float *__restrict__ in_s, const int64_t *__restrict__ in_i,
-                                                        int nlists, int k, float *__restrict__ out_s,
-                                                        int64_t *__restrict__ out_i) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void tournament_merge(const float *__restrict__ in_s, const int64_t *__restrict__ in_i,
+                                                 int nlists, int k, float *__restrict__ out_s,
+                                                 int64_t *__restrict__ out_i, char *smem) {
     float *hs = (float *)smem;                       // [nlists] head score
     int64_t *hi = (int64_t *)(smem + ((nlists * 4 + 15) & ~15));  // [nlists] head idx
     int *hp = (int *)(hi + nlists);                  // [nlists] head position
@@ -314,6 +313,124 @@ __global__ __launch_bounds__(64) void topk_merge_kernel(const float *__restrict_
         }
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+__global__ __launch_bounds__(64) void topk_merge_kernel(const float *__restrict__ in_s, const int64_t *__restrict__ in_i,
+                                                        int nlists, int k, float *__restrict__ out_s,
+                                                        int64_t *__restrict__ out_i) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    tournament_merge(in_s, in_i, nlists, k, out_s, out_i, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// merge of MANY lists (bank-streaming kernel: one short list per wavefront): the tournament above
+// pays one dependent global load per output element, so instead the valid entries (few once a
+// pruning floor is used) are gathered into LDS as 64-bit sort keys and bitonic-sorted by the block.
+//   key = orderable(score) << 32 | ~idx   (descending key order == score desc, index asc)
+// Falls back to the tournament when the entries do not fit (or an index needs more than 32 bits).
+constexpr int MERGE_CAP = 16384;   // 128 KiB of LDS keys
+
+__device__ __forceinline__ unsigned int orderable(float f) {
+    const unsigned int u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float unorderable(unsigned int o) {
+    return __uint_as_float(o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+
+__global__ __launch_bounds__(1024) void topk_merge_sort_kernel(const float *__restrict__ in_s, const int64_t *__restrict__ in_i,
+                                                               int nlists, int k, float *__restrict__ out_s,
+                                                               int64_t *__restrict__ out_i, int *__restrict__ fallback) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];   // [MERGE_CAP]
+    __shared__ int wsum[16];
+    __shared__ int total_s, bad_s;
+    const int tid = threadIdx.x, q = blockIdx.x;
+    const float *ps = in_s + (int64_t)q * nlists * k;
+    const int64_t *pi = in_i + (int64_t)q * nlists * k;
+    if (tid == 0) bad_s = 0;
+    __syncthreads();
+    // valid-prefix length of each list (entries are sorted, padding has idx < 0): binary search
+    int mycount = 0;
+    for (int l = tid; l < nlists; l += 1024) {
+        int lo = 0, hi = k;   // first position with idx < 0
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (pi[(int64_t)l * k + mid] >= 0) lo = mid + 1; else hi = mid;
+        }
+        mycount += lo;
+    }
+    // block exclusive scan of per-thread counts
+    int incl = mycount;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if ((tid & 63) >= o) incl += v;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int w = 0; w < 16; ++w) { const int t = wsum[w]; wsum[w] = run; run += t; }
+        total_s = run;
+    }
+    __syncthreads();
+    const int T = total_s;
+    if (T > MERGE_CAP) {
+        if (tid == 0) fallback[q] = 1;
+        return;
+    }
+    int off = wsum[tid >> 6] + incl - mycount;
+    for (int l = tid; l < nlists; l += 1024) {
+        for (int e = 0; e < k; ++e) {
+            const int64_t ix = pi[(int64_t)l * k + e];
+            if (ix < 0) break;
+            if (ix > 0xFFFFFFFFll) bad_s = 1;
+            keys[off++] = ((unsigned long long)orderable(ps[(int64_t)l * k + e]) << 32) | (unsigned int)(~(unsigned int)ix);
+        }
+    }
+    int n2 = 1;
+    while (n2 < T) n2 <<= 1;
+    if (n2 < 2) n2 = 2;
+    for (int e = T + tid; e < n2; e += 1024) keys[e] = 0ull;   // worst possible key
+    __syncthreads();
+    if (bad_s) {
+        if (tid == 0) fallback[q] = 1;
+        return;
+    }
+    // bitonic sort, descending
+    for (int k2 = 2; k2 <= n2; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n2; i += 1024) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = keys[i], b = keys[ixj];
+                    const bool desc = (i & k2) == 0;
+                    if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int e = tid; e < k; e += 1024) {
+        if (e < T) {
+            const unsigned long long key = keys[e];
+            out_s[(int64_t)q * k + e] = unorderable((unsigned int)(key >> 32));
+            out_i[(int64_t)q * k + e] = (int64_t)(unsigned int)(~(unsigned int)key);
+        } else {
+            out_s[(int64_t)q * k + e] = -INFINITY;
+            out_i[(int64_t)q * k + e] = -1;
+        }
+    }
+    if (tid == 0) fallback[q] = 0;
+}
+
+// tournament for the queries the sort kernel could not take (fallback[q] != 0)
+__global__ __launch_bounds__(64) void topk_merge_fallback_kernel(const float *__restrict__ in_s, const int64_t *__restrict__ in_i,
+                                                                 int nlists, int k, float *__restrict__ out_s,
+                                                                 int64_t *__restrict__ out_i, const int *__restrict__ fallback) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (fallback[blockIdx.x] == 0) return;
+    tournament_merge(in_s, in_i, nlists, k, out_s, out_i, smem);
 }
 
 template <int QT, int BT, bool SO>
@@ -372,7 +489,7 @@ extern "C" int skyemb_weighted_norms(const float *x, const float *w, float *norm
 
 // topk_stream.hip: bank-streaming variant for Q <= 16
 bool skyemb_topk_stream_applicable(int Q, int D, int k);
-int skyemb_topk_stream_lists(int64_t N);
+int skyemb_topk_stream_lists(int64_t N, int D, int k);
 int skyemb_topk_stream_launch(const float *tw, const float *qn, const float *bank, const float *xn, int Q, int64_t N, int D,
                               int k, float eps, int64_t idx_offset, int nlists, float *part_s, int64_t *part_i,
                               const float *thr0, hipStream_t st);
@@ -382,7 +499,7 @@ static bool use_stream(int Q, int D, int k) {
 }
 
 extern "C" int skyemb_cosine_topk_chunks(int64_t N, int Q, int D, int k) {
-    if (use_stream(Q, D, k)) return skyemb_topk_stream_lists(N);
+    if (use_stream(Q, D, k)) return skyemb_topk_stream_lists(N, D, k);
     const bool small = small_tile(Q, k);
     const int QT = small ? 16 : 64, BT = small ? 256 : 128;
     const int qtiles = (Q + QT - 1) / QT;
@@ -402,7 +519,7 @@ extern "C" int skyemb_cosine_topk(const float *tw, const float *qn, const float 
     SKY_CHECK_ARG(N < (1ll << 31), "skyemb_cosine_topk: shard too large (N < 2^31 rows per call)");
     hipStream_t st = (hipStream_t)stream;
     if (use_stream(Q, D, k)) {
-        SKY_CHECK_ARG(nchunks == skyemb_topk_stream_lists(N), "skyemb_cosine_topk: nchunks must come from skyemb_cosine_topk_chunks");
+        SKY_CHECK_ARG(nchunks == skyemb_topk_stream_lists(N, D, k), "skyemb_cosine_topk: nchunks must come from skyemb_cosine_topk_chunks");
         return skyemb_topk_stream_launch(tw, qn, bank, xn, Q, N, D, k, eps, idx_offset, nchunks, part_s, part_i, thr0, st);
     }
     if (small_tile(Q, k))
@@ -425,10 +542,29 @@ extern "C" int skyemb_cosine_scores(const float *tw, const float *qn, const floa
 }
 
 extern "C" int skyemb_topk_merge(const float *in_s, const int64_t *in_i, int Q, int nlists, int k, float *out_s,
-                                 int64_t *out_i, void *stream) {
+                                 int64_t *out_i, void *ws, void *stream) {
     SKY_CHECK_ARG(Q > 0 && nlists > 0 && k > 0, "skyemb_topk_merge: bad shape");
     const size_t smem = ((nlists * 4 + 15) & ~15) + (size_t)nlists * 8 + (size_t)nlists * 4;
     SKY_CHECK_ARG(smem <= 65536, "skyemb_topk_merge: too many lists (%d)", nlists);
+    if (nlists > 32 && ws != nullptr) {
+        // many short lists (bank-streaming kernel): gather + block bitonic sort; per-query fallback to the tournament
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void *)topk_merge_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               MERGE_CAP * 8);
+            if (e != hipSuccess) {
+                skyemb_set_error("skyemb_topk_merge: hipFuncSetAttribute: %s", hipGetErrorString(e));
+                return 2;
+            }
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(topk_merge_sort_kernel, dim3(Q), dim3(1024), (size_t)MERGE_CAP * 8, (hipStream_t)stream, in_s, in_i,
+                           nlists, k, out_s, out_i, (int *)ws);
+        hipLaunchKernelGGL(topk_merge_fallback_kernel, dim3(Q), dim3(64), smem, (hipStream_t)stream, in_s, in_i, nlists, k,
+                           out_s, out_i, (const int *)ws);
+        SKY_LAUNCH_CHECK("skyemb_topk_merge");
+        return 0;
+    }
     hipLaunchKernelGGL(topk_merge_kernel, dim3(Q), dim3(64), smem, (hipStream_t)stream, in_s, in_i, nlists, k, out_s, out_i);
     SKY_LAUNCH_CHECK("skyemb_topk_merge");
     return 0;

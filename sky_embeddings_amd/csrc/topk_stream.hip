@@ -11,7 +11,6 @@
 
 namespace {
 
-constexpr int WAVES = 4;
 constexpr int UNROLL = 4;   // float4 loads per register set (2 sets: up to 8 KiB per wave in flight)
 
 __device__ __forceinline__ float finish_score(float dot, float qn, float xn, float eps) {
@@ -47,7 +46,8 @@ __device__ __forceinline__ void transpose4(float4 &v) {
     swap16(v.w, v.z);   // odd rows' z <-> even rows' w
 }
 
-__global__ __launch_bounds__(256) void cosine_topk_stream_kernel(const float *__restrict__ tw, const float *__restrict__ qn,
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void cosine_topk_stream_kernel(const float *__restrict__ tw, const float *__restrict__ qn,
                                                                  const float *__restrict__ bank, const float *__restrict__ xn,
                                                                  int Q, int64_t N, int D, int k, float eps, int64_t idx_offset,
                                                                  int64_t rows_per_wave, float *__restrict__ part_s,
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void cosine_topk_stream_kernel(const float *__
     float *ls_all = lds + (size_t)nchunk * 64 * 4;                  // [WAVES][16][k]
     int *li_all = (int *)(ls_all + (size_t)WAVES * 16 * k);        // [WAVES][16][k]
     // A operand image: lane (q = l&15, g = l>>4), element m: tw[q][16c + 4m + g]
-    for (int e = tid; e < nchunk * 64; e += 256) {
+    for (int e = tid; e < nchunk * 64; e += WAVES * 64) {
         const int c = e >> 6, l = e & 63, q = l & 15, g = l >> 4;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q < Q) {
@@ -202,21 +202,32 @@ __global__ __launch_bounds__(256) void cosine_topk_stream_kernel(const float *__
 
 bool skyemb_topk_stream_applicable(int Q, int D, int k) { return Q <= 16 && k <= 128 && D % (16 * UNROLL) == 0 && D <= 1024; }
 
-int skyemb_topk_stream_lists(int64_t N) {
+// 8 waves per workgroup when their private lists fit next to the A image in 160 KiB of LDS, else 4
+static int stream_waves(int D, int k) {
+    const size_t img = (size_t)(D >> 4) * 64 * 16;
+    return img + (size_t)2 * 8 * 16 * k * 4 <= 160 * 1024 ? 8 : 4;
+}
+
+int skyemb_topk_stream_lists(int64_t N, int D, int k) {
+    const int waves = stream_waves(D, k);
     int64_t blocks = 256;
-    while (blocks > 1 && blocks * WAVES * 64 > N) blocks >>= 1;   // at least 64 rows per wave
-    return (int)(blocks * WAVES);
+    while (blocks > 1 && blocks * waves * 64 > N) blocks >>= 1;   // at least 64 rows per wave
+    return (int)(blocks * waves);
 }
 
 int skyemb_topk_stream_launch(const float *tw, const float *qn, const float *bank, const float *xn, int Q, int64_t N, int D,
                               int k, float eps, int64_t idx_offset, int nlists, float *part_s, int64_t *part_i,
                               const float *thr0, hipStream_t st) {
-    const int blocks = nlists / WAVES;
-    const size_t smem = sizeof(float) * ((size_t)(D >> 4) * 64 * 4 + 2 * (size_t)WAVES * 16 * k);
+    const int waves = stream_waves(D, k);
+    const int blocks = nlists / waves;
+    const size_t smem = sizeof(float) * ((size_t)(D >> 4) * 64 * 4 + 2 * (size_t)waves * 16 * k);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)cosine_topk_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void *)cosine_topk_stream_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)cosine_topk_stream_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024);
         if (e != hipSuccess) {
             skyemb_set_error("skyemb_cosine_topk(stream): hipFuncSetAttribute: %s", hipGetErrorString(e));
             return 2;
@@ -224,8 +235,12 @@ int skyemb_topk_stream_launch(const float *tw, const float *qn, const float *ban
         attr_set = true;
     }
     int64_t rows_per_wave = ceil_div64(ceil_div64(N, nlists), 16) * 16;
-    hipLaunchKernelGGL(cosine_topk_stream_kernel, dim3(blocks), dim3(256), smem, st, tw, qn, bank, xn, Q, N, D, k, eps,
-                       idx_offset, rows_per_wave, part_s, part_i, thr0);
+    if (waves == 8)
+        hipLaunchKernelGGL(cosine_topk_stream_kernel<8>, dim3(blocks), dim3(512), smem, st, tw, qn, bank, xn, Q, N, D, k, eps,
+                           idx_offset, rows_per_wave, part_s, part_i, thr0);
+    else
+        hipLaunchKernelGGL(cosine_topk_stream_kernel<4>, dim3(blocks), dim3(256), smem, st, tw, qn, bank, xn, Q, N, D, k, eps,
+                           idx_offset, rows_per_wave, part_s, part_i, thr0);
     SKY_LAUNCH_CHECK("skyemb_cosine_topk(stream)");
     return 0;
 }

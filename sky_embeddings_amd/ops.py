@@ -161,8 +161,9 @@ def cosine_topk(tw, qn, bank, xn, k, eps, idx_offset, nchunks, part_s, part_i, t
                                    _p(part_s), _p(part_i), _stream()), "skyemb_cosine_topk")
 
 
-def topk_merge(in_s, in_i, Q, nlists, k, out_s, out_i):
-    check(lib().skyemb_topk_merge(_p(in_s), _p(in_i), Q, nlists, k, _p(out_s), _p(out_i), _stream()),
+def topk_merge(in_s, in_i, Q, nlists, k, out_s, out_i, ws=None):
+    """ws: optional int32 [Q] scratch enabling the gather + block-sort path for many short lists."""
+    check(lib().skyemb_topk_merge(_p(in_s), _p(in_i), Q, nlists, k, _p(out_s), _p(out_i), _p(ws), _stream()),
           "skyemb_topk_merge")
 
 

@@ -65,7 +65,7 @@ def _local_topk(tw, qn, bank, norms, k, eps, idx_offset, thr0=None):
     ops.cosine_topk(tw, qn, bank, norms, k, eps, idx_offset, nch, ps, pi, thr0)
     out_s = torch.empty(Q, k, device=dev)
     out_i = torch.empty(Q, k, device=dev, dtype=torch.int64)
-    ops.topk_merge(ps, pi, Q, nch, k, out_s, out_i)
+    ops.topk_merge(ps, pi, Q, nch, k, out_s, out_i, torch.empty(Q, device=dev, dtype=torch.int32))
     return out_s, out_i
 
 
@@ -76,12 +76,13 @@ def pruning_floor(tw, qn, pb: "PreparedBank", k: int, eps: float, sample_rows: i
     this way).  None when the bank is too small for the extra pass to pay."""
     N = pb.bank.shape[0]
     if sample_rows is None:
-        sample_rows = 128 * k
+        sample_rows = 256 * k
     if N < 8 * sample_rows:
         return None
     sb, sn = pb.sample(sample_rows)
-    s, _ = _local_topk(tw, qn, sb, sn, k, eps, 0)
-    tau = s[:, k - 1].contiguous()
+    sc = torch.empty(tw.shape[0], sb.shape[0], device=tw.device)
+    ops.cosine_scores(tw, qn, sb, sn, eps, sc)          # [Q, sample] score matrix (small)
+    tau = torch.topk(sc, k, dim=1).values[:, k - 1].contiguous()   # host-glue selection on the sample only
     return torch.nextafter(tau, torch.full_like(tau, float("-inf")))
 
 

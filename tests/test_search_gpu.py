@@ -30,7 +30,7 @@ def test_cosine_topk_with_and_without_pruning_floor(Q, N, D, k, prune):
     s, i = search.cosine_topk(torch.from_numpy(q).cuda(), pb, k, prune=prune)
     assert np.array_equal(i.cpu().numpy(), ref_i)
     assert np.array_equal(s.cpu().numpy(), ref_s)
-    if prune and N >= 8 * 128 * k:
+    if prune and N >= 8 * 256 * k:
         tw, qn = search.prepare_queries(torch.from_numpy(q).cuda(), pb.weights)
         floor = search.pruning_floor(tw, qn, pb, k, 1e-6)
         assert floor is not None and bool((floor.cpu().numpy() < ref_s[:, k - 1]).all())   # a valid lower bound
