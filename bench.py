@@ -55,6 +55,55 @@ def ev_time_ms(fn, iters, stream=None):
     return start.elapsed_time(end) / iters
 
 
+def gemm_step_probe(B, dtype, dev, iters=20):
+    """Launch-level roofline of the dominant kernel: every MFMA GEMM launch of one step (forward KC.KC,
+    dgrad KC.RC, wgrad RC.RC + its split-K reduce), each shape timed with HIP events on the launch stream.
+    achieved = sum(2*M*N*K * count) / sum(avg launch time * count); avg_launch_us per kind is what the
+    rocprofv3 kernel_stats average of gemm_pipe_kernel<64,64,A_KC,B_KC,3,4> must agree with."""
+    from sky_embeddings_amd import ops
+    Me, Md = B * 5, B * 17
+    layers = []
+    for M, D, depth in ((Me, 768, 12), (Md, 512, 8)):
+        layers += [(M, 3 * D, D, depth, "bias"), (M, D, D, depth, "resid"), (M, 4 * D, D, depth, "gelu"), (M, D, 4 * D, depth, "dgelu")]
+    layers += [(B * 4, 768, 1280, 1, "bias"), (Me, 512, 768, 1, "bias"), (Md, 1280, 512, 1, "bias")]
+    ws = torch.empty(8 * 1024 * 1024, device=dev)
+    kinds = {k: dict(launches=0, us=0.0, flop=0.0) for k in ("fwd_KC.KC", "dgrad_KC.RC", "wgrad_RC.RC+reduce")}
+    for M, N, K, cnt, epi in layers:
+        x = torch.randn(M, K, device=dev).to(dtype)
+        w = (torch.randn(N, K, device=dev) * 0.05).to(dtype)
+        dy = torch.randn(M, N, device=dev).to(dtype)
+        bias = torch.zeros(N, device=dev)
+        y, y2 = torch.empty(M, N, device=dev, dtype=dtype), torch.empty(M, N, device=dev, dtype=dtype)
+        y32, res = torch.empty(M, N, device=dev), torch.randn(M, N, device=dev)
+        dx, aux = torch.empty(M, K, device=dev, dtype=dtype), torch.randn(M, K, device=dev).to(dtype)
+        dw, db = torch.empty(N, K, device=dev), torch.empty(N, device=dev)
+        if epi == "gelu":
+            fwd = lambda: ops.gemm(x, w, M=M, N=N, K=K, bias=bias, act=ops.ACT_GELU, out=y, out2=y2)
+        elif epi in ("resid", "dgelu"):
+            fwd = lambda: ops.gemm(x, w, M=M, N=N, K=K, bias=bias, resid=res, ldr=N, out_f32=y32, ws=ws)
+        else:
+            fwd = lambda: ops.gemm(x, w, M=M, N=N, K=K, bias=bias, out=y)
+        if epi == "dgelu":
+            dgrad = lambda: ops.gemm(dy, w, M=M, N=K, K=N, a_layout=ops.KC, b_layout=ops.RC, lda=N, ldb=K, act=ops.ACT_DGELU,
+                                     aux=aux, ldaux=K, out=dx, ws=ws)
+        else:
+            dgrad = lambda: ops.gemm(dy, w, M=M, N=K, K=N, a_layout=ops.KC, b_layout=ops.RC, lda=N, ldb=K, out=dx, ws=ws)
+        wgrad = lambda: ops.gemm(dy, x, M=N, N=K, K=M, a_layout=ops.RC, b_layout=ops.RC, lda=N, ldb=K, out_f32=dw, colsum_a=db, ws=ws)
+        for kind, f in zip(kinds, (fwd, dgrad, wgrad)):
+            for _ in range(3):
+                f()
+            ms = ev_time_ms(f, iters)
+            kinds[kind]["launches"] += cnt
+            kinds[kind]["us"] += 1e3 * ms * cnt
+            kinds[kind]["flop"] += 2.0 * M * N * K * cnt
+    tot_us = sum(v["us"] for v in kinds.values())
+    tot_fl = sum(v["flop"] for v in kinds.values())
+    per_kind = {k: dict(launches_per_step=v["launches"], avg_launch_us=v["us"] / v["launches"], tflops=v["flop"] / v["us"] / 1e6)
+                for k, v in kinds.items()}
+    return dict(kernel="gemm_pipe_kernel<64,64,*,*,3,4> (+ splitk_reduce_kernel)", launches_per_step=sum(v["launches"] for v in kinds.values()),
+                ms_per_step=tot_us / 1e3, flop_per_step=tot_fl, tflops=tot_fl / tot_us / 1e6, kinds=per_kind)
+
+
 def bench_pretrain(args, rank, world, dev):
     from sky_embeddings_amd.engine import MAEEngine
     from sky_embeddings_amd.model_config import config_for
@@ -94,19 +143,8 @@ def bench_pretrain(args, rank, world, dev):
     executed, algorithmic = eng.flops_per_image(0.75)
     out = dict(ms_per_step=1e3 * dt / args.steps, images_per_sec=world * B * args.steps / dt, gpu_ms_per_step=gpu_ms,
                loss=float(loss), flops_per_image_executed=executed, flops_per_image_reference=algorithmic, B=B)
-    # launch-level roofline of the dominant kernel (the MFMA GEMM): one decoder fc1 launch
     if rank == 0:
-        from sky_embeddings_amd import ops
-        M, N, K = B * 17, 2048, 512
-        a = torch.randn(M, K, device=dev).to(dtype)
-        w = torch.randn(N, K, device=dev).to(dtype)
-        bias = torch.zeros(N, device=dev)
-        o1, o2 = torch.empty(M, N, device=dev, dtype=dtype), torch.empty(M, N, device=dev, dtype=dtype)
-        f = lambda: ops.gemm(a, w, M=M, N=N, K=K, bias=bias, act=ops.ACT_GELU, out=o1, out2=o2)
-        for _ in range(5):
-            f()
-        ms = ev_time_ms(f, 50)
-        out["gemm_probe"] = dict(shape=[M, N, K], ms=ms, tflops=2.0 * M * N * K / ms / 1e9)
+        out["gemm_probe"] = gemm_step_probe(B, dtype, dev)
     return out, eng
 
 
@@ -162,10 +200,25 @@ def bench_search(args, rank, world, dev):
         thr0 = pruning_floor(tw, qn, pb, k, 1e-6)
         kms = ev_time_ms(lambda: ops.cosine_topk(tw, qn, bank, pb.norms, k, 1e-6, lo, nch, ps, pi, thr0), iters)
         bank_bytes = (hi - lo) * D * 4
-        res[label] = dict(Q=Q, sec=dt, queries_per_sec=Q / dt, kernel_ms=kms,
-                          kernel_hbm_gbs=(bank_bytes + Q * D * 4 + Q * nch * k * 12) / kms / 1e6,
+        kbytes = bank_bytes + (hi - lo) * 4 + Q * D * 4 + Q * nch * k * 12   # bank + row norms + queries + partial lists
+        res[label] = dict(Q=Q, sec=dt, queries_per_sec=Q / dt, kernel_ms=kms, kernel_bytes=kbytes,
+                          kernel_hbm_gbs=kbytes / kms / 1e6,
                           kernel_tflops=2.0 * Q * (hi - lo) * D / kms / 1e9, checksum=int(i.sum().item() % (1 << 31)))
     return res, (queries, w)
+
+
+def pmc_traffic(args):
+    """HBM bytes per launch of the Q=16 streaming kernel from the committed PMC passes (FETCH_SIZE doubled per the gfx950
+    correction, + WRITE_SIZE); counters cannot be read from inside the timed process, so this is the profiles/ figure for
+    the same workload, or None when the workload differs."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_topk_stream_pmc.json")) as f:
+            prof = json.load(f)
+    except OSError:
+        return None
+    if args.bank_rows != 1_000_000 or args.topk != 100 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        return None
+    return prof["kernels"]["cosine_topk_stream_kernel<8>"]["traffic_bytes_per_launch"]
 
 
 def cpu_baselines(args):
@@ -221,6 +274,7 @@ def main():
         executed = pre["flops_per_image_executed"]
         ach = pre["images_per_sec"] / world * executed / 1e12   # per-GPU TFLOP/s, executed FLOPs
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+        gp = pre["gemm_probe"]
         line = {
             "metric": "MAE pretrain images/sec (5x64x64, ViT-B)", "value": pre["images_per_sec"], "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": pre["ms_per_step"],
@@ -230,13 +284,16 @@ def main():
                                    f"bs={pre['B']}/GPU, AdamW+cosine, norm_pix mse",
                        "global_batch": pre["B"] * world, "parallelism": f"dp{world}",
                        "graph": not args.no_graph},
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+            "roofline": {"bound": "mfma", "achieved": gp["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": gp["tflops"] / peak,
                          "traffic": None,
-                         "note": "whole-step rate: executed fwd+bwd FLOPs/image x images / step time (all kernels, "
-                                 "optimiser included); kernel = one MFMA GEMM launch timed with HIP events",
-                         "gpu_ms_per_step": pre["gpu_ms_per_step"], "flops_per_image_executed": executed,
-                         "flops_per_image_reference": pre["flops_per_image_reference"],
-                         "kernel": pre.get("gemm_probe")},
+                         "note": "dominant kernel = the pipelined MFMA GEMM: algorithmic 2MNK FLOPs of every GEMM launch of one "
+                                 "step / their HIP-event launch durations (kernel.kinds: per operand-layout average launch time, "
+                                 "to be compared with the rocprofv3 kernel_stats averages in profiles/); step = whole-step rate "
+                                 "(executed fwd+bwd FLOPs x images / step time, all kernels + optimiser)",
+                         "kernel": gp,
+                         "step": {"achieved": ach, "frac": ach / peak, "gpu_ms_per_step": pre["gpu_ms_per_step"],
+                                  "flops_per_image_executed": executed,
+                                  "flops_per_image_reference": pre["flops_per_image_reference"]}},
             "loss": pre["loss"],
         }
         if search is not None:
@@ -246,7 +303,8 @@ def main():
                 "unit": "queries/sec", "k": args.topk, "Q": ql["Q"], "dtype": "f32", "sharding": f"bank rows / {world}",
                 "q_large": ql, "q_small": qs,
                 "roofline": {"bound": "hbm", "achieved": qs["kernel_hbm_gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                             "frac": qs["kernel_hbm_gbs"] / PEAK_HBM_GBS, "traffic": None,
+                             "frac": qs["kernel_hbm_gbs"] / PEAK_HBM_GBS, "traffic": pmc_traffic(args),
+                             "algorithmic_bytes": qs["kernel_bytes"],
                              "note": "Q=16 bank-streaming launch (HBM-bound regime): (bank shard + queries + partial "
                                      "lists) bytes / kernel time; the Q=10k launch is fp32-MFMA bound: see q_large.kernel_tflops "
                                      f"vs {PEAK_F32_MFMA_TFLOPS} TFLOP/s"},

@@ -353,13 +353,13 @@ int launch(const skyemb_gemm_args &g, hipStream_t st) {
     return launch_n<BM, BN, A_KC, B_KC, 3>(g, st);
 }
 
-template <int BT>
+template <int BM, int BN>
 int dispatch(const skyemb_gemm_args &g, hipStream_t st) {
     const bool a = g.a_layout == SKYEMB_KC, b = g.b_layout == SKYEMB_KC;
-    if (a && b) return launch<BT, BT, true, true>(g, st);
-    if (a && !b) return launch<BT, BT, true, false>(g, st);
-    if (!a && !b) return launch<BT, BT, false, false>(g, st);
-    return launch<BT, BT, false, true>(g, st);
+    if (a && b) return launch<BM, BN, true, true>(g, st);
+    if (a && !b) return launch<BM, BN, true, false>(g, st);
+    if (!a && !b) return launch<BM, BN, false, false>(g, st);
+    return launch<BM, BN, false, true>(g, st);
 }
 
 }  // namespace
@@ -378,7 +378,7 @@ int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
     // few tiles to fill the chip: the wgrads, and every GEMM whose output is [1280 tokens, <= 768]
     int S = 1;
     if (g.ws && g.split_k != 1) {
-        const int64_t tiles = ceil_div64(g.M, tile) * ceil_div64(g.N, tile);
+        const int64_t tiles = ceil_div64(g.M, tile == 12864 ? 128 : tile) * ceil_div64(g.N, tile == 12864 ? 64 : tile);
         const int KT = g.K / BK;
         S = g.split_k > 1 ? g.split_k : (int)(768 / tiles);
         if (S > 8) S = 8;
@@ -387,5 +387,6 @@ int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
         if (S < 1) S = 1;
     }
     g.split_k = S;
-    return tile == 128 ? dispatch<128>(g, st) : dispatch<64>(g, st);
+    if (tile == 12864) return dispatch<128, 64>(g, st);   // experimental 128x64 tile (8 waves)
+    return tile == 128 ? dispatch<128, 128>(g, st) : dispatch<64, 64>(g, st);
 }
