@@ -66,7 +66,7 @@ def gemm_step_probe(B, dtype, dev, iters=20):
     for M, D, depth in ((Me, 768, 12), (Md, 512, 8)):
         layers += [(M, 3 * D, D, depth, "bias"), (M, D, D, depth, "resid"), (M, 4 * D, D, depth, "gelu"), (M, D, 4 * D, depth, "dgelu")]
     layers += [(B * 4, 768, 1280, 1, "bias"), (Me, 512, 768, 1, "bias"), (Md, 1280, 512, 1, "bias")]
-    ws = torch.empty(8 * 1024 * 1024, device=dev)
+    ws = torch.zeros(8 * 1024 * 1024, device=dev)
     kinds = {k: dict(launches=0, us=0.0, flop=0.0) for k in ("fwd_KC.KC", "dgrad_KC.RC", "wgrad_RC.RC+reduce")}
     for M, N, K, cnt, epi in layers:
         x = torch.randn(M, K, device=dev).to(dtype)

@@ -81,9 +81,9 @@ typedef struct skyemb_gemm_args {
     int32_t tile;               /* 0 = auto, 64 or 128 */
     float *colsum_a;            /* optional, A must be RC: colsum_a[m] = sum_k A(m,k)  (bias gradient fused
                                    into the wgrad launch: A = dy, so this is sum over tokens of dy[:, m]) */
-    void *ws;                   /* optional fp32 workspace enabling split-K for plain-epilogue launches (out_f32
-                                   only): partial slabs [split][M][N] + [split][M] are summed by a second
-                                   launch in a fixed order (deterministic) */
+    void *ws;                   /* optional fp32 workspace enabling split-K: partial slabs [split][M][N] + [split][M]
+                                   are summed by a second launch in a fixed order (deterministic), which applies
+                                   the epilogue.  One workspace per stream. */
     int64_t ws_bytes;
     int32_t split_k;            /* 0 = auto (1 when ws == NULL), 1 = off, n = force n-way */
 } skyemb_gemm_args;

@@ -164,8 +164,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_pipe_kernel(const skyemb_gemm_ar
         else issue_rc<BN, NW>(B, g.ldb, n0, g.N, k0, sb, wave, lane);
     };
 
-    const bool do_colsum = !A_KC && g.colsum_a != nullptr && (wg % tiles_n) == 0 && tid < BM;
-    float csum = 0.f;
+    // bias gradient = column sums of the RC A tile, taken by the waves of the first tile column with one extra MFMA
+    // per A fragment against a fragment of ones (exact products, fp32 accumulation in k order)
+    const bool do_colsum = !A_KC && g.colsum_a != nullptr && (wg % tiles_n) == 0 && wn == 0;
+    f32x4 cacc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) cacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
 
     constexpr int AHEAD = NSTAGE - 1;
 #pragma unroll
@@ -177,12 +184,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_pipe_kernel(const skyemb_gemm_ar
         __builtin_amdgcn_s_barrier();
         if (kt + AHEAD < KT) issue(kt + AHEAD, buf >= 1 ? buf - 1 : NSTAGE - 1);   // (kt+AHEAD) % NSTAGE == (buf-1) mod NSTAGE
         const char *sa = smem + buf * STAGE, *sb = sa + A_BYTES;
-        if (!A_KC && do_colsum) {
-            // column sum of the staged [k][rows] A tile (bias gradient): thread t owns row t
-            const int ch = tid >> 3, e = tid & 7;
-#pragma unroll 8
-            for (int k = 0; k < BK; ++k) csum += (float)*(const bf16_t *)(sa + rc_off<BM>(k, ch) + e * 2);
-        }
 #ifdef SKY_NOMATH   // experiment build: LDS-DMA stream + barriers only
         buf = buf + 1 < NSTAGE ? buf + 1 : 0;
         continue;
@@ -201,14 +202,26 @@ __global__ __launch_bounds__(NW * 64) void gemm_pipe_kernel(const skyemb_gemm_ar
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D[n][m]
+            if (!A_KC && do_colsum) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) cacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[i], cacc[i], 0, 0, 0);
+            }
         }
         buf = buf + 1 < NSTAGE ? buf + 1 : 0;
     }
     if (S > 1) {
-        // split-K: raw partial tile (and partial column sums) to the workspace; splitk_reduce finishes
+        // split-K: raw partial tile (and partial column sums) to the workspace; splitk_reduce finishes.
+        // (A fused variant -- last-arriving split reduces behind __threadfence() -- was measured: the device-scope
+        // release is an L2 write-back on this multi-XCD part and costs ~100 us per launch.)
         float *slab = (float *)g.ws + (int64_t)split * g.M * g.N;
         float *cs = (float *)g.ws + (int64_t)S * g.M * g.N + (int64_t)split * g.M;
-        if (!A_KC && do_colsum && m0 + tid < g.M) cs[m0 + tid] = csum;
+        if (!A_KC && do_colsum && lane < 16) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + wm * (BM / WGM) + i * 16 + lane;
+                if (m < g.M) cs[m] = cacc[i][0];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + wm * (BM / WGM) + i * 16 + (lane & 15);
@@ -223,7 +236,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_pipe_kernel(const skyemb_gemm_ar
         }
         return;
     }
-    if (!A_KC && do_colsum && m0 + tid < g.M) g.colsum_a[m0 + tid] = csum;
+    if (!A_KC && do_colsum && lane < 16) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * (BM / WGM) + i * 16 + lane;
+            if (m < g.M) g.colsum_a[m] = cacc[i][0];
+        }
+    }
 
     // ---- epilogue: lane owns row m = ... + (lane&15) and 4 consecutive columns n4 + (0..3) -------
     bf16_t *out = (bf16_t *)g.out;
@@ -317,10 +336,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const skyemb_gemm_ar
     }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE>
+template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int NW = (BM == 128 ? 8 : 4)>
 int launch_n(const skyemb_gemm_args &g, hipStream_t st) {
     constexpr size_t smem = (size_t)NSTAGE * (BM + BN) * BK * 2;
-    constexpr int NW = BM == 128 ? 8 : 4;
     static bool attr_set = false;
     auto kern = gemm_pipe_kernel<BM, BN, A_KC, B_KC, NSTAGE, NW>;
     if (!attr_set) {
@@ -350,6 +368,10 @@ int launch(const skyemb_gemm_args &g, hipStream_t st) {
     static const int stages = []() { const char *e = getenv("SKYEMB_GEMM_STAGES"); return e ? atoi(e) : 3; }();
     if (stages == 2) return launch_n<BM, BN, A_KC, B_KC, 2>(g, st);
     if (stages == 4) return launch_n<BM, BN, A_KC, B_KC, 4>(g, st);
+    if constexpr (BM == 128 && BN == 128) {
+        if (stages == 44) return launch_n<BM, BN, A_KC, B_KC, 4, 4>(g, st);   // experiment: 4 waves of 64x64, 128 KB ring
+        if (stages == 34) return launch_n<BM, BN, A_KC, B_KC, 3, 4>(g, st);
+    }
     return launch_n<BM, BN, A_KC, B_KC, 3>(g, st);
 }
 
@@ -362,6 +384,13 @@ int dispatch(const skyemb_gemm_args &g, hipStream_t st) {
     return launch<BM, BN, false, true>(g, st);
 }
 
+struct TunedGemm {
+    int M, N, K, a_kc, b_kc, tile, split;
+};
+const TunedGemm kTuned[] = {
+#include "gemm_tuned.h"
+    {0, 0, 0, 0, 0, 0, 0}};
+
 }  // namespace
 
 // returns -1 when the problem is outside the fast-path subset (caller falls back to gemm.hip)
@@ -373,16 +402,31 @@ int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
     if (g.a_layout == SKYEMB_KC ? g.M < 1 : (g.M % 8 != 0 || g.M < 8)) return -1;
     if (g.b_layout == SKYEMB_KC ? g.N < 1 : (g.N % 8 != 0 || g.N < 8)) return -1;
     int tile = g.tile;
-    if (tile == 0) tile = 64;   // measured: the 64x64 tile (3 workgroups per CU) beats 128x128 on every ViT-B shape
-    // split-K (deterministic slabs + a reduce launch that applies the epilogue) for launches with too
-    // few tiles to fill the chip: the wgrads, and every GEMM whose output is [1280 tokens, <= 768]
+    int want_split = g.split_k;
+    if (tile == 0 && want_split == 0) {
+        // launch shapes tuned on hardware (tools/gemm_tune.py); anything else goes through the heuristic below
+        static const bool use_table = []() { const char *e = getenv("SKYEMB_GEMM_TUNED"); return !(e && e[0] == '0'); }();
+        if (use_table)
+            for (const TunedGemm *t = kTuned; t->M; ++t)
+                if (t->M == g.M && t->N == g.N && t->K == g.K && t->a_kc == (g.a_layout == SKYEMB_KC) &&
+                    t->b_kc == (g.b_layout == SKYEMB_KC) && (t->split == 1 || g.ws)) {
+                    tile = t->tile;
+                    want_split = t->split;
+                    break;
+                }
+    }
+    if (tile == 0) tile = 64;   // measured: the 64x64 tile (3 workgroups per CU) is the best all-round choice at ViT-B sizes
+    // split-K (deterministic slabs + a reduce launch that applies the epilogue) for launches with too few tiles to
+    // fill the chip.  The reduce launch costs ~5 us, so a split must leave >= 10-12 k-steps per workgroup.
     int S = 1;
-    if (g.ws && g.split_k != 1) {
+    if (g.ws && want_split != 1) {
         const int64_t tiles = ceil_div64(g.M, tile == 12864 ? 128 : tile) * ceil_div64(g.N, tile == 12864 ? 64 : tile);
         const int KT = g.K / BK;
-        S = g.split_k > 1 ? g.split_k : (int)(768 / tiles);
+        const int min_steps = (g.a_layout == SKYEMB_RC && g.b_layout == SKYEMB_RC) ? 10 : 12;
+        S = want_split > 1 ? want_split : (int)(768 / tiles);
         if (S > 8) S = 8;
-        if (S > KT / 4) S = KT / 4;
+        if (want_split <= 1 && S > KT / min_steps) S = KT / min_steps;
+        if (S > KT) S = KT;
         while (S > 1 && (int64_t)S * ((int64_t)g.M * g.N + g.M) * 4 > g.ws_bytes) --S;
         if (S < 1) S = 1;
     }

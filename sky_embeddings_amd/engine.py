@@ -108,7 +108,8 @@ class MAEEngine:
         self._ws = {}
         self._last = None
         # fp32 scratch for split-K GEMM launches (partial slabs; every launch on the stream reuses it)
-        self._splitk_ws = torch.empty(8 * 1024 * 1024, device=self.device, dtype=torch.float32)
+        self._splitk_ws = torch.zeros(8 * 1024 * 1024, device=self.device, dtype=torch.float32)
+        self._side, self._pending = None, {}
         self.initialize_weights(seed)
 
     # ------------------------------------------------------------------ parameters
@@ -332,16 +333,55 @@ class MAEEngine:
         """dy [M,N] (lp), x_in [M,K] (lp): dW[N,K] = dy^T x, db = colsum(dy), optional dx = dy W."""
         st = self.store
         # wgrad; the bias gradient (column sums of dy) rides along in the same launch
-        ops.gemm(dy, x_in, M=N, N=K, K=M, a_layout=RC, b_layout=RC, lda=N, ldb=K, out_f32=st.grad(wname),
-                 colsum_a=st.grad(bname), ws=w["splitk_ws"])
+        self._wgrad(dy, x_in, N, K, M, st.grad(wname), st.grad(bname), w)
         if dx_out is not None:
+            self._before_write(dx_out)
             ops.gemm(dy, st.lp(wname), M=M, N=K, K=N, a_layout=KC, b_layout=RC, lda=N, ldb=K, act=dx_act, aux=dx_aux,
                      ldaux=K, out=dx_out, ws=w["splitk_ws"])
+
+    # -- weight gradients on a side stream: nothing downstream in backward depends on them, so they fill the
+    # ramp / tail bubbles of the dgrad chain.  dy lives in scratch that later layers overwrite: every writer of such a
+    # buffer first waits for the wgrad that still reads it (_before_write).
+    def enable_wgrad_overlap(self, on=True):
+        if on and self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._splitk_ws_side = torch.zeros_like(self._splitk_ws)
+        elif not on:
+            self._side = None
+        self._pending = {}
+
+    def _wgrad(self, dy, x_in, M, N, K, dW, db, w):
+        side = self._side
+        if side is None:
+            ops.gemm(dy, x_in, M=M, N=N, K=K, a_layout=RC, b_layout=RC, lda=M, ldb=N, out_f32=dW, colsum_a=db,
+                     ws=w["splitk_ws"])
+            return
+        ready = torch.cuda.Event()
+        ready.record()
+        side.wait_event(ready)
+        with torch.cuda.stream(side):
+            ops.gemm(dy, x_in, M=M, N=N, K=K, a_layout=RC, b_layout=RC, lda=M, ldb=N, out_f32=dW, colsum_a=db,
+                     ws=self._splitk_ws_side)
+            done = torch.cuda.Event()
+            done.record()
+        self._pending[dy.data_ptr()] = done
+
+    def _before_write(self, buf):
+        if self._side is not None:
+            ev = self._pending.pop(buf.data_ptr(), None)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+
+    def _join_side(self):
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._pending.clear()
 
     def _ln_bwd(self, dy, x, prefix, mean, rstd, g_in, g, g_lp, M, dim, w):
         st = self.store
         nblk = ops.layernorm_bwd_blocks(M)
         part = w["ln_part"][:2 * nblk * dim].view(2, nblk, dim)
+        self._before_write(g_lp)
         ops.layernorm_bwd(dy, x, st.param(f"{prefix}.weight"), mean, rstd, g_in, g, g_lp, part,
                           st.grad(f"{prefix}.weight"), st.grad(f"{prefix}.bias"), M, dim, self.code)
 
@@ -362,6 +402,7 @@ class MAEEngine:
         # attention: xmid = x_in + proj(mha(qkv(ln1(x_in))))
         self._linear_bwd(g_lp, bufs["att"], f"{prefix}.attn.proj.weight", f"{prefix}.attn.proj.bias", M, dim, dim, w,
                          dx_out=datt)
+        self._before_write(dqkv)
         ops.mha_bwd(bufs["qkv"], datt, dqkv, Bsz, N, heads, hd)
         self._linear_bwd(dqkv, bufs["ln1"], f"{prefix}.attn.qkv.weight", f"{prefix}.attn.qkv.bias", M, 3 * dim, dim, w,
                          dx_out=dln)
@@ -393,6 +434,7 @@ class MAEEngine:
         ops.gather_rows(g, w["dec_dst"], None, w["dE"], Me, Dd)
         dln_e = w["dln"][:Me * D].view(Me, D)
         self._linear_bwd(w["dE"], w["lat_lp"], "decoder_embed.weight", "decoder_embed.bias", Me, Dd, D, w, dx_out=dln_e)
+        self._join_side()
 
     def backward_encoder(self, hi=None, lo=0):
         """Encoder blocks hi-1 ... lo (hi=None: from the top, including the final norm)."""
@@ -408,6 +450,7 @@ class MAEEngine:
             self._ln_bwd(dln_e, w["xs"][cfg.depth], "norm", w["lat_mean"], w["lat_rstd"], None, g, g_lp, Me, D, w)
         for i in reversed(range(lo, hi)):
             self._block_bwd(w["xs"][i], w["enc"][i], f"blocks.{i}", Me, D, cfg.num_heads, B, Ne, g, g_lp, w)
+        self._join_side()
 
     def backward_embed(self):
         """Last stage: cls token, patch embedding, patch_mask_values (g = d xs[0])."""
@@ -418,13 +461,13 @@ class MAEEngine:
         g = w["g"][:Me * D].view(Me, D)
         ops.rowsum_select(g, D, None, 0, 1, Ne, B, D, w["rs_part"], st.grad("cls_token").view(D))
         ops.gather_rows(g, w["pe_dst"], None, w["dT"], B * keep, D)
-        ops.gemm(w["dT"], w["patches"], M=D, N=pv, K=B * keep, a_layout=RC, b_layout=RC, lda=D, ldb=pv,
-                 out_f32=st.grad("patch_embed.proj.weight"), colsum_a=st.grad("patch_embed.proj.bias"),
-                 ws=w["splitk_ws"])
+        self._wgrad(w["dT"], w["patches"], D, pv, B * keep, st.grad("patch_embed.proj.weight"),
+                    st.grad("patch_embed.proj.bias"), w)
         ops.gemm(w["dT"], st.lp("patch_embed.proj.weight"), M=B * keep, N=pv, K=D, a_layout=KC, b_layout=RC, lda=D,
                  ldb=pv, out_f32=w["drows"])
         ops.patch_gather_bwd_pmv(imgs, w["ids_keep"], w["drows"], w["pmv_part"], st.grad("patch_mask_values"),
                                  cfg.patch_size, keep)
+        self._join_side()
 
     def backward(self):
         """Gradients of the last :meth:`forward_train` loss into the flat ``g`` buffer (every

@@ -14,6 +14,8 @@ replayed per step.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .distributed import bucket_bounds
@@ -23,7 +25,8 @@ from .optim import CosineLR, FusedAdamW
 class TrainStep:
     def __init__(self, engine, optimizer: FusedAdamW, scheduler: CosineLR, batch_size: int, mask_ratio: float = 0.75,
                  use_graph: bool = True, process_group=None, world_size: int = 1, warmup_iters: int = 2,
-                 staged: bool | None = None, n_encoder_groups: int = 3, bucket_elems: int = 32 * 1024 * 1024):
+                 staged: bool | None = None, n_encoder_groups: int = 3, bucket_elems: int = 32 * 1024 * 1024,
+                 wgrad_overlap: bool | None = None):
         self.engine, self.optimizer, self.scheduler = engine, optimizer, scheduler
         self.mask_ratio = mask_ratio
         self.world_size = world_size
@@ -35,6 +38,11 @@ class TrainStep:
         self.noise = torch.zeros(batch_size, cfg.num_patches, device=dev)
         self.loss = None
         self.staged = (world_size > 1) if staged is None else staged
+        if wgrad_overlap is None:
+            # measured slower on one MI355X (8.96 vs 8.47 ms/step: the cross-branch graph edges cost more than the
+            # bubbles they fill), so off unless asked for
+            wgrad_overlap = os.environ.get("SKYEMB_WGRAD_OVERLAP", "0") == "1"
+        engine.enable_wgrad_overlap(wgrad_overlap)   # weight-gradient GEMMs on a side stream (a parallel graph branch)
         if world_size > 1:
             optimizer.grad_scale = 1.0 / world_size  # DDP mean of per-rank gradients
         # stage list: [(callable, [(start, end) slices of the flat gradient buffer final after it])]

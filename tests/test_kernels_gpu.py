@@ -378,7 +378,7 @@ def test_gemm_split_k_wgrad(ops, split):
     g = torch.Generator().manual_seed(split)
     dy, x = torch.randn(tokens, N, generator=g), torch.randn(tokens, K, generator=g)
     dyr, xr = dy.bfloat16().float(), x.bfloat16().float()
-    ws = torch.empty(4 * 1024 * 1024, device=DEV)
+    ws = torch.zeros(4 * 1024 * 1024, device=DEV)
     outs = []
     for _ in range(2):
         dw = torch.full((N, K), float("nan"), device=DEV)

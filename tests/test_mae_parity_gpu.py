@@ -160,7 +160,8 @@ def test_full_size_config_a_against_oracle():
 
 def test_staged_backward_equals_monolithic_and_graph_replay():
     """The DDP-overlap schedule (forward+decoder | encoder groups | embedding as separate HIP graphs) gives
-    bit-identical gradients to the single-graph schedule, and graph replay equals eager execution."""
+    bit-identical gradients to the single-graph schedule, graph replay equals eager execution, and running the
+    weight-gradient GEMMs on the side stream changes nothing."""
     from sky_embeddings_amd.engine import MAEEngine
     from sky_embeddings_amd.model_config import config_for
     from sky_embeddings_amd.optim import CosineLR, FusedAdamW
@@ -169,10 +170,13 @@ def test_staged_backward_equals_monolithic_and_graph_replay():
     g = torch.Generator().manual_seed(0)
     imgs = torch.randn(8, 5, 64, 64, generator=g).cuda()
     results = []
-    for staged, graph in ((False, False), (False, True), (True, True)):
+    # (staged, graph, weight gradients on the side stream)
+    for staged, graph, overlap in ((False, False, False), (False, False, True), (False, True, True), (True, True, True),
+                                   (True, True, False)):
         eng = MAEEngine(cfg, compute_dtype=torch.bfloat16, seed=1)
         opt = FusedAdamW(eng, lr=1e-3)
-        step = TrainStep(eng, opt, CosineLR(opt, 100), 8, use_graph=graph, staged=staged, n_encoder_groups=4)
+        step = TrainStep(eng, opt, CosineLR(opt, 100), 8, use_graph=graph, staged=staged, n_encoder_groups=4,
+                         wgrad_overlap=overlap)
         torch.manual_seed(123)            # same masking noise stream for every schedule
         for _ in range(3):
             loss = step(imgs)

@@ -28,16 +28,19 @@ layers += [("patch_embed", B * 4, 768, 1280, 1, "bias"), ("dec_embed", Me, 512, 
            ("dec_pred", Md, 1280, 512, 1, "bias")]
 
 
-def timeit(f, iters):
-    for _ in range(3):
-        f()
+def timeit(f, iters=20):
+    """us per call, 20 calls captured into one HIP graph (no host launch floor), replayed 5x"""
+    for _ in range(3): f()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(20): f()
+    g.replay(); torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(iters):
-        f()
-    e.record()
-    e.synchronize()
-    return s.elapsed_time(e) / iters * 1e3  # us
+    for _ in range(5): g.replay()
+    e.record(); e.synchronize()
+    return s.elapsed_time(e) / 100 * 1e3
 
 
 tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
@@ -55,7 +58,7 @@ for name, M, N, K, cnt, epi in layers:
     dx = torch.empty(M, K, device=dev, dtype=T)
     dw = torch.empty(N, K, device=dev)
     db = torch.empty(N, device=dev)
-    ws = torch.empty(8 * 1024 * 1024, device=dev)
+    ws = torch.zeros(8 * 1024 * 1024, device=dev)
     aux = torch.randn(M, K, device=dev).to(T)
     if epi == "gelu":
         fwd = lambda: ops.gemm(x, w, M=M, N=N, K=K, bias=bias, act=ops.ACT_GELU, out=y, out2=y2, tile=args.tile)
