@@ -55,9 +55,24 @@ def ev_time_ms(fn, iters, stream=None):
     return start.elapsed_time(end) / iters
 
 
+def graph_time_ms(fn, reps=20, replays=5):
+    """Average duration of fn() in ms with `reps` calls captured into one HIP graph (the way the step runs them: no host
+    launch floor between kernels), replayed `replays` times between two HIP events on the launch stream."""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    return ev_time_ms(g.replay, replays) / reps
+
+
 def gemm_step_probe(B, dtype, dev, iters=20):
     """Launch-level roofline of the dominant kernel: every MFMA GEMM launch of one step (forward KC.KC,
-    dgrad KC.RC, wgrad RC.RC + its split-K reduce), each shape timed with HIP events on the launch stream.
+    dgrad KC.RC, wgrad RC.RC + its split-K reduce), each shape timed with HIP events around a HIP-graph replay.
     achieved = sum(2*M*N*K * count) / sum(avg launch time * count); avg_launch_us per kind is what the
     rocprofv3 kernel_stats average of gemm_pipe_kernel<64,64,A_KC,B_KC,3,4> must agree with."""
     from sky_embeddings_amd import ops
@@ -90,9 +105,7 @@ def gemm_step_probe(B, dtype, dev, iters=20):
             dgrad = lambda: ops.gemm(dy, w, M=M, N=K, K=N, a_layout=ops.KC, b_layout=ops.RC, lda=N, ldb=K, out=dx, ws=ws)
         wgrad = lambda: ops.gemm(dy, x, M=N, N=K, K=M, a_layout=ops.RC, b_layout=ops.RC, lda=N, ldb=K, out_f32=dw, colsum_a=db, ws=ws)
         for kind, f in zip(kinds, (fwd, dgrad, wgrad)):
-            for _ in range(3):
-                f()
-            ms = ev_time_ms(f, iters)
+            ms = graph_time_ms(f, iters)
             kinds[kind]["launches"] += cnt
             kinds[kind]["us"] += 1e3 * ms * cnt
             kinds[kind]["flop"] += 2.0 * M * N * K * cnt

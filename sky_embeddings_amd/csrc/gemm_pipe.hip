@@ -31,11 +31,30 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU for bf16 outputs.  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, three orders below a bf16
+// ulp; the fp32 parity path in gemm.hip keeps erff): one v_exp + one v_rcp instead of erff's ~40 instructions, and
+// exp(-x^2/2) serves both the erf tail and the Gaussian density of dGELU.  The epilogue of the [tokens, 4*dim] launches
+// was ALU-bound on erff/expf before (dec.fc2 dgrad 36 -> 2x the plain GEMM).
+__device__ __forceinline__ void gelu_parts(float x, float &cdf, float &gauss) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    gauss = __expf(-0.5f * x * x);                       // = exp(-z^2)
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float tail = 0.5f * p * t * gauss;             // 0.5 * erfc(z)
+    cdf = x >= 0.f ? 1.0f - tail : tail;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+    float cdf, gauss;
+    gelu_parts(x, cdf, gauss);
+    return x * cdf;
+}
 __device__ __forceinline__ float dgelu_f(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    float cdf, gauss;
+    gelu_parts(x, cdf, gauss);
+    return fmaf(x * 0.39894228040143267794f, gauss, cdf);
 }
 
 // ---- stage issue -----------------------------------------------------------------------------
