@@ -178,10 +178,17 @@ int set_lds(K kern, size_t smem, const char *name) {
 
 }  // namespace
 
+// attention_mfma.hip: bf16, N <= 32, head dim 32 / 64 (the shapes of the MAE path); -1 = not handled
+int skyemb_mha_mfma_try(bool bwd, const void *qkv, const void *dout, void *out, int B, int N, int H, int hd, hipStream_t st);
+
 extern "C" int skyemb_mha_fwd(const void *qkv, void *out, int dtype, int B, int N, int H, int hd, void *stream) {
     SKY_CHECK_ARG(B > 0 && N > 0 && H > 0 && hd > 0 && hd % 8 == 0, "skyemb_mha_fwd: bad shape (head dim must be a multiple of 8)");
-    const Plan p = make_plan(N, hd, false);
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == SKYEMB_BF16 && skyemb_mha_mfma_try(false, qkv, nullptr, out, B, N, H, hd, st) == 0) {
+        SKY_LAUNCH_CHECK("skyemb_mha_fwd");
+        return 0;
+    }
+    const Plan p = make_plan(N, hd, false);
     dim3 grid((B * H + p.waves - 1) / p.waves), block(64 * p.waves);
     int rc;
     if (dtype == SKYEMB_BF16) {
@@ -200,8 +207,12 @@ extern "C" int skyemb_mha_fwd(const void *qkv, void *out, int dtype, int B, int 
 extern "C" int skyemb_mha_bwd(const void *qkv, const void *dout, void *dqkv, int dtype, int B, int N, int H, int hd,
                               void *stream) {
     SKY_CHECK_ARG(B > 0 && N > 0 && H > 0 && hd > 0 && hd % 8 == 0, "skyemb_mha_bwd: bad shape (head dim must be a multiple of 8)");
-    const Plan p = make_plan(N, hd, true);
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == SKYEMB_BF16 && skyemb_mha_mfma_try(true, qkv, dout, dqkv, B, N, H, hd, st) == 0) {
+        SKY_LAUNCH_CHECK("skyemb_mha_bwd");
+        return 0;
+    }
+    const Plan p = make_plan(N, hd, true);
     dim3 grid((B * H + p.waves - 1) / p.waves), block(64 * p.waves);
     int rc;
     if (dtype == SKYEMB_BF16) {

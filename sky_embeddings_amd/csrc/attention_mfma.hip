@@ -1,0 +1,246 @@
+// Attention core for short sequences (N <= 32 tokens) in bf16: ONE wavefront per (sample, head), every
+// product on v_mfma_f32_32x32x16_bf16, operands loaded straight from HBM into MFMA fragments (16-byte row
+// loads; 2-byte gathers for the operands that are contracted over the token index), no LDS staging.
+//
+// Orientation trick (cdna_hip_programming.md, "an accumulator tile as the next MFMA's operand"): a 32x32 result has its
+// column on the lane and its rows in the 16 registers, so it is directly the operand of a product that sums over its
+// ROW index; element e of lane half g of k-step s is row  pi(s,g,e) = 16 s + 8 (e>>2) + 4 g + (e&3).
+//   forward : ST[j][i] = K Q^T  (softmax over registers + one lane^32 exchange)  ->  O^T = V^T . P^T
+//   backward: both orientations of the scores and of dP are formed (4 cheap MFMAs instead of a transpose):
+//             dQ^T = K^T . dS^T (sum over j),   dK^T = Q^T . dS,   dV^T = dO^T . P  (sum over i)
+// qkv layout is the reference's [B, N, 3, H, hd] (timm Attention: qkv(x).reshape(B,N,3,H,hd)); softmax statistics,
+// probabilities and dS are fp32, rounded to bf16 only as MFMA operands.
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int pi_row(int s, int g, int e) { return 16 * s + 8 * (e >> 2) + 4 * g + (e & 3); }
+__device__ __forceinline__ int acc_row(int reg, int g) { return (reg & 3) + 8 * (reg >> 2) + 4 * g; }
+
+__device__ __forceinline__ bf16x8 zero8() {
+    bf16x8 z;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = (bf16_t)0.0f;
+    return z;
+}
+// row fragment: lane (r, g) holds X[row r][16 s + 8 g + 0..7]  (the A and the B operand maps coincide)
+__device__ __forceinline__ bf16x8 row_frag(const bf16_t *base, int64_t row_stride, int r, int g, int s, int N) {
+    return r < N ? *(const bf16x8 *)(base + (int64_t)r * row_stride + 16 * s + 8 * g) : zero8();
+}
+// transposed fragment for a contraction over the token index: lane (r, g) holds X[token pi(s,g,e)][d = dcol]
+__device__ __forceinline__ bf16x8 tok_frag(const bf16_t *base, int64_t row_stride, int dcol, bool dok, int g, int s, int N) {
+    bf16x8 f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int t = pi_row(s, g, e);
+        f[e] = (dok && t < N) ? base[(int64_t)t * row_stride + dcol] : (bf16_t)0.0f;
+    }
+    return f;
+}
+__device__ __forceinline__ bf16x8 pack_regs(const f32x16 &x, int s) {
+    bf16x8 f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (bf16_t)x[8 * s + e];
+    return f;
+}
+// store the [d][token] result tile: lane (token r, g) owns d = 8 q + 4 g + 0..3 for q = 0..3
+template <int HD>
+__device__ __forceinline__ void store_tile(bf16_t *dst_row, const f32x16 &t, int blk, int g, float scale) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int d0 = 32 * blk + 8 * q + 4 * g;
+        if (d0 < HD) store4<bf16_t>(dst_row + d0, t[4 * q] * scale, t[4 * q + 1] * scale, t[4 * q + 2] * scale, t[4 * q + 3] * scale);
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out, int B,
+                                                           int N, int H) {
+    constexpr int KS = HD / 16, NB = (HD + 31) / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int head = blockIdx.x * 4 + wave;
+    if (head >= B * H) return;
+    const int b = head / H, h = head - b * H;
+    const int D = H * HD;
+    const int64_t rs = 3 * (int64_t)D;
+    const int r = lane & 31, g = lane >> 5;
+    const bf16_t *qb = qkv + (int64_t)b * N * rs + h * HD, *kb = qb + D, *vb = qb + 2 * D;
+    const int NS = N > 16 ? 2 : 1;       // k-steps over the token index
+
+    bf16x8 qf[KS], kf[KS], vt[2][NB];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        qf[s] = row_frag(qb, rs, r, g, s, N);
+        kf[s] = row_frag(kb, rs, r, g, s, N);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+            vt[s][blk] = s < NS ? tok_frag(vb, rs, 32 * blk + r, 32 * blk + r < HD, g, s, N) : zero8();
+
+    f32x16 st;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) st = mfma32(kf[s], qf[s], st);      // ST[j][i] = sum_d K[j][d] Q[i][d]
+
+    const float scale = rsqrtf((float)HD);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        st[e] = acc_row(e, g) < N ? st[e] * scale : -INFINITY;
+        mx = fmaxf(mx, st[e]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        st[e] = __expf(st[e] - mx);
+        sum += st[e];
+    }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] *= inv;
+
+    bf16x8 pf[2] = {pack_regs(st, 0), pack_regs(st, 1)};
+    bf16_t *orow = out + ((int64_t)b * N + r) * D + h * HD;
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+        f32x16 ot;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ot[e] = 0.f;
+        ot = mfma32(vt[0][blk], pf[0], ot);                           // O^T[d][i] = sum_j V[j][d] P[i][j]
+        if (NS > 1) ot = mfma32(vt[1][blk], pf[1], ot);
+        if (r < N) store_tile<HD>(orow, ot, blk, g, 1.0f);
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
+                                                           bf16_t *__restrict__ dqkv, int B, int N, int H) {
+    constexpr int KS = HD / 16, NB = (HD + 31) / 32;
+    __shared__ float stats[4][3][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int head = blockIdx.x * 4 + wave;
+    if (head >= B * H) return;
+    const int b = head / H, h = head - b * H;
+    const int D = H * HD;
+    const int64_t rs = 3 * (int64_t)D;
+    const int r = lane & 31, g = lane >> 5;
+    const bf16_t *qb = qkv + (int64_t)b * N * rs + h * HD, *kb = qb + D, *vb = qb + 2 * D;
+    const bf16_t *ob = dout + (int64_t)b * N * D + h * HD;
+    const int NS = N > 16 ? 2 : 1;
+    const float scale = rsqrtf((float)HD);
+
+    bf16x8 qf[KS], kf[KS], vf[KS], of[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        qf[s] = row_frag(qb, rs, r, g, s, N);
+        kf[s] = row_frag(kb, rs, r, g, s, N);
+        vf[s] = row_frag(vb, rs, r, g, s, N);
+        of[s] = row_frag(ob, D, r, g, s, N);
+    }
+    f32x16 st, sn, dpt, dpn;     // scores / dP with (rows j, col i) and with (rows i, col j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] = sn[e] = dpt[e] = dpn[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        st = mfma32(kf[s], qf[s], st);
+        sn = mfma32(qf[s], kf[s], sn);
+        dpt = mfma32(vf[s], of[s], dpt);      // dP^T[j][i] = sum_d V[j][d] dO[i][d]
+        dpn = mfma32(of[s], vf[s], dpn);
+    }
+    // ---- column-i orientation: softmax statistics, P^T, rowsum, dS^T
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        st[e] = acc_row(e, g) < N ? st[e] * scale : -INFINITY;
+        mx = fmaxf(mx, st[e]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        st[e] = __expf(st[e] - mx);
+        sum += st[e];
+    }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    float rsum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        st[e] *= inv;
+        rsum = fmaf(st[e], dpt[e], rsum);
+    }
+    rsum += __shfl_xor(rsum, 32);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] *= dpt[e] - rsum;             // dS^T[j][i]
+    if (g == 0) {
+        stats[wave][0][r] = mx;
+        stats[wave][1][r] = inv;
+        stats[wave][2][r] = rsum;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- column-j orientation: P and dS with the token i in the registers
+    f32x16 pn;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int i = acc_row(e, g);
+        const float p = (r < N && i < N) ? __expf(sn[e] * scale - stats[wave][0][i]) * stats[wave][1][i] : 0.f;
+        pn[e] = p;
+        sn[e] = p * (dpn[e] - stats[wave][2][i]);                     // dS[i][j]
+    }
+
+    bf16_t *dq = dqkv + ((int64_t)b * N + r) * rs + h * HD, *dk = dq + D, *dv = dq + 2 * D;
+    bf16x8 dst_f[2] = {pack_regs(st, 0), pack_regs(st, 1)};           // dS^T, k = j
+    bf16x8 dsn_f[2] = {pack_regs(sn, 0), pack_regs(sn, 1)};           // dS,   k = i
+    bf16x8 pn_f[2] = {pack_regs(pn, 0), pack_regs(pn, 1)};            // P,    k = i
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+        const int dcol = 32 * blk + r;
+        const bool dok = dcol < HD;
+        f32x16 tq, tk, tv;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tq[e] = tk[e] = tv[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (s < NS) {
+                tq = mfma32(tok_frag(kb, rs, dcol, dok, g, s, N), dst_f[s], tq);   // dQ^T[d][i] = sum_j K[j][d] dS[i][j]
+                tk = mfma32(tok_frag(qb, rs, dcol, dok, g, s, N), dsn_f[s], tk);   // dK^T[d][j] = sum_i Q[i][d] dS[i][j]
+                tv = mfma32(tok_frag(ob, D, dcol, dok, g, s, N), pn_f[s], tv);     // dV^T[d][j] = sum_i dO[i][d] P[i][j]
+            }
+        }
+        if (r < N) {
+            store_tile<HD>(dq, tq, blk, g, scale);
+            store_tile<HD>(dk, tk, blk, g, scale);
+            store_tile<HD>(dv, tv, blk, g, 1.0f);
+        }
+    }
+}
+
+}  // namespace
+
+// returns -1 when the shape is outside this kernel's subset (caller falls back to the LDS kernel of attention.hip)
+int skyemb_mha_mfma_try(bool bwd, const void *qkv, const void *dout, void *out, int B, int N, int H, int hd, hipStream_t st) {
+    if (N > 32 || (hd != 32 && hd != 64)) return -1;
+    static const bool off = []() { const char *e = getenv("SKYEMB_MHA_MFMA"); return e && e[0] == '0'; }();
+    if (off) return -1;
+    const dim3 grid((B * H + 3) / 4), block(256);
+    const bf16_t *x = (const bf16_t *)qkv;
+    if (!bwd) {
+        if (hd == 32) hipLaunchKernelGGL(mha_fwd_mfma_kernel<32>, grid, block, 0, st, x, (bf16_t *)out, B, N, H);
+        else hipLaunchKernelGGL(mha_fwd_mfma_kernel<64>, grid, block, 0, st, x, (bf16_t *)out, B, N, H);
+    } else {
+        if (hd == 32) hipLaunchKernelGGL(mha_bwd_mfma_kernel<32>, grid, block, 0, st, x, (const bf16_t *)dout, (bf16_t *)out, B, N, H);
+        else hipLaunchKernelGGL(mha_bwd_mfma_kernel<64>, grid, block, 0, st, x, (const bf16_t *)dout, (bf16_t *)out, B, N, H);
+    }
+    return 0;
+}

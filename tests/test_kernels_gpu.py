@@ -146,7 +146,8 @@ def test_layernorm(ops, dtype, shape):
 
 # ------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("cfg", [(3, 5, 12, 64), (2, 17, 16, 32), (2, 66, 2, 64), (4, 5, 4, 16), (1, 65, 3, 8)])
+@pytest.mark.parametrize("cfg", [(3, 5, 12, 64), (2, 17, 16, 32), (2, 66, 2, 64), (4, 5, 4, 16), (1, 65, 3, 8),
+                                 (2, 32, 3, 32), (5, 16, 2, 64), (3, 1, 2, 32), (7, 31, 5, 64)])
 def test_attention(ops, dtype, cfg):
     B, N, H, hd = cfg
     D = H * hd
