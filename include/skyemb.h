@@ -126,6 +126,14 @@ int skyemb_layernorm_fwd(const float *x, const float *gamma, const float *beta, 
  * of g_out (or NULL).  dy is `dtype` (or fp32 when dy_is_f32).  dgamma/dbeta: deterministic two-stage
  * reduction through part[2, nblk, D] (fp32 workspace, nblk = skyemb_layernorm_bwd_blocks(M)). */
 int skyemb_layernorm_bwd_blocks(int M);
+/* dgamma == NULL: leave the partial sums in `part` for skyemb_layernorm_bwd_reduce_batch, which finishes the
+ * dgamma / dbeta of many LayerNorms (e.g. all of one backward stage) in ONE launch; `items` is a DEVICE array. */
+typedef struct {
+    const float *part;   /* [2, nblk, D] written by skyemb_layernorm_bwd */
+    float *dgamma, *dbeta;
+    int32_t nblk, D;
+} skyemb_ln_reduce_item;
+int skyemb_layernorm_bwd_reduce_batch(const skyemb_ln_reduce_item *items, int n_items, int max_D, void *stream);
 int skyemb_layernorm_bwd(const void *dy, int dy_is_f32, int dtype, const float *x, const float *gamma,
                          const float *mean, const float *rstd, const float *g_in, float *g_out, void *g_lp,
                          float *part, float *dgamma, float *dbeta, int M, int D, void *stream);

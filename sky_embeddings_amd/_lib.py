@@ -58,6 +58,7 @@ PROTOTYPES = {
                                             c_vp]),
     "skyemb_layernorm_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp]),
     "skyemb_layernorm_bwd_blocks": (c_i32, [c_i32]),
+    "skyemb_layernorm_bwd_reduce_batch": (c_i32, [c_vp, c_i32, c_i32, c_vp]),
     "skyemb_layernorm_bwd": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                      c_i32, c_i32, c_vp]),
     "skyemb_mha_fwd": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),

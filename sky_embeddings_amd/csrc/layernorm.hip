@@ -157,7 +157,35 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float *__rest
     }
 }
 
+// every LayerNorm of a backward stage in one launch: blockIdx.z = item
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_batch_kernel(const skyemb_ln_reduce_item *__restrict__ items) {
+    __shared__ float red[32][33];
+    const skyemb_ln_reduce_item it = items[blockIdx.z];
+    const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int d = blockIdx.x * 32 + col;
+    if (blockIdx.x * 32 >= it.D) return;
+    const float *src = it.part + (int64_t)blockIdx.y * it.nblk * it.D;
+    float acc = 0.f;
+    if (d < it.D)
+        for (int b = rg; b < it.nblk; b += 32) acc += src[(int64_t)b * it.D + d];
+    red[rg][col] = acc;
+    __syncthreads();
+    if (rg == 0 && d < it.D) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) t += red[r][col];
+        (blockIdx.y == 0 ? it.dgamma : it.dbeta)[d] = t;
+    }
+}
+
 }  // namespace
+
+extern "C" int skyemb_layernorm_bwd_reduce_batch(const skyemb_ln_reduce_item *items, int n_items, int max_D, void *stream) {
+    SKY_CHECK_ARG(items && n_items > 0 && n_items <= 65535 && max_D > 0, "skyemb_layernorm_bwd_reduce_batch: bad arguments");
+    hipLaunchKernelGGL(ln_bwd_reduce_batch_kernel, dim3((max_D + 31) / 32, 2, n_items), dim3(1024), 0, (hipStream_t)stream, items);
+    SKY_LAUNCH_CHECK("skyemb_layernorm_bwd_reduce_batch");
+    return 0;
+}
 
 extern "C" int skyemb_layernorm_fwd(const float *x, const float *gamma, const float *beta, void *y, float *y32,
                                     int dtype, float *mean, float *rstd, int M, int D, float eps, void *stream) {

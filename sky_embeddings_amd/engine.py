@@ -110,6 +110,7 @@ class MAEEngine:
         # fp32 scratch for split-K GEMM launches (partial slabs; every launch on the stream reuses it)
         self._splitk_ws = torch.zeros(8 * 1024 * 1024, device=self.device, dtype=torch.float32)
         self._side, self._pending = None, {}
+        self._ln_first = self._ln_count = 0      # LayerNorms of the running backward stage awaiting their batched reduce
         self.initialize_weights(seed)
 
     # ------------------------------------------------------------------ parameters
@@ -209,8 +210,24 @@ class MAEEngine:
             w["datt"] = torch.empty(Mx * Dx, **lp)
             w["dh"] = torch.empty(Hx, **lp)
             w["dqkv"] = torch.empty(3 * Mx * Dx, **lp)
-            nblk = ops.layernorm_bwd_blocks(Mx)
-            w["ln_part"] = torch.empty(2 * nblk * Dx, **f32)
+            # LayerNorm dgamma/dbeta: every LN keeps its own partial sums; ONE batched launch per backward stage
+            # finishes them (42 reduce launches -> 3-6).  Table order = the order backward visits the LNs.
+            order = [("decoder_norm", Md, Dd)]
+            for i in reversed(range(cfg.decoder_depth)):
+                order += [(f"decoder_blocks.{i}.norm2", Md, Dd), (f"decoder_blocks.{i}.norm1", Md, Dd)]
+            order.append(("norm", Me, D))
+            for i in reversed(range(cfg.depth)):
+                order += [(f"blocks.{i}.norm2", Me, D), (f"blocks.{i}.norm1", Me, D)]
+            entries = []
+            w["ln_index"], w["ln_parts"] = {}, []
+            for k, (name, M_, D_) in enumerate(order):
+                nb = ops.layernorm_bwd_blocks(M_)
+                part = torch.empty(2, nb, D_, **f32)
+                w["ln_index"][name] = k
+                w["ln_parts"].append(part)
+                entries.append((part, self.store.grad(f"{name}.weight"), self.store.grad(f"{name}.bias"), nb, D_))
+            w["ln_items"] = ops.ln_reduce_items(entries, dev)
+            w["ln_max_D"] = Dx
             w["dE"] = torch.empty(Me, Dd, **lp)
             w["dT"] = torch.empty(B * keep, D, **lp)
             w["drows"] = torch.empty(B * keep, pv, **f32)
@@ -372,18 +389,24 @@ class MAEEngine:
             if ev is not None:
                 torch.cuda.current_stream().wait_event(ev)
 
-    def _join_side(self):
+    def _end_stage(self, w, last=False):
+        """End of a backward stage: finish the dgamma/dbeta of the LayerNorms it visited (one launch), join the
+        weight-gradient stream."""
+        if self._ln_count:
+            ops.layernorm_bwd_reduce_batch(w["ln_items"], self._ln_first, self._ln_count, w["ln_max_D"])
+        self._ln_first, self._ln_count = (0, 0) if last else (self._ln_first + self._ln_count, 0)
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
             self._pending.clear()
 
     def _ln_bwd(self, dy, x, prefix, mean, rstd, g_in, g, g_lp, M, dim, w):
         st = self.store
-        nblk = ops.layernorm_bwd_blocks(M)
-        part = w["ln_part"][:2 * nblk * dim].view(2, nblk, dim)
+        k = w["ln_index"][prefix]
+        assert k == self._ln_first + self._ln_count, "LayerNorm backward visited out of table order"
+        self._ln_count += 1
         self._before_write(g_lp)
-        ops.layernorm_bwd(dy, x, st.param(f"{prefix}.weight"), mean, rstd, g_in, g, g_lp, part,
-                          st.grad(f"{prefix}.weight"), st.grad(f"{prefix}.bias"), M, dim, self.code)
+        ops.layernorm_bwd(dy, x, st.param(f"{prefix}.weight"), mean, rstd, g_in, g, g_lp, w["ln_parts"][k], None, None,
+                          M, dim, self.code)
 
     def _block_bwd(self, x_in, bufs, prefix, M, dim, heads, Bsz, N, g, g_lp, w):
         """g / g_lp hold d(block output) on entry and d(block input) on exit."""
@@ -421,6 +444,7 @@ class MAEEngine:
         cfg, st = self.cfg, self.store
         L, D, Dd, pv = cfg.num_patches, cfg.embed_dim, cfg.decoder_embed_dim, cfg.patch_dim
         Me, Md = B * Ne, B * Nd
+        self._ln_first = self._ln_count = 0
         dln = w["dln"][:Md * Dd].view(Md, Dd)
         self._linear_bwd(w["dpred"], w["dlat_lp"], "decoder_pred.weight", "decoder_pred.bias", Md, pv, Dd, w, dx_out=dln)
         g = w["g"][:Md * Dd].view(Md, Dd)
@@ -434,7 +458,7 @@ class MAEEngine:
         ops.gather_rows(g, w["dec_dst"], None, w["dE"], Me, Dd)
         dln_e = w["dln"][:Me * D].view(Me, D)
         self._linear_bwd(w["dE"], w["lat_lp"], "decoder_embed.weight", "decoder_embed.bias", Me, Dd, D, w, dx_out=dln_e)
-        self._join_side()
+        self._end_stage(w)
 
     def backward_encoder(self, hi=None, lo=0):
         """Encoder blocks hi-1 ... lo (hi=None: from the top, including the final norm)."""
@@ -450,7 +474,7 @@ class MAEEngine:
             self._ln_bwd(dln_e, w["xs"][cfg.depth], "norm", w["lat_mean"], w["lat_rstd"], None, g, g_lp, Me, D, w)
         for i in reversed(range(lo, hi)):
             self._block_bwd(w["xs"][i], w["enc"][i], f"blocks.{i}", Me, D, cfg.num_heads, B, Ne, g, g_lp, w)
-        self._join_side()
+        self._end_stage(w)
 
     def backward_embed(self):
         """Last stage: cls token, patch embedding, patch_mask_values (g = d xs[0])."""
@@ -467,7 +491,7 @@ class MAEEngine:
                  ldb=pv, out_f32=w["drows"])
         ops.patch_gather_bwd_pmv(imgs, w["ids_keep"], w["drows"], w["pmv_part"], st.grad("patch_mask_values"),
                                  cfg.patch_size, keep)
-        self._join_side()
+        self._end_stage(w, last=True)
 
     def backward(self):
         """Gradients of the last :meth:`forward_train` loss into the flat ``g`` buffer (every

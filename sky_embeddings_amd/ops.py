@@ -95,6 +95,17 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, g_in, g_out, g_lp, part, dgamma, dbe
                                      _p(g_lp), _p(part), _p(dgamma), _p(dbeta), M, D, _stream()), "skyemb_layernorm_bwd")
 
 
+def ln_reduce_items(entries, device):
+    """Device table of skyemb_ln_reduce_item (32 bytes each) from [(part, dgamma, dbeta, nblk, D), ...]."""
+    rows = [[part.data_ptr(), dg.data_ptr(), db.data_ptr(), nblk + (D << 32)] for part, dg, db, nblk, D in entries]
+    return torch.tensor(rows, dtype=torch.int64).to(device)
+
+
+def layernorm_bwd_reduce_batch(items, first, count, max_D):
+    check(lib().skyemb_layernorm_bwd_reduce_batch(items.data_ptr() + 32 * first, count, max_D, _stream()),
+          "skyemb_layernorm_bwd_reduce_batch")
+
+
 def mha_fwd(qkv, out, B, N, H, hd):
     check(lib().skyemb_mha_fwd(_p(qkv), _p(out), dtype_code(qkv.dtype), B, N, H, hd, _stream()), "skyemb_mha_fwd")
 

@@ -144,6 +144,37 @@ def test_layernorm(ops, dtype, shape):
     assert relerr(dgam, gr.grad) < 1e-5 and relerr(dbet, br.grad) < 1e-5
 
 
+def test_layernorm_bwd_batched_reduce(ops):
+    """dgamma/dbeta of several LayerNorms (different M, D) finished by ONE batched launch == the per-LN reduce."""
+    g = torch.Generator().manual_seed(5)
+    code = ops.dtype_code(torch.bfloat16)
+    entries, direct = [], []
+    for M, D in ((4352, 512), (1280, 768), (37, 192)):
+        x = dev(torch.randn(M, D, generator=g))
+        gamma = dev(torch.randn(D, generator=g))
+        dy = dev(torch.randn(M, D, generator=g), torch.bfloat16)
+        mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+        yd = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+        ops.layernorm_fwd(x, gamma, dev(torch.zeros(D)), yd, mean, rstd, M, D, 1e-6)
+        nblk = ops.layernorm_bwd_blocks(M)
+        outs = []
+        for batched in (False, True):
+            part = torch.empty(2, nblk, D, device=DEV)
+            gout, dgam, dbet = torch.empty(M, D, device=DEV), torch.full((D,), float("nan"), device=DEV), torch.full((D,), float("nan"), device=DEV)
+            ops.layernorm_bwd(dy, x, gamma, mean, rstd, None, gout, None, part, None if batched else dgam,
+                              None if batched else dbet, M, D, code)
+            outs.append((part, dgam, dbet, nblk, D))
+        direct.append(outs[0])
+        entries.append(outs[1])
+    items = ops.ln_reduce_items(entries, DEV)
+    ops.layernorm_bwd_reduce_batch(items, 1, 2, 768)      # a sub-range first, then everything
+    assert torch.equal(entries[1][1], direct[1][1]) and torch.equal(entries[2][2], direct[2][2])
+    assert bool(torch.isnan(entries[0][1]).all())
+    ops.layernorm_bwd_reduce_batch(items, 0, 3, 768)
+    for e, d in zip(entries, direct):
+        assert torch.equal(e[1], d[1]) and torch.equal(e[2], d[2])
+
+
 # ------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cfg", [(3, 5, 12, 64), (2, 17, 16, 32), (2, 66, 2, 64), (4, 5, 4, 16), (1, 65, 3, 8),
