@@ -90,6 +90,15 @@ typedef struct skyemb_gemm_args {
 
 int skyemb_gemm(const skyemb_gemm_args *args, void *stream);
 
+/* Grouped launch: n <= 32 independent bf16 problems with the same operand layouts run as ONE grid of 64x64 tiles (the
+ * four weight-gradient GEMMs of a transformer block fill the chip together: no split-K, no reduce launch).
+ * skyemb_gemm_group_plan validates the problems and fills a HOST blob of skyemb_gemm_group_blob_bytes(n) bytes; the
+ * caller copies it to device memory once (pointers inside are fixed) and replays skyemb_gemm_group_launch.
+ * plan returns -1 (with skyemb_last_error set) when a problem is outside the subset: launch them singly then. */
+int64_t skyemb_gemm_group_blob_bytes(int n);
+int skyemb_gemm_group_plan(const skyemb_gemm_args *args, int n, void *blob_host, int64_t blob_bytes, int32_t *total_blocks);
+int skyemb_gemm_group_launch(const void *blob_dev, int total_blocks, int a_layout, int b_layout, void *stream);
+
 /* column sums: out[n] = sum_m X[m,n]; X is `dtype` (bias gradients) or fp32 partials
  * (LayerNorm dgamma/dbeta second stage).  Replaces autograd's bias-gradient reductions. */
 int skyemb_colsum(const void *X, int dtype, int64_t ldx, int M, int N, float *out, void *stream);

@@ -50,6 +50,9 @@ PROTOTYPES = {
     "skyemb_last_error": (ctypes.c_char_p, []),
     "skyemb_version": (c_i32, []),
     "skyemb_gemm": (c_i32, [ctypes.POINTER(GemmArgs), c_vp]),
+    "skyemb_gemm_group_blob_bytes": (c_i64, [c_i32]),
+    "skyemb_gemm_group_plan": (c_i32, [ctypes.POINTER(GemmArgs), c_i32, c_vp, c_i64, ctypes.POINTER(c_i32)]),
+    "skyemb_gemm_group_launch": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp]),
     "skyemb_colsum": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "skyemb_random_mask_from_noise": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "skyemb_patch_gather": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32,

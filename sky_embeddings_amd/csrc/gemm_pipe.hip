@@ -13,6 +13,7 @@
 // consecutive output COLUMNS of one row: 16-byte fp32 / 8-byte bf16 stores, float4 bias loads.
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -141,21 +142,19 @@ __device__ __forceinline__ void wait_stages(int rem) {
 // must cover the L2 latency alone).
 // NW waves per workgroup: 4 (2x2, 64x64 tiles) or 8 (4x2, 128x128 tiles: 64 FLOP/byte and two waves
 // per SIMD even when the launch has a single workgroup per CU).
+// One workgroup's work: tile `tb` of `ntiles` (XCD-aware order), k-range `split` of `S`.
 template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int NW>
-__global__ __launch_bounds__(NW * 64) void gemm_pipe_kernel(const skyemb_gemm_args g) {
+__device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const int tb, const int ntiles, const int split,
+                                               const int S, char *smem) {
     constexpr int WGM = NW / 2;                         // waves along M (x 2 along N)
     constexpr int TM = BM / WGM / 16, TN = BN / 2 / 16;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
     constexpr int NI = (BM + BN) / 8 / NW;              // LDS-DMA instructions per wave per stage
-    extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (g.N + BN - 1) / BN;
-    const int S = g.split_k > 1 ? g.split_k : 1;           // split-K factor (host-resolved)
-    const int ntiles = gridDim.x / S;
-    const int split = blockIdx.x / ntiles, tb = blockIdx.x - split * ntiles;
     int wg;
     {   // XCD-aware tile order (see gemm.hip)
         const int nwg = ntiles, xcd = tb & 7, local = tb >> 3;
@@ -302,6 +301,33 @@ __global__ __launch_bounds__(NW * 64) void gemm_pipe_kernel(const skyemb_gemm_ar
             if (out) store4<bf16_t>(out + (int64_t)orow * g.ldo + n, v[0], v[1], v[2], v[3]);
         }
     }
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_pipe_kernel(const skyemb_gemm_args g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int S = g.split_k > 1 ? g.split_k : 1;           // split-K factor (host-resolved)
+    const int ntiles = gridDim.x / S;
+    const int split = blockIdx.x / ntiles;
+    gemm_pipe_body<BM, BN, A_KC, B_KC, NSTAGE, NW>(g, blockIdx.x - split * ntiles, ntiles, split, S, smem);
+}
+
+// Grouped launch: several independent problems of one operand-layout class in ONE grid (the four weight-gradient
+// GEMMs of a transformer block: together they fill the chip, so none of them needs split-K or its reduce launch).
+// blob = [int32 n, total_blocks, 6 x pad, start[0..n] (multiples of 8), ...pad to 256 B][n x skyemb_gemm_args]
+constexpr int GROUP_HEADER_BYTES = 256, GROUP_MAX = 32;
+template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_pipe_group_kernel(const char *__restrict__ blob) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int *hdr = (const int *)blob;
+    const int n = hdr[0];
+    int p = 0;
+    while (p + 1 < n && (int)blockIdx.x >= hdr[8 + p + 1]) ++p;
+    const skyemb_gemm_args g = ((const skyemb_gemm_args *)(blob + GROUP_HEADER_BYTES))[p];
+    const int tb = blockIdx.x - hdr[8 + p];
+    const int ntiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    if (tb >= ntiles) return;                             // padding up to the next multiple of 8 (keeps tb & 7 == XCD)
+    gemm_pipe_body<BM, BN, A_KC, B_KC, NSTAGE, NW>(g, tb, ntiles, 0, 1, smem);
 }
 
 // second launch of a split-K GEMM: v = sum_s slab[s][m][n] (fixed order, alpha already applied), then
@@ -452,4 +478,54 @@ int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
     g.split_k = S;
     if (tile == 12864) return dispatch<128, 64>(g, st);   // experimental 128x64 tile (8 waves)
     return tile == 128 ? dispatch<128, 128>(g, st) : dispatch<64, 64>(g, st);
+}
+
+// ---- grouped launch (see gemm_pipe_group_kernel) -------------------------------------------------------
+extern "C" int64_t skyemb_gemm_group_blob_bytes(int n) { return GROUP_HEADER_BYTES + (int64_t)n * sizeof(skyemb_gemm_args); }
+
+extern "C" int skyemb_gemm_group_plan(const skyemb_gemm_args *args, int n, void *blob_host, int64_t blob_bytes,
+                                      int32_t *total_blocks) {
+    SKY_CHECK_ARG(args && blob_host && total_blocks && n >= 1 && n <= GROUP_MAX, "skyemb_gemm_group_plan: 1..%d problems", GROUP_MAX);
+    SKY_CHECK_ARG(blob_bytes >= skyemb_gemm_group_blob_bytes(n), "skyemb_gemm_group_plan: blob too small");
+    int *hdr = (int *)blob_host;
+    memset(blob_host, 0, GROUP_HEADER_BYTES);
+    skyemb_gemm_args *out = (skyemb_gemm_args *)((char *)blob_host + GROUP_HEADER_BYTES);
+    int start = 0;
+    for (int i = 0; i < n; ++i) {
+        skyemb_gemm_args g = args[i];
+        const bool ok = g.dtype == SKYEMB_BF16 && g.K % BK == 0 && g.K >= BK && g.N % 4 == 0 && g.a_layout == args[0].a_layout &&
+                        g.b_layout == args[0].b_layout && !(g.ldo32 % 4) && !(g.ldo % 4) && !(g.ldo2 % 4) && !(g.ldr % 4) &&
+                        !(g.ldt % 4) && !(g.ldaux % 4) && (g.a_layout == SKYEMB_KC ? g.M >= 1 : (g.M % 8 == 0 && g.M >= 8)) &&
+                        (g.b_layout == SKYEMB_KC ? g.N >= 1 : (g.N % 8 == 0 && g.N >= 8));
+        if (!ok) {
+            skyemb_set_error("skyemb_gemm_group_plan: problem %d is outside the pipelined bf16 subset or mixes operand layouts", i);
+            return -1;
+        }
+        g.split_k = 1;
+        g.tile = 64;
+        out[i] = g;
+        hdr[8 + i] = start;
+        const int64_t tiles = ceil_div64(g.M, 64) * ceil_div64(g.N, 64);
+        start += (int)((tiles + 7) / 8 * 8);
+    }
+    hdr[8 + n] = start;
+    hdr[0] = n;
+    hdr[1] = start;
+    *total_blocks = start;
+    return 0;
+}
+
+extern "C" int skyemb_gemm_group_launch(const void *blob_dev, int total_blocks, int a_layout, int b_layout, void *stream) {
+    SKY_CHECK_ARG(blob_dev && total_blocks > 0, "skyemb_gemm_group_launch: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    constexpr size_t smem = (size_t)3 * (64 + 64) * BK * 2;
+    const bool a = a_layout == SKYEMB_KC, b = b_layout == SKYEMB_KC;
+#define GROUP_LAUNCH(AK, BKC) hipLaunchKernelGGL((gemm_pipe_group_kernel<64, 64, AK, BKC, 3, 4>), dim3((unsigned)total_blocks), dim3(256), smem, st, (const char *)blob_dev)
+    if (a && b) GROUP_LAUNCH(true, true);
+    else if (a && !b) GROUP_LAUNCH(true, false);
+    else if (!a && !b) GROUP_LAUNCH(false, false);
+    else GROUP_LAUNCH(false, true);
+#undef GROUP_LAUNCH
+    SKY_LAUNCH_CHECK("skyemb_gemm_group_launch");
+    return 0;
 }

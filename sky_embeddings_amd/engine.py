@@ -206,6 +206,7 @@ class MAEEngine:
             Hx = max(Me * int(D * cfg.mlp_ratio), Md * int(Dd * cfg.mlp_ratio))
             w["g"] = torch.empty(Mx * Dx, **f32)
             w["g_lp"] = torch.empty(Mx * Dx, **lp)
+            w["g_lp2"] = torch.empty(Mx * Dx, **lp)   # d(xmid) copy: keeps g_lp (fc2's dy) alive for the grouped wgrad launch
             w["dln"] = torch.empty(Mx * Dx, **lp)
             w["datt"] = torch.empty(Mx * Dx, **lp)
             w["dh"] = torch.empty(Hx, **lp)
@@ -234,6 +235,13 @@ class MAEEngine:
             w["pmv_part"] = torch.empty(B, pv, **f32)
             w["rs_part"] = torch.empty(64, max(D, Dd), **f32)
             w["splitk_ws"] = self._splitk_ws
+            # the four weight-gradient GEMMs of a block as ONE grouped launch (ops.GemmGroup): together they fill the
+            # chip, so none needs split-K slabs or a reduce launch.  bf16 path only; pointers are fixed from here on.
+            w["wgrad_groups"] = {}
+            if self.dtype == torch.bfloat16:
+                for tag, blocks, M_, dim in (("blocks", w["enc"], Me, D), ("decoder_blocks", w["dec"], Md, Dd)):
+                    for i, bufs in enumerate(blocks):
+                        w["wgrad_groups"][f"{tag}.{i}"] = self._make_wgrad_group(f"{tag}.{i}", bufs, M_, dim, w)
         self._ws[key] = w
         return w
 
@@ -346,11 +354,12 @@ class MAEEngine:
         return w["loss"], w["pred"][:, 1:, :], w["mask"]
 
     # ------------------------------------------------------------------ backward
-    def _linear_bwd(self, dy, x_in, wname, bname, M, N, K, w, dx_out=None, dx_act=0, dx_aux=None):
+    def _linear_bwd(self, dy, x_in, wname, bname, M, N, K, w, dx_out=None, dx_act=0, dx_aux=None, wgrad=True):
         """dy [M,N] (lp), x_in [M,K] (lp): dW[N,K] = dy^T x, db = colsum(dy), optional dx = dy W."""
         st = self.store
         # wgrad; the bias gradient (column sums of dy) rides along in the same launch
-        self._wgrad(dy, x_in, N, K, M, st.grad(wname), st.grad(bname), w)
+        if wgrad:
+            self._wgrad(dy, x_in, N, K, M, st.grad(wname), st.grad(bname), w)
         if dx_out is not None:
             self._before_write(dx_out)
             ops.gemm(dy, st.lp(wname), M=M, N=K, K=N, a_layout=KC, b_layout=RC, lda=N, ldb=K, act=dx_act, aux=dx_aux,
@@ -408,6 +417,24 @@ class MAEEngine:
         ops.layernorm_bwd(dy, x, st.param(f"{prefix}.weight"), mean, rstd, g_in, g, g_lp, w["ln_parts"][k], None, None,
                           M, dim, self.code)
 
+    def _wgrad_layers(self, prefix, bufs, M, dim, w):
+        """(dy, x_in, weight, bias, N_out, K_in) of the four linear layers of a block, as backward sees them."""
+        hidden = bufs["hpre"].shape[1]
+        g_lp = w["g_lp"][:M * dim].view(M, dim)
+        g_lp2 = w["g_lp2"][:M * dim].view(M, dim)
+        dh = w["dh"][:M * hidden].view(M, hidden)
+        dqkv = w["dqkv"][:3 * M * dim].view(M, 3 * dim)
+        return [(g_lp, bufs["hact"], f"{prefix}.mlp.fc2", dim, hidden), (dh, bufs["ln2"], f"{prefix}.mlp.fc1", hidden, dim),
+                (g_lp2, bufs["att"], f"{prefix}.attn.proj", dim, dim), (dqkv, bufs["ln1"], f"{prefix}.attn.qkv", 3 * dim, dim)]
+
+    def _make_wgrad_group(self, prefix, bufs, M, dim, w):
+        st = self.store
+        args = [ops.gemm_args(dy, x_in, M=n_out, N=k_in, K=M, a_layout=RC, b_layout=RC, lda=n_out, ldb=k_in,
+                              out_f32=st.grad(f"{name}.weight"), colsum_a=st.grad(f"{name}.bias"))
+                for dy, x_in, name, n_out, k_in in self._wgrad_layers(prefix, bufs, M, dim, w)]
+        grp = ops.GemmGroup(args, self.device)
+        return grp if grp.ok else None
+
     def _block_bwd(self, x_in, bufs, prefix, M, dim, heads, Bsz, N, g, g_lp, w):
         """g / g_lp hold d(block output) on entry and d(block input) on exit."""
         hd = dim // heads
@@ -416,19 +443,24 @@ class MAEEngine:
         dln = w["dln"][:M * dim].view(M, dim)
         datt = w["datt"][:M * dim].view(M, dim)
         dqkv = w["dqkv"][:3 * M * dim].view(M, 3 * dim)
+        group = w["wgrad_groups"].get(prefix) if self._side is None else None
+        single = group is None                      # weight gradients launch by launch (fp32 mode, side-stream mode)
+        g_mid = g_lp if single else w["g_lp2"][:M * dim].view(M, dim)
         # MLP: x_out = xmid + fc2(gelu(fc1(ln2(xmid))))
         self._linear_bwd(g_lp, bufs["hact"], f"{prefix}.mlp.fc2.weight", f"{prefix}.mlp.fc2.bias", M, dim, hidden, w,
-                         dx_out=dh, dx_act=ACT_DGELU, dx_aux=bufs["hpre"])
+                         dx_out=dh, dx_act=ACT_DGELU, dx_aux=bufs["hpre"], wgrad=single)
         self._linear_bwd(dh, bufs["ln2"], f"{prefix}.mlp.fc1.weight", f"{prefix}.mlp.fc1.bias", M, hidden, dim, w,
-                         dx_out=dln)
-        self._ln_bwd(dln, bufs["xmid"], f"{prefix}.norm2", bufs["mean2"], bufs["rstd2"], g, g, g_lp, M, dim, w)
+                         dx_out=dln, wgrad=single)
+        self._ln_bwd(dln, bufs["xmid"], f"{prefix}.norm2", bufs["mean2"], bufs["rstd2"], g, g, g_mid, M, dim, w)
         # attention: xmid = x_in + proj(mha(qkv(ln1(x_in))))
-        self._linear_bwd(g_lp, bufs["att"], f"{prefix}.attn.proj.weight", f"{prefix}.attn.proj.bias", M, dim, dim, w,
-                         dx_out=datt)
+        self._linear_bwd(g_mid, bufs["att"], f"{prefix}.attn.proj.weight", f"{prefix}.attn.proj.bias", M, dim, dim, w,
+                         dx_out=datt, wgrad=single)
         self._before_write(dqkv)
         ops.mha_bwd(bufs["qkv"], datt, dqkv, Bsz, N, heads, hd)
         self._linear_bwd(dqkv, bufs["ln1"], f"{prefix}.attn.qkv.weight", f"{prefix}.attn.qkv.bias", M, 3 * dim, dim, w,
-                         dx_out=dln)
+                         dx_out=dln, wgrad=single)
+        if group is not None:
+            group.launch()      # all four dW / db of the block; must precede norm1's backward, which overwrites g_lp
         self._ln_bwd(dln, x_in, f"{prefix}.norm1", bufs["mean1"], bufs["rstd1"], g, g, g_lp, M, dim, w)
 
     def _bwd_ctx(self):

@@ -34,10 +34,10 @@ def _p(t):
     return t.data_ptr()
 
 
-def gemm(A, B, *, M, N, K, a_layout=KC, b_layout=KC, lda=None, ldb=None, alpha=1.0, bias=None, table=None,
-         tab_row=None, ldt=0, dst_row=None, resid=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, out_f32=None, ldo32=0,
-         out=None, ldo=0, out2=None, ldo2=0, tile=0, colsum_a=None, ws=None, split_k=0):
-    """C[M,N] = alpha * A[M,K] B[N,K]^T with fused epilogue (see include/skyemb.h)."""
+def gemm_args(A, B, *, M, N, K, a_layout=KC, b_layout=KC, lda=None, ldb=None, alpha=1.0, bias=None, table=None,
+              tab_row=None, ldt=0, dst_row=None, resid=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, out_f32=None, ldo32=0,
+              out=None, ldo=0, out2=None, ldo2=0, tile=0, colsum_a=None, ws=None, split_k=0):
+    """skyemb_gemm_args for C[M,N] = alpha * A[M,K] B[N,K]^T with fused epilogue (see include/skyemb.h)."""
     g = GemmArgs()
     g.A, g.B = _p(A), _p(B)
     g.lda = lda if lda is not None else (K if a_layout == KC else M)
@@ -53,7 +53,37 @@ def gemm(A, B, *, M, N, K, a_layout=KC, b_layout=KC, lda=None, ldb=None, alpha=1
     g.tile = tile
     g.colsum_a = _p(colsum_a)
     g.ws, g.ws_bytes, g.split_k = _p(ws), (ws.numel() * ws.element_size() if ws is not None else 0), split_k
+    return g
+
+
+def gemm(A, B, **kw):
+    """C[M,N] = alpha * A[M,K] B[N,K]^T with fused epilogue (see include/skyemb.h)."""
+    g = gemm_args(A, B, **kw)
     check(lib().skyemb_gemm(ctypes.byref(g), _stream()), "skyemb_gemm")
+
+
+class GemmGroup:
+    """Several independent GEMMs of one operand-layout class as ONE launch (skyemb_gemm_group_*).  Built once from
+    gemm_args(...) structs -- the device blob holds the raw pointers, so the operand buffers must stay allocated --
+    and replayed with launch().  `ok` is False when a problem is outside the grouped subset (launch them singly)."""
+
+    def __init__(self, args, device):
+        n = len(args)
+        arr = (GemmArgs * n)(*args)
+        nbytes = lib().skyemb_gemm_group_blob_bytes(n)
+        host = torch.zeros(nbytes, dtype=torch.uint8)
+        total = ctypes.c_int32(0)
+        rc = lib().skyemb_gemm_group_plan(arr, n, host.data_ptr(), nbytes, ctypes.byref(total))
+        self.ok = rc == 0
+        if rc > 0:
+            check(rc, "skyemb_gemm_group_plan")
+        self.total_blocks = total.value
+        self.a_layout, self.b_layout = args[0].a_layout, args[0].b_layout
+        self.blob = host.to(device) if self.ok else None
+
+    def launch(self):
+        check(lib().skyemb_gemm_group_launch(self.blob.data_ptr(), self.total_blocks, self.a_layout, self.b_layout, _stream()),
+              "skyemb_gemm_group_launch")
 
 
 def colsum(X, M, N, out, ldx=None):

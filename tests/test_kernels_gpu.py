@@ -111,6 +111,36 @@ def test_gemm_epilogues(ops, dtype):
     assert float((dg.float().cpu() - refd).abs().max()) < tol * float(refd.abs().max())
 
 
+def test_gemm_group_equals_single_launches(ops):
+    """Four wgrad-shaped problems (different output sizes, shared contraction length) as ONE grouped launch give the
+    same bits as four single launches without split-K; a problem outside the bf16 subset makes the plan refuse."""
+    g = torch.Generator().manual_seed(11)
+    tokens = 320
+    shapes = [(192, 768), (768, 192), (192, 192), (576, 200)]       # (N_out, K_in); 200 -> ragged 64-tile edge
+    args, outs, refs = [], [], []
+    keep = []
+    for n_out, k_in in shapes:
+        dy = dev(torch.randn(tokens, n_out, generator=g), torch.bfloat16)
+        x = dev(torch.randn(tokens, k_in, generator=g), torch.bfloat16)
+        dw, db = torch.full((n_out, k_in), float("nan"), device=DEV), torch.full((n_out,), float("nan"), device=DEV)
+        dw1, db1 = torch.empty(n_out, k_in, device=DEV), torch.empty(n_out, device=DEV)
+        kw = dict(M=n_out, N=k_in, K=tokens, a_layout=ops.RC, b_layout=ops.RC, lda=n_out, ldb=k_in)
+        ops.gemm(dy, x, out_f32=dw1, colsum_a=db1, split_k=1, **kw)
+        args.append(ops.gemm_args(dy, x, out_f32=dw, colsum_a=db, **kw))
+        keep.append((dy, x))
+        outs.append((dw, db))
+        refs.append((dw1, db1))
+    grp = ops.GemmGroup(args, DEV)
+    assert grp.ok and grp.total_blocks % 8 == 0
+    grp.launch()
+    grp.launch()      # replayable
+    for (dw, db), (dw1, db1) in zip(outs, refs):
+        assert torch.equal(dw, dw1) and torch.equal(db, db1)
+    bad = ops.gemm_args(keep[0][0].float(), keep[0][1].float(), M=192, N=768, K=tokens, a_layout=ops.RC, b_layout=ops.RC,
+                        lda=192, ldb=768, out_f32=outs[0][0])
+    assert not ops.GemmGroup([args[1], bad], DEV).ok
+
+
 # ------------------------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(20, 64), (1280, 768), (37, 512), (9, 1280), (5, 192)])
