@@ -43,13 +43,25 @@ class FusedAdamW:
         return None
 
     def step(self):
+        self.begin_step()
+        self.apply_range(0, self.store.n)
+
+    def begin_step(self):
+        """Open optimiser step t; follow with apply_range() calls that together cover [0, n) exactly once (a backward
+        stage's slices can be updated while later stages still compute: see TrainStep)."""
         self.step_count += 1
+
+    def apply_range(self, start, end):
+        """AdamW update of flat elements [start, end) on the current stream (start, end multiples of 8: tensor bounds)."""
         b1, b2 = self.defaults["betas"]
         t = self.step_count
         st = self.store
-        ops.adamw(st.p, st.g, st.m, st.v, st.p_lp, st.n, st.n_decay, self.hyper_device, b1, b2, self.defaults["eps"],
-                  self.param_groups[1]["weight_decay"], grad_scale=self.grad_scale, zero_grad=False, lr=self.lr,
-                  bc1=1.0 - b1 ** t, bc2=1.0 - b2 ** t)
+        n = end - start
+        n_decay = min(max(st.n_decay - start, 0), n)     # layout is [decayed | not decayed]
+        sl = slice(start, end)
+        ops.adamw(st.p[sl], st.g[sl], st.m[sl], st.v[sl], st.p_lp[sl], n, n_decay, self.hyper_device, b1, b2,
+                  self.defaults["eps"], self.param_groups[1]["weight_decay"], grad_scale=self.grad_scale, zero_grad=False,
+                  lr=self.lr, bc1=1.0 - b1 ** t, bc2=1.0 - b2 ** t)
 
     def step_scalars(self, t=None):
         """(lr, 1-b1^t, 1-b2^t) of optimiser step t (default: the next one) for graph-mode callers."""

@@ -171,12 +171,15 @@ def test_staged_backward_equals_monolithic_and_graph_replay():
     imgs = torch.randn(8, 5, 64, 64, generator=g).cuda()
     results = []
     # (staged, graph, weight gradients on the side stream)
-    for staged, graph, overlap in ((False, False, False), (False, False, True), (False, True, True), (True, True, True),
-                                   (True, True, False)):
+    # (staged, graph, weight gradients on the side stream, AdamW of finished stages on the optimiser stream)
+    for staged, graph, overlap, opt_overlap in ((False, False, False, False), (False, False, True, False),
+                                                (False, True, True, False), (True, True, True, True),
+                                                (True, True, False, True), (True, False, False, True),
+                                                (True, True, False, False)):
         eng = MAEEngine(cfg, compute_dtype=torch.bfloat16, seed=1)
         opt = FusedAdamW(eng, lr=1e-3)
         step = TrainStep(eng, opt, CosineLR(opt, 100), 8, use_graph=graph, staged=staged, n_encoder_groups=4,
-                         wgrad_overlap=overlap)
+                         wgrad_overlap=overlap, optimizer_overlap=opt_overlap)
         torch.manual_seed(123)            # same masking noise stream for every schedule
         for _ in range(3):
             loss = step(imgs)
