@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--skip-search", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--skip-feeder", action="store_true")
     ap.add_argument("--bank-rows", type=int, default=1_000_000)
     ap.add_argument("--queries", type=int, default=10_000)
     ap.add_argument("--topk", type=int, default=100)
@@ -158,7 +159,70 @@ def bench_pretrain(args, rank, world, dev):
                loss=float(loss), flops_per_image_executed=executed, flops_per_image_reference=algorithmic, B=B)
     if rank == 0:
         out["gemm_probe"] = gemm_step_probe(B, dtype, dev)
+        out["phases"] = hbm_phases(eng, opt, step, B)
+        if world == 1 and not args.skip_feeder:
+            out["feeder"] = bench_feeder(args, dev, step, B)
     return out, eng
+
+
+def hbm_phases(eng, opt, step, B):
+    """Secondary HBM-bound phases of the step, each timed alone with HIP events: bytes are the algorithmic
+    ones (AdamW: 28 B fp32 state + 2 B bf16 shadow per parameter; patch gather: kept patches in, bf16 rows out; loss:
+    cutouts + predictions in, d pred out)."""
+    from sky_embeddings_amd import ops
+    cfg, st = eng.cfg, eng.store
+    keep = int(cfg.num_patches * 0.25)
+    w = eng._ws[(B, keep, True)]
+    imgs = step.imgs
+    res = {}
+    t = ev_time_ms(opt.step, 10)
+    opt.step_count -= 10                      # probe only: the moments move, the step counter is restored
+    res["adamw"] = dict(ms=t, gbs=st.n * 30 / t / 1e6, bytes=st.n * 30)
+    f = lambda: ops.patch_gather(imgs, st.param("patch_mask_values"), w["ids_keep"], w["patches"], cfg.patch_size, keep,
+                                 cfg.pixel_mean, cfg.pixel_std)
+    t = graph_time_ms(f)
+    nb = B * keep * cfg.patch_dim * (4 + 2)
+    res["patch_gather"] = dict(ms=t, gbs=nb / t / 1e6, bytes=nb)
+    f = lambda: ops.masked_patch_loss(imgs, w["pred"], w["mask"], w["loss"], w["dpred"], None, eng.code, w["loss_ws"],
+                                      cfg.patch_size, 1, cfg.pixel_mean, cfg.pixel_std, cfg.norm_pix_loss, cfg.loss_fn != "mse")
+    t = graph_time_ms(f)
+    nb = imgs.numel() * 4 + w["pred"].numel() * 4 + w["dpred"].numel() * 2
+    res["masked_patch_loss"] = dict(ms=t, gbs=nb / t / 1e6, bytes=nb)
+    return res
+
+
+def bench_feeder(args, dev, step, B):
+    """HDF5 -> HBM feeder (row a1): synthetic cutout file in the reference schema, the batched feeder alone and in the
+    training loop (images/sec including file gather + H2D + clip; page cache warm)."""
+    import tempfile
+    from sky_embeddings_amd import hdf5_lite
+    from sky_embeddings_amd.feeder import CutoutFeeder
+    n = 8192
+    with tempfile.TemporaryDirectory() as d:
+        path = hdf5_lite.make_synthetic_cutouts(os.path.join(d, "cutouts.h5"), n=n, seed=1234)
+        fd = CutoutFeeder(path, B, 64, dev, shuffle=True, seed=0, epochs=1000)
+        it = iter(fd)
+        for _ in range(8):
+            next(it)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(64):
+            next(it)
+        torch.cuda.synchronize(dev)
+        alone = 64 * B / (time.perf_counter() - t0)
+        for _ in range(5):
+            step(next(it)[0])
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(next(it)[0])
+        torch.cuda.synchronize(dev)
+        fed = args.steps * B / (time.perf_counter() - t0)
+        it.close()
+    return dict(file_cutouts=n, feeder_alone_images_per_sec=alone, feeder_alone_gbs=alone * 5 * 64 * 64 * 4 / 1e9,
+                train_images_per_sec_with_feeder=fed,
+                note="mmap'd contiguous HDF5 (page cache) -> native threaded gather -> pinned ring -> one H2D per batch -> "
+                     "device clip/crop, feeding the same TrainStep; `value` itself is measured with the batch resident in HBM")
 
 
 def bench_search(args, rank, world, dev):
@@ -185,7 +249,7 @@ def bench_search(args, rank, world, dev):
     w = w / w.sum()
     pb = PreparedBank(bank, w, idx_offset=lo)
     res = {}
-    for label, Q, iters in (("q_small", 16, 5), ("q_large", args.queries, 2)):
+    for label, Q, iters in (("q1", 1, 5), ("q_small", 16, 5), ("q_large", args.queries, 2)):
         q = queries[:Q]
         cosine_topk(q, pb, k, world_size=world)  # warm-up
         if world > 1:
@@ -308,13 +372,15 @@ def main():
                                   "flops_per_image_executed": executed,
                                   "flops_per_image_reference": pre["flops_per_image_reference"]}},
             "loss": pre["loss"],
+            "phases": pre.get("phases"),
+            "feeder": pre.get("feeder"),
         }
         if search is not None:
             ql, qs = search["q_large"], search["q_small"]
             line["search"] = {
                 "metric": f"cosine top-k queries/sec over {args.bank_rows}x768", "value": ql["queries_per_sec"],
                 "unit": "queries/sec", "k": args.topk, "Q": ql["Q"], "dtype": "f32", "sharding": f"bank rows / {world}",
-                "q_large": ql, "q_small": qs,
+                "q_large": ql, "q_small": qs, "q1": search["q1"],
                 "roofline": {"bound": "hbm", "achieved": qs["kernel_hbm_gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": qs["kernel_hbm_gbs"] / PEAK_HBM_GBS, "traffic": pmc_traffic(args),
                              "algorithmic_bytes": qs["kernel_bytes"],

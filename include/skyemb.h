@@ -191,6 +191,16 @@ int skyemb_adamw(float *p, float *g, float *m, float *v, void *p_lp, int dtype, 
                  float grad_scale, int zero_grad, void *stream);
 int skyemb_cast(const float *src, void *dst, int dtype, int64_t n, void *stream);
 
+/* ------------------------------------------------------------ input feeder -
+ * utils/dataloaders.py:285-328 (H5Dataset.__getitem__): the reference opens the file and reads ONE cutout per python
+ * call.  Here a minibatch of rows is gathered by native threads from the memory-mapped contiguous dataset into a (pinned)
+ * staging buffer -- HOST function, no stream -- copied to the device once, then clipped at pixel_min / pixel_max (NaN
+ * kept) and centre-cropped on the device (utils/dataloaders.py:293-300). */
+int skyemb_gather_rows_host(const void *src, int64_t row_bytes, const int64_t *idx, int64_t n, int64_t src_rows, void *dst,
+                            int nthreads);
+int skyemb_clip_crop(const float *src, float *dst, int64_t n_planes, int Hs, int Ws, int size, float lo, float hi,
+                     int use_lo, int use_hi, void *stream);
+
 /* ------------------------------------------------------ similarity search -
  * utils/similarity.py:98-102: standardise bank rows in place or to `out`:
  * (x - mu) / (sigma + 1e-8). */

@@ -152,7 +152,36 @@ __global__ __launch_bounds__(256) void cast_kernel(const float *__restrict__ src
     }
 }
 
+// feeder tail (utils/dataloaders.py:293-300): clip at pixel_min / pixel_max (NaN compares false: kept) and centre-crop a
+// staged minibatch [n_planes, Hs, Ws] -> [n_planes, size, size]; one thread per output pixel quad when size % 4 == 0
+__global__ __launch_bounds__(256) void clip_crop_kernel(const float *__restrict__ src, float *__restrict__ dst, int64_t n_out,
+                                                        int Hs, int Ws, int size, int top, int left, float lo, float hi,
+                                                        int use_lo, int use_hi) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_out; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % size);
+        const int64_t t = i / size;
+        const int y = (int)(t % size);
+        const int64_t plane = t / size;
+        float v = src[(plane * Hs + top + y) * Ws + left + x];
+        if (use_lo && v < lo) v = lo;
+        if (use_hi && v > hi) v = hi;
+        dst[i] = v;
+    }
+}
+
 }  // namespace
+
+extern "C" int skyemb_clip_crop(const float *src, float *dst, int64_t n_planes, int Hs, int Ws, int size, float lo, float hi,
+                                int use_lo, int use_hi, void *stream) {
+    SKY_CHECK_ARG(src && dst && n_planes > 0 && size > 0 && Hs >= size && Ws >= size, "skyemb_clip_crop: bad shape");
+    const int64_t n_out = n_planes * size * size;
+    int64_t blocks = ceil_div64(n_out, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(clip_crop_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, n_out, Hs, Ws, size,
+                       (Hs - size) / 2, (Ws - size) / 2, lo, hi, use_lo, use_hi);
+    SKY_LAUNCH_CHECK("skyemb_clip_crop");
+    return 0;
+}
 
 extern "C" int skyemb_random_mask_from_noise(const float *noise, int B, int L, int keep, int64_t *ids_restore,
                                              float *mask, int32_t *ids_keep, int32_t *dec_dst, int32_t *dec_tab,

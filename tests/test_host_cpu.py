@@ -205,3 +205,21 @@ def test_backward_stage_ranges_tile_the_gradient_buffer():
         hi, lo = enc_groups[0]
         s, e = ranges[1][0]
         assert s == st.offsets[f"blocks.{lo}.attn.qkv.weight"] and e == st.offsets["decoder_embed.weight"]
+
+
+def test_native_host_gather_rows():
+    """skyemb_gather_rows_host (the feeder's minibatch gather; a HOST function of the C ABI) against numpy indexing."""
+    import ctypes
+    import numpy as np
+    from sky_embeddings_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(0)
+    src = rng.standard_normal((97, 5, 8, 8), dtype=np.float32)
+    idx = rng.integers(0, 97, 40).astype(np.int64)
+    for threads in (1, 3, 64):
+        dst = np.full((40, 5, 8, 8), np.nan, np.float32)
+        assert L.skyemb_gather_rows_host(src.ctypes.data, 5 * 8 * 8 * 4, idx.ctypes.data, 40, 97, dst.ctypes.data, threads) == 0
+        assert np.array_equal(dst, src[idx])
+    bad = np.array([0, 97], dtype=np.int64)
+    assert L.skyemb_gather_rows_host(src.ctypes.data, 1280, bad.ctypes.data, 2, 97, dst.ctypes.data, 2) != 0
+    assert b"out of range" in L.skyemb_last_error()
