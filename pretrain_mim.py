@@ -84,6 +84,16 @@ def main(args):
             n_train = len(f['cutouts'])
         sampler = sdist.DistributedIndexSampler(n_train, rank, world, shuffle=True, seed=1234)
     dataloader_train = build_h5_dataloader(train_file, shuffle=True, sampler=sampler, **common)
+    # MAE mode on a contiguous HDF5 file takes the fast path: the batched HDF5->HBM feeder (no per-item python) feeding
+    # the HIP-graph TrainStep (forward + staged backward, gradient all-reduce overlapped, fused AdamW, cosine LR).  The
+    # per-item loader above still serves SimMIM mask generation, ragged final batches and validation.
+    fast = max_mask_ratio is None and os.environ.get("SKYEMB_FAST_TRAIN", "1") != "0"
+    train_step = None
+    if fast:
+        from sky_embeddings_amd.feeder import CutoutFeeder
+        from sky_embeddings_amd.train_step import TrainStep
+        train_step = TrainStep(model.module.engine, optimizer, lr_scheduler, common['batch_size'], mask_ratio=mask_ratio,
+                               world_size=world)
     dataloader_val = build_h5_dataloader(os.path.join(data_dir, config['DATA']['val_data_file']), shuffle=True, **common)
     if rank == 0:
         print('The training set consists of %i cutouts.' % (len(dataloader_train.dataset)))
@@ -101,17 +111,25 @@ def main(args):
         if sampler is not None:
             sampler.set_epoch(epoch)
         epoch += 1
-        for samples, masks, ra_decs in dataloader_train:
-            samples = samples.to(device, non_blocking=True)
-            # forward + backward, then the RCCL gradient all-reduce, then AdamW (run_iter's order)
-            model.train(True)
-            loss, _, _ = model(samples, ra_dec=ra_decs, mask_ratio=mask_ratio, mask=masks)
-            loss.backward()
-            sdist.allreduce_flat_gradients(model.module.engine.store.g, world)
-            optimizer.step()
-            optimizer.zero_grad(set_to_none=True)
-            lr_scheduler.step()
-            losses_cp['train_loss'].append(loss.detach())
+        loader = dataloader_train
+        if fast:
+            loader = CutoutFeeder(train_file, common['batch_size'], common['img_size'], device, shuffle=True, seed=1234 + epoch,
+                                  rank=rank, world_size=world, drop_last=world > 1)
+        for samples, masks, ra_decs in loader:
+            if fast and samples.shape[0] == common['batch_size']:
+                loss = train_step(samples)
+                losses_cp['train_loss'].append(loss.detach().clone())
+            else:
+                samples = samples.to(device, non_blocking=True)
+                # forward + backward, then the RCCL gradient all-reduce, then AdamW (run_iter's order)
+                model.train(True)
+                loss, _, _ = model(samples, ra_dec=ra_decs, mask_ratio=mask_ratio, mask=masks)
+                loss.backward()
+                sdist.allreduce_flat_gradients(model.module.engine.store.g, world)
+                optimizer.step()
+                optimizer.zero_grad(set_to_none=True)
+                lr_scheduler.step()
+                losses_cp['train_loss'].append(loss.detach())
             if cur_iter % args.verbose_iters == 0:
                 for i, (vs, vm, vr) in enumerate(dataloader_val):
                     model, optimizer, lr_scheduler, losses_cp = run_iter(model, vs.to(device, non_blocking=True), vr, vm,
