@@ -39,7 +39,7 @@ class MAEConfig:
     pixel_mean: float = 0.0
     pixel_std: float = 1.0
     simmim: bool = False
-    ra_dec: bool = False          # LocationEncoder token: not restated yet
+    ra_dec: bool = False          # RA/Dec token from the LocationEncoder (mim_vit.py:209-216, location_encoder.py)
     ln_eps: float = 1e-6          # partial(nn.LayerNorm, eps=1e-6), mim_vit.py:565
 
     @property
@@ -135,6 +135,11 @@ def state_layout(cfg: MAEConfig):
     else:
         out += [("mask_token", (1, 1, Dd)), ("decoder_pos_embed", (1, L + E, Dd))]
     out += [("patch_embed.proj.weight", (D, C, p, p)), ("patch_embed.proj.bias", (D,))]
+    if cfg.ra_dec:   # LocationEncoder("siren", legendre_polys=5, dim_hidden=8, num_layers=1, num_classes=D), mim_vit.py:211-215
+        out += [("ra_dec_embed.neural_network.layers.0.weight", (SIREN_HIDDEN, SH_FEATURES)),
+                ("ra_dec_embed.neural_network.layers.0.bias", (SIREN_HIDDEN,)),
+                ("ra_dec_embed.neural_network.last_layer.weight", (D, SIREN_HIDDEN)),
+                ("ra_dec_embed.neural_network.last_layer.bias", (D,))]
     for i in range(cfg.depth):
         out += _block_names(f"blocks.{i}", D, int(D * cfg.mlp_ratio))
     out += [("norm.weight", (D,)), ("norm.bias", (D,))]
@@ -167,6 +172,12 @@ def init_state(cfg: MAEConfig, seed: int = 0) -> "OrderedDict[str, torch.Tensor]
             t = torch.from_numpy(sincos_pos_embed(shape[-1], cfg.grid, True, cfg.ra_dec)).float().unsqueeze(0)
         elif name in ("cls_token", "mask_token"):
             t = torch.randn(shape, generator=gen) * 0.02
+        elif name.startswith("ra_dec_embed."):
+            # Siren.init_ (location_encoder.py:41-49): first layer U(-1/dim_in, 1/dim_in); last layer
+            # U(-sqrt(6/dim_in)/w0, +) with w0 = 1; biases drawn from the same range
+            dim_in = SH_FEATURES if ".layers.0." in name else SIREN_HIDDEN
+            w_std = (1.0 / dim_in) if ".layers.0." in name else math.sqrt(6.0 / dim_in)
+            t = (torch.rand(shape, generator=gen) * 2 - 1) * w_std
         elif name == "patch_mask_values":
             t = torch.zeros(shape)
         elif name.endswith("norm1.weight") or name.endswith("norm2.weight") or name.endswith("norm.weight"):
@@ -189,10 +200,72 @@ def weight_decay_split(cfg: MAEConfig):
     not optimised."""
     decay, no_decay = [], []
     for name, shape in state_layout(cfg):
-        if name in FROZEN:
+        if name in FROZEN or (cfg.simmim and name == "mask_token"):
+            # SimMIM never uses its (1,1,1) mask_token (mim_vit.py:263): its .grad stays None and torch's AdamW skips
+            # it entirely (no update, no weight decay) -- pinned by the simmim goldens' state_after3/mask_token
             continue
         (no_decay if (len(shape) <= 1 or name.endswith(".bias")) else decay).append(name)
     return decay, no_decay
+
+
+# --------------------------------------------------------------------------
+# RA/Dec token: spherical harmonics (closed form) -> one Siren layer -> linear
+# (utils/location_encoder.py:138-243; mim_vit.py:209-216 builds it with legendre_polys=5, dim_hidden=8, num_layers=1)
+# --------------------------------------------------------------------------
+SH_L = 5
+SH_FEATURES = SH_L * SH_L
+SIREN_HIDDEN = 8
+SIREN_W0_FIRST = 30.0
+
+
+def _assoc_legendre(l, m, x):  # location_encoder.py:138-155
+    pmm = torch.ones_like(x)
+    if m > 0:
+        somx2 = torch.sqrt((1 - x) * (1 + x))
+        fact = 1.0
+        for _ in range(1, m + 1):
+            pmm = pmm * (-fact) * somx2
+            fact += 2.0
+    if l == m:
+        return pmm
+    pmmp1 = x * (2.0 * m + 1.0) * pmm
+    if l == m + 1:
+        return pmmp1
+    pll = torch.zeros_like(x)
+    for ll in range(m + 2, l + 1):
+        pll = ((2.0 * ll - 1.0) * x * pmmp1 - (ll + m - 1.0) * pmm) / (ll - m)
+        pmm, pmmp1 = pmmp1, pll
+    return pll
+
+
+def _sh_norm(l, m):  # location_encoder.py:157-159
+    return math.sqrt((2.0 * l + 1.0) * math.factorial(l - m) / (4 * math.pi * math.factorial(l + m)))
+
+
+def spherical_harmonics(ra_dec):
+    """location_encoder.py:161-206: phi = deg2rad(ra), theta = deg2rad(dec + 90); features ordered l = 0..4, m = -l..l."""
+    phi, theta = torch.deg2rad(ra_dec[:, 0]), torch.deg2rad(ra_dec[:, 1] + 90)
+    ct = torch.cos(theta)
+    Y = []
+    for l in range(SH_L):
+        for m in range(-l, l + 1):
+            if m == 0:
+                y = _sh_norm(l, 0) * _assoc_legendre(l, 0, ct)
+            elif m > 0:
+                y = math.sqrt(2.0) * _sh_norm(l, m) * torch.cos(m * phi) * _assoc_legendre(l, m, ct)
+            else:
+                y = math.sqrt(2.0) * _sh_norm(l, -m) * torch.sin(-m * phi) * _assoc_legendre(l, -m, ct)
+            Y.append(y)
+    return torch.stack(Y, dim=-1)
+
+
+def location_encoder(st, ra_dec):
+    """SirenNet(dim_in=25, dim_hidden=8, num_layers=1, dim_out=D): sin(30 * (W0 sh + b0)) then a plain linear
+    (the last Siren layer's activation is Identity, location_encoder.py:84-85)."""
+    sh = spherical_harmonics(ra_dec)
+    h = torch.sin(SIREN_W0_FIRST * F.linear(sh, st["ra_dec_embed.neural_network.layers.0.weight"],
+                                            st["ra_dec_embed.neural_network.layers.0.bias"]))
+    return F.linear(h, st["ra_dec_embed.neural_network.last_layer.weight"], st["ra_dec_embed.neural_network.last_layer.bias"])
 
 
 # --------------------------------------------------------------------------
@@ -268,7 +341,7 @@ def block(x, st, prefix, num_heads, eps):
     return x
 
 
-def forward_features(st, x, cfg: MAEConfig, mask_ratio=0.0, noise=None, mask=None, reshape_out=True):
+def forward_features(st, x, cfg: MAEConfig, mask_ratio=0.0, noise=None, mask=None, reshape_out=True, ra_dec=None):
     """mim_vit.py:381-438."""
     B = x.shape[0]
     E = cfg.num_extra_tokens
@@ -287,7 +360,8 @@ def forward_features(st, x, cfg: MAEConfig, mask_ratio=0.0, noise=None, mask=Non
             noise = torch.rand(B, x.shape[1])
         x, mask, ids_restore = random_masking_from_noise(x, mask_ratio, noise)
     if cfg.ra_dec:
-        raise NotImplementedError("ra_dec token (LocationEncoder) is a 'next' row, SURVEY §8f")
+        tok = location_encoder(st, ra_dec) + st["pos_embed"][:, 1]          # mim_vit.py:410-414
+        x = torch.cat((tok.unsqueeze(1), x), dim=1)
     cls = (st["cls_token"] + st["pos_embed"][:, :1, :]).expand(B, -1, -1)
     x = torch.cat((cls, x), dim=1)
     for i in range(cfg.depth):
@@ -363,20 +437,20 @@ def forward_loss(imgs, pred, mask, cfg: MAEConfig, nan_safe: bool = False):
     return (loss * mask).sum() / (avg_scale + 1e-5)
 
 
-def forward(st, imgs, cfg: MAEConfig, mask_ratio=0.75, noise=None, mask=None, nan_safe=False):
+def forward(st, imgs, cfg: MAEConfig, mask_ratio=0.75, noise=None, mask=None, nan_safe=False, ra_dec=None):
     """mim_vit.py:552-559 -> (loss, pred, mask, ids_restore, latent)."""
-    latent, mask, ids_restore = forward_features(st, imgs, cfg, mask_ratio=mask_ratio, noise=noise, mask=mask)
+    latent, mask, ids_restore = forward_features(st, imgs, cfg, mask_ratio=mask_ratio, noise=noise, mask=mask, ra_dec=ra_dec)
     pred = forward_decoder(st, latent, ids_restore, cfg)
     loss = forward_loss(norm_inputs(imgs, cfg).detach(), pred, mask, cfg, nan_safe=nan_safe)
     return loss, pred, mask, ids_restore, latent
 
 
-def loss_and_grads(st, imgs, cfg, mask_ratio=0.75, noise=None, mask=None, nan_safe=False):
+def loss_and_grads(st, imgs, cfg, mask_ratio=0.75, noise=None, mask=None, nan_safe=False, ra_dec=None):
     """run_iter's ``loss.backward()`` (utils/pretrain_fns.py:26-34) via torch autograd on CPU."""
     leaf = OrderedDict()
     for k, v in st.items():
         leaf[k] = v.detach().clone().requires_grad_(k not in FROZEN)
-    loss, pred, mask_out, ids_restore, latent = forward(leaf, imgs, cfg, mask_ratio, noise, mask, nan_safe)
+    loss, pred, mask_out, ids_restore, latent = forward(leaf, imgs, cfg, mask_ratio, noise, mask, nan_safe, ra_dec)
     loss.backward()
     grads = OrderedDict((k, (v.grad if v.grad is not None else torch.zeros_like(v)))
                         for k, v in leaf.items() if k not in FROZEN)
@@ -419,8 +493,9 @@ class Trainer:
     def lr(self):
         return cosine_lr(self.t, self.init_lr, self.total, self.flf)
 
-    def step(self, imgs, mask_ratio=0.75, noise=None, mask=None):
-        loss, pred, mask_o, ids, latent, grads = loss_and_grads(self.st, imgs, self.cfg, mask_ratio, noise, mask)
+    def step(self, imgs, mask_ratio=0.75, noise=None, mask=None, ra_dec=None):
+        loss, pred, mask_o, ids, latent, grads = loss_and_grads(self.st, imgs, self.cfg, mask_ratio, noise, mask,
+                                                                 ra_dec=ra_dec)
         lr = self.lr()
         self.t += 1
         for k in self.decay:

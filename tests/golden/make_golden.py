@@ -202,6 +202,70 @@ def mae_case(mim_vit, pgwd, name, *, img, patch, C=5, D=64, depth=2, heads=4, Dd
     print("wrote", name, "loss", float(out["loss"]))
 
 
+def simmim_case(mim_vit, pgwd, name, *, img=64, patch=8, C=5, D=64, depth=2, heads=4, norm_pix=True, loss_fn="L1",
+                nan=False, ra_dec=False, B=3, steps=0, seed=0, pixel_mean=0.1, pixel_std=1.3):
+    """SimMIM mode (mim_vit.py:244-264, 394-399, 431-436, 469, 480-493): per-channel pixel masks, encoder over all tokens,
+    Conv1x1 + PixelShuffle head.  Geometry has img == patch**2 so that the reference's ``tile_size`` upsampling equals
+    the patch size (its head is only shape-valid there)."""
+    assert img == patch * patch
+    torch.manual_seed(seed)
+    model = mim_vit.MaskedAutoencoderViT(img_size=img, patch_size=patch, in_chans=C, embed_dim=D, depth=depth,
+                                         num_heads=heads, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                                         norm_pix_loss=norm_pix, simmim=True, loss_fn=loss_fn, pixel_mean=pixel_mean,
+                                         pixel_std=pixel_std, ra_dec=ra_dec)
+    g = torch.Generator().manual_seed(seed + 100)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if (n.endswith(".bias") or "norm" in n) and "ra_dec_embed" not in n:
+                p.add_(torch.randn(p.shape, generator=g) * 0.05)
+        model.patch_mask_values.copy_(torch.randn(model.patch_mask_values.shape, generator=g) * 0.5)
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(B, C, img, img, generator=g).clamp_(min=-3.0)
+    if nan:
+        x[1, 2] = float("nan")
+        x[2, 0, 3:9, 5:20] = float("nan")
+        x[0, 4, ::7, ::5] = float("nan")
+    # per-channel patch-granular random masks (MaskGenerator semantics, dataloaders.py:197-219), seeded here
+    grid = img // patch
+    m = (torch.rand(B, C, grid, grid, generator=g) < 0.55).float()
+    mask = m.repeat_interleave(patch, dim=2).repeat_interleave(patch, dim=3).contiguous()
+    radec = torch.stack([torch.rand(B, generator=g) * 360.0, torch.rand(B, generator=g) * 180.0 - 90.0], dim=1) if ra_dec else None
+    out = {"imgs": x.numpy().copy(), "pixel_mask": mask.numpy().copy(),
+           "cfg": np.array([img, patch, C, D, depth, heads, int(norm_pix), int(ra_dec)], dtype=np.int64),
+           "loss_fn": np.array(loss_fn), "pixel_mean": np.float64(pixel_mean), "pixel_std": np.float64(pixel_std)}
+    if ra_dec:
+        out["ra_dec"] = radec.numpy().copy()
+    out.update({"state/" + k: v for k, v in sd_np(model.state_dict()).items()})
+    model.train(True)
+    loss, pred, mask_out = model(x, ra_dec=radec, mask=mask)
+    latent, _, _ = model.forward_features(x, ra_dec=radec, mask=mask, reshape_out=False)
+    out.update(loss=loss.detach().numpy().copy(), pred=pred.detach().numpy().copy(), latent=latent.detach().numpy().copy())
+    if ra_dec:
+        out["ra_dec_token"] = model.ra_dec_embed(radec).detach().numpy().copy()
+        out["sh_features"] = model.ra_dec_embed.positional_encoder(radec).detach().numpy().copy()
+    loss.backward()
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            out["grad/" + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+    if steps:
+        model.zero_grad(set_to_none=True)
+        init_lr, wd, total, flf = 1e-3, 0.05, 10, 1e7
+        opt = torch.optim.AdamW(pgwd(model, wd), lr=init_lr, betas=(0.9, 0.95))
+        sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, total, eta_min=init_lr / flf)
+        losses = []
+        for it in range(steps):
+            loss, _, _ = model(x, ra_dec=radec, mask=mask)
+            loss.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            sched.step()
+            losses.append(float(loss))
+        out.update({f"state_after{steps}/" + k: v for k, v in sd_np(model.state_dict()).items() if k != "pos_embed"})
+        out.update(step_losses=np.array(losses), opt_hparams=np.array([init_lr, wd, total, flf]))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name, "loss", float(out["loss"]))
+
+
 def unit_pieces(mim_vit, pos_embed):
     out = {}
     for D in (64, 512, 768, 1024):
@@ -278,10 +342,14 @@ def similarity_cases(sim):
 
 def main():
     pgwd = install_standins()
+    # this repo ships a drop-in ``utils`` package of the same name: keep it off the path so that the REFERENCE is imported
+    repo = os.path.dirname(os.path.dirname(OUT))
+    sys.path[:] = [p for p in sys.path if os.path.abspath(p or os.getcwd()) != repo]
     sys.path.insert(0, REF)
     sys.path.insert(0, os.path.join(REF, "utils"))
     import importlib
     mim_vit = importlib.import_module("utils.mim_vit")
+    assert mim_vit.__file__.startswith(REF), mim_vit.__file__
     sim = importlib.import_module("utils.similarity")
     pos_embed = importlib.import_module("utils.pos_embed")
     torch.set_num_threads(4)
@@ -297,6 +365,11 @@ def main():
     mae_case(mim_vit, pgwd, "mae_tiny_D_l1", img=32, patch=8, norm_pix=True, loss_fn="L1", nan=True, seed=5)
     # E: reference's usual patch size 8 on 64x64 (L=64, 17 kept) with mask_ratio 0.6
     mae_case(mim_vit, pgwd, "mae_tiny_E_p8", img=64, patch=8, D=32, Dd=16, heads=2, dheads=2, mask_ratio=0.6, seed=6)
+    # F-H: SimMIM mode (64/8 geometry): L1 + norm-pix with NaNs (the shipped configs' loss), plain MSE, RA/Dec token
+    simmim_case(mim_vit, pgwd, "simmim_tiny_F_l1_nan", norm_pix=True, loss_fn="L1", nan=True, seed=7, steps=3)
+    simmim_case(mim_vit, pgwd, "simmim_tiny_G_mse", norm_pix=False, loss_fn="mse", seed=8)
+    simmim_case(mim_vit, pgwd, "simmim_tiny_H_radec", norm_pix=True, loss_fn="L1", nan=True, ra_dec=True, D=32, heads=2,
+                seed=9, steps=3)
 
 
 if __name__ == "__main__":

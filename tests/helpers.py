@@ -27,3 +27,17 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def load_simmim_case(name):
+    """SimMIM-mode goldens (tests/golden/make_golden.py simmim_case): -> (npz, cfg, state, imgs, pixel_mask, ra_dec|None)."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    img, patch, C, D, depth, heads, norm_pix, rd = [int(v) for v in z["cfg"]]
+    cfg = mo.config_for("simmim", img_size=img, patch_size=patch, in_chans=C, embed_dim=D, depth=depth, num_heads=heads,
+                        norm_pix_loss=bool(norm_pix), loss_fn=str(z["loss_fn"]), pixel_mean=float(z["pixel_mean"]),
+                        pixel_std=float(z["pixel_std"]), ra_dec=bool(rd))
+    state = OrderedDict()
+    for name_, _shape in mo.state_layout(cfg):
+        state[name_] = torch.from_numpy(z["state/" + name_].copy())
+    ra_dec = torch.from_numpy(z["ra_dec"].copy()) if rd else None
+    return z, cfg, state, torch.from_numpy(z["imgs"].copy()), torch.from_numpy(z["pixel_mask"].copy()), ra_dec

@@ -5,7 +5,7 @@ import torch
 
 from oracle import mae_oracle as mo
 from oracle import similarity_oracle as so
-from tests.helpers import GOLDEN, load_case, rel_err
+from tests.helpers import GOLDEN, load_case, load_simmim_case, rel_err
 
 CASES = ["mae_tiny_A", "mae_tiny_B_nan", "mae_tiny_C_nonorm", "mae_tiny_D_l1", "mae_tiny_E_p8"]
 
@@ -49,6 +49,40 @@ def test_forward_backward_matches_reference(name):
     lat, _, ids0 = mo.forward_features(st, imgs, cfg, 0.0, noise, reshape_out=False)
     assert np.array_equal(ids0.numpy(), z["ids_restore_full"])
     assert rel_err(lat.numpy(), z["latent_full"]) < 2e-6
+
+
+@pytest.mark.parametrize("name", ["simmim_tiny_F_l1_nan", "simmim_tiny_G_mse", "simmim_tiny_H_radec"])
+def test_simmim_mode_matches_reference(name):
+    """SimMIM mode (per-channel pixel masks, all tokens encoded, Conv1x1 + PixelShuffle head, pixel loss) and the
+    RA/Dec token (spherical harmonics -> Siren -> linear), forward / backward / three AdamW steps."""
+    z, cfg, st, imgs, pmask, ra_dec = load_simmim_case(name)
+    assert [k[len("state/"):] for k in z.files if k.startswith("state/")] == [n for n, _ in mo.state_layout(cfg)]
+    loss, pred, _, _, latent, grads = mo.loss_and_grads(st, imgs, cfg, mask=pmask, ra_dec=ra_dec)
+    assert abs(float(loss) - float(z["loss"])) <= 2e-6 * abs(float(z["loss"]))
+    assert rel_err(pred.numpy(), z["pred"]) < 2e-6
+    lat, _, _ = mo.forward_features(st, imgs, cfg, mask=pmask, ra_dec=ra_dec, reshape_out=False)
+    assert rel_err(lat.numpy(), z["latent"]) < 2e-6
+    for k, g in grads.items():
+        ref = z["grad/" + k]
+        assert np.abs(g.numpy() - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1e-8) + 1e-9, k
+    if ra_dec is not None:
+        assert rel_err(mo.spherical_harmonics(ra_dec).numpy(), z["sh_features"]) < 1e-6
+        assert rel_err(mo.location_encoder(st, ra_dec).numpy(), z["ra_dec_token"]) < 1e-6
+    # nan_safe (what the HIP path implements) == the reference here: SimMIM zeroes NaN targets through its mask
+    loss2, _, _, _, _, g2 = mo.loss_and_grads(st, imgs, cfg, mask=pmask, ra_dec=ra_dec, nan_safe=True)
+    assert float(loss2) == float(loss)
+    for k in grads:
+        assert np.abs(g2[k].numpy() - z["grad/" + k]).max() <= 2e-5 * max(np.abs(z["grad/" + k]).max(), 1e-8) + 1e-9, k
+    if "step_losses" in z.files:
+        init_lr, wd, total, flf = [float(v) for v in z["opt_hparams"]]
+        tr = mo.Trainer(cfg, st, init_lr=init_lr, weight_decay=wd, total_iters=int(total), final_lr_factor=flf)
+        for it in range(3):
+            l, *_ = tr.step(imgs, mask=pmask, ra_dec=ra_dec)
+            assert abs(float(l) - float(z["step_losses"][it])) <= 1e-5 * abs(float(z["step_losses"][it]))
+        for k in tr.decay + tr.no_decay:
+            ref = z[f"state_after3/{k}"]
+            assert np.abs(st[k].numpy() - ref).max() <= 3e-6 * max(np.abs(ref).max(), 1e-3) + 5e-3 * init_lr, k
+        assert np.array_equal(st["mask_token"].numpy(), z["state_after3/mask_token"])   # never touched by the optimiser
 
 
 def test_adamw_cosine_steps_match_reference():
