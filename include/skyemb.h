@@ -119,6 +119,24 @@ int skyemb_random_mask_from_noise(const float *noise, int B, int L, int keep, in
 int skyemb_patch_gather(const float *imgs, const float *pmv, const int32_t *ids_keep, void *out, int dtype, int B,
                         int C, int H, int W, int p, int keep, float pixel_mean, float pixel_std, void *stream);
 
+/* SimMIM mode (utils/mim_vit.py:394-399): same with  x = x * (1 - mask) + pmv * mask  after the NaN fill;
+ * pixel_mask fp32 [B,C,H,W], 1 = hidden.  The matching patch_mask_values gradient weights drows by
+ * d x / d pmv = isnan(pixel) ? 1 : pixel_mask. */
+int skyemb_patch_gather_blend(const float *imgs, const float *pmv, const int32_t *ids_keep, const float *pixel_mask, void *out,
+                              int dtype, int B, int C, int H, int W, int p, int keep, float pixel_mean, float pixel_std,
+                              void *stream);
+int skyemb_patch_gather_bwd_pmv_blend(const float *imgs, const int32_t *ids_keep, const float *pixel_mask, const float *drows,
+                                      float *partial, float *dpmv, int B, int C, int H, int W, int p, int keep, void *stream);
+
+/* RA/Dec token (utils/mim_vit.py:209-216, 410-414; utils/location_encoder.py:138-243): real spherical harmonics
+ * (l < 5, 25 features) -> sin(30 (W0 sh + b0)) [8] -> W1 h + b1 (+ pos_row) written to x[b * row_stride + d], d < D.
+ * sh [B,25] and z [B,8] (pre-sine) are saved for the backward, which takes g = d loss / d token rows (same stride) and
+ * returns the four parameter gradients (dz_ws: fp32 [B,8] scratch).  Batch reductions run in a fixed order. */
+int skyemb_radec_token_fwd(const float *ra_dec, const float *W0, const float *b0, const float *W1, const float *b1,
+                           const float *pos_row, float *x, int64_t row_stride, int B, int D, float *sh, float *z, void *stream);
+int skyemb_radec_token_bwd(const float *g, int64_t row_stride, const float *W1, const float *sh, const float *z, float *dz_ws,
+                           float *dW0, float *db0, float *dW1, float *db1, int B, int D, void *stream);
+
 /* gradient of patch_mask_values: dpmv[c,py,px] = sum over gathered NaN pixels of drows (fp32
  * [B*keep, C*p*p]); deterministic two-stage reduction, `partial` is fp32 [B, C*p*p]. */
 int skyemb_patch_gather_bwd_pmv(const float *imgs, const int32_t *ids_keep, const float *drows, float *partial,
@@ -177,6 +195,15 @@ int skyemb_rowsum_select(const float *src, int64_t ld, const float *sel, int row
  * `ws` fp32 workspace of 4*B*L + 4 floats. */
 int skyemb_masked_patch_loss(const float *imgs, const float *pred, const float *mask, float *loss, void *dpred,
                              float *dpred32, int dtype, float *ws, int B, int C, int H, int W, int p, int extra,
+                             float pixel_mean, float pixel_std, int norm_pix, int loss_l1, void *stream);
+
+/* SimMIM mode (utils/mim_vit.py:469, 480-493, 497-521): pixel-wise loss on the head GEMM's token rows
+ * pred_tok fp32 [B*(L+extra), C*p*p] (column c*p*p + py*p + px == PixelShuffle(p) of the Conv1x1 output) with
+ * weights w = pixel_mask where the target is not NaN:  loss = sum(w*l) / (sum(w) + 1e-5), optional per-patch
+ * normalisation of the target.  Outputs: loss, dpred_tok (dtype, same layout; extra rows zero; may be NULL),
+ * pred_img fp32 [B,C,H,W] (the reference's `pred`; may be NULL).  ws: 4*B*L + 4 floats. */
+int skyemb_simmim_pixel_loss(const float *imgs, const float *pred_tok, const float *pixel_mask, float *loss, void *dpred_tok,
+                             int dtype, float *pred_img, float *ws, int B, int C, int H, int W, int p, int extra,
                              float pixel_mean, float pixel_std, int norm_pix, int loss_l1, void *stream);
 
 /* ----------------------------------------------------------- optimiser ----

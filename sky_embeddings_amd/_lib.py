@@ -60,6 +60,12 @@ PROTOTYPES = {
     "skyemb_patch_gather_bwd_pmv": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                             c_vp]),
     "skyemb_layernorm_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp]),
+    "skyemb_patch_gather_blend": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp]),
+    "skyemb_patch_gather_bwd_pmv_blend": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "skyemb_radec_token_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "skyemb_radec_token_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "skyemb_simmim_pixel_loss": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                         c_f32, c_f32, c_i32, c_i32, c_vp]),
     "skyemb_gather_rows_host": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i32]),
     "skyemb_clip_crop": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_f32, c_i32, c_i32, c_vp]),
     "skyemb_layernorm_bwd_blocks": (c_i32, [c_i32]),

@@ -43,10 +43,12 @@ __global__ __launch_bounds__(256) void mask_kernel(const float *__restrict__ noi
 
 // ---- utils/mim_vit.py:385-392 + im2row for Conv2d(k=s=p) --------------------------------------
 // grid = B*keep rows; each thread moves 4 consecutive px of one (c, py)
+// pmask (SimMIM, utils/mim_vit.py:394-399; NULL in MAE mode): x = x * (1 - mask) + pmv * mask after the NaN fill
 template <typename T>
 __global__ __launch_bounds__(256) void patch_gather_kernel(const float *__restrict__ imgs, const float *__restrict__ pmv,
                                                            const int32_t *__restrict__ ids_keep, T *__restrict__ out,
-                                                           int C, int H, int W, int p, int keep, float mean, float stdv) {
+                                                           int C, int H, int W, int p, int keep, float mean, float stdv,
+                                                           const float *__restrict__ pmask) {
     const int row = blockIdx.x;
     const int b = row / keep;
     const int l = ids_keep ? ids_keep[row] : (row - b * keep);
@@ -63,14 +65,21 @@ __global__ __launch_bounds__(256) void patch_gather_kernel(const float *__restri
         o.y = x.y != x.y ? m.y : (x.y - mean) / stdv;
         o.z = x.z != x.z ? m.z : (x.z - mean) / stdv;
         o.w = x.w != x.w ? m.w : (x.w - mean) / stdv;
+        if (pmask) {
+            const float4 k = *(const float4 *)(pmask + (((int64_t)b * C + c) * H + y0 + py) * W + x0 + 4 * px4);
+            o.x = o.x * (1.0f - k.x) + m.x * k.x;
+            o.y = o.y * (1.0f - k.y) + m.y * k.y;
+            o.z = o.z * (1.0f - k.z) + m.z * k.z;
+            o.w = o.w * (1.0f - k.w) + m.w * k.w;
+        }
         store4<T>(out + (int64_t)row * (C * p * p) + 4 * e, o.x, o.y, o.z, o.w);
     }
 }
 
-// partial[b][e] = sum_j isnan(pixel) ? drows[b*keep+j][e] : 0
+// partial[b][e] = sum_j w * drows[b*keep+j][e],  w = d(embedded pixel)/d(pmv) = isnan(pixel) ? 1 : pixel_mask (0 in MAE mode)
 __global__ __launch_bounds__(256) void pmv_partial_kernel(const float *__restrict__ imgs, const int32_t *__restrict__ ids_keep,
                                                           const float *__restrict__ drows, float *__restrict__ partial,
-                                                          int C, int H, int W, int p, int keep) {
+                                                          int C, int H, int W, int p, int keep, const float *__restrict__ pmask) {
     const int b = blockIdx.x;
     const int gw = W / p, pv = C * p * p;
     for (int e = threadIdx.x; e < pv; e += 256) {
@@ -79,8 +88,10 @@ __global__ __launch_bounds__(256) void pmv_partial_kernel(const float *__restric
         for (int j = 0; j < keep; ++j) {
             const int l = ids_keep ? ids_keep[b * keep + j] : j;
             const int y = (l / gw) * p + py, x = (l % gw) * p + px;
-            const float v = imgs[(((int64_t)b * C + c) * H + y) * W + x];
-            if (v != v) acc += drows[((int64_t)b * keep + j) * pv + e];
+            const int64_t pix = (((int64_t)b * C + c) * H + y) * W + x;
+            const float v = imgs[pix];
+            const float wgt = v != v ? 1.0f : (pmask ? pmask[pix] : 0.0f);
+            if (wgt != 0.0f) acc += wgt * drows[((int64_t)b * keep + j) * pv + e];
         }
         partial[(int64_t)b * pv + e] = acc;
     }
@@ -193,21 +204,33 @@ extern "C" int skyemb_random_mask_from_noise(const float *noise, int B, int L, i
     return 0;
 }
 
-extern "C" int skyemb_patch_gather(const float *imgs, const float *pmv, const int32_t *ids_keep, void *out, int dtype,
-                                   int B, int C, int H, int W, int p, int keep, float pixel_mean, float pixel_std,
-                                   void *stream) {
+static int patch_gather_launch(const float *imgs, const float *pmv, const int32_t *ids_keep, const float *pixel_mask, void *out,
+                               int dtype, int B, int C, int H, int W, int p, int keep, float pixel_mean, float pixel_std,
+                               void *stream) {
     SKY_CHECK_ARG(B > 0 && C > 0 && p > 0 && p % 4 == 0 && H % p == 0 && W % p == 0 && keep > 0,
                   "skyemb_patch_gather: bad geometry C=%d H=%d W=%d p=%d keep=%d", C, H, W, p, keep);
     SKY_CHECK_ARG(ids_keep || keep == (H / p) * (W / p), "skyemb_patch_gather: ids_keep == NULL needs keep == L");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SKYEMB_BF16)
         hipLaunchKernelGGL(patch_gather_kernel<bf16_t>, dim3(B * keep), dim3(256), 0, st, imgs, pmv, ids_keep, (bf16_t *)out,
-                           C, H, W, p, keep, pixel_mean, pixel_std);
+                           C, H, W, p, keep, pixel_mean, pixel_std, pixel_mask);
     else
         hipLaunchKernelGGL(patch_gather_kernel<float>, dim3(B * keep), dim3(256), 0, st, imgs, pmv, ids_keep, (float *)out, C,
-                           H, W, p, keep, pixel_mean, pixel_std);
+                           H, W, p, keep, pixel_mean, pixel_std, pixel_mask);
     SKY_LAUNCH_CHECK("skyemb_patch_gather");
     return 0;
+}
+
+extern "C" int skyemb_patch_gather(const float *imgs, const float *pmv, const int32_t *ids_keep, void *out, int dtype,
+                                   int B, int C, int H, int W, int p, int keep, float pixel_mean, float pixel_std,
+                                   void *stream) {
+    return patch_gather_launch(imgs, pmv, ids_keep, nullptr, out, dtype, B, C, H, W, p, keep, pixel_mean, pixel_std, stream);
+}
+
+extern "C" int skyemb_patch_gather_blend(const float *imgs, const float *pmv, const int32_t *ids_keep, const float *pixel_mask,
+                                         void *out, int dtype, int B, int C, int H, int W, int p, int keep, float pixel_mean,
+                                         float pixel_std, void *stream) {
+    return patch_gather_launch(imgs, pmv, ids_keep, pixel_mask, out, dtype, B, C, H, W, p, keep, pixel_mean, pixel_std, stream);
 }
 
 extern "C" int skyemb_colsum(const void *X, int dtype, int64_t ldx, int M, int N, float *out, void *stream) {
@@ -221,13 +244,19 @@ extern "C" int skyemb_colsum(const void *X, int dtype, int64_t ldx, int M, int N
     return 0;
 }
 
-extern "C" int skyemb_patch_gather_bwd_pmv(const float *imgs, const int32_t *ids_keep, const float *drows, float *partial,
-                                           float *dpmv, int B, int C, int H, int W, int p, int keep, void *stream) {
+extern "C" int skyemb_patch_gather_bwd_pmv_blend(const float *imgs, const int32_t *ids_keep, const float *pixel_mask,
+                                                 const float *drows, float *partial, float *dpmv, int B, int C, int H, int W,
+                                                 int p, int keep, void *stream) {
     SKY_CHECK_ARG(B > 0 && C > 0 && p > 0 && keep > 0, "skyemb_patch_gather_bwd_pmv: bad geometry");
     hipLaunchKernelGGL(pmv_partial_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, imgs, ids_keep, drows, partial, C, H,
-                       W, p, keep);
+                       W, p, keep, pixel_mask);
     SKY_LAUNCH_CHECK("skyemb_patch_gather_bwd_pmv");
     return skyemb_colsum(partial, SKYEMB_F32, (int64_t)C * p * p, B, C * p * p, dpmv, stream);
+}
+
+extern "C" int skyemb_patch_gather_bwd_pmv(const float *imgs, const int32_t *ids_keep, const float *drows, float *partial,
+                                           float *dpmv, int B, int C, int H, int W, int p, int keep, void *stream) {
+    return skyemb_patch_gather_bwd_pmv_blend(imgs, ids_keep, nullptr, drows, partial, dpmv, B, C, H, W, p, keep, stream);
 }
 
 extern "C" int skyemb_fill_mask_tokens(float *x, const float *mask, const float *mask_token, const float *dec_pos, int B,

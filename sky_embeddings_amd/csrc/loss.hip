@@ -118,6 +118,93 @@ __global__ __launch_bounds__(256) void loss_pass2(const float *__restrict__ imgs
     }
 }
 
+
+// ---- SimMIM mode (utils/mim_vit.py:469, 480-493, 497-521) ---------------------------------------
+// pred comes straight from the head GEMM as token rows: row b*(L+extra)+extra+l, column c*p*p + py*p + px
+// (= Conv1x1 output channel c*up^2 + i*up + j of PixelShuffle(up = p), utils/mim_vit.py:254-261); the pixel-shuffled
+// image pred_img [B,C,H,W] is only materialised when the caller asks for it.  Weights: w = pixel_mask where the
+// target is not NaN, else 0;  loss = sum(w * l) / (sum(w) + 1e-5).
+
+// element e' = (c*p + py)*p + px of patch l -> pixel index in [B,C,H,W]
+__device__ __forceinline__ int64_t simmim_pixel(int b, int l, int e, int C, int H, int W, int p) {
+    const int px = e % p, py = (e / p) % p, c = e / (p * p);
+    const int gw = W / p;
+    return (((int64_t)b * C + c) * H + (l / gw) * p + py) * W + (l % gw) * p + px;
+}
+
+__global__ __launch_bounds__(256) void simmim_pass1(const float *__restrict__ imgs, const float *__restrict__ pred,
+                                                    const float *__restrict__ pmask, float *__restrict__ ws, int C, int H,
+                                                    int W, int p, int L, int extra, float mean, float stdv, int norm_pix,
+                                                    int loss_l1) {
+    __shared__ float red[4];
+    const int b = blockIdx.x / L, l = blockIdx.x % L;
+    const int pv = C * p * p;
+    float *o = ws + (int64_t)blockIdx.x * 4;
+    float mu = 0.f, istd = 1.f;
+    if (norm_pix) {   // NaN-aware mean and biased variance over the whole patch vector (patch_mean_and_var)
+        float s = 0.f, n = 0.f;
+        for (int e = threadIdx.x; e < pv; e += 256) {
+            const float t = (imgs[simmim_pixel(b, l, e, C, H, W, p)] - mean) / stdv;
+            if (t == t) { s += t; n += 1.f; }
+        }
+        s = block_sum(s, red);
+        n = block_sum(n, red);
+        mu = s / n;
+        float q = 0.f;
+        for (int e = threadIdx.x; e < pv; e += 256) {
+            const float t = (imgs[simmim_pixel(b, l, e, C, H, W, p)] - mean) / stdv;
+            if (t == t) { const float d = t - mu; q += d * d; }
+        }
+        q = block_sum(q, red);
+        istd = 1.0f / sqrtf(q / n + 1.0e-6f);
+    }
+    const float *pr = pred + ((int64_t)b * (L + extra) + extra + l) * pv;
+    float s = 0.f, n = 0.f;
+    for (int e = threadIdx.x; e < pv; e += 256) {
+        const int64_t pix = simmim_pixel(b, l, e, C, H, W, p);
+        float t = (imgs[pix] - mean) / stdv;
+        if (norm_pix) t = (t - mu) * istd;
+        const float d = t - pr[e];
+        const float w = pmask[pix];
+        if (d == d) { s += w * (loss_l1 ? fabsf(d) : d * d); n += w; }
+    }
+    s = block_sum(s, red);
+    n = block_sum(n, red);
+    if (threadIdx.x == 0) { o[0] = s; o[1] = n; o[2] = mu; o[3] = istd; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void simmim_pass2(const float *__restrict__ imgs, const float *__restrict__ pred,
+                                                    const float *__restrict__ pmask, const float *__restrict__ ws,
+                                                    T *__restrict__ dpred, float *__restrict__ pred_img, int C, int H, int W,
+                                                    int p, int L, int extra, float mean, float stdv, int norm_pix,
+                                                    int loss_l1, int BL) {
+    const int Nd = L + extra;
+    const int b = blockIdx.x / Nd, r = blockIdx.x % Nd;
+    const int pv = C * p * p;
+    const int64_t off = (int64_t)blockIdx.x * pv;
+    const int l = r - extra;
+    if (l < 0) {   // cls / RA-Dec rows take no part in the reconstruction
+        if (dpred)
+            for (int e = threadIdx.x; e < pv; e += 256) dpred[off + e] = from_f32<T>(0.f);
+        return;
+    }
+    const float inv = ws[4 * (int64_t)BL + 1];
+    const float mu = ws[((int64_t)b * L + l) * 4 + 2], istd = ws[((int64_t)b * L + l) * 4 + 3];
+    for (int e = threadIdx.x; e < pv; e += 256) {
+        const int64_t pix = simmim_pixel(b, l, e, C, H, W, p);
+        const float pe = pred[off + e];
+        if (pred_img) pred_img[pix] = pe;
+        if (!dpred) continue;
+        float t = (imgs[pix] - mean) / stdv;
+        if (norm_pix) t = (t - mu) * istd;
+        const float d = pe - t;
+        float g = 0.f;
+        if (d == d) g = pmask[pix] * (loss_l1 ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : 2.f * d) * inv;
+        dpred[off + e] = from_f32<T>(g);
+    }
+}
+
 }  // namespace
 
 extern "C" int skyemb_masked_patch_loss(const float *imgs, const float *pred, const float *mask, float *loss, void *dpred,
@@ -140,5 +227,27 @@ extern "C" int skyemb_masked_patch_loss(const float *imgs, const float *pred, co
                                dpred32, C, H, W, p, L, extra, pixel_mean, pixel_std, norm_pix, loss_l1, BL);
     }
     SKY_LAUNCH_CHECK("skyemb_masked_patch_loss");
+    return 0;
+}
+
+extern "C" int skyemb_simmim_pixel_loss(const float *imgs, const float *pred_tok, const float *pixel_mask, float *loss,
+                                        void *dpred_tok, int dtype, float *pred_img, float *ws, int B, int C, int H, int W,
+                                        int p, int extra, float pixel_mean, float pixel_std, int norm_pix, int loss_l1,
+                                        void *stream) {
+    SKY_CHECK_ARG(B > 0 && C > 0 && p > 0 && H % p == 0 && W % p == 0 && extra >= 0 && pixel_mask, "skyemb_simmim_pixel_loss: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int L = (H / p) * (W / p), BL = B * L;
+    hipLaunchKernelGGL(simmim_pass1, dim3(BL), dim3(256), 0, st, imgs, pred_tok, pixel_mask, ws, C, H, W, p, L, extra, pixel_mean,
+                       pixel_std, norm_pix, loss_l1);
+    hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(256), 0, st, ws, loss, BL, 1.0f);   // scale = sum(w) (n/numel*numel)
+    if (dpred_tok || pred_img) {
+        if (dtype == SKYEMB_BF16)
+            hipLaunchKernelGGL(simmim_pass2<bf16_t>, dim3(B * (L + extra)), dim3(256), 0, st, imgs, pred_tok, pixel_mask, ws,
+                               (bf16_t *)dpred_tok, pred_img, C, H, W, p, L, extra, pixel_mean, pixel_std, norm_pix, loss_l1, BL);
+        else
+            hipLaunchKernelGGL(simmim_pass2<float>, dim3(B * (L + extra)), dim3(256), 0, st, imgs, pred_tok, pixel_mask, ws,
+                               (float *)dpred_tok, pred_img, C, H, W, p, L, extra, pixel_mean, pixel_std, norm_pix, loss_l1, BL);
+    }
+    SKY_LAUNCH_CHECK("skyemb_simmim_pixel_loss");
     return 0;
 }

@@ -23,7 +23,8 @@ import torch
 
 from . import ops
 from ._lib import ACT_DGELU, ACT_GELU, BF16, F32, KC, RC
-from .model_config import FROZEN, MAEConfig, sincos_pos_embed, state_layout, weight_decay_split, xavier_bound
+from .model_config import (FROZEN, SH_FEATURES, SIREN_HIDDEN, MAEConfig, not_optimised, sincos_pos_embed, state_layout,
+                           weight_decay_split, xavier_bound)
 
 
 def _pad8(n):
@@ -55,14 +56,15 @@ class ParamStore:
         self.m = torch.zeros(self.n, device=device, dtype=torch.float32)
         self.v = torch.zeros(self.n, device=device, dtype=torch.float32)
         self.p_lp = torch.zeros(self.n, device=device, dtype=lp_dtype)
-        self.frozen = {k: torch.zeros(shapes[k], device=device, dtype=torch.float32) for k in FROZEN}
+        # tensors of the state dict that no optimiser step touches (sincos tables; SimMIM's unused mask_token)
+        self.frozen = {k: torch.zeros(shapes[k], device=device, dtype=torch.float32) for k in not_optimised(cfg) if k in shapes}
 
     def _view(self, buf, name):
         o = self.offsets[name]
         return buf[o:o + int(np.prod(self.shapes[name]))].view(self.shapes[name])
 
     def param(self, name):
-        return self.frozen[name] if name in FROZEN else self._view(self.p, name)
+        return self.frozen[name] if name in self.frozen else self._view(self.p, name)
 
     def grad(self, name):
         return self._view(self.g, name)
@@ -94,10 +96,14 @@ def stage_gradient_ranges(store: ParamStore, cfg: MAEConfig, n_encoder_groups: i
 
 
 class MAEEngine:
+    _modes = "mae"      # SimMIMEngine (simmim_engine.py) handles simmim=True and the RA/Dec token
+
     def __init__(self, cfg: MAEConfig, device="cuda", compute_dtype=torch.bfloat16, seed=None):
-        if cfg.simmim or cfg.ra_dec or cfg.attn_pool:
-            raise NotImplementedError(
-                "SimMIM head / ra_dec token / attn_pool are 'next' rows (SURVEY.md §8f); this round builds the MAE path")
+        if cfg.attn_pool:
+            raise NotImplementedError("attn_pool (timm AttentionPoolLatent) is a 'next' row (SURVEY.md §8f)")
+        if (cfg.simmim or cfg.ra_dec) and self._modes == "mae":
+            raise NotImplementedError("simmim=True / ra_dec=True are served by sky_embeddings_amd.simmim_engine.SimMIMEngine "
+                                      "(the RA/Dec token in MAE mode is a 'next' row, SURVEY.md §8f)")
         assert cfg.embed_dim % cfg.num_heads == 0 and cfg.decoder_embed_dim % cfg.decoder_num_heads == 0
         assert cfg.embed_dim % 8 == 0 and cfg.decoder_embed_dim % 8 == 0 and cfg.patch_size % 4 == 0
         self.cfg = cfg
@@ -126,9 +132,15 @@ class MAEEngine:
                 t = torch.randn(shape, generator=gen) * 0.02
             elif name == "patch_mask_values":
                 t = torch.zeros(shape)
-            elif name == "patch_embed.proj.bias":
-                b = 1.0 / math.sqrt(cfg.patch_dim)
+            elif name == "patch_embed.proj.bias" or name.startswith("decoder.0."):
+                # nn.Conv2d default init, untouched by _init_weights: U(+-1/sqrt(fan_in)) for weight and bias
+                b = 1.0 / math.sqrt(cfg.patch_dim if name.startswith("patch_embed") else cfg.embed_dim)
                 t = (torch.rand(shape, generator=gen) * 2 - 1) * b
+            elif name.startswith("ra_dec_embed."):
+                # Siren.init_ (utils/location_encoder.py:41-49): first layer U(+-1/dim_in); last U(+-sqrt(6/dim_in)) (w0 = 1)
+                first = ".layers.0." in name
+                w_std = (1.0 / SH_FEATURES) if first else math.sqrt(6.0 / SIREN_HIDDEN)
+                t = (torch.rand(shape, generator=gen) * 2 - 1) * w_std
             elif name.endswith("norm1.weight") or name.endswith("norm2.weight") or name.endswith("norm.weight"):
                 t = torch.ones(shape)
             elif name.endswith(".bias"):
@@ -136,9 +148,12 @@ class MAEEngine:
             else:
                 t = (torch.rand(shape, generator=gen) * 2 - 1) * xavier_bound(shape)
             st.param(name).copy_(t)
-        for k in FROZEN:
-            tab = sincos_pos_embed(st.shapes[k][-1], cfg.grid, True, cfg.ra_dec)
-            st.frozen[k].copy_(torch.from_numpy(tab).float().unsqueeze(0))
+        for k in st.frozen:
+            if k in FROZEN:
+                tab = sincos_pos_embed(st.shapes[k][-1], cfg.grid, True, cfg.ra_dec)
+                st.frozen[k].copy_(torch.from_numpy(tab).float().unsqueeze(0))
+            else:
+                st.frozen[k].copy_(torch.randn(st.shapes[k], generator=gen) * 0.02)   # SimMIM's unused mask_token
         st.refresh_lp()
 
     def state_dict(self):

@@ -99,16 +99,34 @@ def _block(prefix, dim, hidden):
     ]
 
 
+SH_FEATURES, SIREN_HIDDEN = 25, 8   # LocationEncoder("siren", legendre_polys=5, dim_hidden=8, num_layers=1): mim_vit.py:211-215
+
+
 def state_layout(cfg: MAEConfig):
-    """Ordered (name, shape) == reference ``state_dict()`` (MAE mode; SimMIM head is a 'next' row)."""
+    """Ordered (name, shape) == reference ``state_dict()`` (utils/mim_vit.py:206-283; MAE and SimMIM modes).
+    SimMIM head: Conv1x1 to ``up**2 * C`` channels + PixelShuffle(up) with up = patch_size -- the reference writes
+    ``tile_size`` (utils/mim_vit.py:255), which only gives an image-shaped prediction when img_size == patch_size**2,
+    where the two coincide."""
     D, Dd, p, C = cfg.embed_dim, cfg.decoder_embed_dim, cfg.patch_size, cfg.in_chans
     L, E = cfg.num_patches, cfg.num_extra_tokens
-    out = [("cls_token", (1, 1, D)), ("pos_embed", (1, L + E, D)), ("patch_mask_values", (C, p, p)),
-           ("mask_token", (1, 1, Dd)), ("decoder_pos_embed", (1, L + E, Dd)),
-           ("patch_embed.proj.weight", (D, C, p, p)), ("patch_embed.proj.bias", (D,))]
+    out = [("cls_token", (1, 1, D)), ("pos_embed", (1, L + E, D)), ("patch_mask_values", (C, p, p))]
+    if cfg.simmim:
+        out.append(("mask_token", (1, 1, 1)))
+    else:
+        out += [("mask_token", (1, 1, Dd)), ("decoder_pos_embed", (1, L + E, Dd))]
+    out += [("patch_embed.proj.weight", (D, C, p, p)), ("patch_embed.proj.bias", (D,))]
+    if cfg.ra_dec:
+        out += [("ra_dec_embed.neural_network.layers.0.weight", (SIREN_HIDDEN, SH_FEATURES)),
+                ("ra_dec_embed.neural_network.layers.0.bias", (SIREN_HIDDEN,)),
+                ("ra_dec_embed.neural_network.last_layer.weight", (D, SIREN_HIDDEN)),
+                ("ra_dec_embed.neural_network.last_layer.bias", (D,))]
     for i in range(cfg.depth):
         out += _block(f"blocks.{i}", D, int(D * cfg.mlp_ratio))
-    out += [("norm.weight", (D,)), ("norm.bias", (D,)), ("decoder_embed.weight", (Dd, D)), ("decoder_embed.bias", (Dd,))]
+    out += [("norm.weight", (D,)), ("norm.bias", (D,))]
+    if cfg.simmim:
+        out += [("decoder.0.weight", (p * p * C, D, 1, 1)), ("decoder.0.bias", (p * p * C,))]
+        return out
+    out += [("decoder_embed.weight", (Dd, D)), ("decoder_embed.bias", (Dd,))]
     for i in range(cfg.decoder_depth):
         out += _block(f"decoder_blocks.{i}", Dd, int(Dd * cfg.mlp_ratio))
     out += [("decoder_norm.weight", (Dd,)), ("decoder_norm.bias", (Dd,)),
@@ -119,12 +137,19 @@ def state_layout(cfg: MAEConfig):
 FROZEN = ("pos_embed", "decoder_pos_embed")  # requires_grad=False parameters (utils/mim_vit.py:228,273)
 
 
+def not_optimised(cfg: MAEConfig):
+    """State tensors the optimiser never touches: the frozen tables, and SimMIM's (1,1,1) ``mask_token``, which no
+    forward uses (utils/mim_vit.py:263) -- its .grad stays None, so torch's AdamW skips it (no update, no decay)."""
+    return FROZEN + (("mask_token",) if cfg.simmim else ())
+
+
 def weight_decay_split(cfg: MAEConfig):
     """timm ``param_groups_weight_decay`` as called at utils/mim_vit.py:126: no decay iff
-    ndim <= 1 or the name ends with '.bias'; frozen tensors are not optimised."""
+    ndim <= 1 or the name ends with '.bias'; frozen / never-used tensors are not optimised."""
     decay, no_decay = [], []
+    skip = not_optimised(cfg)
     for name, shape in state_layout(cfg):
-        if name in FROZEN:
+        if name in skip:
             continue
         (no_decay if (len(shape) <= 1 or name.endswith(".bias")) else decay).append(name)
     return decay, no_decay

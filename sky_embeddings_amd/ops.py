@@ -109,6 +109,38 @@ def patch_gather_bwd_pmv(imgs, ids_keep, drows, partial, dpmv, p, keep):
                                             keep, _stream()), "skyemb_patch_gather_bwd_pmv")
 
 
+def patch_gather_blend(imgs, pmv, ids_keep, pixel_mask, out, p, keep, pixel_mean, pixel_std):
+    """SimMIM input path: NaN fill, then x * (1 - mask) + pmv * mask (pixel_mask None == patch_gather)."""
+    B, C, H, W = imgs.shape
+    check(lib().skyemb_patch_gather_blend(_p(imgs), _p(pmv), _p(ids_keep), _p(pixel_mask), _p(out), dtype_code(out.dtype), B, C,
+                                          H, W, p, keep, pixel_mean, pixel_std, _stream()), "skyemb_patch_gather_blend")
+
+
+def patch_gather_bwd_pmv_blend(imgs, ids_keep, pixel_mask, drows, partial, dpmv, p, keep):
+    B, C, H, W = imgs.shape
+    check(lib().skyemb_patch_gather_bwd_pmv_blend(_p(imgs), _p(ids_keep), _p(pixel_mask), _p(drows), _p(partial), _p(dpmv), B,
+                                                  C, H, W, p, keep, _stream()), "skyemb_patch_gather_bwd_pmv_blend")
+
+
+def radec_token_fwd(ra_dec, W0, b0, W1, b1, pos_row, x_rows, row_stride, B, D, sh, z):
+    """x_rows: fp32 view starting at the first RA/Dec token row; consecutive samples are row_stride floats apart."""
+    check(lib().skyemb_radec_token_fwd(_p(ra_dec), _p(W0), _p(b0), _p(W1), _p(b1), _p(pos_row), _p(x_rows), row_stride, B, D,
+                                       _p(sh), _p(z), _stream()), "skyemb_radec_token_fwd")
+
+
+def radec_token_bwd(g_rows, row_stride, W1, sh, z, dz_ws, dW0, db0, dW1, db1, B, D):
+    check(lib().skyemb_radec_token_bwd(_p(g_rows), row_stride, _p(W1), _p(sh), _p(z), _p(dz_ws), _p(dW0), _p(db0), _p(dW1),
+                                       _p(db1), B, D, _stream()), "skyemb_radec_token_bwd")
+
+
+def simmim_pixel_loss(imgs, pred_tok, pixel_mask, loss, dpred_tok, dtype, pred_img, ws, p, extra, pixel_mean, pixel_std,
+                      norm_pix, loss_l1):
+    B, C, H, W = imgs.shape
+    check(lib().skyemb_simmim_pixel_loss(_p(imgs), _p(pred_tok), _p(pixel_mask), _p(loss), _p(dpred_tok), dtype, _p(pred_img),
+                                         _p(ws), B, C, H, W, p, extra, pixel_mean, pixel_std, int(norm_pix), int(loss_l1),
+                                         _stream()), "skyemb_simmim_pixel_loss")
+
+
 def layernorm_fwd(x, gamma, beta, y, mean, rstd, M, D, eps, y32=None, dtype=None):
     code = dtype if dtype is not None else dtype_code(y.dtype)
     check(lib().skyemb_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(y32), code, _p(mean), _p(rstd), M, D, eps,
