@@ -36,6 +36,10 @@ class TrainStep:
         dev = engine.device
         self.imgs = torch.zeros(batch_size, cfg.in_chans, cfg.img_size, cfg.img_size, device=dev)
         self.noise = torch.zeros(batch_size, cfg.num_patches, device=dev)
+        # SimMIM mode (SimMIMEngine): the per-pixel mask and the RA/Dec pairs are step inputs too
+        self.simmim = bool(cfg.simmim)
+        self.pixel_mask = torch.zeros_like(self.imgs) if self.simmim else None
+        self.ra_dec = torch.zeros(batch_size, 2, device=dev) if (self.simmim and cfg.ra_dec) else None
         self.loss = None
         if staged is None:
             env = os.environ.get("SKYEMB_STAGED")
@@ -88,17 +92,25 @@ class TrainStep:
                 self.graphs.append(g)
 
     def _forward(self):
+        if self.simmim:
+            self.loss, self.pred, self.mask = self.engine.forward_train(self.imgs, mask=self.pixel_mask, ra_dec=self.ra_dec)
+            return
         # utils/mim_vit.py:363 draws the masking noise inside forward; keep it inside the step
         self.noise.uniform_()
         self.loss, self.pred, self.mask = self.engine.forward_train(self.imgs, self.mask_ratio, self.noise)
 
-    def load_batch(self, imgs):
-        """Stage the next minibatch (device or pinned host tensor) into the static input buffer."""
+    def load_batch(self, imgs, mask=None, ra_dec=None):
+        """Stage the next minibatch (device or pinned host tensors) into the static input buffers."""
         self.imgs.copy_(imgs, non_blocking=True)
+        if self.simmim:
+            assert mask is not None, "SimMIM steps need the per-pixel mask"
+            self.pixel_mask.copy_(mask, non_blocking=True)
+            if self.ra_dec is not None:
+                self.ra_dec.copy_(ra_dec, non_blocking=True)
 
-    def __call__(self, imgs=None):
+    def __call__(self, imgs=None, mask=None, ra_dec=None):
         if imgs is not None:
-            self.load_batch(imgs)
+            self.load_batch(imgs, mask, ra_dec)
         works = []
         g = self.engine.store.g
         overlap = self.optimizer_overlap

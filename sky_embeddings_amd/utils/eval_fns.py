@@ -22,9 +22,12 @@ def mae_predict(model, dataloader, device, mask_ratio, single_batch=True):
         for samples, mask, ra_decs in dataloader:
             samples = samples.to(device, non_blocking=True)
             loss, pred, mask = model(samples, ra_dec=ra_decs, mask_ratio=mask_ratio, mask=mask)
-            pred = mod.unpatchify(pred)
-            mask = mask.detach().unsqueeze(-1).repeat(1, 1, mod.patch_embed.patch_size[0] ** 2 * mod.in_chans)
-            mask = mod.unpatchify(mask)
+            if not mod.simmim:   # MAE: patch rows -> image; SimMIM predictions and masks are images already
+                pred = mod.unpatchify(pred)
+                mask = mask.detach().unsqueeze(-1).repeat(1, 1, mod.patch_embed.patch_size[0] ** 2 * mod.in_chans)
+                mask = mod.unpatchify(mask)
+            else:
+                pred = pred.clone()
             pred = mod.denorm_imgs(samples, pred)
             pred = torch.einsum('nchw->nhwc', pred).detach().clone()
             mask = torch.einsum('nchw->nhwc', mask).detach()

@@ -54,7 +54,8 @@ class _LossBackward(torch.autograd.Function):
 
 
 class MaskedAutoencoderViT:
-    """Masked Autoencoder with VisionTransformer backbone (utils/mim_vit.py:183-559), MAE mode."""
+    """Masked Autoencoder with VisionTransformer backbone (utils/mim_vit.py:183-559): MAE mode (MAEEngine) and SimMIM
+    mode with the optional RA/Dec token (SimMIMEngine)."""
 
     def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=1024, depth=24, num_heads=16,
                  decoder_embed_dim=512, decoder_depth=8, decoder_num_heads=16, mlp_ratio=4., norm_layer=None,
@@ -72,7 +73,11 @@ class MaskedAutoencoderViT:
         self.num_extra_tokens = 2 if ra_dec else 1
         self.tile_size = img_size // patch_size
         self.patch_embed = _PatchEmbedInfo(self.cfg)
-        self.engine = MAEEngine(self.cfg, device=device, compute_dtype=compute_dtype, seed=seed)
+        if simmim:
+            from ..simmim_engine import SimMIMEngine
+            self.engine = SimMIMEngine(self.cfg, device=device, compute_dtype=compute_dtype, seed=seed)
+        else:
+            self.engine = MAEEngine(self.cfg, device=device, compute_dtype=compute_dtype, seed=seed)
         self.training = True
         self._hook = torch.zeros(1, device=self.engine.device, requires_grad=True)
 
@@ -130,14 +135,29 @@ class MaskedAutoencoderViT:
         return x.to(self.engine.device, torch.float32).contiguous()
 
     def forward_features(self, x, ra_dec=None, mask_ratio=0, mask=None, reshape_out=True, noise=None):
-        """utils/mim_vit.py:381-438 -> (latent [B, 1+keep, D], mask [B,L], ids_restore [B,L]).
-        As in the reference, mask_ratio=0 keeps every patch but in SHUFFLED order."""
+        """utils/mim_vit.py:381-438.  MAE mode -> (latent [B, 1+keep, D], mask [B,L], ids_restore [B,L]); as in the
+        reference, mask_ratio=0 keeps every patch but in SHUFFLED order.  SimMIM mode -> tokens in
+        order, (latent, pixel mask, None); reshape_out=True drops the extra tokens and returns [B, D, h, w]."""
+        if self.simmim:
+            m = None if mask is None else mask.to(self.engine.device)
+            latent, m, _ = self.engine.forward_features(self._prep(x), mask=m, ra_dec=ra_dec)
+            latent = latent.clone()
+            if reshape_out:
+                latent = latent[:, self.num_extra_tokens:]
+                B, L, C = latent.shape
+                H = W = int(L ** 0.5)
+                latent = latent.permute(0, 2, 1).reshape(B, C, H, W)
+            return latent, m, None
         latent, m, ids = self.engine.forward_features(self._prep(x), mask_ratio=mask_ratio, noise=noise)
         return latent.clone(), m.clone(), ids.clone()
 
     def forward(self, imgs, ra_dec=None, mask_ratio=0.75, mask=None, denorm_out=False, noise=None):
-        """utils/mim_vit.py:552-559 -> (loss, pred [B,L,p*p*C], mask [B,L])."""
-        loss, pred, m = self.engine.forward_train(self._prep(imgs), mask_ratio=mask_ratio, noise=noise)
+        """utils/mim_vit.py:552-559 -> (loss, pred, mask): MAE pred [B,L,p*p*C], mask [B,L]; SimMIM pred [B,C,H,W] and
+        the per-pixel mask it was given."""
+        if self.simmim:
+            loss, pred, m = self.engine.forward_train(self._prep(imgs), mask=mask.to(self.engine.device), ra_dec=ra_dec)
+        else:
+            loss, pred, m = self.engine.forward_train(self._prep(imgs), mask_ratio=mask_ratio, noise=noise)
         if torch.is_grad_enabled():
             loss = _LossBackward.apply(self._hook, self.engine, loss)
         else:

@@ -143,3 +143,40 @@ def test_pretrain_entry_point_runs(tmp_path):
     ck = torch.load(str(work / "models" / "mim_t.pth.tar"), map_location="cpu", weights_only=False)
     assert set(ck) == {"batch_iters", "losses", "optimizer", "lr_scheduler", "model"}
     assert len(ck["model"]) == 255 - 0 and ck["batch_iters"] >= 5 and len(ck["losses"]["val_loss"]) >= 1
+
+
+def test_simmim_radec_model_through_the_module_api(tmp_path):
+    """A SimMIM + RA/Dec configuration (what the reference's shipped inis train) through utils.mim_vit.build_model,
+    the per-item loader with MaskGenerator, run_iter, checkpoint / resume, mae_latent and mae_predict."""
+    from collections import defaultdict
+    from sky_embeddings_amd import hdf5_lite
+    from sky_embeddings_amd.utils.dataloaders import build_h5_dataloader
+    from sky_embeddings_amd.utils.eval_fns import mae_latent, mae_predict
+    from sky_embeddings_amd.utils.mim_vit import build_model
+    from sky_embeddings_amd.utils.pretrain_fns import run_iter
+    cfg = _tiny_ini(tmp_path, total_iters=20, bs=8)
+    cfg["ARCHITECTURE"].update(model_type="simmim", patch_size="8", img_size="64", embed_dim="96", ra_dec="True")
+    cfg["TRAINING"].update(loss_fn="L1", norm_pix_loss="True", max_mask_ratio="0.9", compute_dtype="f32", init_lr="0.0005")
+    path = hdf5_lite.make_synthetic_cutouts(str(tmp_path / "c.h5"), n=32, seed=3, nan_fraction=0.05)
+    fn = str(tmp_path / "simmim.pth.tar")
+    model, losses, cur_iter, opt, sched = build_model(cfg, fn, "cuda", build_optimizer=True)
+    assert model.module.simmim and model.module.num_extra_tokens == 2
+    dl = build_h5_dataloader(path, batch_size=8, num_workers=0, patch_size=8, num_channels=5, max_mask_ratio=0.9, img_size=64,
+                             num_patches=model.module.patch_embed.num_patches, shuffle=False)
+    lc = defaultdict(list)
+    for epoch in range(3):
+        for samples, masks, ra_decs in dl:
+            model, opt, sched, lc = run_iter(model, samples.cuda(), ra_decs, masks, None, opt, sched, lc, mode="train")
+    tl = [float(v) for v in lc["train_loss"]]
+    assert all(np.isfinite(tl)) and np.mean(tl[-4:]) < np.mean(tl[:4]), tl
+    torch.save({"batch_iters": 12, "losses": dict(losses), "optimizer": opt.state_dict(), "lr_scheduler": sched.state_dict(),
+                "model": {k: v.detach().cpu() for k, v in model.module.state_dict().items()}}, fn)
+    model2, _, it2, opt2, _ = build_model(cfg, fn, "cuda", build_optimizer=True)
+    assert it2 == 13 and opt2.step_count == opt.step_count
+    for k, v in model.module.state_dict().items():
+        assert torch.equal(v, model2.module.state_dict()[k]), k
+    lat = mae_latent(model, dl, "cuda", n_batches=2, verbose=0, remove_cls=False)
+    lat = lat[0] if isinstance(lat, tuple) else lat
+    assert tuple(lat.shape[1:]) == (2 + 64, 96) and bool(torch.isfinite(torch.as_tensor(lat)).all())
+    pred, masked, orig = mae_predict(model, dl, "cuda", None)
+    assert pred.shape == orig.shape == (8, 64, 64, 5)

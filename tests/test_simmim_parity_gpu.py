@@ -79,3 +79,27 @@ def test_simmim_three_optimiser_steps_match_reference(name):
         tol = 5e-6 * max(float(np.abs(ref).max()), 1e-3) + 5e-2 * init_lr
         assert float(np.abs(sd[k].cpu().numpy() - ref).max()) <= tol, k
     assert np.array_equal(sd["mask_token"].cpu().numpy(), z["state_after3/mask_token"])
+
+
+def test_simmim_graph_step_equals_eager_and_staged():
+    """TrainStep in SimMIM mode: HIP-graph replay (monolithic and staged) == eager execution, bit for bit."""
+    from sky_embeddings_amd.optim import CosineLR, FusedAdamW
+    from sky_embeddings_amd.train_step import TrainStep
+    z, cfg, st, imgs, pmask, ra_dec = load_simmim_case("simmim_tiny_H_radec")
+    B = 8
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, cfg.in_chans, cfg.img_size, cfg.img_size, generator=g).cuda()
+    m = (torch.rand(B, cfg.in_chans, cfg.grid, cfg.grid, generator=g) < 0.5).float()
+    m = m.repeat_interleave(cfg.patch_size, 2).repeat_interleave(cfg.patch_size, 3).contiguous().cuda()
+    rd = torch.stack([torch.rand(B, generator=g) * 360, torch.rand(B, generator=g) * 180 - 90], 1).cuda()
+    results = []
+    for staged, graph in ((False, False), (False, True), (True, True)):
+        eng = make_engine(cfg, st, torch.bfloat16)
+        opt = FusedAdamW(eng, lr=1e-3)
+        step = TrainStep(eng, opt, CosineLR(opt, 100), B, use_graph=graph, staged=staged, n_encoder_groups=2)
+        for _ in range(3):
+            loss = step(x, m, rd)
+        torch.cuda.synchronize()
+        results.append((float(loss), eng.store.g.clone(), eng.store.p.clone()))
+    for r in results[1:]:
+        assert r[0] == results[0][0] and torch.equal(r[1], results[0][1]) and torch.equal(r[2], results[0][2])
