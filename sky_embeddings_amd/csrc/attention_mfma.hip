@@ -226,15 +226,259 @@ __global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(const bf16_t *__restr
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// 32 < N <= 128 (SimMIM sequences: 65 / 66 tokens): one workgroup per (sample, head), wave s owns token strip
+// [32 s, 32 s + 32) both as QUERY strip (softmax statistics, output / dQ) and as KEY strip (dK, dV).  Same orientation
+// trick per 32x32 tile; the statistics of every query row travel through LDS between the two phases of backward.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int MAX_NT = 4;
+
+__device__ __forceinline__ bf16x8 row_frag_at(const bf16_t *base, int64_t row_stride, int row, int g, int s, int N) {
+    return row < N ? *(const bf16x8 *)(base + (int64_t)row * row_stride + 16 * s + 8 * g) : zero8();
+}
+// lane (r, g): X[token row0 + pi(s,g,e)][dcol]
+__device__ __forceinline__ bf16x8 tok_frag_at(const bf16_t *base, int64_t row_stride, int row0, int dcol, bool dok, int g, int s, int N) {
+    bf16x8 f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int t = row0 + pi_row(s, g, e);
+        f[e] = (dok && t < N) ? base[(int64_t)t * row_stride + dcol] : (bf16_t)0.0f;
+    }
+    return f;
+}
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) z[e] = 0.f;
+    return z;
+}
+
+template <int HD, int NT>
+__global__ __launch_bounds__(64 * NT) void mha_fwd_strip_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out, int B,
+                                                                int N, int H) {
+    constexpr int KS = HD / 16, NB = (HD + 31) / 32;
+    const int lane = threadIdx.x & 63, strip = threadIdx.x >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int D = H * HD;
+    const int64_t rs = 3 * (int64_t)D;
+    const int r = lane & 31, g = lane >> 5;
+    const bf16_t *qb = qkv + (int64_t)b * N * rs + h * HD, *kb = qb + D, *vb = qb + 2 * D;
+    const int my = 32 * strip + r;                        // this lane's query token
+    const float scale = rsqrtf((float)HD);
+
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[s] = row_frag_at(qb, rs, my, g, s, N);
+    f32x16 st[NT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        st[t] = zero16();
+        if (32 * t < N) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) st[t] = mfma32(row_frag_at(kb, rs, 32 * t + r, g, s, N), qf[s], st[t]);   // ST[j][i]
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            st[t][e] = 32 * t + acc_row(e, g) < N ? st[t][e] * scale : -INFINITY;
+            mx = fmaxf(mx, st[t][e]);
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            st[t][e] = __expf(st[t][e] - mx);
+            sum += st[t][e];
+        }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    bf16_t *orow = out + ((int64_t)b * N + my) * D + h * HD;
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+        const int dcol = 32 * blk + r;
+        f32x16 ot = zero16();
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                if (32 * t + 16 * s < N) {
+                    bf16x8 pf;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)(st[t][8 * s + e] * inv);
+                    ot = mfma32(tok_frag_at(vb, rs, 32 * t, dcol, dcol < HD, g, s, N), pf, ot);   // O^T[d][i] += V[j][d] P[i][j]
+                }
+        if (my < N) store_tile<HD>(orow, ot, blk, g, 1.0f);
+    }
+}
+
+template <int HD, int NT>
+__global__ __launch_bounds__(64 * NT) void mha_bwd_strip_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
+                                                                bf16_t *__restrict__ dqkv, int B, int N, int H) {
+    constexpr int KS = HD / 16, NB = (HD + 31) / 32;
+    __shared__ float stats[3][32 * MAX_NT];               // per query token: softmax max, 1 / sum, rowsum(P dP)
+    const int lane = threadIdx.x & 63, strip = threadIdx.x >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int D = H * HD;
+    const int64_t rs = 3 * (int64_t)D;
+    const int r = lane & 31, g = lane >> 5;
+    const bf16_t *qb = qkv + (int64_t)b * N * rs + h * HD, *kb = qb + D, *vb = qb + 2 * D;
+    const bf16_t *ob = dout + (int64_t)b * N * D + h * HD;
+    const int my = 32 * strip + r;
+    const float scale = rsqrtf((float)HD);
+    bf16_t *dq = dqkv + ((int64_t)b * N + my) * rs + h * HD, *dk = dq + D, *dv = dq + 2 * D;
+
+    // ---- phase A: my query strip against every key tile: statistics, dS^T, dQ
+    {
+        bf16x8 qf[KS], of[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            qf[s] = row_frag_at(qb, rs, my, g, s, N);
+            of[s] = row_frag_at(ob, D, my, g, s, N);
+        }
+        f32x16 st[NT], dpt[NT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            st[t] = zero16();
+            dpt[t] = zero16();
+            if (32 * t < N) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    st[t] = mfma32(row_frag_at(kb, rs, 32 * t + r, g, s, N), qf[s], st[t]);
+                    dpt[t] = mfma32(row_frag_at(vb, rs, 32 * t + r, g, s, N), of[s], dpt[t]);   // dP^T[j][i]
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                st[t][e] = 32 * t + acc_row(e, g) < N ? st[t][e] * scale : -INFINITY;
+                mx = fmaxf(mx, st[t][e]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                st[t][e] = __expf(st[t][e] - mx);
+                sum += st[t][e];
+            }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        float rsum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                st[t][e] *= inv;
+                rsum = fmaf(st[t][e], dpt[t][e], rsum);
+            }
+        rsum += __shfl_xor(rsum, 32);
+        if (g == 0) {
+            stats[0][my] = mx;
+            stats[1][my] = inv;
+            stats[2][my] = rsum;
+        }
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+            const int dcol = 32 * blk + r;
+            f32x16 tq = zero16();
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    if (32 * t + 16 * s < N) {
+                        bf16x8 df;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) df[e] = (bf16_t)(st[t][8 * s + e] * (dpt[t][8 * s + e] - rsum));   // dS^T[j][i]
+                        tq = mfma32(tok_frag_at(kb, rs, 32 * t, dcol, dcol < HD, g, s, N), df, tq);   // dQ^T[d][i] += K[j][d] dS[i][j]
+                    }
+            if (my < N) store_tile<HD>(dq, tq, blk, g, scale);
+        }
+    }
+    __syncthreads();
+    // ---- phase B: my key strip against every query tile: P, dS (tokens i in the registers), dK, dV
+    {
+        bf16x8 kf[KS], vf[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            kf[s] = row_frag_at(kb, rs, my, g, s, N);
+            vf[s] = row_frag_at(vb, rs, my, g, s, N);
+        }
+        f32x16 tk[NB], tv[NB];
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+            tk[blk] = zero16();
+            tv[blk] = zero16();
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (32 * t >= N) break;
+            f32x16 sn = zero16(), dpn = zero16();
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 qt = row_frag_at(qb, rs, 32 * t + r, g, s, N), ot = row_frag_at(ob, D, 32 * t + r, g, s, N);
+                sn = mfma32(qt, kf[s], sn);            // S[i][j]: rows i = 32 t + acc_row, col j = my
+                dpn = mfma32(ot, vf[s], dpn);          // dP[i][j]
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = 32 * t + acc_row(e, g);
+                const bool ok = my < N && i < N;
+                const float p = ok ? __expf(sn[e] * scale - stats[0][i]) * stats[1][i] : 0.f;
+                dpn[e] = ok ? p * (dpn[e] - stats[2][i]) : 0.f;   // dS[i][j]
+                sn[e] = p;
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (32 * t + 16 * s >= N) break;
+                const bf16x8 pf = pack_regs(sn, s), df = pack_regs(dpn, s);
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk) {
+                    const int dcol = 32 * blk + r;
+                    tk[blk] = mfma32(tok_frag_at(qb, rs, 32 * t, dcol, dcol < HD, g, s, N), df, tk[blk]);   // dK^T[d][j] += Q[i][d] dS[i][j]
+                    tv[blk] = mfma32(tok_frag_at(ob, D, 32 * t, dcol, dcol < HD, g, s, N), pf, tv[blk]);    // dV^T[d][j] += dO[i][d] P[i][j]
+                }
+            }
+        }
+        if (my < N) {
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                store_tile<HD>(dk, tk[blk], blk, g, scale);
+                store_tile<HD>(dv, tv[blk], blk, g, 1.0f);
+            }
+        }
+    }
+}
+
+template <int HD, int NT>
+void launch_strip(bool bwd, const bf16_t *x, const bf16_t *dout, bf16_t *out, int B, int N, int H, hipStream_t st) {
+    const dim3 grid(B * H), block(64 * NT);
+    if (!bwd) hipLaunchKernelGGL((mha_fwd_strip_kernel<HD, NT>), grid, block, 0, st, x, out, B, N, H);
+    else hipLaunchKernelGGL((mha_bwd_strip_kernel<HD, NT>), grid, block, 0, st, x, dout, out, B, N, H);
+}
+
 }  // namespace
 
 // returns -1 when the shape is outside this kernel's subset (caller falls back to the LDS kernel of attention.hip)
 int skyemb_mha_mfma_try(bool bwd, const void *qkv, const void *dout, void *out, int B, int N, int H, int hd, hipStream_t st) {
-    if (N > 32 || (hd != 32 && hd != 64)) return -1;
+    if (N > 32 * MAX_NT || (hd != 32 && hd != 64)) return -1;
     static const bool off = []() { const char *e = getenv("SKYEMB_MHA_MFMA"); return e && e[0] == '0'; }();
     if (off) return -1;
-    const dim3 grid((B * H + 3) / 4), block(256);
     const bf16_t *x = (const bf16_t *)qkv;
+    if (N > 32) {
+        const int nt = (N + 31) / 32;
+#define STRIP(HD_, NT_) launch_strip<HD_, NT_>(bwd, x, (const bf16_t *)dout, (bf16_t *)out, B, N, H, st)
+        if (hd == 32) { if (nt == 2) STRIP(32, 2); else if (nt == 3) STRIP(32, 3); else STRIP(32, 4); }
+        else { if (nt == 2) STRIP(64, 2); else if (nt == 3) STRIP(64, 3); else STRIP(64, 4); }
+#undef STRIP
+        return 0;
+    }
+    const dim3 grid((B * H + 3) / 4), block(256);
     if (!bwd) {
         if (hd == 32) hipLaunchKernelGGL(mha_fwd_mfma_kernel<32>, grid, block, 0, st, x, (bf16_t *)out, B, N, H);
         else hipLaunchKernelGGL(mha_fwd_mfma_kernel<64>, grid, block, 0, st, x, (bf16_t *)out, B, N, H);

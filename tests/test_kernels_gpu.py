@@ -208,7 +208,8 @@ def test_layernorm_bwd_batched_reduce(ops):
 # ------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cfg", [(3, 5, 12, 64), (2, 17, 16, 32), (2, 66, 2, 64), (4, 5, 4, 16), (1, 65, 3, 8),
-                                 (2, 32, 3, 32), (5, 16, 2, 64), (3, 1, 2, 32), (7, 31, 5, 64)])
+                                 (2, 32, 3, 32), (5, 16, 2, 64), (3, 1, 2, 32), (7, 31, 5, 64),
+                                 (2, 65, 4, 32), (1, 100, 2, 32), (3, 33, 2, 32), (2, 97, 3, 32), (2, 64, 2, 64)])
 def test_attention(ops, dtype, cfg):
     B, N, H, hd = cfg
     D = H * hd
@@ -227,6 +228,23 @@ def test_attention(ops, dtype, cfg):
     tol = 6e-3 if dtype == torch.bfloat16 else 3e-6
     assert relerr(out.float(), o.detach()) < tol
     assert relerr(dqkv.float(), q_r.grad) < tol
+
+
+def test_attention_mfma_strips_full_width(ops):
+    """N = 128 (four 32-token strips per head), bf16 MFMA path only (the fp32 LDS kernel stops below that)."""
+    B, N, H, hd = 2, 128, 3, 64
+    D = H * hd
+    g = torch.Generator().manual_seed(9)
+    qkv, dout = torch.randn(B, N, 3 * D, generator=g), torch.randn(B, N, D, generator=g)
+    q_r = qkv.bfloat16().float().requires_grad_(True)
+    t = q_r.reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    o = (((t[0] * hd ** -0.5) @ t[1].transpose(-2, -1)).softmax(-1) @ t[2]).transpose(1, 2).reshape(B, N, D)
+    o.backward(dout.bfloat16().float())
+    out = torch.empty(B, N, D, device=DEV, dtype=torch.bfloat16)
+    dqkv = torch.empty(B, N, 3 * D, device=DEV, dtype=torch.bfloat16)
+    ops.mha_fwd(dev(qkv, torch.bfloat16), out, B, N, H, hd)
+    ops.mha_bwd(dev(qkv, torch.bfloat16), dev(dout, torch.bfloat16), dqkv, B, N, H, hd)
+    assert relerr(out.float(), o.detach()) < 6e-3 and relerr(dqkv.float(), q_r.grad) < 6e-3
 
 
 # ------------------------------------------------------------------------------------ front end
