@@ -18,9 +18,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float *__restrict__ p, float
     const float step_size = lr / bc1;
     const float bc2_sqrt = sqrtf(bc2);
     const float decay = 1.0f - lr * wd;
-    // streamed once per step: non-temporal loads / stores keep the 1.8 GB of optimiser state out of L2 and the
-    // Infinity Cache (the bf16 shadow, which the next forward reads, is stored normally); two float4 groups per thread
-    // and iteration keep 8 loads in flight per lane
+    // two float4 groups per thread and iteration keep 8 loads in flight per lane (non-temporal loads / stores were tried:
+    // no gain at 4.8 TB/s)
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 2 * stride) {
         f32x4 pv[2], gv[2], mv[2], vv[2];
@@ -28,10 +27,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float *__restrict__ p, float
         for (int u = 0; u < 2; ++u) {
             const int64_t i = i0 + u * stride;
             if (i < n4) {
-                pv[u] = __builtin_nontemporal_load((const f32x4 *)(p + 4 * i));
-                gv[u] = __builtin_nontemporal_load((const f32x4 *)(g + 4 * i));
-                mv[u] = __builtin_nontemporal_load((const f32x4 *)(m + 4 * i));
-                vv[u] = __builtin_nontemporal_load((const f32x4 *)(v + 4 * i));
+                pv[u] = *(const f32x4 *)(p + 4 * i);
+                gv[u] = *(const f32x4 *)(g + 4 * i);
+                mv[u] = *(const f32x4 *)(m + 4 * i);
+                vv[u] = *(const f32x4 *)(v + 4 * i);
             }
         }
 #pragma unroll
@@ -40,18 +39,22 @@ __global__ __launch_bounds__(256) void adamw_kernel(float *__restrict__ p, float
             if (i >= n4) break;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                // every rounding is pinned (explicit fmaf, no compiler contraction): the update of an element must not
+                // depend on which launch / unroll slot it lands in -- a step applied range by range (TrainStep's
+                // optimiser overlap) is bit-identical to one launch over the whole buffer
+#pragma clang fp contract(off)
                 const float gj = gv[u][j] * grad_scale;
                 float pj = pv[u][j];
-                if (4 * i + j < n_decay) pj *= decay;                       // p.mul_(1 - lr*wd)
-                const float mj = mv[u][j] * beta1 + gj * (1.0f - beta1);      // exp_avg.lerp_(grad, 1-beta1)
-                const float vj = vv[u][j] * beta2 + gj * gj * (1.0f - beta2); // exp_avg_sq.mul_().addcmul_()
+                if (4 * i + j < n_decay) pj *= decay;                                   // p.mul_(1 - lr*wd)
+                const float mj = fmaf(mv[u][j], beta1, gj * (1.0f - beta1));             // exp_avg.lerp_(grad, 1-beta1)
+                const float vj = fmaf(vv[u][j], beta2, (gj * gj) * (1.0f - beta2));      // exp_avg_sq.mul_().addcmul_()
                 const float denom = sqrtf(vj) / bc2_sqrt + eps;
-                pj -= step_size * (mj / denom);                              // p.addcdiv_(m, denom, -step_size)
+                pj = fmaf(-step_size, mj / denom, pj);                                  // p.addcdiv_(m, denom, -step_size)
                 pv[u][j] = pj; mv[u][j] = mj; vv[u][j] = vj;
             }
-            __builtin_nontemporal_store(pv[u], (f32x4 *)(p + 4 * i));
-            __builtin_nontemporal_store(mv[u], (f32x4 *)(m + 4 * i));
-            __builtin_nontemporal_store(vv[u], (f32x4 *)(v + 4 * i));
+            *(f32x4 *)(p + 4 * i) = pv[u];
+            *(f32x4 *)(m + 4 * i) = mv[u];
+            *(f32x4 *)(v + 4 * i) = vv[u];
             if (LP) store4<T>(p_lp + 4 * i, pv[u][0], pv[u][1], pv[u][2], pv[u][3]);
             if (zero_grad) *(float4 *)(g + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
