@@ -72,8 +72,9 @@ def graph_time_ms(fn, reps=20, replays=5):
 
 
 def gemm_step_probe(B, dtype, dev, iters=20):
-    """Launch-level roofline of the dominant kernel: every MFMA GEMM launch of one step (forward KC.KC,
-    dgrad KC.RC, wgrad RC.RC + its split-K reduce), each shape timed with HIP events around a HIP-graph replay.
+    """Launch-level roofline of the dominant kernel: every MFMA GEMM launch of one step (forward KC.KC, dgrad KC.RC,
+    wgrad RC.RC: one grouped launch per transformer block + three single ones), each timed with HIP events around a
+    HIP-graph replay.
     achieved = sum(2*M*N*K * count) / sum(avg launch time * count); avg_launch_us per kind is what the
     rocprofv3 kernel_stats average of gemm_pipe_kernel<64,64,A_KC,B_KC,3,4> must agree with."""
     from sky_embeddings_amd import ops
@@ -83,7 +84,9 @@ def gemm_step_probe(B, dtype, dev, iters=20):
         layers += [(M, 3 * D, D, depth, "bias"), (M, D, D, depth, "resid"), (M, 4 * D, D, depth, "gelu"), (M, D, 4 * D, depth, "dgelu")]
     layers += [(B * 4, 768, 1280, 1, "bias"), (Me, 512, 768, 1, "bias"), (Md, 1280, 512, 1, "bias")]
     ws = torch.zeros(8 * 1024 * 1024, device=dev)
-    kinds = {k: dict(launches=0, us=0.0, flop=0.0) for k in ("fwd_KC.KC", "dgrad_KC.RC", "wgrad_RC.RC+reduce")}
+    kinds = {k: dict(launches=0, us=0.0, flop=0.0) for k in ("fwd_KC.KC", "dgrad_KC.RC", "wgrad_RC.RC")}
+    keep = []                                      # grouped launches hold raw pointers: keep the operands alive
+    groups = {}                                    # (M tokens, depth) -> gemm_args of that block's four weight gradients
     for M, N, K, cnt, epi in layers:
         x = torch.randn(M, K, device=dev).to(dtype)
         w = (torch.randn(N, K, device=dev) * 0.05).to(dtype)
@@ -93,6 +96,7 @@ def gemm_step_probe(B, dtype, dev, iters=20):
         y32, res = torch.empty(M, N, device=dev), torch.randn(M, N, device=dev)
         dx, aux = torch.empty(M, K, device=dev, dtype=dtype), torch.randn(M, K, device=dev).to(dtype)
         dw, db = torch.empty(N, K, device=dev), torch.empty(N, device=dev)
+        keep.append((x, dy, dw, db))
         if epi == "gelu":
             fwd = lambda: ops.gemm(x, w, M=M, N=N, K=K, bias=bias, act=ops.ACT_GELU, out=y, out2=y2)
         elif epi in ("resid", "dgelu"):
@@ -104,17 +108,30 @@ def gemm_step_probe(B, dtype, dev, iters=20):
                                      aux=aux, ldaux=K, out=dx, ws=ws)
         else:
             dgrad = lambda: ops.gemm(dy, w, M=M, N=K, K=N, a_layout=ops.KC, b_layout=ops.RC, lda=N, ldb=K, out=dx, ws=ws)
-        wgrad = lambda: ops.gemm(dy, x, M=N, N=K, K=M, a_layout=ops.RC, b_layout=ops.RC, lda=N, ldb=K, out_f32=dw, colsum_a=db, ws=ws)
-        for kind, f in zip(kinds, (fwd, dgrad, wgrad)):
+        wkw = dict(M=N, N=K, K=M, a_layout=ops.RC, b_layout=ops.RC, lda=N, ldb=K, out_f32=dw, colsum_a=db)
+        timed = [("fwd_KC.KC", fwd), ("dgrad_KC.RC", dgrad)]
+        if cnt > 1 and dtype == torch.bfloat16:    # a transformer-block layer: its dW/db ride in the block's grouped launch
+            groups.setdefault((M, cnt), []).append(ops.gemm_args(dy, x, **wkw))
+        else:
+            timed.append(("wgrad_RC.RC", lambda: ops.gemm(dy, x, ws=ws, **wkw)))
+            kinds["wgrad_RC.RC"]["flop"] += 2.0 * M * N * K * cnt
+        for kind, f in timed:
             ms = graph_time_ms(f, iters)
             kinds[kind]["launches"] += cnt
             kinds[kind]["us"] += 1e3 * ms * cnt
-            kinds[kind]["flop"] += 2.0 * M * N * K * cnt
+            if kind != "wgrad_RC.RC":
+                kinds[kind]["flop"] += 2.0 * M * N * K * cnt
+    for (M, cnt), args in groups.items():
+        grp = ops.GemmGroup(args, dev)
+        ms = graph_time_ms(grp.launch, iters)
+        kinds["wgrad_RC.RC"]["launches"] += cnt
+        kinds["wgrad_RC.RC"]["us"] += 1e3 * ms * cnt
+        kinds["wgrad_RC.RC"]["flop"] += sum(2.0 * a.M * a.N * a.K for a in args) * cnt
     tot_us = sum(v["us"] for v in kinds.values())
     tot_fl = sum(v["flop"] for v in kinds.values())
     per_kind = {k: dict(launches_per_step=v["launches"], avg_launch_us=v["us"] / v["launches"], tflops=v["flop"] / v["us"] / 1e6)
                 for k, v in kinds.items()}
-    return dict(kernel="gemm_pipe_kernel<64,64,*,*,3,4> (+ splitk_reduce_kernel)", launches_per_step=sum(v["launches"] for v in kinds.values()),
+    return dict(kernel="gemm_pipe_kernel<64|128x64, ...> / gemm_pipe_group_kernel (the four dW of a block per launch) (+ splitk_reduce_kernel)", launches_per_step=sum(v["launches"] for v in kinds.values()),
                 ms_per_step=tot_us / 1e3, flop_per_step=tot_fl, tflops=tot_fl / tot_us / 1e6, kinds=per_kind)
 
 
