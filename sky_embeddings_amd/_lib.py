@@ -15,7 +15,7 @@ import subprocess
 import torch  # noqa: F401  (import order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libskyemb.so")
+SO_PATH = os.environ.get("SKYEMB_LIB") or os.path.join(_HERE, "libskyemb.so")   # SKYEMB_LIB: experiment builds
 CSRC = os.path.join(_HERE, "csrc")
 
 BF16, F32 = 0, 1
