@@ -87,39 +87,44 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     return v;
 }
 
-template <int R>
+template <int R, int NT>
 __device__ __forceinline__ void load_rows(const float *__restrict__ X, int64_t r0, int64_t rows, int D, int k0, int tid,
-                                          float4 (&reg)[(R * BK / 4 + 255) / 256]) {
-    constexpr int NV = (R * BK / 4 + 255) / 256;
+                                          float4 (&reg)[(R * BK / 4 + NT - 1) / NT]) {
+    constexpr int NV = (R * BK / 4 + NT - 1) / NT;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int v = tid + i * 256;
+        const int v = tid + i * NT;
         const int r = v >> 2, k = (v & 3) * 4;
-        const bool ok = (R * BK / 4 >= 256 || v < R * BK / 4) && r0 + r < rows && k0 + k < D;
+        const bool ok = (R * BK / 4 % NT == 0 || v < R * BK / 4) && r0 + r < rows && k0 + k < D;
         reg[i] = ok ? *(const float4 *)(X + (r0 + r) * D + k0 + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
-template <int R>
-__device__ __forceinline__ void store_rows(float *s, int tid, const float4 (&reg)[(R * BK / 4 + 255) / 256]) {
-    constexpr int NV = (R * BK / 4 + 255) / 256;
+template <int R, int NT>
+__device__ __forceinline__ void store_rows(float *s, int tid, const float4 (&reg)[(R * BK / 4 + NT - 1) / NT]) {
+    constexpr int NV = (R * BK / 4 + NT - 1) / NT;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int v = tid + i * 256;
-        if (R * BK / 4 >= 256 || v < R * BK / 4) *(float4 *)&s[(v >> 2) * PITCH + (v & 3) * 4] = reg[i];
+        const int v = tid + i * NT;
+        if (R * BK / 4 % NT == 0 || v < R * BK / 4) *(float4 *)&s[(v >> 2) * PITCH + (v & 3) * 4] = reg[i];
     }
 }
 
-// QT queries x BT bank rows per tile; 4 waves as WM x WN.
-template <int QT, int BT, bool SCORES_ONLY>
-__global__ __launch_bounds__(256) void cosine_topk_kernel(const float *__restrict__ tw, const float *__restrict__ qn,
-                                                          const float *__restrict__ bank, const float *__restrict__ xn,
-                                                          int Q, int64_t N, int D, int k, float eps, int64_t idx_offset,
-                                                          int nchunks, int64_t rows_per_chunk, float *__restrict__ part_s,
-                                                          int64_t *__restrict__ part_i, float *__restrict__ scores,
-                                                          const float *__restrict__ thr0) {
-    constexpr int WM = QT >= 64 ? 2 : 1, WN = 4 / WM;
+// QT queries x BT bank rows per tile; NW waves as WM x WN.  NW = 8 (two waves per SIMD: one wave's MFMAs cover the other's
+// LDS / barrier waits) for the many-query tile 64 x 256; its score tile is exchanged in 128-column slabs to fit the LDS.
+template <int QT, int BT, bool SCORES_ONLY, int NW>
+__global__ __launch_bounds__(64 * NW) void cosine_topk_kernel(const float *__restrict__ tw, const float *__restrict__ qn,
+                                                              const float *__restrict__ bank, const float *__restrict__ xn,
+                                                              int Q, int64_t N, int D, int k, float eps, int64_t idx_offset,
+                                                              int nchunks, int64_t rows_per_chunk, float *__restrict__ part_s,
+                                                              int64_t *__restrict__ part_i, float *__restrict__ scores,
+                                                              const float *__restrict__ thr0) {
+    constexpr int NT = 64 * NW;
+    constexpr int WM = QT >= 64 ? 2 : 1, WN = NW / WM;
     constexpr int TM = QT / WM / 16, TN = BT / WN / 16;
-    constexpr int SCP = BT + 1;
+    constexpr int SLAB = NW > 4 ? 128 : BT, NSLAB = BT / SLAB;      // score-tile columns exchanged per epilogue pass
+    constexpr int SCP = SLAB + 1;
+    constexpr int QPW = QT / NW;                                     // queries whose lists a wave owns
+    static_assert(BT / WN <= SLAB && SLAB % (BT / WN) == 0 && QT % NW == 0, "tile / wave layout");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *sA0 = lds, *sA1 = sA0 + QT * PITCH, *sB0 = sA1 + QT * PITCH, *sB1 = sB0 + BT * PITCH;
     float *sc = sB1 + BT * PITCH;            // [QT][SCP]
@@ -135,9 +140,9 @@ __global__ __launch_bounds__(256) void cosine_topk_kernel(const float *__restric
     if (c_end > N) c_end = N;
     const int KT = (D + BK - 1) / BK;
 
-    int cnt[QT / 4];  // per-wave list sizes for its queries (static indexing below)
+    int cnt[QPW];  // per-wave list sizes for its queries (static indexing below)
 #pragma unroll
-    for (int i = 0; i < QT / 4; ++i) cnt[i] = 0;
+    for (int i = 0; i < QPW; ++i) cnt[i] = 0;
 
     for (int64_t nb = c_begin; nb < c_end; nb += BT) {
         f32x4 acc[TM][TN];
@@ -145,18 +150,18 @@ __global__ __launch_bounds__(256) void cosine_topk_kernel(const float *__restric
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        float4 ra[(QT * BK / 4 + 255) / 256], rb[(BT * BK / 4 + 255) / 256];
-        load_rows<QT>(tw, q0, Q, D, 0, tid, ra);
-        load_rows<BT>(bank, nb, c_end, D, 0, tid, rb);
+        float4 ra[(QT * BK / 4 + NT - 1) / NT], rb[(BT * BK / 4 + NT - 1) / NT];
+        load_rows<QT, NT>(tw, q0, Q, D, 0, tid, ra);
+        load_rows<BT, NT>(bank, nb, c_end, D, 0, tid, rb);
         __syncthreads();  // previous tile's epilogue is done with LDS
-        store_rows<QT>(sA0, tid, ra);
-        store_rows<BT>(sB0, tid, rb);
+        store_rows<QT, NT>(sA0, tid, ra);
+        store_rows<BT, NT>(sB0, tid, rb);
         __syncthreads();
         for (int kt = 0; kt < KT; ++kt) {
             const bool more = kt + 1 < KT;
             if (more) {
-                load_rows<QT>(tw, q0, Q, D, (kt + 1) * BK, tid, ra);
-                load_rows<BT>(bank, nb, c_end, D, (kt + 1) * BK, tid, rb);
+                load_rows<QT, NT>(tw, q0, Q, D, (kt + 1) * BK, tid, ra);
+                load_rows<BT, NT>(bank, nb, c_end, D, (kt + 1) * BK, tid, rb);
             }
             const float *cA = (kt & 1) ? sA1 : sA0;
             const float *cB = (kt & 1) ? sB1 : sB0;
@@ -176,84 +181,90 @@ __global__ __launch_bounds__(256) void cosine_topk_kernel(const float *__restric
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
             }
             if (more) {
-                store_rows<QT>((kt & 1) ? sA0 : sA1, tid, ra);
-                store_rows<BT>((kt & 1) ? sB0 : sB1, tid, rb);
+                store_rows<QT, NT>((kt & 1) ? sA0 : sA1, tid, ra);
+                store_rows<BT, NT>((kt & 1) ? sB0 : sB1, tid, rb);
             }
             __syncthreads();
         }
-        // ---- finish scores into the LDS score tile (C/D: col = lane&15 -> bank row, row -> query) ----
+        // ---- finish scores into the LDS score tile (C/D: col = lane&15 -> bank row, row -> query), SLAB columns per pass ----
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int slab = 0; slab < NSLAB; ++slab) {
+            if (slab > 0) __syncthreads();          // the previous slab's scan is done with sc
+            if ((wn * (BT / WN)) / SLAB == slab) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qr = wm * (QT / WM) + i * 16 + 4 * (lane >> 4) + r;
-                const bool qok = q0 + qr < Q;
-                const float qnv = qok ? qn[q0 + qr] : 0.f;
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int c = wn * (BT / WN) + j * 16 + (lane & 15);
-                    const bool ok = qok && nb + c < c_end;
-                    sc[qr * SCP + c] = ok ? finish_score(acc[i][j][r], qnv, xn[nb + c], eps) : -INFINITY;
-                }
-            }
-        __syncthreads();
-        if (SCORES_ONLY) {
-            for (int e = tid; e < QT * BT; e += 256) {
-                const int qr = e / BT, c = e % BT;
-                if (q0 + qr < Q && nb + c < c_end) scores[(int64_t)(q0 + qr) * N + nb + c] = sc[qr * SCP + c];
-            }
-        } else {
-            // ---- per-query threshold-filtered sorted insertion; wave w owns queries w*(QT/4).. ----
+                    for (int r = 0; r < 4; ++r) {
+                        const int qr = wm * (QT / WM) + i * 16 + 4 * (lane >> 4) + r;
+                        const bool qok = q0 + qr < Q;
+                        const float qnv = qok ? qn[q0 + qr] : 0.f;
 #pragma unroll
-            for (int qi = 0; qi < QT / 4; ++qi) {
-                const int qq = wave * (QT / 4) + qi;
-                if (q0 + qq >= Q) continue;
-                float *lsq = ls + qq * k;
-                int *liq = li + qq * k;
-                int n_in = cnt[qi];
-                const float floor_thr = thr0 ? thr0[q0 + qq] : -INFINITY;   // valid lower bound of the global k-th best
-                float thr = n_in == k ? lsq[k - 1] : floor_thr;
-                for (int t = 0; t < BT / 64; ++t) {
-                    const float v = sc[qq * SCP + t * 64 + lane];
-                    unsigned long long m = __ballot(v > thr);
-                    while (m) {
-                        const int src = __builtin_ctzll(m);
-                        m &= m - 1;
-                        const float cv = __shfl(v, src, 64);
-                        if (!(cv > thr)) continue;  // threshold rose during this batch
-                        int pos = 0;
-                        for (int e = lane; e < n_in; e += 64) pos += lsq[e] >= cv ? 1 : 0;
-                        pos = wave_sum_i(pos);
-                        const int new_n = n_in < k ? n_in + 1 : k;
-                        // shift [pos, new_n-1) down by one, highest 64-chunk first (read-then-write per chunk)
-                        for (int e0 = ((new_n - 1) / 64) * 64; e0 >= 0; e0 -= 64) {
-                            const int e = e0 + lane;
-                            const bool mv = e >= pos && e < new_n - 1;
-                            float sv = 0.f;
-                            int iv = 0;
-                            if (mv) { sv = lsq[e]; iv = liq[e]; }
-                            __builtin_amdgcn_wave_barrier();
-                            if (mv) { lsq[e + 1] = sv; liq[e + 1] = iv; }
-                            __builtin_amdgcn_wave_barrier();
+                        for (int j = 0; j < TN; ++j) {
+                            const int c = wn * (BT / WN) + j * 16 + (lane & 15);
+                            const bool ok = qok && nb + c < c_end;
+                            sc[qr * SCP + c - slab * SLAB] = ok ? finish_score(acc[i][j][r], qnv, xn[nb + c], eps) : -INFINITY;
                         }
-                        if (lane == 0) {
-                            lsq[pos] = cv;
-                            liq[pos] = (int)(nb - 0 + t * 64 + src);  // row index local to this bank shard
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                        n_in = new_n;
-                        thr = n_in == k ? lsq[k - 1] : floor_thr;
                     }
+            }
+            __syncthreads();
+            if (SCORES_ONLY) {
+                for (int e = tid; e < QT * SLAB; e += NT) {
+                    const int qr = e / SLAB, c = e % SLAB + slab * SLAB;
+                    if (q0 + qr < Q && nb + c < c_end) scores[(int64_t)(q0 + qr) * N + nb + c] = sc[qr * SCP + c - slab * SLAB];
                 }
-                cnt[qi] = n_in;
+            } else {
+                // ---- per-query threshold-filtered sorted insertion; wave w owns queries w*QPW.. ----
+#pragma unroll
+                for (int qi = 0; qi < QPW; ++qi) {
+                    const int qq = wave * QPW + qi;
+                    if (q0 + qq >= Q) continue;
+                    float *lsq = ls + qq * k;
+                    int *liq = li + qq * k;
+                    int n_in = cnt[qi];
+                    const float floor_thr = thr0 ? thr0[q0 + qq] : -INFINITY;   // valid lower bound of the global k-th best
+                    float thr = n_in == k ? lsq[k - 1] : floor_thr;
+                    for (int t = 0; t < SLAB / 64; ++t) {
+                        const float v = sc[qq * SCP + t * 64 + lane];
+                        unsigned long long m = __ballot(v > thr);
+                        while (m) {
+                            const int src = __builtin_ctzll(m);
+                            m &= m - 1;
+                            const float cv = __shfl(v, src, 64);
+                            if (!(cv > thr)) continue;  // threshold rose during this batch
+                            int pos = 0;
+                            for (int e = lane; e < n_in; e += 64) pos += lsq[e] >= cv ? 1 : 0;
+                            pos = wave_sum_i(pos);
+                            const int new_n = n_in < k ? n_in + 1 : k;
+                            // shift [pos, new_n-1) down by one, highest 64-chunk first (read-then-write per chunk)
+                            for (int e0 = ((new_n - 1) / 64) * 64; e0 >= 0; e0 -= 64) {
+                                const int e = e0 + lane;
+                                const bool mv = e >= pos && e < new_n - 1;
+                                float sv = 0.f;
+                                int iv = 0;
+                                if (mv) { sv = lsq[e]; iv = liq[e]; }
+                                __builtin_amdgcn_wave_barrier();
+                                if (mv) { lsq[e + 1] = sv; liq[e + 1] = iv; }
+                                __builtin_amdgcn_wave_barrier();
+                            }
+                            if (lane == 0) {
+                                lsq[pos] = cv;
+                                liq[pos] = (int)(nb + slab * SLAB + t * 64 + src);  // row index local to this bank shard
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                            n_in = new_n;
+                            thr = n_in == k ? lsq[k - 1] : floor_thr;
+                        }
+                    }
+                    cnt[qi] = n_in;
+                }
             }
         }
     }
     if (!SCORES_ONLY) {
         __syncthreads();
 #pragma unroll
-        for (int qi = 0; qi < QT / 4; ++qi) {
-            const int qq = wave * (QT / 4) + qi;
+        for (int qi = 0; qi < QPW; ++qi) {
+            const int qq = wave * QPW + qi;
             if (q0 + qq >= Q) continue;
             const int64_t o = ((int64_t)(q0 + qq) * nchunks + chunk) * k;
             for (int e = lane; e < k; e += 64) {
@@ -433,16 +444,17 @@ __global__ __launch_bounds__(64) void topk_merge_fallback_kernel(const float *__
     tournament_merge(in_s, in_i, nlists, k, out_s, out_i, smem);
 }
 
-template <int QT, int BT, bool SO>
+template <int QT, int BT, bool SO, int NW = 4>
 int launch_topk(const float *tw, const float *qn, const float *bank, const float *xn, int Q, int64_t N, int D, int k,
                 float eps, int64_t idx_offset, int nchunks, float *part_s, int64_t *part_i, float *scores, hipStream_t st,
                 const char *name, const float *thr0 = nullptr) {
-    const size_t smem = sizeof(float) * (2 * QT * PITCH + 2 * BT * PITCH + QT * (BT + 1) + (SO ? 0 : 2 * (size_t)QT * k));
+    constexpr int SLAB = NW > 4 ? 128 : BT;   // score-tile columns per epilogue pass (cosine_topk_kernel)
+    const size_t smem = sizeof(float) * (2 * QT * PITCH + 2 * BT * PITCH + QT * (SLAB + 1) + (SO ? 0 : 2 * (size_t)QT * k));
     if (smem > 160 * 1024) {
         skyemb_set_error("%s: k=%d needs %zu B of LDS (max 160 KiB)", name, k, smem);
         return 1;
     }
-    auto kern = cosine_topk_kernel<QT, BT, SO>;
+    auto kern = cosine_topk_kernel<QT, BT, SO, NW>;
     if (smem > 65536) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) {
@@ -452,7 +464,7 @@ int launch_topk(const float *tw, const float *qn, const float *bank, const float
     }
     int64_t rows_per_chunk = ceil_div64(ceil_div64(N, nchunks), BT) * BT;
     const int qtiles = (Q + QT - 1) / QT;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(qtiles * nchunks)), dim3(256), smem, st, tw, qn, bank, xn, Q, N, D, k, eps,
+    hipLaunchKernelGGL(kern, dim3((unsigned)(qtiles * nchunks)), dim3(64 * NW), smem, st, tw, qn, bank, xn, Q, N, D, k, eps,
                        idx_offset, nchunks, rows_per_chunk, part_s, part_i, scores, thr0);
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) {
@@ -463,6 +475,11 @@ int launch_topk(const float *tw, const float *qn, const float *bank, const float
 }
 
 inline bool small_tile(int Q, int k) { return Q <= 16 || k > 128; }
+// many-query tile: 64 x 256 with 8 waves (two per SIMD) by default; SKYEMB_TOPK_NW=4 keeps the 64 x 128 four-wave tile
+inline bool wide_tile() {
+    static const bool on = []() { const char *e = getenv("SKYEMB_TOPK_NW"); return !(e && e[0] == '4'); }();
+    return on;
+}
 
 }  // namespace
 
@@ -501,7 +518,7 @@ static bool use_stream(int Q, int D, int k) {
 extern "C" int skyemb_cosine_topk_chunks(int64_t N, int Q, int D, int k) {
     if (use_stream(Q, D, k)) return skyemb_topk_stream_lists(N, D, k);
     const bool small = small_tile(Q, k);
-    const int QT = small ? 16 : 64, BT = small ? 256 : 128;
+    const int QT = small ? 16 : 64, BT = small ? 256 : (wide_tile() ? 256 : 128);
     const int qtiles = (Q + QT - 1) / QT;
     int64_t want = 1024 / qtiles;
     if (want < 1) want = 1;
@@ -525,6 +542,9 @@ extern "C" int skyemb_cosine_topk(const float *tw, const float *qn, const float 
     if (small_tile(Q, k))
         return launch_topk<16, 256, false>(tw, qn, bank, xn, Q, N, D, k, eps, idx_offset, nchunks, part_s, part_i, nullptr,
                                            st, "skyemb_cosine_topk", thr0);
+    if (wide_tile())
+        return launch_topk<64, 256, false, 8>(tw, qn, bank, xn, Q, N, D, k, eps, idx_offset, nchunks, part_s, part_i, nullptr,
+                                              st, "skyemb_cosine_topk", thr0);
     return launch_topk<64, 128, false>(tw, qn, bank, xn, Q, N, D, k, eps, idx_offset, nchunks, part_s, part_i, nullptr, st,
                                        "skyemb_cosine_topk", thr0);
 }
