@@ -63,6 +63,9 @@ def main(args):
     model_filename = os.path.join(model_dir, model_name + '.pth.tar')
     torch.manual_seed(0)  # identical initial weights on every rank
     model, losses, cur_iter, optimizer, lr_scheduler = build_model(config, model_filename, device, build_optimizer=True)
+    # from here on every rank draws its OWN random stream (MAE masking noise inside TrainStep, SimMIM mask generators in the
+    # loader workers): seed = base + rank, so the global batch sees world x the mask diversity
+    torch.manual_seed(1 + rank)
     optimizer.grad_scale = 1.0 / world
 
     if 'mim' in config['ARCHITECTURE']['model_type']:

@@ -48,8 +48,10 @@ class CutoutFeeder:
         self.depth, self.threads, self.epochs = max(2, depth), threads, epochs
         self.batch_size = self.B                                  # DataLoader-compatible attribute (pretrain_mim.py:93)
         self.dataset = self
-        n_local = len(self.indices[self.rank::self.world])
-        self._nb = n_local // self.B if drop_last else (n_local + self.B - 1) // self.B
+        # every rank must run the SAME number of steps per epoch (each step issues collectives): with several ranks the
+        # shards are cut to the common length len // world before batching (DistributedIndexSampler does the same)
+        n_local = len(self.indices) // self.world if self.world > 1 else len(self.indices)
+        self._nb = n_local // self.B if (drop_last or self.world > 1) else (n_local + self.B - 1) // self.B
         # ring: pinned host slots, device staging + device output per slot
         self._pinned = [torch.empty(self.B, self.C, self.Hs, self.Ws, dtype=torch.float32).pin_memory() for _ in range(self.depth)]
         self._radec_pin = [torch.empty(self.B, 2, dtype=torch.float32).pin_memory() for _ in range(self.depth)]

@@ -71,19 +71,37 @@ class FusedAdamW:
 
     # ---- torch.optim.AdamW-compatible (de)serialisation --------------------------------------
     def _index(self):
+        """Parameter names in torch's id order: timm param_groups_weight_decay walks named_parameters() once and fills
+        [no_decay, decay].  SimMIM's ``mask_token`` (requires_grad, ndim 3 -> decay group, utils/mim_vit.py:264) belongs
+        to that list although no forward uses it: its id exists in ``param_groups`` and it has no ``state`` entry
+        (torch keeps none for a parameter whose grad is None).  ``None`` marks such a stateless id."""
+        from .model_config import FROZEN, state_layout
         st = self.store
-        return list(st.no_decay) + list(st.decay)
+        stateless = {n for n in st.frozen if n not in FROZEN}
+        if not stateless:
+            return list(st.no_decay), list(st.decay)
+        no_decay, decay = [], []
+        have = set(st.no_decay) | set(st.decay)
+        for name, shape in state_layout(st.cfg):
+            if name in have:
+                (no_decay if name in st.no_decay else decay).append(name)
+            elif name in stateless:
+                (no_decay if (len(shape) <= 1 or name.endswith(".bias")) else decay).append(None)
+        return no_decay, decay
 
     def state_dict(self):
         st = self.store
-        names = self._index()
+        no_decay, decay = self._index()
+        names = no_decay + decay
         state = {}
         if self.step_count > 0:
             for i, n in enumerate(names):
+                if n is None:
+                    continue
                 state[i] = {"step": torch.tensor(float(self.step_count)),
                             "exp_avg": st._view(st.m, n).detach().clone(),
                             "exp_avg_sq": st._view(st.v, n).detach().clone()}
-        nd = len(st.no_decay)
+        nd = len(no_decay)
         groups = []
         for gi, ids in enumerate((list(range(nd)), list(range(nd, len(names))))):
             g = dict(self.param_groups[gi])
@@ -94,9 +112,11 @@ class FusedAdamW:
 
     def load_state_dict(self, sd):
         st = self.store
-        names = self._index()
+        no_decay, decay = self._index()
+        names = no_decay + decay
         groups = sd["param_groups"]
-        assert sum(len(g["params"]) for g in groups) == len(names), "optimizer state does not match this model"
+        assert [len(g["params"]) for g in groups] == [len(no_decay), len(decay)], \
+            "optimizer state does not match this model (parameter counts per weight-decay group differ)"
         for g_new, g_old in zip(self.param_groups, groups):
             for k in ("lr", "initial_lr", "weight_decay", "eps"):
                 if k in g_old:
@@ -107,7 +127,7 @@ class FusedAdamW:
         steps = set()
         for i, n in enumerate(names):
             s = sd["state"].get(i)
-            if s is None:
+            if s is None or n is None:
                 continue
             st._view(st.m, n).copy_(s["exp_avg"].to(torch.float32))
             st._view(st.v, n).copy_(s["exp_avg_sq"].to(torch.float32))

@@ -11,8 +11,8 @@ Build extensions (all optional, defaults reproduce the reference):
     (reference draws ``torch.rand`` internally, utils/mim_vit.py:363);
   * ``[TRAINING] compute_dtype = bf16|f32`` (default bf16; f32 = exact-fp32 MFMA parity mode).
 Deviation: NaN target pixels contribute a ZERO gradient (the reference's MSE backward is NaN
-there); SimMIM / ra_dec / attn_pool configurations raise NotImplementedError
-(next rows).
+there).  SimMIM configurations (``model_type`` simmim / mimlarge / mimhuge, with or without the RA/Dec
+token) run on ``sky_embeddings_amd.simmim_engine.SimMIMEngine``.
 """
 from __future__ import annotations
 

@@ -340,6 +340,55 @@ def similarity_cases(sim):
     print("wrote similarity")
 
 
+class TokenStub(nn.Module):
+    """Stand-in for the encoder behind mae_simsearch (the driver only needs forward_features and
+    num_extra_tokens): cls row = mean of the patch rows, patch rows = fixed linear map of 4x4 pixel blocks."""
+    num_extra_tokens = 1
+
+    def __init__(self, W):
+        super().__init__()
+        self.W = W
+
+    def forward_features(self, x, ra_dec=None, mask_ratio=0, mask=None, reshape_out=False):
+        B, C, H, Wd = x.shape
+        p = x.reshape(B, C, H // 4, 4, Wd // 4, 4).permute(0, 2, 4, 1, 3, 5).reshape(B, (H // 4) * (Wd // 4), C * 16)
+        tok = p @ self.W.to(p.device)
+        return torch.cat((tok.mean(dim=1, keepdim=True), tok), dim=1), None, None
+
+
+def simsearch_cases(sim):
+    """utils/similarity.py:37-132 (mae_simsearch) executed end to end around the stub encoder: flat and tile-nested
+    loaders, every token-selection mode, cosine and MSE.  RA column carries the sample index."""
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    N, B, C, S, D, n_save = 160, 16, 2, 8, 24, 12
+    W = torch.randn(C * 16, D, generator=g) / 4
+    x = torch.randn(N, C, S, S, generator=g)
+    x[40:48] = x[3:11] * 1.01 + 0.01          # near-duplicates of target-like rows: a non-trivial ranking
+    rd = torch.stack([torch.arange(N, dtype=torch.float32), torch.rand(N, generator=g)], dim=1)
+    stub = TokenStub(W)
+    tgt = stub.forward_features(x[3:11] + 0.05 * torch.randn(8, C, S, S, generator=g))[0]
+    out["ss/W"], out["ss/x"], out["ss/ra_dec"], out["ss/target_latent"] = W.numpy(), x.numpy(), rd.numpy(), tgt.numpy()
+    flat = [(x[i:i + B], torch.zeros(B), rd[i:i + B]) for i in range(0, N, B)]
+    tiles = [([[x[i:i + B], x[i + B:i + 2 * B]]], [[torch.zeros(B), torch.zeros(B)]], [[rd[i:i + B], rd[i + B:i + 2 * B]]])
+             for i in range(0, N, 2 * B)]
+    cases = [("cos_min", dict(metric="cosine", combine="min")), ("cos_mean_nw", dict(metric="cosine", combine="mean", use_weights=False)),
+             ("cos_max_pool", dict(metric="cosine", combine="min", max_pool=True)), ("cos_cls", dict(metric="cosine", combine="max", cls_token=True)),
+             ("mse_mean", dict(metric="MSE", combine="mean")), ("mae_min_nb3", dict(metric="MAE", combine="min", n_batches=3))]
+    import contextlib, io
+    for name, kw in cases:
+        for nested, loader in ((False, flat), (True, tiles)):
+            with contextlib.redirect_stdout(io.StringIO()):
+                bs, bl, brd, bsc = sim.mae_simsearch(stub, tgt, loader, torch.device("cpu"), nested_batches=nested, n_save=n_save,
+                                                     verbose=1000, **kw)
+            key = f"ss/{name}/{'tiles' if nested else 'flat'}"
+            out[key + "/scores"], out[key + "/idx"] = bsc.numpy(), brd[:, 0].numpy().astype(np.int64)
+            out[key + "/latent"] = bl.numpy()
+            assert torch.equal(bs, x[brd[:, 0].long()])
+    np.savez_compressed(os.path.join(OUT, "simsearch_driver.npz"), **out)
+    print("wrote simsearch_driver")
+
+
 def main():
     pgwd = install_standins()
     # this repo ships a drop-in ``utils`` package of the same name: keep it off the path so that the REFERENCE is imported
@@ -353,6 +402,11 @@ def main():
     sim = importlib.import_module("utils.similarity")
     pos_embed = importlib.import_module("utils.pos_embed")
     torch.set_num_threads(4)
+    only = sys.argv[1:]                      # e.g. `make_golden.py simsearch` regenerates one family
+    if "simsearch" in only or not only:
+        simsearch_cases(sim)
+    if only:
+        return
     unit_pieces(mim_vit, pos_embed)
     similarity_cases(sim)
     # A: BASELINE geometry (64/16, 5 bands), clean input, 3 optimiser steps

@@ -43,6 +43,49 @@ def test_similarity_module_matches_reference_goldens():
         assert np.array_equal(brd[:, 0].cpu().numpy().astype(np.int64), z[f"stream/{metric}_best_idx"])
 
 
+def test_mae_simsearch_driver_matches_reference_goldens():
+    """utils.similarity.mae_simsearch (pool-based driver, HIP cosine + standardise kernels) against outputs of the
+    REFERENCE's mae_simsearch captured around the same stub encoder (tests/golden/make_golden.py simsearch_cases):
+    flat and tile-nested loaders, every token-selection mode, cosine / MSE / MAE, an n_batches limit."""
+    from sky_embeddings_amd.utils import similarity as sim
+    z = np.load(os.path.join(GOLDEN, "simsearch_driver.npz"))
+    W = torch.from_numpy(z["ss/W"]).cuda()
+
+    class TokenStub(torch.nn.Module):
+        num_extra_tokens = 1
+
+        def forward_features(self, x, ra_dec=None, mask_ratio=0, mask=None, reshape_out=False):
+            B, C, H, Wd = x.shape
+            p = x.reshape(B, C, H // 4, 4, Wd // 4, 4).permute(0, 2, 4, 1, 3, 5).reshape(B, (H // 4) * (Wd // 4), C * 16)
+            tok = p @ W
+            return torch.cat((tok.mean(dim=1, keepdim=True), tok), dim=1), None, None
+
+    x, rd, tgt = torch.from_numpy(z["ss/x"]), torch.from_numpy(z["ss/ra_dec"]), torch.from_numpy(z["ss/target_latent"])
+    N, B, n_save = x.shape[0], 16, 12
+    flat = [(x[i:i + B], torch.zeros(B), rd[i:i + B]) for i in range(0, N, B)]
+    tiles = [([[x[i:i + B], x[i + B:i + 2 * B]]], [[torch.zeros(B), torch.zeros(B)]], [[rd[i:i + B], rd[i + B:i + 2 * B]]])
+             for i in range(0, N, 2 * B)]
+    cases = [("cos_min", dict(metric="cosine", combine="min")), ("cos_mean_nw", dict(metric="cosine", combine="mean", use_weights=False)),
+             ("cos_max_pool", dict(metric="cosine", combine="min", max_pool=True)), ("cos_cls", dict(metric="cosine", combine="max", cls_token=True)),
+             ("mse_mean", dict(metric="MSE", combine="mean")), ("mae_min_nb3", dict(metric="MAE", combine="min", n_batches=3))]
+    stub = TokenStub()
+    for name, kw in cases:
+        for nested, loader in ((False, flat), (True, tiles)):
+            bs, bl, brd, bsc = sim.mae_simsearch(stub, tgt, loader, torch.device("cuda"), nested_batches=nested, n_save=n_save,
+                                                 verbose=0, **kw)
+            key = f"ss/{name}/{'tiles' if nested else 'flat'}"
+            ref_s, ref_i = z[key + "/scores"], z[key + "/idx"]
+            got_i = brd[:, 0].cpu().numpy().astype(np.int64)
+            assert np.abs(bsc.cpu().numpy() - ref_s).max() <= 5e-6 * max(1.0, np.abs(ref_s).max()), key
+            # same winners in the same order wherever the reference's own score gap exceeds the rounding band
+            gap_ok = np.abs(np.diff(ref_s)) > 1e-5 * max(1.0, np.abs(ref_s).max())
+            firm = np.concatenate(([True], gap_ok)) & np.concatenate((gap_ok, [True]))
+            assert np.array_equal(got_i[firm], ref_i[firm]), (key, got_i, ref_i)
+            assert set(got_i[:-1]) <= set(ref_i) | set(got_i[~firm]), key
+            assert torch.equal(bs.cpu(), x[torch.from_numpy(got_i)]), key
+            assert np.allclose(bl.cpu().numpy()[firm], z[key + "/latent"][firm], rtol=1e-4, atol=1e-5), key
+
+
 def _tiny_ini(tmp_path, total_iters=6, bs=8):
     cfg = configparser.ConfigParser()
     cfg.read(os.path.join(ROOT, "configs", "mim_1.ini"))

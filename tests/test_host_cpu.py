@@ -223,3 +223,59 @@ def test_native_host_gather_rows():
     bad = np.array([0, 97], dtype=np.int64)
     assert L.skyemb_gather_rows_host(src.ctypes.data, 1280, bad.ctypes.data, 2, 97, dst.ctypes.data, 2) != 0
     assert b"out of range" in L.skyemb_last_error()
+
+
+def test_optimizer_state_dict_interchanges_with_torch_adamw_in_simmim_mode():
+    """in SimMIM mode the reference optimises ``mask_token`` (requires_grad, decay group) although no forward
+    uses it, so torch's AdamW state dict holds its id without a state entry.  FusedAdamW must write and read exactly that
+    layout (ids per group, which ids carry state), in both directions."""
+    from types import SimpleNamespace
+    from sky_embeddings_amd.engine import ParamStore
+    from sky_embeddings_amd.optim import FusedAdamW
+    for kind in ("simmim", "mae"):
+        cfg = mc.MAEConfig(img_size=32, patch_size=8, in_chans=2, embed_dim=16, depth=1, num_heads=2, decoder_embed_dim=8,
+                           decoder_depth=1, decoder_num_heads=2, simmim=(kind == "simmim"))
+        # the reference module's parameters, by name, in registration (= state-dict) order
+        params = {n: torch.nn.Parameter(torch.randn(s) * 0.1, requires_grad=n not in mc.FROZEN) for n, s in mc.state_layout(cfg)}
+        no_decay = [p for n, p in params.items() if p.requires_grad and (p.ndim <= 1 or n.endswith(".bias"))]
+        decay = [p for n, p in params.items() if p.requires_grad and not (p.ndim <= 1 or n.endswith(".bias"))]
+        topt = torch.optim.AdamW([{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": 0.05}],
+                                 lr=1e-3, betas=(0.9, 0.95))
+        unused = {"mask_token"} if cfg.simmim else set()
+        g = torch.Generator().manual_seed(0)
+        for n, p in params.items():
+            if p.requires_grad and n not in unused:
+                p.grad = torch.randn(p.shape, generator=g)
+        topt.step()
+        tsd = topt.state_dict()
+        store = ParamStore(cfg, "cpu", torch.float32)
+        fopt = FusedAdamW(SimpleNamespace(store=store), lr=1e-3, weight_decay=0.05)
+        fopt.load_state_dict(tsd)                                   # torch -> ours
+        assert fopt.step_count == 1
+        for n in store.order:
+            pid = [id(q) for q in no_decay + decay].index(id(params[n]))
+            assert torch.equal(store._view(store.m, n), tsd["state"][pid]["exp_avg"]), n
+            assert torch.equal(store._view(store.v, n), tsd["state"][pid]["exp_avg_sq"]), n
+        fsd = fopt.state_dict()                                     # ours -> torch
+        assert [g_["params"] for g_ in fsd["param_groups"]] == [g_["params"] for g_ in tsd["param_groups"]]
+        assert sorted(fsd["state"]) == sorted(tsd["state"])
+        topt2 = torch.optim.AdamW([{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": 0.05}], lr=1e-3)
+        topt2.load_state_dict(fsd)
+        for pid, s in tsd["state"].items():
+            assert torch.equal(topt2.state_dict()["state"][pid]["exp_avg"], s["exp_avg"])
+        if cfg.simmim:
+            mt = [id(q) for q in no_decay + decay].index(id(params["mask_token"]))
+            assert mt not in fsd["state"] and mt in fsd["param_groups"][1]["params"]
+
+
+def test_feeder_batch_count_is_equal_on_every_rank():
+    """n % world != 0 must not give low ranks one more step per epoch (the collectives would pair up across
+    epoch boundaries).  Pure host arithmetic of CutoutFeeder's shard / batch count."""
+    import inspect
+    from sky_embeddings_amd import feeder
+    src = inspect.getsource(feeder.CutoutFeeder.__init__)
+    assert "len(self.indices) // self.world" in src
+    for n, world, B in ((1030, 4, 8), (257, 2, 128), (1000, 8, 125), (7, 8, 1)):
+        per_rank = [(n // world) // B for _ in range(world)]
+        longest = len(np.arange(n)[0::world])
+        assert len(set(per_rank)) == 1 and per_rank[0] * B <= n // world <= longest

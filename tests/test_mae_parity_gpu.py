@@ -131,14 +131,15 @@ def test_adamw_cosine_training_steps_match_reference():
     assert opt3.step_count == 4 and torch.equal(opt.store.m, m_before)
 
 
-def test_full_size_config_a_against_oracle():
-    """BASELINE config A (MAE ViT-B/16, 5x64x64, mask 0.75) at B=8: f32 mode vs the CPU oracle."""
+@pytest.mark.parametrize("B", [8, 256])
+def test_full_size_config_a_against_oracle(B):
+    """BASELINE config A (MAE ViT-B/16, 5x64x64, mask 0.75) vs the CPU oracle: B=8, and B=256 -- the batch bench.py times
+    (BASELINE configs[1]); f32 parity mode and the bf16 mode the benchmark runs."""
     from sky_embeddings_amd.engine import MAEEngine
     from sky_embeddings_amd.model_config import config_for
     cfg_o = mo.config_for("base", patch_size=16, in_chans=5, img_size=64, embed_dim=768)
     st = mo.init_state(cfg_o, seed=0)
     g = torch.Generator().manual_seed(1234)
-    B = 8
     imgs = torch.randn(B, 5, 64, 64, generator=g).clamp_(min=-3.0)
     noise = torch.rand(B, 16, generator=g)
     loss_o, pred_o, mask_o, _, _, grads_o = mo.loss_and_grads(st, imgs, cfg_o, 0.75, noise)

@@ -57,3 +57,40 @@ def test_sharded_bank_merge_equals_single_bank():
     assert torch.equal(out_i, whole_i) and torch.equal(out_s, whole_s)
     ref_s, ref_i = so.cosine_topk_np(q, x, k, None)
     assert np.array_equal(out_i.cpu().numpy(), ref_i)
+
+
+def test_full_size_bank_1m_x_768_against_oracle():
+    """BASELINE configs[3] at full size on one GPU: 1,000,000 x 768 fp32 bank, k = 100, weighted.  The Q = 16 launch
+    (bank-streaming kernel) and a 32-query sample of the Q = 10,000 launch (tiled many-query kernel, whatever stages it
+    runs) must equal oracle/topk_oracle.c bit for bit: scores and indices."""
+    from sky_embeddings_amd import search
+    N, D, k, Q = 1_000_000, 768, 100, 10_000
+    g = torch.Generator(device="cuda").manual_seed(2024)
+    bank = torch.empty(N, D, device="cuda")
+    for s0 in range(0, N, 50_000):
+        bank[s0:s0 + 50_000] = torch.randn(50_000, D, device="cuda", generator=g)
+    # exact duplicates of good rows far apart in the bank: ties must resolve to the lower index at full size too
+    bank[N - 3] = bank[17]
+    bank[N // 2 + 5] = bank[123_456]
+    queries = torch.randn(Q, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2025))
+    queries[5] = bank[17] + 0.01 * queries[5]          # a query whose best rows are the planted duplicates
+    queries[4242] = bank[123_456] + 0.01 * queries[4242]
+    w = 1.0 / (torch.rand(D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(7)) + 0.5) ** 2
+    w = w / w.sum()
+    pb = search.PreparedBank(bank, w)
+    s16, i16 = search.cosine_topk(queries[:16], pb, k)
+    sL, iL = search.cosine_topk(queries, pb, k)
+    torch.cuda.synchronize()
+    sample = np.unique(np.concatenate(([0, 5, 15, 16, 63, 64, 4242, Q - 1], np.random.default_rng(1).integers(0, Q, 24))))[:32]
+    x = bank.cpu().numpy()
+    qh = queries.cpu().numpy()
+    wh = w.cpu().numpy()
+    ref_s, ref_i = so.cosine_topk_np(qh[:16], x, k, wh)
+    assert np.array_equal(i16.cpu().numpy(), ref_i) and np.array_equal(s16.cpu().numpy(), ref_s)
+    assert ref_i[5, 0] == 17 and (N - 3) in ref_i[5, :2]
+    ref_s, ref_i = so.cosine_topk_np(qh[sample], x, k, wh)
+    got_i, got_s = iL.cpu().numpy()[sample], sL.cpu().numpy()[sample]
+    assert np.array_equal(got_i, ref_i), np.argwhere(got_i != ref_i)[:5]
+    assert np.array_equal(got_s, ref_s)
+    # and the two kernels agree with each other on the queries both served
+    assert torch.equal(iL[:16], i16) and torch.equal(sL[:16], s16)

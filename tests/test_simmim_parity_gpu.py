@@ -103,3 +103,84 @@ def test_simmim_graph_step_equals_eager_and_staged():
         results.append((float(loss), eng.store.g.clone(), eng.store.p.clone()))
     for r in results[1:]:
         assert r[0] == results[0][0] and torch.equal(r[1], results[0][1]) and torch.equal(r[2], results[0][2])
+
+
+def _mim19_batch(cfg, B, seed, ratio=0.6):
+    """Synthetic mim_19 batch: cutouts clipped at -3, a NaN band now and then, per-channel patch masks of
+    ceil(L * ratio) patches each (utils/dataloaders.py:197-219 at its maximum ratio)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, cfg.in_chans, cfg.img_size, cfg.img_size, generator=g).clamp_(min=-3.0)
+    x[:, 3][torch.rand(B, generator=g) < 0.1] = float("nan")
+    L, p = cfg.num_patches, cfg.patch_size
+    count = int(np.ceil(L * ratio))
+    m = torch.zeros(B, cfg.in_chans, L)
+    for b in range(B):
+        for c in range(cfg.in_chans):
+            m[b, c, torch.randperm(L, generator=g)[:count]] = 1
+    m = m.view(B, cfg.in_chans, cfg.grid, cfg.grid).repeat_interleave(p, 2).repeat_interleave(p, 3).contiguous()
+    return x, m, count
+
+
+def test_mim19_geometry_against_oracle():
+    """BASELINE configs[4] geometry (SimMIM head on 5x128x128 cutouts with 16x16 patches: L = 64, up = patch_size) at a
+    narrow width vs the CPU oracle: loss, prediction image, every gradient (f32 parity mode) and the bf16 mode."""
+    from oracle import mae_oracle as mo
+    kw = dict(img_size=128, patch_size=16, in_chans=5, embed_dim=64, depth=2, num_heads=4, norm_pix_loss=True, loss_fn="L1")
+    cfg_o = mo.config_for("simmim", **kw)
+    st = mo.init_state(cfg_o, seed=5)
+    x, m, _ = _mim19_batch(cfg_o, 6, seed=19)
+    x[1, 3] = float("nan")                       # one missing band (NaN -> learned fill value, excluded from the loss)
+    x[4, 0, 10:20, 30:50] = float("nan")
+    loss_o, pred_o, _, _, _, grads_o = mo.loss_and_grads(st, x, cfg_o, None, None, mask=m)
+    for dtype in (torch.float32, torch.bfloat16):
+        f32 = dtype == torch.float32
+        eng = make_engine(cfg_o, st, dtype)
+        loss, pred, _ = eng.forward_train(x.cuda(), mask=m.cuda())
+        eng.backward()
+        torch.cuda.synchronize()
+        assert pred.shape == (6, 5, 128, 128)
+        assert abs(float(loss) - float(loss_o)) <= (2e-5 if f32 else 1e-2) * abs(float(loss_o))
+        assert rel_err(pred.cpu().numpy(), pred_o.numpy()) < (2e-5 if f32 else 3e-2)
+        for k in eng.store.order:
+            r = grads_o[k].numpy()
+            gk = eng.store.grad(k).cpu().numpy().reshape(r.shape)
+            scale = max(float(np.abs(r).max()), 1e-6)
+            if f32:
+                assert float(np.abs(gk - r).max()) <= 2e-4 * scale, (k, float(np.abs(gk - r).max()), scale)
+            else:
+                assert rel_err(gk, r) < 8e-2 or float(np.abs(gk - r).max()) < 6e-2 * scale, k
+
+
+def test_mim19_full_size_step_properties():
+    """configs/mim_19.ini at full size (SimMIM ViT-Large/16, 5x128x128, B = 128, bf16): the ini builds the model the
+    BASELINE names, the loss is finite and close to the untrained level, every gradient is finite, the HIP-graph step
+    equals the eager step bit for bit, and the mask statistics are the generator's."""
+    import configparser, os
+    from sky_embeddings_amd.model_config import config_for
+    from sky_embeddings_amd.optim import CosineLR, FusedAdamW
+    from sky_embeddings_amd.simmim_engine import SimMIMEngine
+    from sky_embeddings_amd.train_step import TrainStep
+    ini = configparser.ConfigParser()
+    ini.read(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "mim_19.ini"))
+    a, t = ini["ARCHITECTURE"], ini["TRAINING"]
+    cfg = config_for(a["model_type"], img_size=int(a["img_size"]), patch_size=int(a["patch_size"]), in_chans=int(a["num_channels"]),
+                     embed_dim=int(a["embed_dim"]), norm_pix_loss=t.getboolean("norm_pix_loss"), loss_fn=t["loss_fn"])
+    assert (cfg.simmim, cfg.depth, cfg.num_heads, cfg.embed_dim, cfg.num_patches, cfg.patch_dim) == (True, 24, 16, 1024, 64, 1280)
+    B = int(t["batch_size"])
+    assert B == 128 and float(t["max_mask_ratio"]) == 0.6
+    x, m, count = _mim19_batch(cfg, B, seed=1)
+    assert count == 39 and int(m[:, :, ::16, ::16].sum()) == B * 5 * 39
+    results = []
+    for graph in (False, True):
+        eng = SimMIMEngine(cfg, device="cuda", compute_dtype=torch.bfloat16, seed=0)
+        opt = FusedAdamW(eng, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
+        step = TrainStep(eng, opt, CosineLR(opt, 1000), B, use_graph=graph)
+        losses = [float(step(x.cuda(), m.cuda())) for _ in range(3)]
+        torch.cuda.synchronize()
+        assert all(np.isfinite(losses)) and 0.3 < losses[0] < 3.0, losses      # L1 on norm-pix targets of an untrained net ~ 0.8
+        assert losses[2] < losses[0]
+        assert bool(torch.isfinite(eng.store.g).all())
+        results.append((losses, eng.store.p.clone()))
+        del step, opt, eng
+        torch.cuda.empty_cache()
+    assert results[0][0] == results[1][0] and torch.equal(results[0][1], results[1][1])
