@@ -90,14 +90,24 @@ typedef struct skyemb_gemm_args {
 
 int skyemb_gemm(const skyemb_gemm_args *args, void *stream);
 
-/* Grouped launch: n <= 32 independent bf16 problems with the same operand layouts run as ONE grid of 64x64 tiles (the
- * four weight-gradient GEMMs of a transformer block fill the chip together: no split-K, no reduce launch).
+/* Grouped launch: n <= 32 independent bf16 problems run as ONE grid (the four weight-gradient GEMMs of a transformer
+ * block fill the chip together: no split-K, no reduce launch).
  * skyemb_gemm_group_plan validates the problems and fills a HOST blob of skyemb_gemm_group_blob_bytes(n) bytes; the
  * caller copies it to device memory once (pointers inside are fixed) and replays skyemb_gemm_group_launch.
  * plan returns -1 (with skyemb_last_error set) when a problem is outside the subset: launch them singly then. */
+typedef struct skyemb_gemm_group_info {
+    int32_t total_blocks; /* grid size of the launch                                                          */
+    int32_t tile;         /* tile code the plan chose (BM * 1000 + BN): 64064, 128064 or 128128               */
+    int32_t class_mask;   /* operand-layout classes present: 1 KC.KC, 2 KC.RC (dgrad), 4 RC.RC (wgrad)        */
+    int32_t reserved;
+} skyemb_gemm_group_info;
 int64_t skyemb_gemm_group_blob_bytes(int n);
-int skyemb_gemm_group_plan(const skyemb_gemm_args *args, int n, void *blob_host, int64_t blob_bytes, int32_t *total_blocks);
-int skyemb_gemm_group_launch(const void *blob_dev, int total_blocks, int a_layout, int b_layout, void *stream);
+/* tile = 0: chosen from the total tile count.  The problems share ONE tile shape and may mix the data-gradient
+ * (KC.RC) and weight-gradient (RC.RC) layout classes: a Linear's dX and dW read the same dY and do not depend on
+ * each other, so one launch computes both. */
+int skyemb_gemm_group_plan(const skyemb_gemm_args *args, int n, int tile, void *blob_host, int64_t blob_bytes,
+                           skyemb_gemm_group_info *info);
+int skyemb_gemm_group_launch(const void *blob_dev, const skyemb_gemm_group_info *info, void *stream);
 
 /* column sums: out[n] = sum_m X[m,n]; X is `dtype` (bias gradients) or fp32 partials
  * (LayerNorm dgamma/dbeta second stage).  Replaces autograd's bias-gradient reductions. */

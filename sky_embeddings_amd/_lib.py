@@ -45,14 +45,18 @@ class GemmArgs(ctypes.Structure):
     ]
 
 
+class GemmGroupInfo(ctypes.Structure):
+    _fields_ = [("total_blocks", c_i32), ("tile", c_i32), ("class_mask", c_i32), ("reserved", c_i32)]
+
+
 # name -> (restype, argtypes); must list every symbol include/skyemb.h declares (tests check this)
 PROTOTYPES = {
     "skyemb_last_error": (ctypes.c_char_p, []),
     "skyemb_version": (c_i32, []),
     "skyemb_gemm": (c_i32, [ctypes.POINTER(GemmArgs), c_vp]),
     "skyemb_gemm_group_blob_bytes": (c_i64, [c_i32]),
-    "skyemb_gemm_group_plan": (c_i32, [ctypes.POINTER(GemmArgs), c_i32, c_vp, c_i64, ctypes.POINTER(c_i32)]),
-    "skyemb_gemm_group_launch": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "skyemb_gemm_group_plan": (c_i32, [ctypes.POINTER(GemmArgs), c_i32, c_i32, c_vp, c_i64, ctypes.POINTER(GemmGroupInfo)]),
+    "skyemb_gemm_group_launch": (c_i32, [c_vp, ctypes.POINTER(GemmGroupInfo), c_vp]),
     "skyemb_colsum": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "skyemb_random_mask_from_noise": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "skyemb_patch_gather": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32,

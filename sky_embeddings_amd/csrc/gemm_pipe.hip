@@ -58,6 +58,13 @@ __device__ __forceinline__ float dgelu_f(float x) {
     return fmaf(x * 0.39894228040143267794f, gauss, cdf);
 }
 
+__device__ __forceinline__ void store8(bf16_t *p, const float (&v)[8]) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+    *(bf16x8 *)p = o;
+}
+
 // ---- stage issue -----------------------------------------------------------------------------
 // KC operand: R rows x 64 k.  One wave-instruction = 8 rows x 128 B.
 template <int R, int NW>
@@ -75,10 +82,11 @@ __device__ __forceinline__ void issue_kc(const bf16_t *__restrict__ X, int64_t l
 }
 // XOR applied to the 16-byte chunk index of k-row k in an RC image [64 k][R rows]: makes the 8 k-rows
 // that one half-wave of a ds_read_b64_tr_b16 touches land on disjoint bank ranges (checked
-// exhaustively with the bank rules of MI355X_MICROARCH.md: conflict-free for R = 128 and R = 64).
+// exhaustively with the bank rules of MI355X_MICROARCH.md: conflict-free for R = 64, 128 and 256 -- a 512-byte k-row
+// is two 256-byte bank rows, the XOR stays inside each).
 template <int R>
 __device__ __forceinline__ int rc_swz(int k) {
-    return R == 128 ? (((k & 3) << 1) | (((k >> 3) & 1) << 3)) : ((((k >> 1) & 1) << 1) | (((k >> 3) & 1) << 2));
+    return R >= 128 ? (((k & 3) << 1) | (((k >> 3) & 1) << 3)) : ((((k >> 1) & 1) << 1) | (((k >> 3) & 1) << 2));
 }
 // RC operand: 64 k-rows x R rows (R*2 bytes per k-row).  One wave-instruction = 1 KiB = 512/R k-rows.
 template <int R, int NW>
@@ -137,23 +145,24 @@ __device__ __forceinline__ void wait_stages(int rem) {
     }
 }
 
-// NSTAGE-deep LDS ring: NSTAGE-1 k-tiles are in flight ahead of the one being consumed.  3 stages
-// when several workgroups share a CU, 6 when the launch has about one workgroup per CU (its loads
-// must cover the L2 latency alone).
-// NW waves per workgroup: 4 (2x2, 64x64 tiles) or 8 (4x2, 128x128 tiles: 64 FLOP/byte and two waves
-// per SIMD even when the launch has a single workgroup per CU).
+// NSTAGE-deep LDS ring: NSTAGE-1 k-tiles are in flight ahead of the one being consumed.
+// WM x WN waves per workgroup, each owning a (BM/WM) x (BN/WN) block of the tile: 2x2 on 64x64 (32x32 per wave),
+// 4x2 on 128x64, 2x2 / 4x2 on 128x128 (64x64 / 32x64 per wave), 4x2 on 256x128 (64x64 per wave).  A wave tile of
+// 64x64 reads 8 fragments for 16 MFMAs (32x32: 4 for 4), i.e. half the LDS read traffic per FLOP.
 // One workgroup's work: tile `tb` of `ntiles` (XCD-aware order), k-range `split` of `S`.
-template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int NW>
+template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int WM, int WN>
 __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const int tb, const int ntiles, const int split,
                                                const int S, char *smem) {
-    constexpr int WGM = NW / 2;                         // waves along M (x 2 along N)
-    constexpr int TM = BM / WGM / 16, TN = BN / 2 / 16;
+    constexpr int NW = WM * WN;
+    constexpr int SM = BM / WM, SN = BN / WN;           // rows / columns of the tile owned by one wave
+    constexpr int TM = SM / 16, TN = SN / 16;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
     constexpr int NI = (BM + BN) / 8 / NW;              // LDS-DMA instructions per wave per stage
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && SM % 16 == 0 && SN % 16 == 0, "tile / wave grid mismatch");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int tiles_n = (g.N + BN - 1) / BN;
     int wg;
     {   // XCD-aware tile order (see gemm.hip)
@@ -212,10 +221,10 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
             bf16x8 fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                fa[i] = A_KC ? frag_kc(sa, wm * (BM / WGM) + i * 16, kk, lane) : frag_rc<BM>(sa, wm * (BM / WGM) + i * 16, kk, lane);
+                fa[i] = A_KC ? frag_kc(sa, wm * SM + i * 16, kk, lane) : frag_rc<BM>(sa, wm * SM + i * 16, kk, lane);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                fb[j] = B_KC ? frag_kc(sb, wn * (BN / 2) + j * 16, kk, lane) : frag_rc<BN>(sb, wn * (BN / 2) + j * 16, kk, lane);
+                fb[j] = B_KC ? frag_kc(sb, wn * SN + j * 16, kk, lane) : frag_rc<BN>(sb, wn * SN + j * 16, kk, lane);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -228,97 +237,96 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
         }
         buf = buf + 1 < NSTAGE ? buf + 1 : 0;
     }
-    if (S > 1) {
-        // split-K: raw partial tile (and partial column sums) to the workspace; splitk_reduce finishes.
-        // (A fused variant -- last-arriving split reduces behind __threadfence() -- was measured: the device-scope
-        // release is an L2 write-back on this multi-XCD part and costs ~100 us per launch.)
-        float *slab = (float *)g.ws + (int64_t)split * g.M * g.N;
-        float *cs = (float *)g.ws + (int64_t)S * g.M * g.N + (int64_t)split * g.M;
-        if (!A_KC && do_colsum && lane < 16) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int m = m0 + wm * (BM / WGM) + i * 16 + lane;
-                if (m < g.M) cs[m] = cacc[i][0];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * (BM / WGM) + i * 16 + (lane & 15);
-            if (m >= g.M) continue;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * (BN / 2) + j * 16 + 4 * (lane >> 4);
-                if (n >= g.N) continue;
-                *(float4 *)(slab + (int64_t)m * g.N + n) =
-                    make_float4(acc[i][j][0] * g.alpha, acc[i][j][1] * g.alpha, acc[i][j][2] * g.alpha, acc[i][j][3] * g.alpha);
-            }
-        }
-        return;
-    }
+    // ---- epilogue ------------------------------------------------------------------------------------------------
+    // The accumulators leave the MFMA with one ROW per lane (16 rows per wave-instruction): stored as they stand, a
+    // wave-instruction scatters 64 pieces of 8-16 bytes over 16 rows, and the launch ends in a store phase at ~1.3 TB/s
+    // (measured: the K -> 0 intercept of the [4352, 2048] bf16 launch was 13 us for 17.8 MB).  So the tile is transposed
+    // through LDS (the ring is free now) and written in pieces of 8 consecutive columns per lane, consecutive lanes on
+    // consecutive pieces of a row: every wave-instruction writes whole 128-byte lines.  The fused inputs (bias, table
+    // rows, residual, dGELU operand) are read in the same lane order.
+    float *cs_out = S > 1 ? (float *)g.ws + (int64_t)S * g.M * g.N + (int64_t)split * g.M : g.colsum_a;
     if (!A_KC && do_colsum && lane < 16) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * (BM / WGM) + i * 16 + lane;
-            if (m < g.M) g.colsum_a[m] = cacc[i][0];
+            const int m = m0 + wm * SM + i * 16 + lane;
+            if (m < g.M) cs_out[m] = cacc[i][0];
         }
     }
-
-    // ---- epilogue: lane owns row m = ... + (lane&15) and 4 consecutive columns n4 + (0..3) -------
+    constexpr int PITCH = BN * 4 + 16;                   // bytes per tile row in LDS (+16: conflict-free b128 writes)
+    __builtin_amdgcn_s_barrier();                        // every wave is done with the fragments of the last stage
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int r = wm * SM + i * 16 + (lane & 15), c = wn * SN + j * 16 + 4 * (lane >> 4);
+            *(f32x4 *)(smem + r * PITCH + c * 4) = acc[i][j] * g.alpha;
+        }
+    __syncthreads();
+    constexpr int PPR = BN / 8, PIECES = BM * PPR;       // pieces (8 columns) per row / per tile
     bf16_t *out = (bf16_t *)g.out;
     bf16_t *out2 = (bf16_t *)g.out2;
     const bf16_t *aux = (const bf16_t *)g.aux;
+    float *slab = S > 1 ? (float *)g.ws + (int64_t)split * g.M * g.N : nullptr;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * (BM / WGM) + i * 16 + (lane & 15);
-        if (m >= g.M) continue;
+    for (int p = tid; p < PIECES; p += NW * 64) {
+        const int r = p / PPR, c = (p % PPR) * 8;
+        const int m = m0 + r, n = n0 + c;
+        if (m >= g.M || n >= g.N) continue;
+        const float4 lo = *(const float4 *)(smem + r * PITCH + c * 4), hi = *(const float4 *)(smem + r * PITCH + c * 4 + 16);
+        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#ifdef SKY_NOSTORE   // experiment build: everything but the global traffic of the epilogue
+        asm volatile("" ::"v"(v[0]), "v"(v[7]));
+        continue;
+#endif
+        if (S > 1) {   // split-K: raw partial tile to the workspace; splitk_reduce_kernel finishes (full epilogue there)
+            *(float4 *)(slab + (int64_t)m * g.N + n) = lo;
+            *(float4 *)(slab + (int64_t)m * g.N + n + 4) = hi;
+            continue;
+        }
         const int orow = g.dst_row ? g.dst_row[m] : m;
         if (orow < 0) continue;
-        const float *trow = g.table ? g.table + (int64_t)g.tab_row[m] * g.ldt : nullptr;
+        auto add8 = [&](const float *src) {
+            const float4 a = *(const float4 *)src, b = *(const float4 *)(src + 4);
+            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+        };
+        if (g.bias) add8(g.bias + n);
+        if (g.table) add8(g.table + (int64_t)g.tab_row[m] * g.ldt + n);
+        if (g.resid) add8(g.resid + (int64_t)orow * g.ldr + n);
+        if (g.act == SKYEMB_ACT_GELU) {
+            if (out2) store8(out2 + (int64_t)orow * g.ldo2 + n, v);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (BN / 2) + j * 16 + 4 * (lane >> 4);
-            if (n >= g.N) continue;
-            float v[4] = {acc[i][j][0] * g.alpha, acc[i][j][1] * g.alpha, acc[i][j][2] * g.alpha, acc[i][j][3] * g.alpha};
-            if (g.bias) {
-                const float4 b = *(const float4 *)(g.bias + n);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            }
-            if (trow) {
-                const float4 t = *(const float4 *)(trow + n);
-                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-            }
-            if (g.resid) {
-                const float4 t = *(const float4 *)(g.resid + (int64_t)orow * g.ldr + n);
-                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-            }
-            if (g.act == SKYEMB_ACT_GELU) {
-                if (out2) store4<bf16_t>(out2 + (int64_t)orow * g.ldo2 + n, v[0], v[1], v[2], v[3]);
-                v[0] = gelu_f(v[0]); v[1] = gelu_f(v[1]); v[2] = gelu_f(v[2]); v[3] = gelu_f(v[3]);
-            } else if (g.act == SKYEMB_ACT_DGELU) {
-                const float4 a = load4<bf16_t>(aux + (int64_t)m * g.ldaux + n);
-                v[0] *= dgelu_f(a.x); v[1] *= dgelu_f(a.y); v[2] *= dgelu_f(a.z); v[3] *= dgelu_f(a.w);
-            }
-            if (g.out_f32) *(float4 *)(g.out_f32 + (int64_t)orow * g.ldo32 + n) = make_float4(v[0], v[1], v[2], v[3]);
-            if (out) store4<bf16_t>(out + (int64_t)orow * g.ldo + n, v[0], v[1], v[2], v[3]);
+            for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+        } else if (g.act == SKYEMB_ACT_DGELU) {
+            const bf16x8 a = *(const bf16x8 *)(aux + (int64_t)m * g.ldaux + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= dgelu_f((float)a[e]);
         }
+        if (g.out_f32) {
+            *(float4 *)(g.out_f32 + (int64_t)orow * g.ldo32 + n) = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4 *)(g.out_f32 + (int64_t)orow * g.ldo32 + n + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        if (out) store8(out + (int64_t)orow * g.ldo + n, v);
     }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int NW>
-__global__ __launch_bounds__(NW * 64) void gemm_pipe_kernel(const skyemb_gemm_args g) {
+template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(const skyemb_gemm_args g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int S = g.split_k > 1 ? g.split_k : 1;           // split-K factor (host-resolved)
     const int ntiles = gridDim.x / S;
     const int split = blockIdx.x / ntiles;
-    gemm_pipe_body<BM, BN, A_KC, B_KC, NSTAGE, NW>(g, blockIdx.x - split * ntiles, ntiles, split, S, smem);
+    gemm_pipe_body<BM, BN, A_KC, B_KC, NSTAGE, WM, WN>(g, blockIdx.x - split * ntiles, ntiles, split, S, smem);
 }
 
-// Grouped launch: several independent problems of one operand-layout class in ONE grid (the four weight-gradient
-// GEMMs of a transformer block: together they fill the chip, so none of them needs split-K or its reduce launch).
+// Grouped launch: several independent problems in ONE grid (the four weight-gradient GEMMs of a transformer block,
+// optionally with the data-gradient GEMM they share an operand with: together they fill the chip, so none of them needs
+// split-K or its reduce launch, and a small dgrad no longer leaves most CUs idle).  One tile shape per launch; the
+// problems may be of different operand-layout classes (CLASSES = bit mask of the classes compiled into this instance:
+// 1 KC.KC, 2 KC.RC, 4 RC.RC, 8 RC.KC).
 // blob = [int32 n, total_blocks, 6 x pad, start[0..n] (multiples of 8), ...pad to 256 B][n x skyemb_gemm_args]
 constexpr int GROUP_HEADER_BYTES = 256, GROUP_MAX = 32;
-template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int NW>
-__global__ __launch_bounds__(NW * 64) void gemm_pipe_group_kernel(const char *__restrict__ blob) {
+template <int BM, int BN, int NSTAGE, int WM, int WN, int CLASSES>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_group_kernel(const char *__restrict__ blob) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int *hdr = (const int *)blob;
     const int n = hdr[0];
@@ -328,7 +336,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_pipe_group_kernel(const char *__
     const int tb = blockIdx.x - hdr[8 + p];
     const int ntiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     if (tb >= ntiles) return;                             // padding up to the next multiple of 8 (keeps tb & 7 == XCD)
-    gemm_pipe_body<BM, BN, A_KC, B_KC, NSTAGE, NW>(g, tb, ntiles, 0, 1, smem);
+    const bool a = g.a_layout == SKYEMB_KC, b = g.b_layout == SKYEMB_KC;   // workgroup-uniform
+    if constexpr (CLASSES & 1) if (a && b) return gemm_pipe_body<BM, BN, true, true, NSTAGE, WM, WN>(g, tb, ntiles, 0, 1, smem);
+    if constexpr (CLASSES & 2) if (a && !b) return gemm_pipe_body<BM, BN, true, false, NSTAGE, WM, WN>(g, tb, ntiles, 0, 1, smem);
+    if constexpr (CLASSES & 4) if (!a && !b) return gemm_pipe_body<BM, BN, false, false, NSTAGE, WM, WN>(g, tb, ntiles, 0, 1, smem);
+    if constexpr (CLASSES & 8) if (!a && b) return gemm_pipe_body<BM, BN, false, true, NSTAGE, WM, WN>(g, tb, ntiles, 0, 1, smem);
 }
 
 // second launch of a split-K GEMM: v = sum_s slab[s][m][n] (fixed order, alpha already applied), then
@@ -382,11 +394,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const skyemb_gemm_ar
     }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int NW = (BM == 128 ? 8 : 4)>
+template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int WM, int WN>
 int launch_n(const skyemb_gemm_args &g, hipStream_t st) {
-    constexpr size_t smem = (size_t)NSTAGE * (BM + BN) * BK * 2;
+    constexpr size_t ring = (size_t)NSTAGE * (BM + BN) * BK * 2, image = (size_t)BM * (BN * 4 + 16);   // k-loop ring / epilogue tile
+    constexpr size_t smem = ring > image ? ring : image;
     static bool attr_set = false;
-    auto kern = gemm_pipe_kernel<BM, BN, A_KC, B_KC, NSTAGE, NW>;
+    auto kern = gemm_pipe_kernel<BM, BN, A_KC, B_KC, NSTAGE, WM, WN>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) {
@@ -397,7 +410,7 @@ int launch_n(const skyemb_gemm_args &g, hipStream_t st) {
     }
     const int64_t tiles = ceil_div64(g.M, BM) * ceil_div64(g.N, BN);
     const int S = g.split_k > 1 ? g.split_k : 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * S)), dim3(NW * 64), smem, st, g);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * S)), dim3(WM * WN * 64), smem, st, g);
     if (S > 1) {
         int64_t blocks = ceil_div64((int64_t)g.M * g.N / 4, 256);
         if (blocks > 1024) blocks = 1024;
@@ -407,27 +420,42 @@ int launch_n(const skyemb_gemm_args &g, hipStream_t st) {
     return 0;
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC>
-int launch(const skyemb_gemm_args &g, hipStream_t st) {
-    // (a 6-deep ring for launches with ~1 workgroup per CU was measured: no gain -- those launches are
-    // bound by the per-wave issue chain, not by loads in flight)
-    static const int stages = []() { const char *e = getenv("SKYEMB_GEMM_STAGES"); return e ? atoi(e) : 3; }();
-    if (stages == 2) return launch_n<BM, BN, A_KC, B_KC, 2>(g, st);
-    if (stages == 4) return launch_n<BM, BN, A_KC, B_KC, 4>(g, st);
-    if constexpr (BM == 128 && BN == 128) {
-        if (stages == 44) return launch_n<BM, BN, A_KC, B_KC, 4, 4>(g, st);   // experiment: 4 waves of 64x64, 128 KB ring
-        if (stages == 34) return launch_n<BM, BN, A_KC, B_KC, 3, 4>(g, st);
-    }
-    return launch_n<BM, BN, A_KC, B_KC, 3>(g, st);
-}
-
-template <int BM, int BN>
+template <int BM, int BN, int NSTAGE, int WM, int WN>
 int dispatch(const skyemb_gemm_args &g, hipStream_t st) {
     const bool a = g.a_layout == SKYEMB_KC, b = g.b_layout == SKYEMB_KC;
-    if (a && b) return launch<BM, BN, true, true>(g, st);
-    if (a && !b) return launch<BM, BN, true, false>(g, st);
-    if (!a && !b) return launch<BM, BN, false, false>(g, st);
-    return launch<BM, BN, false, true>(g, st);
+    if (a && b) return launch_n<BM, BN, true, true, NSTAGE, WM, WN>(g, st);
+    if (a && !b) return launch_n<BM, BN, true, false, NSTAGE, WM, WN>(g, st);
+    if (!a && !b) return launch_n<BM, BN, false, false, NSTAGE, WM, WN>(g, st);
+    return launch_n<BM, BN, false, true, NSTAGE, WM, WN>(g, st);
+}
+
+// Launch shapes.  code = variant * 1,000,000 + BM * 1000 + BN; X(variant, BM, BN, NSTAGE, WM, WN).
+// LDS per workgroup = NSTAGE * (BM + BN) * 128 B, which fixes the workgroups per CU (160 KiB): 64x64 x3 = 48 KB -> 3;
+// 128x64 x3 = 72 KB -> 2; 128x128 x3 = 96 KB -> 1, x2 = 64 KB -> 2; 256x128 x3 = 144 KB -> 1.
+#define SKY_GEMM_PRODUCT_VARIANTS(X) \
+    X(0, 64, 64, 3, 2, 2)            \
+    X(0, 128, 64, 3, 4, 2)           \
+    X(0, 128, 128, 3, 4, 2)
+#ifdef SKY_GEMM_LAB   // experiment builds (tools/ubench/gemm_lab.hip): every shape under study
+#define SKY_GEMM_VARIANTS(X) SKY_GEMM_PRODUCT_VARIANTS(X) SKY_GEMM_LAB_VARIANTS(X)
+#else
+#define SKY_GEMM_VARIANTS(X) SKY_GEMM_PRODUCT_VARIANTS(X)
+#endif
+
+int dispatch_code(int code, const skyemb_gemm_args &g, hipStream_t st) {
+#define X(V, BM_, BN_, NS, WM_, WN_) \
+    if (code == V * 1000000 + BM_ * 1000 + BN_) return dispatch<BM_, BN_, NS, WM_, WN_>(g, st);
+    SKY_GEMM_VARIANTS(X)
+#undef X
+    skyemb_set_error("skyemb_gemm(pipe): unknown tile code %d", code);
+    return 1;
+}
+void tile_dims(int code, int &bm, int &bn) {
+    bm = (code % 1000000) / 1000;
+    bn = code % 1000;
+}
+int canonical_tile(int tile) {   // legacy codes of the round-1 ABI
+    return tile == 64 ? 64064 : tile == 128 ? 128128 : tile == 12864 ? 128064 : tile;
 }
 
 struct TunedGemm {
@@ -442,12 +470,15 @@ const TunedGemm kTuned[] = {
 // returns -1 when the problem is outside the fast-path subset (caller falls back to gemm.hip)
 int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
     skyemb_gemm_args g = g_in;
-    if (g.dtype != SKYEMB_BF16 || g.K % BK != 0 || g.N % 4 != 0) return -1;
+    if (g.dtype != SKYEMB_BF16 || g.K % BK != 0 || g.N % 8 != 0) return -1;
     // alignment of the vectorised epilogue operands
-    if ((g.ldo32 % 4) || (g.ldo % 4) || (g.ldo2 % 4) || (g.ldr % 4) || (g.ldt % 4) || (g.ldaux % 4)) return -1;
+    if ((g.ldo32 % 4) || (g.ldo % 8) || (g.ldo2 % 8) || (g.ldr % 4) || (g.ldt % 4) || (g.ldaux % 8)) return -1;
+    if (!aligned16(g.out) || !aligned16(g.out2) || !aligned16(g.aux) || !aligned16(g.out_f32) || !aligned16(g.resid) ||
+        !aligned16(g.bias) || !aligned16(g.table))
+        return -1;
     if (g.a_layout == SKYEMB_KC ? g.M < 1 : (g.M % 8 != 0 || g.M < 8)) return -1;
     if (g.b_layout == SKYEMB_KC ? g.N < 1 : (g.N % 8 != 0 || g.N < 8)) return -1;
-    int tile = g.tile;
+    int tile = canonical_tile(g.tile);
     int want_split = g.split_k;
     if (tile == 0 && want_split == 0) {
         // launch shapes tuned on hardware (tools/gemm_tune.py); anything else goes through the heuristic below
@@ -456,24 +487,26 @@ int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
             for (const TunedGemm *t = kTuned; t->M; ++t)
                 if (t->M == g.M && t->N == g.N && t->K == g.K && t->a_kc == (g.a_layout == SKYEMB_KC) &&
                     t->b_kc == (g.b_layout == SKYEMB_KC) && (t->split == 1 || g.ws)) {
-                    tile = t->tile;
+                    tile = canonical_tile(t->tile);
                     want_split = t->split;
                     break;
                 }
     }
     if (tile == 0) {
         static const int env_tile = []() { const char *e = getenv("SKYEMB_GEMM_TILE"); return e ? atoi(e) : 0; }();   // experiments
-        tile = env_tile;
+        tile = canonical_tile(env_tile);
     }
     // measured: the 64x64 tile (3 workgroups per CU) is the best all-round choice at ViT-B sizes; launches with several
     // full rounds of 128x64 tiles (ViT-L token counts) gain ~5 % from the larger tile's lower L2->LDS traffic
-    if (tile == 0 && ceil_div64(g.M, 128) * ceil_div64(g.N, 64) >= 2048) tile = 12864;
-    if (tile == 0) tile = 64;
+    if (tile == 0 && ceil_div64(g.M, 128) * ceil_div64(g.N, 64) >= 2048) tile = 128064;
+    if (tile == 0) tile = 64064;
+    int bm, bn;
+    tile_dims(tile, bm, bn);
     // split-K (deterministic slabs + a reduce launch that applies the epilogue) for launches with too few tiles to
     // fill the chip.  The reduce launch costs ~5 us, so a split must leave >= 10-12 k-steps per workgroup.
     int S = 1;
     if (g.ws && want_split != 1) {
-        const int64_t tiles = ceil_div64(g.M, tile == 12864 ? 128 : tile) * ceil_div64(g.N, tile == 12864 ? 64 : tile);
+        const int64_t tiles = ceil_div64(g.M, bm) * ceil_div64(g.N, bn);
         const int KT = g.K / BK;
         const int min_steps = (g.a_layout == SKYEMB_RC && g.b_layout == SKYEMB_RC) ? 10 : 12;
         S = want_split > 1 ? want_split : (int)(768 / tiles);
@@ -484,56 +517,108 @@ int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
         if (S < 1) S = 1;
     }
     g.split_k = S;
-    if (tile == 12864) return dispatch<128, 64>(g, st);   // experimental 128x64 tile (8 waves)
-    return tile == 128 ? dispatch<128, 128>(g, st) : dispatch<64, 64>(g, st);
+    return dispatch_code(tile, g, st);
 }
 
 // ---- grouped launch (see gemm_pipe_group_kernel) -------------------------------------------------------
 extern "C" int64_t skyemb_gemm_group_blob_bytes(int n) { return GROUP_HEADER_BYTES + (int64_t)n * sizeof(skyemb_gemm_args); }
 
-extern "C" int skyemb_gemm_group_plan(const skyemb_gemm_args *args, int n, void *blob_host, int64_t blob_bytes,
-                                      int32_t *total_blocks) {
-    SKY_CHECK_ARG(args && blob_host && total_blocks && n >= 1 && n <= GROUP_MAX, "skyemb_gemm_group_plan: 1..%d problems", GROUP_MAX);
+static int class_bit(const skyemb_gemm_args &g) {
+    const bool a = g.a_layout == SKYEMB_KC, b = g.b_layout == SKYEMB_KC;
+    return a ? (b ? 1 : 2) : (b ? 8 : 4);
+}
+
+extern "C" int skyemb_gemm_group_plan(const skyemb_gemm_args *args, int n, int tile, void *blob_host, int64_t blob_bytes,
+                                      skyemb_gemm_group_info *info) {
+    SKY_CHECK_ARG(args && blob_host && info && n >= 1 && n <= GROUP_MAX, "skyemb_gemm_group_plan: 1..%d problems", GROUP_MAX);
     SKY_CHECK_ARG(blob_bytes >= skyemb_gemm_group_blob_bytes(n), "skyemb_gemm_group_plan: blob too small");
+    tile = canonical_tile(tile);
+    if (tile == 0) {
+        // default: 128x64 tiles once they still give every CU two workgroups' worth of tiles, else 64x64
+        int64_t t12864 = 0;
+        for (int i = 0; i < n; ++i) t12864 += ceil_div64(args[i].M, 128) * ceil_div64(args[i].N, 64);
+        tile = t12864 >= 320 ? 128064 : 64064;
+    }
+    SKY_CHECK_ARG(tile == 64064 || tile == 128064 || tile == 128128, "skyemb_gemm_group_plan: tile %d is not built for grouped launches", tile);
+    int bm, bn;
+    tile_dims(tile, bm, bn);
     int *hdr = (int *)blob_host;
     memset(blob_host, 0, GROUP_HEADER_BYTES);
     skyemb_gemm_args *out = (skyemb_gemm_args *)((char *)blob_host + GROUP_HEADER_BYTES);
-    int start = 0;
+    int start = 0, mask = 0;
     for (int i = 0; i < n; ++i) {
         skyemb_gemm_args g = args[i];
-        const bool ok = g.dtype == SKYEMB_BF16 && g.K % BK == 0 && g.K >= BK && g.N % 4 == 0 && g.a_layout == args[0].a_layout &&
-                        g.b_layout == args[0].b_layout && !(g.ldo32 % 4) && !(g.ldo % 4) && !(g.ldo2 % 4) && !(g.ldr % 4) &&
-                        !(g.ldt % 4) && !(g.ldaux % 4) && (g.a_layout == SKYEMB_KC ? g.M >= 1 : (g.M % 8 == 0 && g.M >= 8)) &&
-                        (g.b_layout == SKYEMB_KC ? g.N >= 1 : (g.N % 8 == 0 && g.N >= 8));
+        const bool ok = g.dtype == SKYEMB_BF16 && g.K % BK == 0 && g.K >= BK && g.N % 8 == 0 && !(g.ldo32 % 4) && !(g.ldo % 8) &&
+                        !(g.ldo2 % 8) && !(g.ldr % 4) && !(g.ldt % 4) && !(g.ldaux % 8) &&
+                        (g.a_layout == SKYEMB_KC ? g.M >= 1 : (g.M % 8 == 0 && g.M >= 8)) &&
+                        (g.b_layout == SKYEMB_KC ? g.N >= 1 : (g.N % 8 == 0 && g.N >= 8)) && aligned16(g.A) && aligned16(g.B) &&
+                        aligned16(g.out) && aligned16(g.out2) && aligned16(g.aux) && aligned16(g.out_f32) && aligned16(g.resid) &&
+                        aligned16(g.bias) && aligned16(g.table) && (g.out || g.out_f32);
         if (!ok) {
-            skyemb_set_error("skyemb_gemm_group_plan: problem %d is outside the pipelined bf16 subset or mixes operand layouts", i);
+            skyemb_set_error("skyemb_gemm_group_plan: problem %d is outside the pipelined bf16 subset", i);
             return -1;
         }
         g.split_k = 1;
-        g.tile = 64;
+        g.tile = tile;
         out[i] = g;
+        mask |= class_bit(g);
         hdr[8 + i] = start;
-        const int64_t tiles = ceil_div64(g.M, 64) * ceil_div64(g.N, 64);
+        const int64_t tiles = ceil_div64(g.M, bm) * ceil_div64(g.N, bn);
         start += (int)((tiles + 7) / 8 * 8);
+    }
+    // instances are built for: one class alone, and data-gradient (KC.RC) + weight-gradient (RC.RC) together
+    if (!(mask == 1 || mask == 2 || mask == 4 || mask == 6)) {
+        skyemb_set_error("skyemb_gemm_group_plan: operand-layout mix %d is not built (single class, or KC.RC with RC.RC)", mask);
+        return -1;
     }
     hdr[8 + n] = start;
     hdr[0] = n;
     hdr[1] = start;
-    *total_blocks = start;
+    info->total_blocks = start;
+    info->tile = tile;
+    info->class_mask = mask;
+    info->reserved = 0;
     return 0;
 }
 
-extern "C" int skyemb_gemm_group_launch(const void *blob_dev, int total_blocks, int a_layout, int b_layout, void *stream) {
-    SKY_CHECK_ARG(blob_dev && total_blocks > 0, "skyemb_gemm_group_launch: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
-    constexpr size_t smem = (size_t)3 * (64 + 64) * BK * 2;
-    const bool a = a_layout == SKYEMB_KC, b = b_layout == SKYEMB_KC;
-#define GROUP_LAUNCH(AK, BKC) hipLaunchKernelGGL((gemm_pipe_group_kernel<64, 64, AK, BKC, 3, 4>), dim3((unsigned)total_blocks), dim3(256), smem, st, (const char *)blob_dev)
-    if (a && b) GROUP_LAUNCH(true, true);
-    else if (a && !b) GROUP_LAUNCH(true, false);
-    else if (!a && !b) GROUP_LAUNCH(false, false);
-    else GROUP_LAUNCH(false, true);
-#undef GROUP_LAUNCH
+template <int BM, int BN, int NSTAGE, int WM, int WN, int CLASSES>
+static int group_launch_n(const void *blob_dev, int total_blocks, hipStream_t st) {
+    constexpr size_t ring = (size_t)NSTAGE * (BM + BN) * BK * 2, image = (size_t)BM * (BN * 4 + 16);
+    constexpr size_t smem = ring > image ? ring : image;
+    static bool attr_set = false;
+    auto kern = gemm_pipe_group_kernel<BM, BN, NSTAGE, WM, WN, CLASSES>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) {
+            skyemb_set_error("skyemb_gemm_group_launch: hipFuncSetAttribute(%zu B LDS): %s", smem, hipGetErrorString(e));
+            return 2;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)total_blocks), dim3(WM * WN * 64), smem, st, (const char *)blob_dev);
     SKY_LAUNCH_CHECK("skyemb_gemm_group_launch");
     return 0;
+}
+template <int BM, int BN, int NSTAGE, int WM, int WN>
+static int group_launch_classes(const void *blob_dev, int total_blocks, int mask, hipStream_t st) {
+    switch (mask) {
+        case 1: return group_launch_n<BM, BN, NSTAGE, WM, WN, 1>(blob_dev, total_blocks, st);
+        case 2: return group_launch_n<BM, BN, NSTAGE, WM, WN, 2>(blob_dev, total_blocks, st);
+        case 4: return group_launch_n<BM, BN, NSTAGE, WM, WN, 4>(blob_dev, total_blocks, st);
+        case 6: return group_launch_n<BM, BN, NSTAGE, WM, WN, 6>(blob_dev, total_blocks, st);
+    }
+    skyemb_set_error("skyemb_gemm_group_launch: class mask %d not built", mask);
+    return 1;
+}
+
+extern "C" int skyemb_gemm_group_launch(const void *blob_dev, const skyemb_gemm_group_info *info, void *stream) {
+    SKY_CHECK_ARG(blob_dev && info && info->total_blocks > 0, "skyemb_gemm_group_launch: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    switch (info->tile) {
+        case 64064: return group_launch_classes<64, 64, 3, 2, 2>(blob_dev, info->total_blocks, info->class_mask, st);
+        case 128064: return group_launch_classes<128, 64, 3, 4, 2>(blob_dev, info->total_blocks, info->class_mask, st);
+        case 128128: return group_launch_classes<128, 128, 3, 4, 2>(blob_dev, info->total_blocks, info->class_mask, st);
+    }
+    skyemb_set_error("skyemb_gemm_group_launch: tile %d not built", info->tile);
+    return 1;
 }

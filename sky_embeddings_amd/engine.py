@@ -115,7 +115,7 @@ class MAEEngine:
         self._last = None
         # fp32 scratch for split-K GEMM launches (partial slabs; every launch on the stream reuses it)
         self._splitk_ws = torch.zeros(8 * 1024 * 1024, device=self.device, dtype=torch.float32)
-        self._side, self._pending = None, {}
+        self._side, self._pending, self._group_done = None, {}, None
         self._ln_first = self._ln_count = 0      # LayerNorms of the running backward stage awaiting their batched reduce
         self.initialize_weights(seed)
 
@@ -222,6 +222,10 @@ class MAEEngine:
             w["g"] = torch.empty(Mx * Dx, **f32)
             w["g_lp"] = torch.empty(Mx * Dx, **lp)
             w["g_lp2"] = torch.empty(Mx * Dx, **lp)   # d(xmid) copy: keeps g_lp (fc2's dy) alive for the grouped wgrad launch
+            # second set of the four dy buffers a block's grouped weight-gradient launch reads: consecutive blocks
+            # alternate between the sets, so that launch can run on the side stream under the NEXT block's dgrad chain
+            w["g_lp_b"], w["g_lp2_b"] = torch.empty(Mx * Dx, **lp), torch.empty(Mx * Dx, **lp)
+            w["dh_b"], w["dqkv_b"] = torch.empty(Hx, **lp), torch.empty(3 * Mx * Dx, **lp)
             w["dln"] = torch.empty(Mx * Dx, **lp)
             w["datt"] = torch.empty(Mx * Dx, **lp)
             w["dh"] = torch.empty(Hx, **lp)
@@ -422,6 +426,7 @@ class MAEEngine:
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
             self._pending.clear()
+            self._group_done = None
 
     def _ln_bwd(self, dy, x, prefix, mean, rstd, g_in, g, g_lp, M, dim, w):
         st = self.store
@@ -432,13 +437,24 @@ class MAEEngine:
         ops.layernorm_bwd(dy, x, st.param(f"{prefix}.weight"), mean, rstd, g_in, g, g_lp, w["ln_parts"][k], None, None,
                           M, dim, self.code)
 
+    def _bwd_set(self, prefix):
+        """Scratch set (0 / 1) of a block's backward: blocks alternate, the top block of a stack uses set 0."""
+        stack, i = prefix.rsplit(".", 1)
+        depth = self.cfg.depth if stack == "blocks" else self.cfg.decoder_depth
+        return (depth - 1 - int(i)) & 1
+
+    @staticmethod
+    def _scratch(w, key, s, n):
+        return (w[key] if s == 0 or (key + "_b") not in w else w[key + "_b"])[:n]
+
     def _wgrad_layers(self, prefix, bufs, M, dim, w):
         """(dy, x_in, weight, bias, N_out, K_in) of the four linear layers of a block, as backward sees them."""
         hidden = bufs["hpre"].shape[1]
-        g_lp = w["g_lp"][:M * dim].view(M, dim)
-        g_lp2 = w["g_lp2"][:M * dim].view(M, dim)
-        dh = w["dh"][:M * hidden].view(M, hidden)
-        dqkv = w["dqkv"][:3 * M * dim].view(M, 3 * dim)
+        s = self._bwd_set(prefix)
+        g_lp = self._scratch(w, "g_lp", s, M * dim).view(M, dim)
+        g_lp2 = self._scratch(w, "g_lp2", s, M * dim).view(M, dim)
+        dh = self._scratch(w, "dh", s, M * hidden).view(M, hidden)
+        dqkv = self._scratch(w, "dqkv", s, 3 * M * dim).view(M, 3 * dim)
         return [(g_lp, bufs["hact"], f"{prefix}.mlp.fc2", dim, hidden), (dh, bufs["ln2"], f"{prefix}.mlp.fc1", hidden, dim),
                 (g_lp2, bufs["att"], f"{prefix}.attn.proj", dim, dim), (dqkv, bufs["ln1"], f"{prefix}.attn.qkv", 3 * dim, dim)]
 
@@ -451,16 +467,20 @@ class MAEEngine:
         return grp if grp.ok else None
 
     def _block_bwd(self, x_in, bufs, prefix, M, dim, heads, Bsz, N, g, g_lp, w):
-        """g / g_lp hold d(block output) on entry and d(block input) on exit."""
+        """g holds d(block output) on entry and d(block input) on exit (fp32); its compute-dtype copy is read from the
+        block's scratch set and written to the other set (the next block's)."""
         hd = dim // heads
         hidden = bufs["hpre"].shape[1]
-        dh = w["dh"][:M * hidden].view(M, hidden)
+        s = self._bwd_set(prefix)
+        g_lp = self._scratch(w, "g_lp", s, M * dim).view(M, dim)
+        g_lp_next = self._scratch(w, "g_lp", s ^ 1, M * dim).view(M, dim)
+        dh = self._scratch(w, "dh", s, M * hidden).view(M, hidden)
+        dqkv = self._scratch(w, "dqkv", s, 3 * M * dim).view(M, 3 * dim)
         dln = w["dln"][:M * dim].view(M, dim)
         datt = w["datt"][:M * dim].view(M, dim)
-        dqkv = w["dqkv"][:3 * M * dim].view(M, 3 * dim)
-        group = w["wgrad_groups"].get(prefix) if self._side is None else None
-        single = group is None                      # weight gradients launch by launch (fp32 mode, side-stream mode)
-        g_mid = g_lp if single else w["g_lp2"][:M * dim].view(M, dim)
+        group = w["wgrad_groups"].get(prefix)
+        single = group is None                      # weight gradients launch by launch (fp32 mode)
+        g_mid = g_lp if single else self._scratch(w, "g_lp2", s, M * dim).view(M, dim)
         # MLP: x_out = xmid + fc2(gelu(fc1(ln2(xmid))))
         self._linear_bwd(g_lp, bufs["hact"], f"{prefix}.mlp.fc2.weight", f"{prefix}.mlp.fc2.bias", M, dim, hidden, w,
                          dx_out=dh, dx_act=ACT_DGELU, dx_aux=bufs["hpre"], wgrad=single)
@@ -474,9 +494,24 @@ class MAEEngine:
         ops.mha_bwd(bufs["qkv"], datt, dqkv, Bsz, N, heads, hd)
         self._linear_bwd(dqkv, bufs["ln1"], f"{prefix}.attn.qkv.weight", f"{prefix}.attn.qkv.bias", M, 3 * dim, dim, w,
                          dx_out=dln, wgrad=single)
+        prev_done = self._group_done
         if group is not None:
-            group.launch()      # all four dW / db of the block; must precede norm1's backward, which overwrites g_lp
-        self._ln_bwd(dln, x_in, f"{prefix}.norm1", bufs["mean1"], bufs["rstd1"], g, g, g_lp, M, dim, w)
+            # all four dW / db of the block in ONE launch.  With the side stream it runs under the next block's dgrad
+            # chain (a bandwidth-bound launch next to a chain of latency-bound ones); its four dy live in this block's
+            # scratch set, which nothing writes before the norm1 backward of the NEXT block (waited for below)
+            if self._side is None:
+                group.launch()
+            else:
+                ready = torch.cuda.Event()
+                ready.record()
+                self._side.wait_event(ready)
+                with torch.cuda.stream(self._side):
+                    group.launch()
+                    self._group_done = torch.cuda.Event()
+                    self._group_done.record()
+        if prev_done is not None:
+            torch.cuda.current_stream().wait_event(prev_done)   # the previous block's launch still reads g_lp_next
+        self._ln_bwd(dln, x_in, f"{prefix}.norm1", bufs["mean1"], bufs["rstd1"], g, g, g_lp_next, M, dim, w)
 
     def _bwd_ctx(self):
         assert self._last is not None, "backward() without forward_train()"

@@ -10,7 +10,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ACT_DGELU, ACT_GELU, ACT_NONE, BF16, F32, KC, RC, GemmArgs, check, lib
+from ._lib import ACT_DGELU, ACT_GELU, ACT_NONE, BF16, F32, KC, RC, GemmArgs, GemmGroupInfo, check, lib
 
 TORCH_DTYPE = {BF16: torch.bfloat16, F32: torch.float32}
 
@@ -63,27 +63,26 @@ def gemm(A, B, **kw):
 
 
 class GemmGroup:
-    """Several independent GEMMs of one operand-layout class as ONE launch (skyemb_gemm_group_*).  Built once from
-    gemm_args(...) structs -- the device blob holds the raw pointers, so the operand buffers must stay allocated --
-    and replayed with launch().  `ok` is False when a problem is outside the grouped subset (launch them singly)."""
+    """Several independent GEMMs as ONE launch (skyemb_gemm_group_*): one tile shape (``tile`` = 0 lets the plan choose),
+    data-gradient (KC.RC) and weight-gradient (RC.RC) problems may share a launch.  Built once from gemm_args(...)
+    structs -- the device blob holds the raw pointers, so the operand buffers must stay allocated -- and replayed with
+    launch().  `ok` is False when a problem is outside the grouped subset (launch them singly)."""
 
-    def __init__(self, args, device):
+    def __init__(self, args, device, tile=0):
         n = len(args)
         arr = (GemmArgs * n)(*args)
         nbytes = lib().skyemb_gemm_group_blob_bytes(n)
         host = torch.zeros(nbytes, dtype=torch.uint8)
-        total = ctypes.c_int32(0)
-        rc = lib().skyemb_gemm_group_plan(arr, n, host.data_ptr(), nbytes, ctypes.byref(total))
+        self.info = GemmGroupInfo()
+        rc = lib().skyemb_gemm_group_plan(arr, n, tile, host.data_ptr(), nbytes, ctypes.byref(self.info))
         self.ok = rc == 0
         if rc > 0:
             check(rc, "skyemb_gemm_group_plan")
-        self.total_blocks = total.value
-        self.a_layout, self.b_layout = args[0].a_layout, args[0].b_layout
+        self.total_blocks = self.info.total_blocks
         self.blob = host.to(device) if self.ok else None
 
     def launch(self):
-        check(lib().skyemb_gemm_group_launch(self.blob.data_ptr(), self.total_blocks, self.a_layout, self.b_layout, _stream()),
-              "skyemb_gemm_group_launch")
+        check(lib().skyemb_gemm_group_launch(self.blob.data_ptr(), ctypes.byref(self.info), _stream()), "skyemb_gemm_group_launch")
 
 
 def colsum(X, M, N, out, ldx=None):

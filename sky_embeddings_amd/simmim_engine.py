@@ -83,6 +83,9 @@ class SimMIMEngine(MAEEngine):
             w["datt"] = torch.empty(M * D, **lp)
             w["dh"] = torch.empty(M * hidden, **lp)
             w["dqkv"] = torch.empty(3 * M * D, **lp)
+            # second scratch set (see MAEEngine._workspace): consecutive blocks alternate between the two
+            w["g_lp_b"], w["g_lp2_b"] = torch.empty(M * D, **lp), torch.empty(M * D, **lp)
+            w["dh_b"], w["dqkv_b"] = torch.empty(M * hidden, **lp), torch.empty(3 * M * D, **lp)
             w["dT"] = torch.empty(B * L, D, **lp)
             w["drows"] = torch.empty(B * L, pv, **f32)
             w["pmv_part"] = torch.empty(B, pv, **f32)

@@ -12,7 +12,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 cfg = config_for("base", img_size=64, patch_size=16, in_chans=5, embed_dim=768, norm_pix_loss=True, loss_fn="mse")
 eng = MAEEngine(cfg, device="cuda", compute_dtype=torch.bfloat16, seed=0)
 opt = FusedAdamW(eng, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
-step = TrainStep(eng, opt, CosineLR(opt, 1_000_000), B, mask_ratio=0.75)
+step = TrainStep(eng, opt, CosineLR(opt, 1_000_000), B, mask_ratio=0.75, use_graph=os.environ.get("SKYEMB_NO_GRAPH", "0") != "1")
 imgs = torch.randn(B, 5, 64, 64, device="cuda").clamp_(min=-3.0)
 step(imgs); torch.cuda.synchronize()
 t0 = time.perf_counter()

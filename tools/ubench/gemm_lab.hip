@@ -1,0 +1,311 @@
+// GEMM lab: times launch shapes (tile code x split-K) of the pipelined bf16 GEMM on the layer shapes of one MAE ViT-B
+// step, standalone (no torch), and checks every variant against a naive fp32 kernel.
+//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DSKY_GEMM_LAB tools/ubench/gemm_lab.hip -o tools/ubench/gemm_lab
+//   run:   tools/ubench/gemm_lab [codes...]      (default: every compiled variant)
+// Timing: each (shape, config) is launched over a rotation of 6 operand sets (the weights of six different layers: cold
+// in L2, as in the training step, where a layer's weights were last read a whole step earlier) between two HIP events.
+#define SKY_GEMM_LAB_VARIANTS(X) \
+    X(1, 64, 64, 4, 2, 2)        \
+    X(0, 64, 128, 3, 2, 4)       \
+    X(1, 64, 128, 3, 2, 2)       \
+    X(1, 128, 64, 3, 2, 2)       \
+    X(1, 128, 128, 3, 2, 2)      \
+    X(2, 128, 128, 2, 2, 2)      \
+    X(3, 128, 128, 4, 2, 2)      \
+    X(4, 128, 128, 4, 4, 2)      \
+    X(5, 128, 128, 2, 4, 2)      \
+    X(0, 256, 128, 3, 4, 2)      \
+    X(1, 256, 128, 2, 4, 2)      \
+    X(2, 256, 128, 3, 4, 4)      \
+    X(0, 128, 256, 3, 2, 4)      \
+    X(1, 128, 256, 2, 2, 4)
+#include "../../sky_embeddings_amd/csrc/gemm_pipe.hip"
+
+#include <stdarg.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+#include <tuple>
+
+static char g_err[512];
+void skyemb_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+#define CK(x)                                                                              \
+    do {                                                                                   \
+        hipError_t e_ = (x);                                                               \
+        if (e_ != hipSuccess) {                                                            \
+            fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+            exit(1);                                                                       \
+        }                                                                                  \
+    } while (0)
+
+__global__ void fill_bf16(bf16_t *p, size_t n, unsigned seed, float scale) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned x = (unsigned)i * 2654435761u + seed;
+        x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; x *= 3266489917u; x ^= x >> 16;
+        p[i] = (bf16_t)(((int)(x & 0xffff) - 32768) * (scale / 32768.f));
+    }
+}
+// naive reference: v[m,n] = sum_k A(m,k) B(n,k) in fp32 (+ bias + resid), gelu optional
+__global__ void ref_gemm(const bf16_t *A, const bf16_t *B, int M, int N, int K, int64_t lda, int64_t ldb, int a_kc, int b_kc,
+                         const float *bias, const float *resid, float *out) {
+    const int n = blockIdx.x * 16 + (threadIdx.x & 15), m = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (m >= M || n >= N) return;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float a = (float)(a_kc ? A[(int64_t)m * lda + k] : A[(int64_t)k * lda + m]);
+        const float b = (float)(b_kc ? B[(int64_t)n * ldb + k] : B[(int64_t)k * ldb + n]);
+        acc = fmaf(a, b, acc);
+    }
+    if (bias) acc += bias[n];
+    if (resid) acc += resid[(int64_t)m * N + n];
+    out[(int64_t)m * N + n] = acc;
+}
+
+__global__ void empty_kernel(float *p) {
+    extern __shared__ char sm[];
+    if (p == nullptr) sm[threadIdx.x] = 1;
+}
+
+struct Shape {
+    const char *name;
+    int M, N, K, a_kc, b_kc;   // GEMM view: out[M,N], contraction K
+    int count;                 // launches per step
+    int epi;                   // 0 bias->bf16, 1 bias+resid->f32, 2 bias+gelu (2 bf16 outs), 3 dgelu, 4 wgrad (f32 + colsum)
+};
+
+int main(int argc, char **argv) {
+    const int B = 256, Me = B * 5, Md = B * 17;
+    std::vector<Shape> shapes;
+    for (int dec = 0; dec < 2; ++dec) {
+        const int M = dec ? Md : Me, D = dec ? 512 : 768, cnt = dec ? 8 : 12;
+        const char *t = dec ? "dec" : "enc";
+        static char names[64][32];
+        static int ni = 0;
+        auto nm = [&](const char *l, const char *k) { snprintf(names[ni], 32, "%s.%s.%s", t, l, k); return names[ni++]; };
+        shapes.push_back({nm("qkv", "fwd"), M, 3 * D, D, 1, 1, cnt, 0});
+        shapes.push_back({nm("proj", "fwd"), M, D, D, 1, 1, cnt, 1});
+        shapes.push_back({nm("fc1", "fwd"), M, 4 * D, D, 1, 1, cnt, 2});
+        shapes.push_back({nm("fc2", "fwd"), M, D, 4 * D, 1, 1, cnt, 1});
+        shapes.push_back({nm("qkv", "dgrad"), M, D, 3 * D, 1, 0, cnt, 0});
+        shapes.push_back({nm("proj", "dgrad"), M, D, D, 1, 0, cnt, 0});
+        shapes.push_back({nm("fc1", "dgrad"), M, D, 4 * D, 1, 0, cnt, 0});
+        shapes.push_back({nm("fc2", "dgrad"), M, 4 * D, D, 1, 0, cnt, 3});
+        shapes.push_back({nm("qkv", "wgrad"), 3 * D, D, M, 0, 0, cnt, 4});
+        shapes.push_back({nm("proj", "wgrad"), D, D, M, 0, 0, cnt, 4});
+        shapes.push_back({nm("fc1", "wgrad"), 4 * D, D, M, 0, 0, cnt, 4});
+        shapes.push_back({nm("fc2", "wgrad"), D, 4 * D, M, 0, 0, cnt, 4});
+    }
+    std::vector<int> codes;
+    for (int i = 1; i < argc; ++i) codes.push_back(atoi(argv[i]));
+    if (codes.empty()) {
+#define X(V, BM_, BN_, NS, WM_, WN_) codes.push_back(V * 1000000 + BM_ * 1000 + BN_);
+        SKY_GEMM_VARIANTS(X)
+#undef X
+    }
+    const int ROT = 6;
+    const size_t max_a = (size_t)Md * 2048, max_b = (size_t)3072 * 4352, max_o = (size_t)Md * 2048;
+    bf16_t *A[ROT], *Bm[ROT], *aux;
+    float *o32, *ref, *bias, *resid, *colsum, *ws;
+    bf16_t *o16, *o16b;
+    for (int r = 0; r < ROT; ++r) {
+        CK(hipMalloc(&A[r], max_a * 2));
+        CK(hipMalloc(&Bm[r], max_b * 2));
+        fill_bf16<<<1024, 256>>>(A[r], max_a, 17 + r, 1.0f);
+        fill_bf16<<<1024, 256>>>(Bm[r], max_b, 91 + r, 0.05f);
+    }
+    CK(hipMalloc(&aux, max_o * 2));
+    fill_bf16<<<1024, 256>>>(aux, max_o, 5, 1.0f);
+    CK(hipMalloc(&o32, max_o * 4)); CK(hipMalloc(&ref, max_o * 4)); CK(hipMalloc(&resid, max_o * 4));
+    CK(hipMalloc(&o16, max_o * 2)); CK(hipMalloc(&o16b, max_o * 2));
+    CK(hipMalloc(&bias, 8192 * 4)); CK(hipMalloc(&colsum, 8192 * 4));
+    const size_t ws_bytes = 256u << 20;
+    CK(hipMalloc(&ws, ws_bytes));
+    CK(hipMemset(bias, 0, 8192 * 4)); CK(hipMemset(resid, 0, max_o * 4));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<float> h_out(max_o), h_ref(max_o);
+
+    auto make_args = [&](const Shape &s, int r, int code, int split) {
+        skyemb_gemm_args g;
+        memset(&g, 0, sizeof g);
+        g.A = A[r]; g.B = Bm[r];
+        g.a_layout = s.a_kc ? SKYEMB_KC : SKYEMB_RC; g.b_layout = s.b_kc ? SKYEMB_KC : SKYEMB_RC;
+        g.lda = s.a_kc ? s.K : s.M; g.ldb = s.b_kc ? s.K : s.N;
+        g.M = s.M; g.N = s.N; g.K = s.K; g.dtype = SKYEMB_BF16; g.alpha = 1.f;
+        g.tile = code; g.split_k = split; g.ws = ws; g.ws_bytes = (int64_t)ws_bytes;
+        switch (s.epi) {
+            case 0: g.bias = bias; g.out = o16; g.ldo = s.N; break;
+            case 1: g.bias = bias; g.resid = resid; g.ldr = s.N; g.out_f32 = o32; g.ldo32 = s.N; break;
+            case 2: g.bias = bias; g.act = SKYEMB_ACT_GELU; g.out = o16; g.ldo = s.N; g.out2 = o16b; g.ldo2 = s.N; break;
+            case 3: g.act = SKYEMB_ACT_DGELU; g.aux = aux; g.ldaux = s.N; g.out = o16; g.ldo = s.N; break;
+            default: g.out_f32 = o32; g.ldo32 = s.N; g.colsum_a = colsum; break;
+        }
+        return g;
+    };
+
+    // ---- correctness of every variant on two shapes per layout class (plain f32 output, no activation)
+    int bad = 0;
+    for (int code : codes) {
+        for (const Shape &s0 : shapes) {
+            if (strcmp(s0.name, "enc.proj.fwd") && strcmp(s0.name, "enc.qkv.dgrad") && strcmp(s0.name, "enc.proj.wgrad") &&
+                strcmp(s0.name, "enc.fc2.dgrad"))
+                continue;
+            Shape s = s0;
+            s.epi = 1;
+            skyemb_gemm_args g = make_args(s, 0, code, 1);
+            g.resid = nullptr; g.bias = nullptr;
+            CK(hipMemset(o32, 0xff, (size_t)s.M * s.N * 4));
+            if (skyemb_gemm_pipe_try(g, 0) != 0) { printf("code %d shape %s: launch refused: %s\n", code, s.name, g_err); ++bad; continue; }
+            ref_gemm<<<dim3((s.N + 15) / 16, (s.M + 15) / 16), 256>>>(A[0], Bm[0], s.M, s.N, s.K, g.lda, g.ldb, s.a_kc, s.b_kc, nullptr,
+                                                                       nullptr, ref);
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(h_out.data(), o32, (size_t)s.M * s.N * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(h_ref.data(), ref, (size_t)s.M * s.N * 4, hipMemcpyDeviceToHost));
+            double maxe = 0, maxr = 0;
+            for (size_t i = 0; i < (size_t)s.M * s.N; ++i) {
+                maxe = std::max(maxe, (double)fabsf(h_out[i] - h_ref[i]));
+                maxr = std::max(maxr, (double)fabsf(h_ref[i]));
+            }
+            if (!(maxe <= 2e-3 * maxr)) { printf("code %d shape %s: MISMATCH max err %g (max |ref| %g)\n", code, s.name, maxe, maxr); ++bad; }
+        }
+    }
+    if (getenv("LAB_NOCHECK")) bad = 0;
+    printf("correctness: %s\n", bad ? "FAILED" : "all variants match the naive reference");
+    if (bad) return 1;
+
+    // ---- timing
+    auto time_us = [&](const Shape &s, int code, int split) -> float {
+        const int iters = 30;
+        for (int i = 0; i < ROT; ++i) {
+            skyemb_gemm_args g = make_args(s, i % ROT, code, split);
+            if (skyemb_gemm_pipe_try(g, 0) != 0) return -1.f;
+        }
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < iters; ++i) {
+            skyemb_gemm_args g = make_args(s, i % ROT, code, split);
+            skyemb_gemm_pipe_try(g, 0);
+        }
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        return ms * 1e3f / iters;
+    };
+    if (getenv("LAB_EMPTY")) {
+        for (auto cfg : {std::tuple<int, int, int>{960, 256, 49152}, {2176, 256, 49152}, {480, 512, 73728}, {240, 512, 98304}, {544, 512, 98304}}) {
+            const int grid = std::get<0>(cfg), thr = std::get<1>(cfg), lds = std::get<2>(cfg);
+            hipFuncSetAttribute((const void *)empty_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            for (int i = 0; i < 5; ++i) empty_kernel<<<grid, thr, lds>>>(o32);
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < 50; ++i) empty_kernel<<<grid, thr, lds>>>(o32);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("empty kernel grid %d x %d threads, %d B LDS: %.2f us per launch\n", grid, thr, lds, ms * 1e3f / 50);
+        }
+    }
+    if (getenv("LAB_GROUPS")) {
+        // grouped launches of one transformer block's backward: the four dW alone (round-1 schedule), and each dW with
+        // the dX that shares its dY, per tile shape
+        char *blob_dev;
+        CK(hipMalloc(&blob_dev, 65536));
+        const size_t slot = (size_t)3072 * 768;
+        float *o32g;
+        CK(hipMalloc(&o32g, 4 * slot * 4));
+        std::vector<char> blob_host(65536);
+        auto group_us = [&](std::vector<skyemb_gemm_args> probs, int tile) -> float {
+            skyemb_gemm_group_info info;
+            if (skyemb_gemm_group_plan(probs.data(), (int)probs.size(), tile, blob_host.data(), 65536, &info) != 0) return -1.f;
+            CK(hipMemcpy(blob_dev, blob_host.data(), 65536, hipMemcpyHostToDevice));
+            for (int i = 0; i < 3; ++i) if (skyemb_gemm_group_launch(blob_dev, &info, 0) != 0) return -1.f;
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < 20; ++i) skyemb_gemm_group_launch(blob_dev, &info, 0);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            return ms * 1e3f / 20;
+        };
+        for (int dec = 0; dec < 2; ++dec) {
+            const int base = dec * 12;
+            auto prob = [&](int idx, int r) {
+                skyemb_gemm_args g = make_args(shapes[base + idx], r, 0, 1);
+                // distinct outputs per problem so that nothing aliases
+                if (g.out_f32) g.out_f32 = o32g + (size_t)(r % 4) * slot;   // every weight gradient of a block fits one slot
+                return g;
+            };
+            // indices: 4 qkv.dgrad 5 proj.dgrad 6 fc1.dgrad 7 fc2.dgrad 8 qkv.wgrad 9 proj.wgrad 10 fc1.wgrad 11 fc2.wgrad
+            for (int tile : {64064, 128064, 128128}) {
+                const float w4 = group_us({prob(8, 0), prob(9, 1), prob(10, 2), prob(11, 3)}, tile);
+                float singles = 0, pairs = 0;
+                for (int l = 0; l < 4; ++l) {
+                    singles += time_us(shapes[base + 4 + l], 0, 0);
+                    pairs += group_us({prob(4 + l, 0), prob(8 + l, 1)}, tile);
+                }
+                // shifted pairing: dX(fc2) alone, dX(fc1)+dW(fc2), dX(proj)+dW(fc1), dX(qkv)+dW(proj), dW(qkv) rides with the next block's dX(fc2)
+                const float shifted = group_us({prob(7, 0), prob(8, 1)}, tile) + group_us({prob(6, 0), prob(11, 1)}, tile) +
+                                      group_us({prob(5, 0), prob(10, 1)}, tile) + group_us({prob(4, 0), prob(9, 1)}, tile);
+                printf("%s block bwd, tile %6d: 4 dW grouped %.1f us + 4 dX single (product) %.1f = %.1f | 4 x (dX+dW) %.1f | shifted pairs %.1f\n",
+                       dec ? "dec" : "enc", tile, w4, singles, w4 + singles, pairs, shifted);
+            }
+        }
+        return 0;
+    }
+    if (getenv("LAB_KSWEEP")) {
+        // time vs K at fixed M, N: the intercept is the launch + prologue + epilogue cost, the slope the k-loop
+        const int epi = atoi(getenv("LAB_KSWEEP"));
+        for (int code : codes) {
+            int bm, bn;
+            tile_dims(code, bm, bn);
+            for (auto mn : {std::pair<int, int>{1280, 3072}, {1280, 768}, {4352, 2048}, {4352, 512}}) {
+                const int64_t tiles = ceil_div64(mn.first, bm) * ceil_div64(mn.second, bn);
+                printf("ksweep code %7d epi %d M %d N %d (%4ld tiles):", code, epi, mn.first, mn.second, (long)tiles);
+                float t768 = 0, t1536 = 0;
+                for (int K : {64, 256, 768, 1536}) {
+                    if ((size_t)mn.first * K > max_a || (size_t)mn.second * K > max_b) continue;
+                    Shape s{"k", mn.first, mn.second, K, 1, 1, 1, epi};
+                    const float t = time_us(s, code, 1);
+                    printf("  K%d:%.1f", K, t);
+                    if (K == 768) t768 = t;
+                    if (K == 1536) t1536 = t;
+                }
+                const double per_step = (t1536 - t768) / 12.0;
+                printf("  | %.2f us/k-step = %.1f TB/s L2->LDS\n", per_step, tiles * (bm + bn) * 128.0 / per_step / 1e6);
+            }
+        }
+        return 0;
+    }
+    double tot_base = 0, tot_best = 0;
+    for (const Shape &s : shapes) {
+        struct R { int code, split; float us; };
+        std::vector<R> res;
+        const float base = time_us(s, 0, 0);    // current product choice (tuned table / heuristic)
+        for (int code : codes) {
+            int bm, bn;
+            tile_dims(code, bm, bn);
+            const int64_t tiles = ceil_div64(s.M, bm) * ceil_div64(s.N, bn);
+            for (int split : {1, 2, 3, 4, 6, 8}) {
+                if (split > 1 && (tiles * split > 1100 || s.K / 64 / split < 4)) continue;
+                const float us = time_us(s, code, split);
+                if (us > 0) res.push_back({code, split, us});
+            }
+        }
+        std::sort(res.begin(), res.end(), [](const R &a, const R &b) { return a.us < b.us; });
+        const double flop = 2.0 * s.M * s.N * s.K;
+        printf("%-16s M%5d N%5d K%5d  product %6.1f us (%4.0f TF/s) |", s.name, s.M, s.N, s.K, base, flop / base / 1e6);
+        for (size_t i = 0; i < res.size() && i < 6; ++i) printf("  %d/s%d:%.1f", res[i].code, res[i].split, res[i].us);
+        printf("\n");
+        fflush(stdout);
+        tot_base += base * s.count;
+        tot_best += std::min(base, res.empty() ? base : res[0].us) * s.count;
+    }
+    printf("per step (block layers only): product %.3f ms, best-of %.3f ms\n", tot_base / 1e3, tot_best / 1e3);
+    return 0;
+}
