@@ -2,7 +2,9 @@
 """Benchmark of the hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...; started WITHOUT a
+    launcher, `--gpus N` spawns the N ranks itself -- before this process makes any GPU call -- and fails if the node
+    shows fewer than N devices)
 
 Headline (BASELINE.json metric, configs[1]): MAE pretraining images/sec -- ViT-B/16 MAE, 5x64x64
 cutouts, mask 0.75, batch 256 per GPU, bf16 MFMA GEMMs with fp32 accumulation / statistics /
@@ -30,14 +32,16 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU (BASELINE: 256)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP graph replay")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--skip-search", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-feeder", action="store_true")
+    ap.add_argument("--skip-mim19", action="store_true", help="skip the BASELINE configs[4] leg (SimMIM ViT-L/16, 5x128x128)")
+    ap.add_argument("--probe", action="store_true", help="also time every GEMM shape of the step alone (HIP-graph probe)")
     ap.add_argument("--bank-rows", type=int, default=1_000_000)
     ap.add_argument("--queries", type=int, default=10_000)
     ap.add_argument("--topk", type=int, default=100)
@@ -135,7 +139,20 @@ def gemm_step_probe(B, dtype, dev, iters=20):
                 ms_per_step=tot_us / 1e3, flop_per_step=tot_fl, tflops=tot_fl / tot_us / 1e6, kinds=per_kind)
 
 
+def gemm_flops_per_step(cfg, B, mask_ratio=0.75):
+    """Algorithmic 2*M*N*K of every MFMA GEMM launch of one step (forward, data gradient, weight gradient of every
+    Linear, the patch embedding on the kept patches only): the `executed` figure of MAEEngine.flops_per_image minus the
+    attention core."""
+    L, D, Dd, pv = cfg.num_patches, cfg.embed_dim, cfg.decoder_embed_dim, cfg.patch_dim
+    keep = int(L * (1 - mask_ratio))
+    Ne, Nd, r = 1 + keep, 1 + L, cfg.mlp_ratio
+    lin = lambda n, d, depth: depth * 2 * n * d * (3 * d + d + 2 * r * d)
+    fwd = lin(Ne, D, cfg.depth) + 2 * Ne * D * Dd + lin(Nd, Dd, cfg.decoder_depth) + 2 * Nd * Dd * pv + 2 * keep * pv * D
+    return 3.0 * fwd * B
+
+
 def bench_pretrain(args, rank, world, dev):
+    from sky_embeddings_amd import _lib
     from sky_embeddings_amd.engine import MAEEngine
     from sky_embeddings_amd.model_config import config_for
     from sky_embeddings_amd.optim import CosineLR, FusedAdamW
@@ -143,6 +160,7 @@ def bench_pretrain(args, rank, world, dev):
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     cfg = config_for("base", img_size=64, patch_size=16, in_chans=5, embed_dim=768, norm_pix_loss=True, loss_fn="mse")
     eng = MAEEngine(cfg, device=dev, compute_dtype=dtype, seed=0)       # same weights on every rank
+    torch.manual_seed(1234 + rank)                                      # ... but its own masking-noise stream (seed = base + rank)
     opt = FusedAdamW(eng, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
     sched = CosineLR(opt, 1_000_000, eta_min=1e-4 / 1e7)
     B = args.batch
@@ -155,18 +173,21 @@ def bench_pretrain(args, rank, world, dev):
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
+    def timed(fn, n):
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for i in range(n):
+            out = fn(pool[i % 2])
+        e1.record()
+        barrier()
+        dt = time.perf_counter() - t0
+        return dt, e0.elapsed_time(e1) / n, out
+
     for i in range(args.warmup):
         step(pool[i % 2])
-    barrier()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for i in range(args.steps):
-        loss = step(pool[i % 2])
-    e1.record()
-    barrier()
-    dt = time.perf_counter() - t0
-    gpu_ms = e0.elapsed_time(e1) / args.steps
+    dt, gpu_ms, loss = timed(step, args.steps)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -175,11 +196,87 @@ def bench_pretrain(args, rank, world, dev):
     out = dict(ms_per_step=1e3 * dt / args.steps, images_per_sec=world * B * args.steps / dt, gpu_ms_per_step=gpu_ms,
                loss=float(loss), flops_per_image_executed=executed, flops_per_image_reference=algorithmic, B=B)
     if rank == 0:
-        out["gemm_probe"] = gemm_step_probe(B, dtype, dev)
+        # In-step time of the dominant kernel family: the same step with the MFMA GEMM launches left out (the C ABI's
+        # measurement switch), HIP events over the same number of steps; the difference is what the GEMM launches take
+        # INSIDE the step (cold weights, launch gaps and all) -- the figure rocprofv3's kernel_stats must agree with.
+        st = eng.store
+        snap = [t.clone() for t in (st.p, st.m, st.v, st.p_lp)]
+        counters = (opt.step_count, sched.last_epoch)
+        _lib.lib().skyemb_debug_skip(1)
+        try:
+            bare = TrainStep(eng, opt, sched, B, mask_ratio=0.75, use_graph=not args.no_graph, world_size=1)
+            for i in range(3):
+                bare(pool[i % 2])
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(args.steps):
+                bare(pool[i % 2])
+            e1.record()
+            e1.synchronize()
+            bare_ms = e0.elapsed_time(e1) / args.steps
+        finally:
+            _lib.lib().skyemb_debug_skip(0)
+            for dst, src in zip((st.p, st.m, st.v, st.p_lp), snap):
+                dst.copy_(src)
+            opt.step_count, sched.last_epoch = counters
+            sched._apply()
+        del bare, snap
+        gf = gemm_flops_per_step(cfg, B)
+        gemm_ms = gpu_ms - bare_ms
+        launches = 83 * 2 + 23                       # forward, dgrad singles; 20 grouped + 3 single wgrad launches
+        out["gemm_in_step"] = dict(ms_per_step=gemm_ms, step_without_gemm_ms=bare_ms, flop_per_step=gf, launches_per_step=launches,
+                                   avg_launch_us=1e3 * gemm_ms / launches, tflops=gf / gemm_ms / 1e9)
+        if args.probe:
+            out["gemm_probe"] = gemm_step_probe(B, dtype, dev)
         out["phases"] = hbm_phases(eng, opt, step, B)
         if world == 1 and not args.skip_feeder:
             out["feeder"] = bench_feeder(args, dev, step, B)
     return out, eng
+
+
+def bench_mim19(args, dev):
+    """BASELINE configs[4]: configs/mim_19.ini -- SimMIM ViT-Large/16 on 5x128x128 cutouts, mask ratio 0.6, bs 128, bf16."""
+    import configparser
+    import numpy as np
+    from sky_embeddings_amd.model_config import config_for
+    from sky_embeddings_amd.optim import CosineLR, FusedAdamW
+    from sky_embeddings_amd.simmim_engine import SimMIMEngine
+    from sky_embeddings_amd.train_step import TrainStep
+    ini = configparser.ConfigParser()
+    ini.read(os.path.join(ROOT, "configs", "mim_19.ini"))
+    a, t = ini["ARCHITECTURE"], ini["TRAINING"]
+    cfg = config_for(a["model_type"], img_size=int(a["img_size"]), patch_size=int(a["patch_size"]), in_chans=int(a["num_channels"]),
+                     embed_dim=int(a["embed_dim"]), norm_pix_loss=t.getboolean("norm_pix_loss"), loss_fn=t["loss_fn"])
+    B = int(t["batch_size"])
+    eng = SimMIMEngine(cfg, device=dev, compute_dtype=torch.bfloat16, seed=0)
+    opt = FusedAdamW(eng, lr=float(t["init_lr"]), betas=(0.9, 0.95), weight_decay=float(t["weight_decay"]))
+    step = TrainStep(eng, opt, CosineLR(opt, 1_000_000), B)
+    g = torch.Generator(device=dev).manual_seed(19)
+    x = torch.randn(B, cfg.in_chans, cfg.img_size, cfg.img_size, device=dev, generator=g).clamp_(min=-3.0)
+    L, p = cfg.num_patches, cfg.patch_size
+    count = int(np.ceil(L * float(t["max_mask_ratio"])))
+    order = torch.rand(B, cfg.in_chans, L, device=dev, generator=g).argsort(dim=2)
+    m = (order < count).float().view(B, cfg.in_chans, cfg.grid, cfg.grid).repeat_interleave(p, 2).repeat_interleave(p, 3).contiguous()
+    for _ in range(3):
+        loss = step(x, m)
+    torch.cuda.synchronize(dev)
+    n = 10
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        loss = step(x, m)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    executed, algorithmic = eng.flops_per_image()
+    res = dict(workload="configs/mim_19.ini: SimMIM ViT-Large/16, 5x128x128, 39 of 64 patches masked per channel (ratio 0.6), "
+                        f"bs={B}, L1 + norm-pix, AdamW+cosine, bf16", ms_per_step=ms, images_per_sec=B / ms * 1e3,
+               tflops=B / ms * executed / 1e9, frac_of_bf16_peak=B / ms * executed / 1e9 / PEAK_BF16_TFLOPS,
+               flops_per_image_executed=executed, params=int(eng.store.n), loss=float(loss))
+    del step, opt, eng
+    torch.cuda.empty_cache()
+    return res
 
 
 def hbm_phases(eng, opt, step, B):
@@ -298,7 +395,7 @@ def bench_search(args, rank, world, dev):
         res[label] = dict(Q=Q, sec=dt, queries_per_sec=Q / dt, kernel_ms=kms, kernel_bytes=kbytes,
                           kernel_hbm_gbs=kbytes / kms / 1e6,
                           kernel_tflops=2.0 * Q * (hi - lo) * D / kms / 1e9, checksum=int(i.sum().item() % (1 << 31)))
-    return res, (queries, w)
+    return res, (queries, w, bank)
 
 
 def pmc_traffic(args):
@@ -315,60 +412,98 @@ def pmc_traffic(args):
     return prof["kernels"]["cosine_topk_stream_kernel<8>"]["traffic_bytes_per_launch"]
 
 
-def cpu_baselines(args):
-    """Oracle timed on the host cores (rank 0, N=1 only), bounded samples."""
+def cpu_baselines(args, search_inputs):
+    """The CPU restatement (oracle/) timed on this box's host cores, rank 0 at N = 1 only, on bounded samples of the SAME
+    workloads (BASELINE.md section 3): pretraining = config A at B = 256, one warm-up + three timed optimiser steps;
+    search = Q = 1 and Q = 64 over the full bank, k as benchmarked."""
     from oracle import mae_oracle as mo
     from oracle import similarity_oracle as so
-    import numpy as np
     threads = torch.get_num_threads()
     cfg = mo.config_for("base", patch_size=16, in_chans=5, img_size=64, embed_dim=768)
     st = mo.init_state(cfg, seed=0)
     tr = mo.Trainer(cfg, st, init_lr=1e-4, weight_decay=0.05, total_iters=1_000_000, final_lr_factor=1e7)
-    B = 32
+    B = args.batch
     g = torch.Generator().manual_seed(1234)
     imgs = torch.randn(B, 5, 64, 64, generator=g).clamp_(min=-3.0)
+    tr.step(imgs, 0.75, torch.rand(B, 16, generator=g))                       # warm-up (thread pool, allocator)
     t0 = time.perf_counter()
-    tr.step(imgs, 0.75, torch.rand(B, 16, generator=g))
-    dt = time.perf_counter() - t0
+    for _ in range(3):
+        tr.step(imgs, 0.75, torch.rand(B, 16, generator=g))
+    dt = (time.perf_counter() - t0) / 3
     pre = dict(value=B / dt, unit="images/sec", cores=threads, kind="port",
-               sample=f"1 optimiser step (fwd+bwd+AdamW) of B={B} at config A, torch fp32 CPU restatement (oracle/mae_oracle.py)")
-    rng = np.random.default_rng(2024)
-    n = 100_000
-    x = rng.standard_normal((n, 768), dtype=np.float32)
-    q = rng.standard_normal((16, 768), dtype=np.float32)
-    w = np.ones(768, np.float32) / 768
-    so.cosine_topk_np(q[:1], x[:1000], 10, w)
-    t0 = time.perf_counter()
-    so.cosine_topk_np(q, x, args.topk, w)
-    dt = time.perf_counter() - t0
-    sea = dict(value=16 / (dt * args.bank_rows / n), unit="queries/sec", cores=so.num_threads(), kind="port",
-               sample=f"Q=16, k={args.topk} over a {n}-row slice of the bank (oracle/topk_oracle.c, OpenMP), scaled to {args.bank_rows} rows")
+               sample=f"config A at B={B}: 1 warm-up + 3 timed optimiser steps (fwd+bwd+AdamW), torch fp32 CPU restatement "
+                      f"(oracle/mae_oracle.py), {dt:.2f} s per step")
+    sea = None
+    if search_inputs is not None:
+        queries, w, bank = search_inputs
+        x = bank.cpu().numpy()
+        q = queries[:64].cpu().numpy()
+        wh = w.cpu().numpy()
+        so.cosine_topk_np(q[:1], x[:1000], 10, wh)                           # loads the library, spins up OpenMP
+        legs = {}
+        for Q in (1, 64):
+            t0 = time.perf_counter()
+            so.cosine_topk_np(q[:Q], x, args.topk, wh)
+            legs[Q] = time.perf_counter() - t0
+        sea = dict(value=64 / legs[64], unit="queries/sec", cores=so.num_threads(), kind="port",
+                   sample=f"Q=64, k={args.topk} over the full {x.shape[0]}x{x.shape[1]} bank (oracle/topk_oracle.c, OpenMP): "
+                          f"{legs[64]:.2f} s; Q=1: {legs[1]:.2f} s = {1 / legs[1]:.2f} queries/sec",
+                   q1_queries_per_sec=1 / legs[1])
     return pre, sea
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run, as the driver does.
+    Nothing in this process has touched the GPU (device_count() does not initialise it on this image)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible on this node", file=sys.stderr)
+        return 3
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     pre, eng = bench_pretrain(args, rank, world, dev)
     del eng
     torch.cuda.empty_cache()
-    search = None
+    search = search_inputs = None
     if not args.skip_search:
-        search, _ = bench_search(args, rank, world, dev)
+        search, search_inputs = bench_search(args, rank, world, dev)
+    mim19 = None
+    if rank == 0 and world == 1 and not args.skip_mim19:
+        mim19 = bench_mim19(args, dev)
     if rank == 0:
         executed = pre["flops_per_image_executed"]
         ach = pre["images_per_sec"] / world * executed / 1e12   # per-GPU TFLOP/s, executed FLOPs
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
-        gp = pre["gemm_probe"]
+        gi = pre["gemm_in_step"]
+        kernel = dict(kernel="gemm_pipe_kernel<BM,BN,A_KC,B_KC,3,WM,WN> (forward KC.KC, data gradient KC.RC) + "
+                             "gemm_pipe_group_kernel<128,64,3,4,2,4> (the four weight gradients of a block per launch) "
+                             "(+ splitk_reduce_kernel)", **gi)
+        if "gemm_probe" in pre:
+            kernel["isolated_probe"] = pre["gemm_probe"]
         line = {
             "metric": "MAE pretrain images/sec (5x64x64, ViT-B)", "value": pre["images_per_sec"], "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": pre["ms_per_step"],
@@ -377,14 +512,16 @@ def main():
             "config": {"workload": "mim_32.ini-as-BASELINE configs[1]: MAE ViT-Base/16, 5x64x64, mask_ratio=0.75, "
                                    f"bs={pre['B']}/GPU, AdamW+cosine, norm_pix mse",
                        "global_batch": pre["B"] * world, "parallelism": f"dp{world}",
+                       "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
                        "graph": not args.no_graph},
-            "roofline": {"bound": "mfma", "achieved": gp["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": gp["tflops"] / peak,
-                         "traffic": None,
-                         "note": "dominant kernel = the pipelined MFMA GEMM: algorithmic 2MNK FLOPs of every GEMM launch of one "
-                                 "step / their HIP-event launch durations (kernel.kinds: per operand-layout average launch time, "
-                                 "to be compared with the rocprofv3 kernel_stats averages in profiles/); step = whole-step rate "
+            "roofline": {"bound": "mfma", "achieved": gi["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": gi["tflops"] / peak,
+                         "traffic": gemm_pmc_traffic(),
+                         "note": "dominant kernel family = the pipelined MFMA GEMM launches: algorithmic 2MNK FLOPs of every GEMM "
+                                 "launch of one step / their IN-STEP time = HIP-event time of the timed steps minus the same "
+                                 "steps replayed with the GEMM launches left out (kernel.step_without_gemm_ms); agrees with the "
+                                 "sum of the gemm_pipe_* rows of the rocprofv3 kernel_stats in profiles/.  step = whole-step rate "
                                  "(executed fwd+bwd FLOPs x images / step time, all kernels + optimiser)",
-                         "kernel": gp,
+                         "kernel": kernel,
                          "step": {"achieved": ach, "frac": ach / peak, "gpu_ms_per_step": pre["gpu_ms_per_step"],
                                   "flops_per_image_executed": executed,
                                   "flops_per_image_reference": pre["flops_per_image_reference"]}},
@@ -392,6 +529,8 @@ def main():
             "phases": pre.get("phases"),
             "feeder": pre.get("feeder"),
         }
+        if mim19 is not None:
+            line["extra"] = {"mim_19": mim19}
         if search is not None:
             ql, qs = search["q_large"], search["q_small"]
             line["search"] = {
@@ -402,18 +541,27 @@ def main():
                              "frac": qs["kernel_hbm_gbs"] / PEAK_HBM_GBS, "traffic": pmc_traffic(args),
                              "algorithmic_bytes": qs["kernel_bytes"],
                              "note": "Q=16 bank-streaming launch (HBM-bound regime): (bank shard + queries + partial "
-                                     "lists) bytes / kernel time; the Q=10k launch is fp32-MFMA bound: see q_large.kernel_tflops "
-                                     f"vs {PEAK_F32_MFMA_TFLOPS} TFLOP/s"},
+                                     "lists) bytes / kernel time; the Q=10k path: see q_large"},
             }
         if world == 1 and not args.skip_cpu:
-            cpre, csea = cpu_baselines(args)
+            cpre, csea = cpu_baselines(args, search_inputs)
             line["cpu_baseline"] = cpre
-            if search is not None:
+            if search is not None and csea is not None:
                 line["search"]["cpu_baseline"] = csea
         print(json.dumps(line))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def gemm_pmc_traffic():
+    """HBM bytes per GEMM launch (average over the launches of one step) from the committed PMC passes of this round
+    (profiles/r02_gemm_pmc.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_gemm_pmc.json")) as f:
+            return json.load(f)["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 if __name__ == "__main__":

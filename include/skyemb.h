@@ -41,6 +41,10 @@ extern "C" {
 
 const char *skyemb_last_error(void);
 int skyemb_version(void);
+/* Measurement aid for bench.py: entry points of the kernel families in `mask` return 0 without launching (bit 0: the MFMA
+ * GEMM launches), so a timed region with and without them gives the family's in-step time.  Returns the previous mask.
+ * Not part of the drop-in surface; results are garbage while a bit is set. */
+int skyemb_debug_skip(int mask);
 
 /* ---------------------------------------------------------------- GEMM ----
  * Replaces every nn.Linear / Conv2d(k=s=p) contraction of timm PatchEmbed / Block /
@@ -222,10 +226,12 @@ int skyemb_simmim_pixel_loss(const float *imgs, const float *pred_tok, const flo
  * elements [0, n_decay) use weight decay `wd`, the rest 0.  Step scalars {lr, 1-beta1^t, 1-beta2^t}
  * come from `hyper` (device fp32[4], for launches captured in a HIP graph) when non-NULL, else
  * from the lr/bc1/bc2 arguments.  Also refreshes the dtype shadow copy `p_lp` used by the GEMMs
- * (NULL to skip), scales gradients by grad_scale (DDP averaging) and optionally zeroes g. */
-int skyemb_adamw(float *p, float *g, float *m, float *v, void *p_lp, int dtype, int64_t n, int64_t n_decay,
+ * (NULL to skip), scales gradients by grad_scale (DDP averaging) and optionally zeroes g.  `g` holds `grad_dtype`
+ * elements: SKYEMB_F32 (the flat gradient buffer the kernels write), or SKYEMB_BF16 (the copy a bf16 gradient
+ * all-reduce worked on: half the xGMI bytes per step). */
+int skyemb_adamw(float *p, void *g, float *m, float *v, void *p_lp, int dtype, int64_t n, int64_t n_decay,
                  const float *hyper, float lr, float bc1, float bc2, float beta1, float beta2, float eps, float wd,
-                 float grad_scale, int zero_grad, void *stream);
+                 float grad_scale, int zero_grad, int grad_dtype, void *stream);
 int skyemb_cast(const float *src, void *dst, int dtype, int64_t n, void *stream);
 
 /* ------------------------------------------------------------ input feeder -

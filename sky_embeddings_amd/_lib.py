@@ -53,6 +53,7 @@ class GemmGroupInfo(ctypes.Structure):
 PROTOTYPES = {
     "skyemb_last_error": (ctypes.c_char_p, []),
     "skyemb_version": (c_i32, []),
+    "skyemb_debug_skip": (c_i32, [c_i32]),
     "skyemb_gemm": (c_i32, [ctypes.POINTER(GemmArgs), c_vp]),
     "skyemb_gemm_group_blob_bytes": (c_i64, [c_i32]),
     "skyemb_gemm_group_plan": (c_i32, [ctypes.POINTER(GemmArgs), c_i32, c_i32, c_vp, c_i64, ctypes.POINTER(GemmGroupInfo)]),
@@ -84,7 +85,7 @@ PROTOTYPES = {
     "skyemb_masked_patch_loss": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32,
                                          c_i32, c_i32, c_f32, c_f32, c_i32, c_i32, c_vp]),
     "skyemb_adamw": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_vp, c_f32, c_f32, c_f32, c_f32,
-                             c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
+                             c_f32, c_f32, c_f32, c_f32, c_i32, c_i32, c_vp]),
     "skyemb_cast": (c_i32, [c_vp, c_vp, c_i32, c_i64, c_vp]),
     "skyemb_standardise": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
     "skyemb_weighted_norms": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),

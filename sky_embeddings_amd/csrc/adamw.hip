@@ -7,8 +7,8 @@
 
 namespace {
 
-template <typename T, bool LP>
-__global__ __launch_bounds__(256) void adamw_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
+template <typename T, bool LP, typename GT>
+__global__ __launch_bounds__(256) void adamw_kernel(float *__restrict__ p, GT *__restrict__ g, float *__restrict__ m,
                                                     float *__restrict__ v, T *__restrict__ p_lp, int64_t n4,
                                                     int64_t n_decay, const float *__restrict__ hyper, float lr_arg,
                                                     float bc1_arg, float bc2_arg, float beta1, float beta2, float eps,
@@ -28,7 +28,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float *__restrict__ p, float
             const int64_t i = i0 + u * stride;
             if (i < n4) {
                 pv[u] = *(const f32x4 *)(p + 4 * i);
-                gv[u] = *(const f32x4 *)(g + 4 * i);
+                const float4 gl = load4<GT>(g + 4 * i);          // fp32 gradients, or the bf16 ones a bf16 all-reduce left
+                gv[u] = (f32x4){gl.x, gl.y, gl.z, gl.w};
                 mv[u] = *(const f32x4 *)(m + 4 * i);
                 vv[u] = *(const f32x4 *)(v + 4 * i);
             }
@@ -56,31 +57,38 @@ __global__ __launch_bounds__(256) void adamw_kernel(float *__restrict__ p, float
             *(f32x4 *)(m + 4 * i) = mv[u];
             *(f32x4 *)(v + 4 * i) = vv[u];
             if (LP) store4<T>(p_lp + 4 * i, pv[u][0], pv[u][1], pv[u][2], pv[u][3]);
-            if (zero_grad) *(float4 *)(g + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (zero_grad) store4<GT>(g + 4 * i, 0.f, 0.f, 0.f, 0.f);
         }
     }
 }
 
 }  // namespace
 
-extern "C" int skyemb_adamw(float *p, float *g, float *m, float *v, void *p_lp, int dtype, int64_t n, int64_t n_decay,
+extern "C" int skyemb_adamw(float *p, void *g, float *m, float *v, void *p_lp, int dtype, int64_t n, int64_t n_decay,
                             const float *hyper, float lr, float bc1, float bc2, float beta1, float beta2, float eps,
-                            float wd, float grad_scale, int zero_grad, void *stream) {
+                            float wd, float grad_scale, int zero_grad, int grad_dtype, void *stream) {
     SKY_CHECK_ARG(n > 0 && n % 4 == 0 && n_decay >= 0 && n_decay <= n, "skyemb_adamw: n must be a positive multiple of 4");
-    SKY_CHECK_ARG(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), "skyemb_adamw: unaligned buffers");
+    SKY_CHECK_ARG(aligned16(p) && aligned16(m) && aligned16(v) && (((uintptr_t)g) & 7) == 0, "skyemb_adamw: unaligned buffers");
+    SKY_CHECK_ARG(grad_dtype == SKYEMB_F32 || grad_dtype == SKYEMB_BF16, "skyemb_adamw: bad grad_dtype %d", grad_dtype);
     int64_t blocks = ceil_div64(n / 4, 256);
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)blocks), block(256);
-    if (!p_lp)
-        hipLaunchKernelGGL((adamw_kernel<float, false>), grid, block, 0, st, p, g, m, v, (float *)nullptr, n / 4, n_decay,
-                           hyper, lr, bc1, bc2, beta1, beta2, eps, wd, grad_scale, zero_grad);
-    else if (dtype == SKYEMB_BF16)
-        hipLaunchKernelGGL((adamw_kernel<bf16_t, true>), grid, block, 0, st, p, g, m, v, (bf16_t *)p_lp, n / 4, n_decay,
-                           hyper, lr, bc1, bc2, beta1, beta2, eps, wd, grad_scale, zero_grad);
-    else
-        hipLaunchKernelGGL((adamw_kernel<float, true>), grid, block, 0, st, p, g, m, v, (float *)p_lp, n / 4, n_decay, hyper,
-                           lr, bc1, bc2, beta1, beta2, eps, wd, grad_scale, zero_grad);
+#define ADAMW_LAUNCH(T, LP, GT, lp_ptr)                                                                                        \
+    hipLaunchKernelGGL((adamw_kernel<T, LP, GT>), grid, block, 0, st, p, (GT *)g, m, v, lp_ptr, n / 4, n_decay, hyper, lr, bc1, \
+                       bc2, beta1, beta2, eps, wd, grad_scale, zero_grad)
+    const bool g16 = grad_dtype == SKYEMB_BF16;
+    if (!p_lp) {
+        if (g16) ADAMW_LAUNCH(float, false, bf16_t, (float *)nullptr);
+        else ADAMW_LAUNCH(float, false, float, (float *)nullptr);
+    } else if (dtype == SKYEMB_BF16) {
+        if (g16) ADAMW_LAUNCH(bf16_t, true, bf16_t, (bf16_t *)p_lp);
+        else ADAMW_LAUNCH(bf16_t, true, float, (bf16_t *)p_lp);
+    } else {
+        if (g16) ADAMW_LAUNCH(float, true, bf16_t, (float *)p_lp);
+        else ADAMW_LAUNCH(float, true, float, (float *)p_lp);
+    }
+#undef ADAMW_LAUNCH
     SKY_LAUNCH_CHECK("skyemb_adamw");
     return 0;
 }

@@ -16,6 +16,7 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 #define SKYEMB_WAVE 64
 
 void skyemb_set_error(const char *fmt, ...);
+int skyemb_skip_mask(void);   // api.cpp: measurement aid, see skyemb_debug_skip
 
 // Also drops any stale sticky HIP error left by other code in this thread (e.g. a device probe),
 // so that SKY_LAUNCH_CHECK reports only this call's launches.  Every launching entry point starts

@@ -311,6 +311,7 @@ extern "C" int skyemb_gemm(const skyemb_gemm_args *args, void *stream) {
     SKY_CHECK_ARG(!g.table || g.tab_row, "skyemb_gemm: table without tab_row");
     SKY_CHECK_ARG(!g.colsum_a || g.a_layout == SKYEMB_RC, "skyemb_gemm: colsum_a needs an RC A operand");
     hipStream_t st = (hipStream_t)stream;
+    if (skyemb_skip_mask() & 1) return 0;
     static const bool use_pipe = []() { const char *e = getenv("SKYEMB_GEMM_PIPE"); return !(e && e[0] == '0'); }();
     if (use_pipe) {
         const int rc = skyemb_gemm_pipe_try(g, st);

@@ -613,6 +613,7 @@ static int group_launch_classes(const void *blob_dev, int total_blocks, int mask
 
 extern "C" int skyemb_gemm_group_launch(const void *blob_dev, const skyemb_gemm_group_info *info, void *stream) {
     SKY_CHECK_ARG(blob_dev && info && info->total_blocks > 0, "skyemb_gemm_group_launch: bad arguments");
+    if (skyemb_skip_mask() & 1) return 0;
     hipStream_t st = (hipStream_t)stream;
     switch (info->tile) {
         case 64064: return group_launch_classes<64, 64, 3, 2, 2>(blob_dev, info->total_blocks, info->class_mask, st);

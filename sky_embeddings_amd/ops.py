@@ -205,7 +205,7 @@ def adamw(p, g, m, v, p_lp, n, n_decay, hyper, beta1, beta2, eps, wd, grad_scale
     """hyper: device fp32[4] {lr, 1-b1^t, 1-b2^t} (graph-safe) or None to pass lr/bc1/bc2 by value."""
     code = dtype_code(p_lp.dtype) if p_lp is not None else F32
     check(lib().skyemb_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_lp), code, n, n_decay, _p(hyper), lr, bc1, bc2, beta1,
-                             beta2, eps, wd, grad_scale, int(zero_grad), _stream()), "skyemb_adamw")
+                             beta2, eps, wd, grad_scale, int(zero_grad), dtype_code(g.dtype), _stream()), "skyemb_adamw")
 
 
 def cast(src, dst, n):

@@ -29,6 +29,9 @@ class FusedAdamW:
         # graph mode: step scalars live in device memory (kernel arguments are frozen in a HIP graph)
         self.hyper_device = None
         self.process_group = process_group
+        # gradient source of the update: the engine's flat fp32 buffer, or (set by TrainStep for bf16 gradient
+        # communication) a flat bf16 copy of it that the all-reduce summed over the ranks
+        self.grad_buffer = None
 
     @property
     def lr(self):
@@ -59,7 +62,8 @@ class FusedAdamW:
         n = end - start
         n_decay = min(max(st.n_decay - start, 0), n)     # layout is [decayed | not decayed]
         sl = slice(start, end)
-        ops.adamw(st.p[sl], st.g[sl], st.m[sl], st.v[sl], st.p_lp[sl], n, n_decay, self.hyper_device, b1, b2,
+        g = st.g if self.grad_buffer is None else self.grad_buffer
+        ops.adamw(st.p[sl], g[sl], st.m[sl], st.v[sl], st.p_lp[sl], n, n_decay, self.hyper_device, b1, b2,
                   self.defaults["eps"], self.param_groups[1]["weight_decay"], grad_scale=self.grad_scale, zero_grad=False,
                   lr=self.lr, bc1=1.0 - b1 ** t, bc2=1.0 - b2 ** t)
 

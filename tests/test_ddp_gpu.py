@@ -1,0 +1,89 @@
+"""GPU: the N > 1 training step really executed -- two processes, one TrainStep each (HIP-graph stages, per-stage
+gradient all-reduce, fused AdamW), against ONE process on the concatenated batch.  On a box with two GPUs the ranks use
+RCCL on their own device; on a one-GPU box both ranks share cuda:0 and the collectives go through gloo (the schedule,
+the bucketing, the bf16 / fp32 gradient communication and the optimiser are the same code either way)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+STEPS, B_RANK, WORLD, LR = 3, 4, 2, 1e-3
+
+
+def _data():
+    g = torch.Generator().manual_seed(42)
+    imgs = torch.randn(WORLD * B_RANK, 5, 64, 64, generator=g).clamp_(min=-3.0)
+    noise = torch.rand(STEPS, WORLD * B_RANK, 16, generator=g)
+    return imgs, noise
+
+
+def _make(dev, B, world, **kw):
+    from sky_embeddings_amd.engine import MAEEngine
+    from sky_embeddings_amd.model_config import config_for
+    from sky_embeddings_amd.optim import CosineLR, FusedAdamW
+    from sky_embeddings_amd.train_step import TrainStep
+    cfg = config_for("tiny", img_size=64, patch_size=16, in_chans=5, embed_dim=192)
+    eng = MAEEngine(cfg, device=dev, compute_dtype=torch.bfloat16, seed=1)
+    opt = FusedAdamW(eng, lr=LR, betas=(0.9, 0.95), weight_decay=0.05)
+    step = TrainStep(eng, opt, CosineLR(opt, 100), B, world_size=world, external_noise=True, n_encoder_groups=3, **kw)
+    return eng, step
+
+
+def _rank_main(rank, port, out_dir, grad_comm, use_nccl):
+    import torch.distributed as dist
+    dev = torch.device("cuda", rank if use_nccl else 0)
+    torch.cuda.set_device(dev)
+    if use_nccl:
+        dist.init_process_group("nccl", rank=rank, world_size=WORLD, init_method=f"tcp://127.0.0.1:{port}", device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=WORLD, init_method=f"tcp://127.0.0.1:{port}")
+    imgs, noise = _data()
+    rows = slice(rank * B_RANK, (rank + 1) * B_RANK)
+    eng, step = _make(dev, B_RANK, WORLD, grad_comm=grad_comm)
+    assert step.staged and len(step.stages) >= 4          # decoder | encoder groups | embedding: comm overlaps backward
+    losses = []
+    for it in range(STEPS):
+        step.noise.copy_(noise[it][rows])
+        losses.append(float(step(imgs[rows].to(dev))))
+    torch.cuda.synchronize(dev)
+    torch.save({"losses": losses, "p": eng.store.p.cpu()}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("grad_comm", ["f32", "bf16"])
+def test_two_rank_training_step_matches_one_rank_on_the_concatenated_batch(tmp_path, grad_comm):
+    import torch.multiprocessing as mp
+    use_nccl = torch.cuda.device_count() >= WORLD
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_rank_main, args=(port, str(tmp_path), grad_comm, use_nccl), nprocs=WORLD, join=True)
+    r = [torch.load(tmp_path / f"rank{k}.pt") for k in range(WORLD)]
+    # the replicas stay identical, bit for bit
+    assert torch.equal(r[0]["p"], r[1]["p"])
+    # one process, the whole batch, fp32 gradients
+    imgs, noise = _data()
+    eng, step = _make(torch.device("cuda", 0), WORLD * B_RANK, 1)
+    p0 = eng.store.p.cpu().clone()
+    ref_losses = []
+    for it in range(STEPS):
+        step.noise.copy_(noise[it])
+        ref_losses.append(float(step(imgs.cuda())))
+    torch.cuda.synchronize()
+    ref = eng.store.p.cpu()
+    mean_losses = np.mean([r[0]["losses"], r[1]["losses"]], axis=0)
+    # MAE mode masks the same number of patches per sample, so the mean of the rank losses is the global loss and the mean of
+    # the rank gradients the global gradient
+    assert np.allclose(mean_losses, ref_losses, rtol=2e-4 if grad_comm == "f32" else 2e-3), (mean_losses, ref_losses)
+    moved = (ref - p0).abs()
+    err = (r[0]["p"] - ref).abs()
+    # Adam moves every element by ~lr per step; summation order (f32) or bf16 rounding of the gradients can change the
+    # move of an element whose gradient is rounding noise, but not the bulk
+    frac_close = float((err <= (0.05 if grad_comm == "f32" else 0.25) * LR * STEPS).float().mean())
+    assert frac_close > (0.999 if grad_comm == "f32" else 0.98), frac_close
+    assert float(err.max()) <= 2.5 * LR * STEPS and float(moved.max()) > 0.5 * LR

@@ -28,6 +28,7 @@
 #include <tuple>
 
 static char g_err[512];
+int skyemb_skip_mask(void) { return 0; }
 void skyemb_set_error(const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
