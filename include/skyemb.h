@@ -270,6 +270,25 @@ int skyemb_cosine_topk(const float *tw, const float *qn, const float *bank, cons
  * path used for the many short lists of the bank-streaming kernel (per-query fallback to the tournament). */
 int skyemb_topk_merge(const float *in_s, const int64_t *in_i, int Q, int nlists, int k, float *out_s,
                       int64_t *out_i, void *ws, void *stream);
+
+/* Many-query exact top-k in two stages (Q >= 64): an fp16 matrix-core pass over a half-precision image of the bank with
+ * a proven error bound keeps, per query, only the rows whose score could still reach its top-k; the survivors are
+ * re-scored with the contract's fp32 fma chain.  Results are bit-identical to skyemb_cosine_topk + skyemb_topk_merge.
+ * Replaces the same reference code as skyemb_cosine_topk (utils/similarity.py:18-35,149-172).
+ *   skyemb_bank16_prepare   once per bank / weights: bank16 = fp16 rows scaled by 2^-e_i (skyemb_bank16_bytes(N, D) bytes),
+ *                           rowp = 4 floats per row {xn 2^-e, ||x'||_2, 2^-e, xn}, skyemb_bank16_rowp_rows(N) rows (whole tiles)
+ *   skyemb_cosine_topk_prefiltered   whole pipeline on `stream`; out_s / out_i [Q, k] final lists; redo[q] != 0 marks a query
+ *                           whose answer could not be certified (too many near-ties, candidate overflow, fewer than k
+ *                           finite rows): the caller runs those through skyemb_cosine_topk.  thr0 as in skyemb_cosine_topk
+ *                           (NULL: the first bank slice supplies the floor).  ws: skyemb_topk_prefilter_ws_bytes(Q, D, k). */
+int skyemb_topk_prefilter_applicable(int Q, int64_t N, int D, int k);
+int64_t skyemb_topk_prefilter_ws_bytes(int Q, int D, int k);
+int64_t skyemb_bank16_bytes(int64_t N, int D);
+int64_t skyemb_bank16_rowp_rows(int64_t N);
+int skyemb_bank16_prepare(const float *bank, const float *xn, int64_t N, int D, void *bank16, float *rowp, void *stream);
+int skyemb_cosine_topk_prefiltered(const float *tw, const float *qn, int Q, const float *bank, const float *xn, const void *bank16,
+                                   const float *rowp, int64_t N, int D, int k, float eps, int64_t idx_offset, const float *thr0,
+                                   void *ws, int64_t ws_bytes, float *out_s, int64_t *out_i, int *redo, void *stream);
 /* plain score matrix for the reference-shaped path with P>1 patches per sample
  * (utils/similarity.py:262-267 combine over patches happens on these): scores [Q, N]. */
 int skyemb_cosine_scores(const float *tw, const float *qn, const float *bank, const float *xn, int Q, int64_t N,

@@ -93,6 +93,13 @@ PROTOTYPES = {
     "skyemb_cosine_topk": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_f32, c_i64, c_i32, c_vp, c_vp,
                                    c_vp, c_vp]),
     "skyemb_topk_merge": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "skyemb_topk_prefilter_applicable": (c_i32, [c_i32, c_i64, c_i32, c_i32]),
+    "skyemb_topk_prefilter_ws_bytes": (c_i64, [c_i32, c_i32, c_i32]),
+    "skyemb_bank16_bytes": (c_i64, [c_i64, c_i32]),
+    "skyemb_bank16_rowp_rows": (c_i64, [c_i64]),
+    "skyemb_bank16_prepare": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp]),
+    "skyemb_cosine_topk_prefiltered": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_f32, c_i64, c_vp,
+                                               c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "skyemb_cosine_scores": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_f32, c_vp, c_vp]),
 }
 

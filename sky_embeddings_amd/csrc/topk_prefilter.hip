@@ -1,0 +1,706 @@
+// Many-query weighted-cosine top-k in two stages (utils/similarity.py:18-35,149-172; contract: oracle/topk_oracle.c):
+//
+//   stage 1 (prefilter)  approximate dot products on the fp16 matrix cores with a PROVEN error bound,
+//                        every (query, row) pair whose score could still reach the query's top-k is appended to
+//                        the query's candidate list;
+//   stage 2 (exact)      the few survivors are re-scored with the contract's fp32 fma chain and ordered
+//                        (score desc, index asc): the result is bit-identical to the exact kernel's.
+//
+// The exact-fp32 kernel (topk.hip) is bound by the fp32 matrix rate (157 TFLOP/s: 15.4 TFLOP at Q = 10k over 1M x 768);
+// fp16 operands run 16x faster per MFMA and halve the bank bytes.
+//
+// Arithmetic of stage 1.  Row i of the bank is stored as x^_i = fp16(x_i * 2^-e_i) (e_i puts the row maximum in
+// [2^13, 2^14)); the weighted query tw_q = w * t_q as q' = tw_q * 2^-f_q split into qh = fp16(q'), ql = fp16(q' - qh).
+//   dot^ = sum_d (qh_d + ql_d) * x^_d          two v_mfma_f32_16x16x32_f16 passes into one fp32 accumulator
+// Products of two fp16 numbers are exact in fp32.  Against the contract's chain dot' = chain(tw, x) * 2^-(e+f):
+//   |dot^ - dot'| <= eps_a * ||q'||_2 * ||x'||_2,
+//   eps_a = 2^-11 (fp16 rounding of x', relative) + 2^-21 (residual of the query split and the cross term)
+//         + 6.06 * D * 2^-24 (fp32 accumulation of 2D products in any order, priced at one ulp each in case the matrix
+//           core truncates, + the chain's own D roundings)
+//         + 2 * sqrt(D) * 2^-27 (fp16 subnormals of either operand, even if the matrix core flushes them to zero: absolute
+//           errors <= 2^-14 per element, expressed through the row / query maxima >= 2^13).
+// With den = fmaf(qn, xn, eps) > 0 the exact score e = dot' * 2^(e+f) / den therefore lies in
+//   [L, U] = (dot^ -+ eps_a ||q'|| ||x'||) * 2^(e+f) / den   (widened by 2^-22 relative for the divisions).
+// A threshold tau_q that is a lower bound of the query's true k-th best exact score makes "U >= tau_q" a necessary
+// condition for membership in the top-k.  tau_q is the k-th largest L over the candidates found so far -- real rows, so
+// always a valid bound -- and is refreshed between the phases of the pass (bank slices of 1/32, 3/32, 12/32, 16/32 of
+// the tiles after a first slice that takes everything): the candidate lists stay at a few hundred entries per query.
+// At the end the K' candidates with the largest U are re-scored exactly; the answer is accepted when its k-th best
+// exact score beats the U of every candidate that was NOT re-scored, otherwise the query is flagged and the caller
+// runs it through the exact kernel (never observed on embedding-like data; forced in the tests).
+#include "common.h"
+#include <math.h>
+#include <stdlib.h>
+
+namespace {
+
+typedef _Float16 half_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 half8;
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
+
+constexpr int QT = 128, BT = 256, BK = 32, NW = 8, NT = NW * 64;   // queries x bank rows per tile, k-step, waves
+constexpr int A_BYTES = QT * BK * 2, B_BYTES = BT * BK * 2, STAGE = 2 * A_BYTES + B_BYTES;   // hi + lo + bank = 32 KiB
+constexpr int NSTAGE = 4, AHEAD = NSTAGE - 1;   // 96 KiB of LDS-DMA in flight per CU: one workgroup per CU has to cover the
+                                                 // L2 latency alone (a 2 x 64 KiB ring ran at 23 GB/s per CU: 2.8 us per k-step)
+constexpr int NI = (2 * QT + BT) / 16 / NW;     // LDS-DMA instructions per wave per stage (one = 16 rows x 64 B)
+constexpr int GQ = 5;                     // query tiles (hi + lo = 384 KiB each at D = 768) kept hot in an XCD's L2
+constexpr int RESCORE_MAX = 256;          // K': candidates re-scored exactly per query
+
+__device__ __forceinline__ void glds16(const void *src, char *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gvoid_t *)src, (lvoid_t *)lds_wave_base, 16, 0, 0);
+}
+
+__host__ __device__ inline double eps_a_of(int D) {
+    return 0x1p-11 + 0x1p-21 + 6.06 * D * 0x1p-24 + 2.0 * sqrt((double)D) * 0x1p-27;
+}
+
+// ---- preparation --------------------------------------------------------------------------------------------------
+// one wave per row: scale exponent, fp16 image, ||x'||_2 (rounded up), scaled weighted norm.
+// rowp[i] = {xn * 2^-e, ||x'||_2 (1 + D 2^-22), 2^-e, xn}; rows N .. rows_padded-1 (whole tiles of BT rows) hold a sentinel
+__global__ __launch_bounds__(256) void bank16_kernel(const float *__restrict__ bank, const float *__restrict__ xn, int64_t N, int D,
+                                                      half_t *__restrict__ bank16, float4 *__restrict__ rowp, int64_t rows_padded) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) {
+        // padding up to a whole bank tile: ||x'|| = NaN makes the candidate test fail for every query
+        if (row < rows_padded && lane == 0) rowp[row] = make_float4(0.f, NAN, 0.f, 0.f);
+        return;
+    }
+    const float *x = bank + row * D;
+    float mx = 0.f;
+    for (int d = lane * 4; d < D; d += 256) {
+        const float4 v = *(const float4 *)(x + d);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    mx = wave_max(mx);
+    half_t *o = bank16 + row * D;
+    if (!(mx < INFINITY)) {
+        // a row with an infinite element cannot be bounded: fp16 zeros + ||x'|| = inf make every query keep it as a
+        // candidate (U = inf), so the exact stage decides
+        for (int d = lane * 4; d < D; d += 256) *(uint2 *)(o + d) = make_uint2(0u, 0u);
+        if (lane == 0) rowp[row] = make_float4(xn[row], INFINITY, 1.0f, xn[row]);
+        return;
+    }
+    int e = 0;
+    if (mx > 0.f) {
+        (void)frexpf(mx, &e);            // mx = m * 2^e, m in [0.5, 1)
+        e -= 14;                         // mx * 2^-e in [2^13, 2^14)
+    }
+    const float s = ldexpf(1.0f, -e);
+    float ss = 0.f;
+    for (int d = lane * 4; d < D; d += 256) {
+        const float4 v = *(const float4 *)(x + d);
+        const float a = v.x * s, b = v.y * s, c = v.z * s, dd = v.w * s;
+        ss = fmaf(a, a, fmaf(b, b, fmaf(c, c, fmaf(dd, dd, ss))));
+        typedef __attribute__((ext_vector_type(4))) _Float16 half4;
+        half4 h;
+        h[0] = (half_t)a; h[1] = (half_t)b; h[2] = (half_t)c; h[3] = (half_t)dd;
+        *(half4 *)(o + d) = h;
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) {
+        const float nx = sqrtf(ss) * (1.0f + (float)D * 0x1p-22f);
+        const float xnv = xn[row];
+        rowp[row] = make_float4(xnv * s, nx, s, xnv);
+    }
+}
+
+// queries: tw[q] -> qh, ql (fp16, scaled by 2^-f); qbase[q] = {qn * 2^-f, eps_a * ||q'|| (1 + D 2^-22), 2^-f, qn}
+__global__ __launch_bounds__(256) void query16_kernel(const float *__restrict__ tw, const float *__restrict__ qn, int Q, int D,
+                                                       half_t *__restrict__ qh, half_t *__restrict__ ql, float4 *__restrict__ qbase,
+                                                       float eps_a) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    const float *x = tw + (int64_t)q * D;
+    float mx = 0.f;
+    for (int d = lane * 4; d < D; d += 256) {
+        const float4 v = *(const float4 *)(x + d);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    mx = wave_max(mx);
+    int e = 0;
+    if (mx > 0.f && mx < INFINITY) {
+        (void)frexpf(mx, &e);
+        e -= 14;
+    }
+    const float s = ldexpf(1.0f, -e);
+    float ss = 0.f;
+    for (int d = lane * 4; d < D; d += 256) {
+        const float4 v = *(const float4 *)(x + d);
+        const float a[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+        typedef __attribute__((ext_vector_type(4))) _Float16 half4;
+        half4 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ss = fmaf(a[j], a[j], ss);
+            h[j] = (half_t)a[j];
+            l[j] = (half_t)(a[j] - (float)h[j]);      // exact difference in fp32, then one fp16 rounding
+        }
+        *(half4 *)(qh + (int64_t)q * D + d) = h;
+        *(half4 *)(ql + (int64_t)q * D + d) = l;
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) {
+        const float nq = sqrtf(ss) * (1.0f + (float)D * 0x1p-22f);
+        qbase[q] = make_float4(qn[q] * s, eps_a * nq, s, qn[q]);
+    }
+}
+
+// ---- stage 1 ------------------------------------------------------------------------------------------------------
+// Operand tile (rows x 32 k, fp16): 64-byte rows; 16-byte chunk c of row r is stored at chunk c ^ swz(r), the XOR applied
+// to the per-lane SOURCE address (the LDS-DMA destination is wave base + lane * 16).  One instruction = 16 rows.
+// swz makes the four 16-lane groups of a ds_read_b128 fragment read ({rows 0-3, 12-15 of chunk c, rows 4-11 of chunk c+1}
+// and the like, MI355X_MICROARCH.md LDS table) hit 16 distinct 16-byte slots of the 256-byte bank row.
+__device__ __forceinline__ int swz(int r) {
+    const int g = (r >> 2) & 3;
+    return (((g ^ (g >> 1)) & 1) << 1) | (g >> 1);          // g = 0,1,2,3 -> 0,2,3,1
+}
+template <int R>
+__device__ __forceinline__ void issue_rows(const half_t *__restrict__ X, int64_t ld, int64_t r0, int64_t rows, int k0, char *sbase,
+                                           int wave, int lane) {
+    constexpr int PER_WAVE = R / 16 / NW;
+    const int rr = lane >> 2, cs = (lane & 3) ^ swz(rr);
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) {
+        const int rows16 = (wave * PER_WAVE + j) * 16;
+        int64_t gr = r0 + rows16 + rr;
+        gr = gr < rows ? gr : rows - 1;          // rows past the edge feed pairs that the epilogue ignores
+        glds16(X + gr * ld + k0 + cs * 8, sbase + rows16 * 64);
+    }
+}
+__device__ __forceinline__ half8 frag(const char *sbase, int rbase, int lane) {
+    const int r = rbase + (lane & 15);
+    const int c = (lane >> 4) ^ swz(r);
+    return *(const half8 *)(sbase + r * 64 + (c << 4));
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// qpar[q] = {a, b, c, _}: the pair (q, i) is a candidate iff  dot^ + c * nx'_i >= a * xn'_i + b * se_i
+//   a = tau * qn'   b = tau * eps * 2^-f   (both lowered by 2^-20 relative: covers the roundings of this test)   c = eps_a ||q'||
+// Work items: bank tile t of [t0, t1) x query tile; bank tiles are dealt to the XCDs (t - t0) % 8 == blockIdx.x % 8, and an
+// XCD walks its items group-of-GQ-query-tiles outermost, then bank tile, then query tile: the GQ query tiles stay in its
+// L2 while its bank tiles stream through once per group.  The LDS ring never drains between items.
+template <bool TAKE_ALL>
+__global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict__ qh, const half_t *__restrict__ ql,
+                                                       const half_t *__restrict__ bank16, const float4 *__restrict__ rowp,
+                                                       const float4 *__restrict__ qpar, int Q, int64_t N, int D, int t0, int t1,
+                                                       int cap, int *__restrict__ cnt, int *__restrict__ cand_i,
+                                                       float *__restrict__ cand_d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 *spar = (float4 *)(smem + NSTAGE * STAGE);        // [QT] test parameters of the item's queries
+    float4 *srow = spar + QT;                                 // [BT] constants of the item's bank rows
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;                 // 2 x 4 waves: 64 queries x 64 rows each
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, nlocal = gridDim.x >> 3;
+    const int T = t1 - t0, Tx = xcd < T ? (T - xcd + 7) / 8 : 0;
+    const int nqt = (Q + QT - 1) / QT;
+    const int full = nqt / GQ, last = nqt % GQ;
+    const int items = Tx * nqt;                               // < 2^31: a shard has < 2^31 rows
+    const int KT = D / BK;
+    // this workgroup's items: local, local + nlocal, ...
+    const int my_items = items > local ? (items - local + nlocal - 1) / nlocal : 0;
+    if (my_items == 0) return;
+
+    auto item_of = [&](int n, int &qt, int &t) {            // n-th item of this workgroup -> (query tile, bank tile)
+        const int idx = local + n * nlocal;
+        const int per_full = GQ * Tx;
+        int g, within, tt;
+        if (idx < per_full * full) {
+            g = idx / per_full;
+            const int rem = idx - g * per_full;
+            tt = rem / GQ;
+            within = rem - tt * GQ;
+        } else {
+            g = full;
+            const int rem = idx - per_full * full;
+            tt = rem / last;
+            within = rem - tt * last;
+        }
+        qt = __builtin_amdgcn_readfirstlane(g * GQ + within);
+        t = __builtin_amdgcn_readfirstlane(t0 + tt * 8 + xcd);
+    };
+    // the stage being issued runs one k-step ahead of the one being computed, across item boundaries
+    int n_iss = 0, kt_iss = 0, qt_iss, t_iss;
+    item_of(0, qt_iss, t_iss);
+    auto issue_next = [&](int buf) {
+        char *sa = smem + buf * STAGE;
+        const int k0 = kt_iss * BK;
+        issue_rows<QT>(qh, D, (int64_t)qt_iss * QT, Q, k0, sa, wave, lane);
+        issue_rows<QT>(ql, D, (int64_t)qt_iss * QT, Q, k0, sa + A_BYTES, wave, lane);
+        issue_rows<BT>(bank16, D, (int64_t)t_iss * BT, N, k0, sa + 2 * A_BYTES, wave, lane);
+        if (++kt_iss == KT) {
+            kt_iss = 0;
+            if (++n_iss < my_items) item_of(n_iss, qt_iss, t_iss);
+        }
+    };
+
+    f32x4 acc[4][4];
+    int qt = 0, t = 0, buf = 0;
+    const int steps = my_items * KT;
+#pragma unroll
+    for (int p = 0; p < AHEAD; ++p)
+        if (p < steps) issue_next(p);
+    int s = 0;
+    for (int n = 0; n < my_items; ++n) {
+      item_of(n, qt, t);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int kt = 0; kt < KT; ++kt, ++s, buf = buf + 1 < NSTAGE ? buf + 1 : 0) {
+        // stage s has landed (this wave's pieces); up to AHEAD - 1 younger stages stay in flight.  (The ordinary loads of
+        // the per-item constants below are younger still: they can only make this wait stricter, never weaker.)
+        const int rem = steps - 1 - s;
+        if (rem >= 2) wait_vmcnt<2 * NI>();
+        else if (rem == 1) wait_vmcnt<NI>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                          // ... everybody's; and the buffer of step s - 1 is free
+        if (kt == 0) {
+            // test parameters of the item's 128 queries (2 KiB) and constants of its 256 rows (4 KiB) go to LDS by the same
+            // DMA path, issued BEFORE this step's stage: two steps on they are older than everything a counted wait leaves
+            // in flight, so they have landed long before the item's epilogue (KT >= 4).  Both arrays are padded to whole
+            // tiles with entries no pair can pass (init_state_kernel / bank16_kernel).
+            if (wave < 2) glds16((const char *)(qpar + (int64_t)qt * QT) + wave * 1024 + lane * 16, (char *)spar + wave * 1024);
+            else if (wave < 6) glds16((const char *)(rowp + (int64_t)t * BT) + (wave - 2) * 1024 + lane * 16, (char *)srow + (wave - 2) * 1024);
+        }
+        const char *sa = smem + buf * STAGE, *sl = sa + A_BYTES, *sb = sa + 2 * A_BYTES;
+        {
+            half8 fh[4], fl[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fh[i] = frag(sa, wm * 64 + i * 16, lane);
+                fl[i] = frag(sl, wm * 64 + i * 16, lane);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = frag(sb, wn * 64 + j * 16, lane);
+            // the four LDS-DMA instructions of the next stage cost ~100+ issue cycles each: they go BETWEEN the MFMAs (whose
+            // execution covers them), not in front of them
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i == 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s + AHEAD < steps) issue_next(buf >= 1 ? buf - 1 : NSTAGE - 1);   // (s + AHEAD) % NSTAGE == (buf - 1) mod NSTAGE
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[i], fb[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        if (kt == KT - 1) {
+            // ---- epilogue of the item: lane holds queries 4*(lane>>4)+r (r = 0..3) x bank row (lane & 15) per 16x16 block.
+            // All 64 tests of the lane are branch-free (a bit mask); only lanes that found something enter the append path.
+            float4 rp[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rp[j] = srow[wn * 64 + j * 16 + (lane & 15)];
+            unsigned int mlo = 0, mhi = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float4 p = spar[wm * 64 + i * 16 + 4 * (lane >> 4) + r];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float rhs = fmaf(p.x, rp[j].x, p.y * rp[j].z);
+                        const float lhs = fmaf(p.z, rp[j].y, acc[i][j][r]);
+                        const int e = (i * 4 + r) * 4 + j;
+                        const unsigned int bit = lhs >= rhs ? (1u << (e & 31)) : 0u;
+                        if (e < 32) mlo |= bit; else mhi |= bit;
+                    }
+                }
+            if (TAKE_ALL) {
+                // first slice: every (query, row) pair of the slice is a candidate, slot = row within the slice (no counters);
+                // pairs that fail even the open test (NaN) are stored as -inf and dropped by the select step
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int q = qt * QT + wm * 64 + i * 16 + 4 * (lane >> 4) + r;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int64_t row = (int64_t)t * BT + wn * 64 + j * 16 + (lane & 15);
+                            const int e = (i * 4 + r) * 4 + j;
+                            const bool pass = ((e < 32 ? mlo : mhi) >> (e & 31)) & 1u;
+                            if (q < Q && row < N) {
+                                const int64_t o = (int64_t)q * cap + (row - (int64_t)t0 * BT);
+                                cand_i[o] = (int)row;
+                                cand_d[o] = pass ? acc[i][j][r] : -INFINITY;
+                            }
+                        }
+                    }
+            } else if (mlo | mhi) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int e0 = (i * 4 + r) * 4;
+                        if (((e0 < 32 ? mlo : mhi) >> (e0 & 31)) & 15u) {
+                            const int q = qt * QT + wm * 64 + i * 16 + 4 * (lane >> 4) + r;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (((e0 < 32 ? mlo : mhi) >> ((e0 + j) & 31)) & 1u) {
+                                    const int pos = atomicAdd(cnt + q, 1);
+                                    if (pos < cap) {
+                                        cand_i[(int64_t)q * cap + pos] = t * BT + wn * 64 + j * 16 + (lane & 15);
+                                        cand_d[(int64_t)q * cap + pos] = acc[i][j][r];
+                                    }
+                                }
+                        }
+                    }
+            }
+            // (spar / srow are refilled one barrier later at the earliest: after every wave has left this block)
+        }
+      }
+    }
+}
+
+// ---- between phases: new threshold, compaction; last phase: pick the candidates to re-score ---------------------------------
+__device__ __forceinline__ unsigned int orderable(float f) {
+    const unsigned int u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float unorderable(unsigned int o) { return __uint_as_float(o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
+
+// key of the kth largest (1-based, kth <= n) among keys[0..n) (LDS); 4 radix passes of 8 bits.  All threads return it.
+__device__ unsigned int radix_kth_largest(const unsigned int *keys, int n, int kth, int *hist, int tid, int nthreads) {
+    unsigned int prefix = 0, mask = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int b = tid; b < 256; b += nthreads) hist[b] = 0;
+        __syncthreads();
+        for (int e = tid; e < n; e += nthreads) {
+            const unsigned int kx = keys[e];
+            if ((kx & mask) == prefix) atomicAdd(&hist[(kx >> shift) & 255], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0, b = 255;
+            for (; b > 0; --b) {
+                if (run + hist[b] >= kth) break;
+                run += hist[b];
+            }
+            hist[256] = b;
+            hist[257] = kth - run;
+        }
+        __syncthreads();
+        const int b = hist[256];
+        kth = hist[257];
+        prefix |= (unsigned int)b << shift;
+        mask |= 255u << shift;
+        __syncthreads();
+    }
+    return prefix;
+}
+
+// one workgroup (256 threads) per query.  state[q] = {tau (current threshold), overflow flag as float, -, -}
+// final == 0: tau <- max(tau, k-th largest L); keep the candidates with U >= tau; write the test parameters of the next phase.
+// final == 1: sel_i[q][0..nsel) <- the (up to) RESCORE_MAX candidates with the largest U; bound[q] = largest U NOT selected
+//             (-inf when every candidate is selected).
+__global__ __launch_bounds__(256) void select_kernel(int Q, int k, int cap, float eps, const float4 *__restrict__ qbase,
+                                                     const float4 *__restrict__ rowp, int *__restrict__ cnt,
+                                                     int *__restrict__ cand_i, float *__restrict__ cand_d,
+                                                     float4 *__restrict__ qpar, float *__restrict__ tau_q, int *__restrict__ overflow,
+                                                     int final, int *__restrict__ sel_i, int *__restrict__ nsel,
+                                                     float *__restrict__ bound) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned int *kL = (unsigned int *)smem;                  // [cap] orderable(L)
+    unsigned int *kU = kL + cap;                              // [cap] orderable(U)
+    int *hist = (int *)(kU + cap);                            // [258]
+    int *scan = hist + 260;                                   // [8]
+    const int tid = threadIdx.x, q = blockIdx.x;
+    const int raw = cnt[q];
+    if (raw > cap && tid == 0) overflow[q] = 1;
+    const int n = raw < cap ? raw : cap;
+    const float4 qb = qbase[q];                               // {qn', eps_a ||q'||, 2^-f, qn}
+    int *ci = cand_i + (int64_t)q * cap;
+    float *cd = cand_d + (int64_t)q * cap;
+    const float inv_sf = 1.0f / qb.z;                         // 2^f (exact)
+    for (int e = tid; e < n; e += 256) {
+        const float4 rp = rowp[ci[e]];                        // {xn', ||x'||, 2^-e, xn}
+        const float den = fmaf(qb.w, rp.w, eps);
+        const float sc = inv_sf * (1.0f / rp.z);              // 2^(e+f), exact
+        const float err = qb.y * rp.y;
+        const float hi = (cd[e] + err) * sc, lo = (cd[e] - err) * sc;
+        float U = hi / den, L = lo / den;
+        U = U >= 0.f ? U * (1.0f + 0x1p-21f) : U * (1.0f - 0x1p-21f);
+        L = L >= 0.f ? L * (1.0f - 0x1p-21f) : L * (1.0f + 0x1p-21f);
+        if (!(U == U)) U = INFINITY;                          // never drop what cannot be bounded
+        if (!(L == L)) L = -INFINITY;
+        kL[e] = orderable(L);
+        kU[e] = orderable(U);
+    }
+    __syncthreads();
+    float tau = tau_q[q];
+    if (!final) {
+        if (n >= k) {
+            const float kth = unorderable(radix_kth_largest(kL, n, k, hist, tid, 256));
+            tau = fmaxf(tau, kth);
+        }
+        // compaction: survivors keep their relative order (deterministic lists)
+        const unsigned int tk = orderable(tau);
+        int kept = 0;
+        for (int base = 0; base < n; base += 256) {
+            const int e = base + tid;
+            const bool keep = e < n && kU[e] >= tk;
+            int idx_v = 0;
+            float d_v = 0.f;
+            if (keep) { idx_v = ci[e]; d_v = cd[e]; }
+            const unsigned long long m = __ballot(keep);
+            if ((tid & 63) == 0) scan[tid >> 6] = __builtin_popcountll(m);
+            __syncthreads();
+            int off = kept;
+            for (int w = 0; w < (tid >> 6); ++w) off += scan[w];
+            const int tot = scan[0] + scan[1] + scan[2] + scan[3];
+            off += __builtin_popcountll(m & ((1ull << (tid & 63)) - 1));
+            __syncthreads();                                   // reads of this batch precede writes (off <= e)
+            if (keep) { ci[off] = idx_v; cd[off] = d_v; }
+            kept += tot;
+            __syncthreads();
+        }
+        if (tid == 0) {
+            cnt[q] = kept;
+            tau_q[q] = tau;
+            // test parameters of the next phase (see prefilter_kernel); tau = -inf -> everything passes
+            const float t = tau > -3.0e38f ? tau : -3.0e38f;
+            float a = t * qb.x, b = t * eps * qb.z;
+            a -= fabsf(a) * 0x1p-20f;
+            b -= fabsf(b) * 0x1p-20f;
+            if (!(a > -3.0e38f)) a = -3.0e38f;
+            qpar[q] = make_float4(a, b, qb.y, 0.f);
+        }
+        return;
+    }
+    // ---- final: the RESCORE_MAX largest U
+    int *so = sel_i + (int64_t)q * RESCORE_MAX;
+    if (n <= RESCORE_MAX) {
+        for (int e = tid; e < n; e += 256) so[e] = ci[e];
+        if (tid == 0) { nsel[q] = n; bound[q] = -INFINITY; }
+        return;
+    }
+    const unsigned int uk = radix_kth_largest(kU, n, RESCORE_MAX, hist, tid, 256);   // RESCORE_MAX-th largest U
+    // strictly larger first, then ties of uk in list order until the quota is full; bound = uk if anything with U <= uk is left
+    if (tid == 0) { hist[0] = 0; hist[1] = 0; }
+    __syncthreads();
+    for (int e = tid; e < n; e += 256)
+        if (kU[e] > uk) so[atomicAdd(&hist[0], 1)] = ci[e];
+    __syncthreads();
+    const int above = hist[0];
+    for (int e = tid; e < n; e += 256)
+        if (kU[e] == uk) {
+            const int p = atomicAdd(&hist[1], 1);
+            if (above + p < RESCORE_MAX) so[above + p] = ci[e];
+        }
+    __syncthreads();
+    if (tid == 0) {
+        nsel[q] = RESCORE_MAX;
+        bound[q] = unorderable(uk);                            // every candidate left out has U <= uk
+    }
+}
+
+// ---- stage 2: exact scores of the selected candidates, final order, acceptance test ------------------------------------------
+__device__ __forceinline__ float finish_score(float dot, float qn, float xn, float eps) {
+    const float den = fmaf(qn, xn, eps);
+    const float s = __fdiv_rn(dot, den);
+    return s == s ? s : -INFINITY;
+}
+
+// one workgroup (256 threads) per query; thread c owns candidate c: the contract's fma chain over d = 0..D-1
+__global__ __launch_bounds__(256) void rescore_kernel(const float *__restrict__ tw, const float *__restrict__ qn,
+                                                      const float *__restrict__ bank, const float *__restrict__ xn, int Q, int D,
+                                                      int k, float eps, int64_t idx_offset, const int *__restrict__ sel_i,
+                                                      const int *__restrict__ nsel, const float *__restrict__ bound,
+                                                      const int *__restrict__ overflow, float *__restrict__ out_s,
+                                                      int64_t *__restrict__ out_i, int *__restrict__ redo) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *sq = (float *)smem;                                // [D] weighted query
+    float *ss = sq + D;                                       // [RESCORE_MAX] exact scores
+    int *si = (int *)(ss + RESCORE_MAX);                      // [RESCORE_MAX] rows
+    const int tid = threadIdx.x, q = blockIdx.x;
+    const int n = nsel[q];
+    for (int d = tid; d < D; d += 256) sq[d] = tw[(int64_t)q * D + d];
+    __syncthreads();
+    float sc = -INFINITY;
+    int row = 0x7fffffff;
+    if (tid < n) {
+        row = sel_i[(int64_t)q * RESCORE_MAX + tid];
+        const float *x = bank + (int64_t)row * D;
+        float acc = 0.f;
+        for (int d = 0; d < D; d += 4) {      // explicit fmaf only: nothing here for the compiler to contract
+            const float4 v = *(const float4 *)(x + d);
+            acc = fmaf(sq[d], v.x, acc);
+            acc = fmaf(sq[d + 1], v.y, acc);
+            acc = fmaf(sq[d + 2], v.z, acc);
+            acc = fmaf(sq[d + 3], v.w, acc);
+        }
+        sc = finish_score(acc, qn[q], xn[row], eps);
+    }
+    ss[tid] = sc;
+    si[tid] = row;
+    __syncthreads();
+    // rank by counting: (score desc, row asc)
+    int rank = 0;
+    if (tid < n) {
+        for (int e = 0; e < n; ++e) {
+            const float s2 = ss[e];
+            const int r2 = si[e];
+            rank += (s2 > sc || (s2 == sc && r2 < row)) ? 1 : 0;
+        }
+        if (rank < k) {
+            out_s[(int64_t)q * k + rank] = sc;
+            out_i[(int64_t)q * k + rank] = idx_offset + row;
+        }
+        if (rank == k - 1) {
+            // accepted iff the k-th best exact score beats (strictly) the upper bound of everything that was not re-scored
+            redo[q] = (overflow[q] || !(sc > bound[q])) ? 1 : 0;
+        }
+    }
+    if (n < k) {                                              // fewer candidates than k (tiny shard, NaN rows): the exact kernel decides
+        if (tid == 0) redo[q] = 1;
+        for (int e = n + tid; e < k; e += 256) {
+            out_s[(int64_t)q * k + e] = -INFINITY;
+            out_i[(int64_t)q * k + e] = -1;
+        }
+    }
+}
+
+__global__ void init_state_kernel(int Q, int Q_padded, const float *__restrict__ thr0, const float4 *__restrict__ qbase, float eps,
+                                  float4 *__restrict__ qpar, float *__restrict__ tau_q, int *__restrict__ cnt,
+                                  int *__restrict__ overflow, int first_rows) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= Q) {
+        if (q < Q_padded) qpar[q] = make_float4(NAN, 0.f, 0.f, 0.f);   // padding of the last query tile: no pair passes
+        return;
+    }
+    const float tau = thr0 ? thr0[q] : -INFINITY;
+    tau_q[q] = tau;
+    cnt[q] = thr0 ? 0 : first_rows;          // without a floor the first slice is taken whole: slot = row (prefilter_kernel<true>)
+    overflow[q] = 0;
+    const float4 qb = qbase[q];
+    const float t = tau > -3.0e38f ? tau : -3.0e38f;
+    float a = t * qb.x, b = t * eps * qb.z;
+    a -= fabsf(a) * 0x1p-20f;
+    b -= fabsf(b) * 0x1p-20f;
+    if (!(a > -3.0e38f)) a = -3.0e38f;
+    qpar[q] = make_float4(a, b, qb.y, 0.f);
+}
+
+struct Workspace {
+    half_t *qh, *ql;
+    float4 *qbase, *qpar;
+    float *tau, *bound, *cand_d;
+    int *cnt, *overflow, *cand_i, *sel_i, *nsel;
+};
+inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
+int64_t carve(char *base, int Q, int D, int cap, Workspace *w) {
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        char *p = base ? base + off : nullptr;
+        off += align256(bytes);
+        return p;
+    };
+    char *p;
+    p = take((int64_t)Q * D * 2); if (w) w->qh = (half_t *)p;
+    p = take((int64_t)Q * D * 2); if (w) w->ql = (half_t *)p;
+    p = take((int64_t)Q * 16); if (w) w->qbase = (float4 *)p;
+    p = take((int64_t)((Q + QT - 1) / QT * QT) * 16); if (w) w->qpar = (float4 *)p;
+    p = take((int64_t)Q * 4); if (w) w->tau = (float *)p;
+    p = take((int64_t)Q * 4); if (w) w->bound = (float *)p;
+    p = take((int64_t)Q * 4); if (w) w->cnt = (int *)p;
+    p = take((int64_t)Q * 4); if (w) w->overflow = (int *)p;
+    p = take((int64_t)Q * 4); if (w) w->nsel = (int *)p;
+    p = take((int64_t)Q * RESCORE_MAX * 4); if (w) w->sel_i = (int *)p;
+    p = take((int64_t)Q * cap * 4); if (w) w->cand_i = (int *)p;
+    p = take((int64_t)Q * cap * 4); if (w) w->cand_d = (float *)p;
+    return off;
+}
+
+}  // namespace
+
+extern "C" int skyemb_topk_prefilter_applicable(int Q, int64_t N, int D, int k) {
+    // the fp16 pass pays from a few query tiles on; the re-score list must leave room above k
+    return Q >= 64 && D % BK == 0 && D >= 4 * BK && D <= 4096 && k >= 1 && k <= RESCORE_MAX - 64 && N >= 8 * BT && N < (1ll << 31);
+}
+static int skyemb_topk_prefilter_cap(int k) { return k <= 128 ? 4096 : 8192; }
+
+extern "C" int64_t skyemb_bank16_bytes(int64_t N, int D) { return N * D * 2; }
+
+extern "C" int64_t skyemb_bank16_rowp_rows(int64_t N) { return ceil_div64(N, BT) * BT; }
+
+extern "C" int skyemb_bank16_prepare(const float *bank, const float *xn, int64_t N, int D, void *bank16, float *rowp, void *stream) {
+    SKY_CHECK_ARG(bank && xn && bank16 && rowp && N > 0 && D > 0 && D % 4 == 0, "skyemb_bank16_prepare: bad arguments");
+    const int64_t padded = skyemb_bank16_rowp_rows(N);
+    hipLaunchKernelGGL(bank16_kernel, dim3((unsigned)ceil_div64(padded, 4)), dim3(256), 0, (hipStream_t)stream, bank, xn, N, D,
+                       (half_t *)bank16, (float4 *)rowp, padded);
+    SKY_LAUNCH_CHECK("skyemb_bank16_prepare");
+    return 0;
+}
+
+extern "C" int64_t skyemb_topk_prefilter_ws_bytes(int Q, int D, int k) { return carve(nullptr, Q, D, skyemb_topk_prefilter_cap(k), nullptr); }
+
+extern "C" int skyemb_cosine_topk_prefiltered(const float *tw, const float *qn, int Q, const float *bank, const float *xn,
+                                              const void *bank16, const float *rowp, int64_t N, int D, int k, float eps,
+                                              int64_t idx_offset, const float *thr0, void *ws, int64_t ws_bytes, float *out_s,
+                                              int64_t *out_i, int *redo, void *stream) {
+    SKY_CHECK_ARG(tw && qn && bank && xn && bank16 && rowp && ws && out_s && out_i && redo, "skyemb_cosine_topk_prefiltered: null argument");
+    SKY_CHECK_ARG(skyemb_topk_prefilter_applicable(Q, N, D, k), "skyemb_cosine_topk_prefiltered: outside the prefiltered subset "
+                  "(Q >= 64, D %% 64 == 0, k <= %d, N >= %d)", RESCORE_MAX - 64, 8 * BT);
+    const int cap = skyemb_topk_prefilter_cap(k);
+    SKY_CHECK_ARG(ws_bytes >= skyemb_topk_prefilter_ws_bytes(Q, D, k), "skyemb_cosine_topk_prefiltered: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    Workspace w;
+    carve((char *)ws, Q, D, cap, &w);
+    const float eps_a = (float)(eps_a_of(D) * (1.0 + 1e-6));
+    hipLaunchKernelGGL(query16_kernel, dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, st, tw, qn, Q, D, w.qh, w.ql, w.qbase, eps_a);
+    const int T = (int)ceil_div64(N, BT);
+    // phases: [0, first) is taken whole unless a floor came in; then slices ending at 1/32, 1/8, 1/2 and all of the tiles
+    int first = (int)(cap / 2 / BT);                           // rows of the take-everything slice <= cap / 2
+    if (first < 1) first = 1;
+    if (first > T) first = T;
+    const int64_t first_rows = (int64_t)first * BT < N ? (int64_t)first * BT : N;
+    const int Q_padded = (Q + QT - 1) / QT * QT;
+    hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((Q_padded + 255) / 256)), dim3(256), 0, st, Q, Q_padded, thr0, w.qbase, eps,
+                       w.qpar, w.tau, w.cnt, w.overflow, (int)first_rows);
+    static bool attr_set = false;
+    constexpr int smem1 = NSTAGE * STAGE + (QT + BT) * 16;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)prefilter_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem1);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)prefilter_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem1);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8192 * 4 + 272 * 4);
+        if (e != hipSuccess) {
+            skyemb_set_error("skyemb_cosine_topk_prefiltered: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return 2;
+        }
+        attr_set = true;
+    }
+    int ends[5] = {first, T / 32, T / 8, T / 2, T};
+    int t0 = 0;
+    const size_t smem_sel = (size_t)2 * cap * 4 + 272 * 4;
+    for (int p = 0; p < 5; ++p) {
+        int t1 = ends[p];
+        if (p == 0 && thr0) continue;                          // a valid floor is as good as the first slice
+        if (t1 <= t0) continue;
+        if (t1 > T) t1 = T;
+        if (p == 0)
+            hipLaunchKernelGGL(prefilter_kernel<true>, dim3(256), dim3(NT), smem1, st, w.qh, w.ql, (const half_t *)bank16,
+                               (const float4 *)rowp, w.qpar, Q, N, D, t0, t1, cap, w.cnt, w.cand_i, w.cand_d);
+        else
+            hipLaunchKernelGGL(prefilter_kernel<false>, dim3(256), dim3(NT), smem1, st, w.qh, w.ql, (const half_t *)bank16,
+                               (const float4 *)rowp, w.qpar, Q, N, D, t0, t1, cap, w.cnt, w.cand_i, w.cand_d);
+        const int final = t1 == T;
+        hipLaunchKernelGGL(select_kernel, dim3((unsigned)Q), dim3(256), smem_sel, st, Q, k, cap, eps, w.qbase, (const float4 *)rowp,
+                           w.cnt, w.cand_i, w.cand_d, w.qpar, w.tau, w.overflow, final, w.sel_i, w.nsel, w.bound);
+        t0 = t1;
+    }
+    hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)Q), dim3(256), (size_t)D * 4 + RESCORE_MAX * 8, st, tw, qn, bank, xn, Q, D, k, eps,
+                       idx_offset, w.sel_i, w.nsel, w.bound, w.overflow, out_s, out_i, redo);
+    SKY_LAUNCH_CHECK("skyemb_cosine_topk_prefiltered");
+    return 0;
+}

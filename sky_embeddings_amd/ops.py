@@ -233,6 +233,31 @@ def cosine_topk(tw, qn, bank, xn, k, eps, idx_offset, nchunks, part_s, part_i, t
                                    _p(part_s), _p(part_i), _stream()), "skyemb_cosine_topk")
 
 
+def topk_prefilter_applicable(Q, N, D, k):
+    return bool(lib().skyemb_topk_prefilter_applicable(Q, N, D, k))
+
+
+def bank16_prepare(bank, xn):
+    """fp16 image of the bank for the prefiltered many-query top-k: (bank16 [N, D] half, rowp [N, 4] float)."""
+    N, D = bank.shape
+    bank16 = torch.empty(N, D, device=bank.device, dtype=torch.float16)
+    rowp = torch.empty(lib().skyemb_bank16_rowp_rows(N), 4, device=bank.device, dtype=torch.float32)   # whole tiles of rows
+    check(lib().skyemb_bank16_prepare(_p(bank), _p(xn), N, D, _p(bank16), _p(rowp), _stream()), "skyemb_bank16_prepare")
+    return bank16, rowp
+
+
+def cosine_topk_prefiltered(tw, qn, bank, xn, bank16, rowp, k, eps, idx_offset, out_s, out_i, redo, thr0=None, ws=None):
+    Q, D = tw.shape
+    N = bank.shape[0]
+    need = lib().skyemb_topk_prefilter_ws_bytes(Q, D, k)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, device=tw.device, dtype=torch.uint8)
+    check(lib().skyemb_cosine_topk_prefiltered(_p(tw), _p(qn), Q, _p(bank), _p(xn), _p(bank16), _p(rowp), N, D, k, eps, idx_offset,
+                                               _p(thr0), _p(ws), ws.numel(), _p(out_s), _p(out_i), _p(redo), _stream()),
+          "skyemb_cosine_topk_prefiltered")
+    return ws
+
+
 def topk_merge(in_s, in_i, Q, nlists, k, out_s, out_i, ws=None):
     """ws: optional int32 [Q] scratch enabling the gather + block-sort path for many short lists."""
     check(lib().skyemb_topk_merge(_p(in_s), _p(in_i), Q, nlists, k, _p(out_s), _p(out_i), _p(ws), _stream()),

@@ -23,12 +23,21 @@ class PreparedBank:
         self.bank, self.idx_offset = bank, int(idx_offset)
         self.norms = torch.empty(bank.shape[0], device=bank.device)
         self._sample = None
+        self._half = None
         self.set_weights(weights)
 
     def set_weights(self, weights):
         self.weights = None if weights is None else weights.to(self.bank.device, torch.float32).contiguous()
         ops.weighted_norms(self.bank, self.weights, self.norms)
         self._sample = None
+        self._half = None
+
+    def half_image(self):
+        """(bank16, rowp): the fp16 image + per-row constants the prefiltered many-query search runs on; built on first
+        use (one pass over the bank, +50 % bank memory) and kept until the weights change."""
+        if self._half is None:
+            self._half = ops.bank16_prepare(self.bank, self.norms)
+        return self._half
 
     def sample(self, rows: int):
         """A strided row sample (bank rows + norms) used to derive the pruning floor of a search."""
@@ -86,18 +95,52 @@ def pruning_floor(tw, qn, pb: "PreparedBank", k: int, eps: float, sample_rows: i
     return torch.nextafter(tau, torch.full_like(tau, float("-inf")))
 
 
+def _prefilter_enabled():
+    import os
+    return os.environ.get("SKYEMB_TOPK_PREFILTER", "1") != "0"
+
+
+def _local_topk_prefiltered(tw, qn, pb: "PreparedBank", k, eps):
+    """Two-stage exact top-k of this rank's shard (csrc/topk_prefilter.hip); queries the second stage could not certify
+    (redo flags) go through the exact fp32 kernel."""
+    Q = tw.shape[0]
+    dev = tw.device
+    bank16, rowp = pb.half_image()
+    out_s = torch.empty(Q, k, device=dev)
+    out_i = torch.empty(Q, k, device=dev, dtype=torch.int64)
+    redo = torch.empty(Q, device=dev, dtype=torch.int32)
+    ops.cosine_topk_prefiltered(tw, qn, pb.bank, pb.norms, bank16, rowp, k, eps, pb.idx_offset, out_s, out_i, redo)
+    again = torch.nonzero(redo).squeeze(1)                 # host sync: a handful of bytes per search
+    if again.numel():
+        tw2, qn2 = tw.index_select(0, again).contiguous(), qn.index_select(0, again).contiguous()
+        thr0 = pruning_floor(tw2, qn2, pb, k, eps)
+        s2, i2 = _local_topk(tw2, qn2, pb.bank, pb.norms, k, eps, pb.idx_offset, thr0)
+        out_s.index_copy_(0, again, s2)
+        out_i.index_copy_(0, again, i2)
+    return out_s, out_i, int(again.numel())
+
+
 def cosine_topk(queries: torch.Tensor, bank, k: int, weights: torch.Tensor | None = None, eps: float = 1e-6,
-                process_group=None, world_size: int = 1, prune: bool = True):
+                process_group=None, world_size: int = 1, prune: bool = True, stats: dict | None = None):
     """-> (scores f32 [Q,k], indices i64 [Q,k]).  ``bank`` is a [N,D] tensor or a PreparedBank
-    (this rank's shard; ``idx_offset`` = first global row of the shard)."""
+    (this rank's shard; ``idx_offset`` = first global row of the shard).  Many queries (Q >= 64) take the two-stage
+    path (fp16 matrix-core prefilter with a proven error bound, exact fp32 re-score of the survivors: same results bit
+    for bit); SKYEMB_TOPK_PREFILTER=0 keeps every search on the exact fp32 kernels."""
     pb = bank if isinstance(bank, PreparedBank) else PreparedBank(bank, weights)
     q = queries.to(pb.bank.device, torch.float32).contiguous()
     Q, D = q.shape
     N = pb.bank.shape[0]
     assert D == pb.bank.shape[1]
     tw, qn = prepare_queries(q, pb.weights)
-    thr0 = pruning_floor(tw, qn, pb, k, eps) if prune else None
-    out_s, out_i = _local_topk(tw, qn, pb.bank, pb.norms, k, eps, pb.idx_offset, thr0)
+    if _prefilter_enabled() and ops.topk_prefilter_applicable(Q, N, D, k):
+        out_s, out_i, n_redo = _local_topk_prefiltered(tw, qn, pb, k, eps)
+        if stats is not None:
+            stats.update(path="prefiltered", redone=n_redo)
+    else:
+        thr0 = pruning_floor(tw, qn, pb, k, eps) if prune else None
+        out_s, out_i = _local_topk(tw, qn, pb.bank, pb.norms, k, eps, pb.idx_offset, thr0)
+        if stats is not None:
+            stats.update(path="exact", redone=0)
     if world_size > 1:
         from .distributed import gather_topk
         gs, gi = gather_topk(out_s, out_i, world_size, process_group)   # RCCL all-gather -> [Q, world, k]

@@ -94,3 +94,75 @@ def test_full_size_bank_1m_x_768_against_oracle():
     assert np.array_equal(got_s, ref_s)
     # and the two kernels agree with each other on the queries both served
     assert torch.equal(iL[:16], i16) and torch.equal(sL[:16], s16)
+
+
+def _oracle_equal(q, x, w, k, **kw):
+    from sky_embeddings_amd import search
+    stats = {}
+    pb = search.PreparedBank(torch.from_numpy(x).cuda(), None if w is None else torch.from_numpy(w).cuda())
+    s, i = search.cosine_topk(torch.from_numpy(q).cuda(), pb, k, stats=stats, **kw)
+    ref_s, ref_i = so.cosine_topk_np(q, x, k, w)
+    assert np.array_equal(i.cpu().numpy(), ref_i), (stats, np.argwhere(i.cpu().numpy() != ref_i)[:5])
+    assert np.array_equal(s.cpu().numpy(), ref_s), stats
+    return stats
+
+
+@pytest.mark.parametrize("Q,N,D,k,weighted", [(64, 2048, 128, 10, True), (130, 21000, 128, 100, True), (300, 60000, 768, 100, False),
+                                              (77, 9000, 192, 150, True), (1000, 30000, 160, 1, True)])
+def test_prefiltered_many_query_topk_is_bit_exact(Q, N, D, k, weighted):
+    """Two-stage path (fp16 matrix-core prefilter with a proven bound -> exact fp32 re-score) == oracle, bit for bit:
+    ragged query / bank tiles, k up to the re-score quota, duplicates inside and across bank slices."""
+    rng = np.random.default_rng(Q * 7 + N)
+    q = rng.standard_normal((Q, D), dtype=np.float32)
+    x = (rng.standard_normal((N, D)) * rng.uniform(0.2, 5.0, size=(N, 1))).astype(np.float32)   # rows of very different scale
+    sc0 = so.cosine_scores_np(q[:1], x, None)[0]
+    best = np.argsort(-sc0)[:3]
+    x[N - 1], x[N // 2 + 1], x[7] = x[best[0]], x[best[1]], x[best[2]]      # exact ties: lower index first
+    w = None
+    if weighted:
+        w = (1.0 / (rng.random(D, dtype=np.float32) + 0.05) ** 2).astype(np.float32)   # weights spread over 2.5 decades
+        w /= w.sum()
+    stats = _oracle_equal(q, x, w, k)
+    assert stats["path"] == "prefiltered" and stats["redone"] <= Q // 10
+
+
+def test_prefiltered_topk_certification_failures_fall_back_to_the_exact_kernel():
+    """A bank crowded around the k-th score (hundreds of near-duplicates of the query's best rows), rows with NaN / Inf /
+    all zeros, a zero query: the second stage cannot certify every answer from its re-score quota -- those queries are
+    flagged and re-run by the exact kernel; results stay bit-identical to the oracle."""
+    rng = np.random.default_rng(5)
+    Q, N, D, k = 96, 12000, 128, 60
+    q = rng.standard_normal((Q, D), dtype=np.float32)
+    x = rng.standard_normal((N, D), dtype=np.float32)
+    x[1000:1600] = q[3] + 1e-5 * rng.standard_normal((600, D)).astype(np.float32)    # 600 rows within ~1e-7 of each other for query 3
+    x[2000:2300] = 2.5 * q[10] + 1e-6 * rng.standard_normal((300, D)).astype(np.float32)
+    x[50] = np.nan
+    x[51, 7] = np.inf
+    x[52] = 0.0
+    x[53, :] = 1e-30                                                                  # underflows in the fp16 image
+    q[20] = 0.0
+    w = rng.random(D, dtype=np.float32) + 0.1
+    w /= w.sum()
+    stats = _oracle_equal(q, x, w, k)
+    assert stats["path"] == "prefiltered" and stats["redone"] >= 2                    # queries 3 and 10 at least
+
+
+def test_prefiltered_equals_exact_kernel_at_mid_size():
+    """200k x 256 bank, 512 queries: the two device paths agree bit for bit (no CPU oracle at this size)."""
+    import os
+    from sky_embeddings_amd import search
+    g = torch.Generator(device="cuda").manual_seed(3)
+    bank = torch.randn(200_000, 256, device="cuda", generator=g)
+    queries = torch.randn(512, 256, device="cuda", generator=g)
+    w = torch.rand(256, device="cuda", generator=g) + 0.1
+    pb = search.PreparedBank(bank, w / w.sum())
+    st = {}
+    s1, i1 = search.cosine_topk(queries, pb, 100, stats=st)
+    assert st["path"] == "prefiltered" and st["redone"] == 0
+    os.environ["SKYEMB_TOPK_PREFILTER"] = "0"
+    try:
+        s2, i2 = search.cosine_topk(queries, pb, 100, stats=st)
+    finally:
+        del os.environ["SKYEMB_TOPK_PREFILTER"]
+    assert st["path"] == "exact"
+    assert torch.equal(i1, i2) and torch.equal(s1, s2)
