@@ -241,6 +241,13 @@ int skyemb_cast(const float *src, void *dst, int dtype, int64_t n, void *stream)
  * kept) and centre-cropped on the device (utils/dataloaders.py:293-300). */
 int skyemb_gather_rows_host(const void *src, int64_t row_bytes, const int64_t *idx, int64_t n, int64_t src_rows, void *dst,
                             int nthreads);
+/* Chunked HDF5 dataset -> contiguous row-major image (host threads; see hdf5_lite.py).  The reference's ETL writes its
+ * train / validation files chunked (data_processing/2_create_h5_files.py:70-81: maxshape=(None, ...) + resize); they are
+ * un-chunked once into a cache file and then served by the mmap fast path above.  file_base / file_bytes: the mapped file;
+ * chunk i: byte address chunk_addr[i], element offsets chunk_off[i*rank ..], extent chunk_dims (edge chunks stored whole). */
+int skyemb_h5_unchunk_host(const void *file_base, int64_t file_bytes, const int64_t *chunk_addr, const int64_t *chunk_off,
+                           int64_t nchunks, int rank, const int64_t *chunk_dims, const int64_t *dset_dims, int elem_size, void *dst,
+                           int nthreads);
 int skyemb_clip_crop(const float *src, float *dst, int64_t n_planes, int Hs, int Ws, int size, float lo, float hi,
                      int use_lo, int use_hi, void *stream);
 

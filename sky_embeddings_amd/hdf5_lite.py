@@ -2,20 +2,31 @@
 
 Schema (reference ``data_processing/utils.py:333-361``, ``configs/README.md:10-13``): root-level
 datasets ``cutouts float32 [N,C,H,W]``, ``ra``/``dec`` float32 [N], optional ``zspec``,
-``zspec_err``, ``class`` -- created with ``create_dataset(name, shape, dtype)`` i.e. CONTIGUOUS
-layout, no filters.  That subset of the HDF5 1.x file format is what this module reads
-(superblock v0/v1, v1 object headers incl. continuation blocks, v1 group B-trees + local heaps,
-dataspace v1/v2, fixed-point / IEEE float little-endian datatypes, contiguous (and compact) data
-layout v3) and writes (the synthetic-data generator).  Chunked / compressed / new-style-group
-files raise ``NotImplementedError`` naming the feature.  Datasets are exposed as ``numpy.memmap``
-views, so a [N,5,64,64] cutout file is read with plain coalesced page-cache I/O instead of the
-reference's per-item ``h5py.File`` open (utils/dataloaders.py:289).
+``zspec_err``, ``class``.  The per-tile temp files and the train/validation splits are created with
+``create_dataset(name, shape, dtype)`` (CONTIGUOUS layout: data_processing/utils.py:346-350,
+4_split_dataset.py:32); the combined files with ``create_dataset(k, shape, maxshape=(None, ...))`` +
+``resize`` (CHUNKED layout with h5py's automatic chunk shape, no filters:
+data_processing/2_create_h5_files.py:70-81, 3_combine_h5_files.py:37-52, create_datasets.py:78-85).
+This module reads that subset of the HDF5 1.x file format (superblock v0/v1, v1 object headers incl.
+continuation blocks, v1 group B-trees + local heaps, dataspace v1/v2 incl. maximum dimensions,
+fixed-point / IEEE float little-endian datatypes, data layout v3: contiguous, compact and chunked with the
+v1 chunk B-tree) and writes it (the synthetic-data generator; chunked files for round-trip tests).
+Compressed / new-style-group files raise ``NotImplementedError`` naming the feature.
+
+Contiguous datasets are exposed as ``numpy.memmap`` views, so a [N,5,64,64] cutout file is read with plain
+coalesced page-cache I/O instead of the reference's per-item ``h5py.File`` open (utils/dataloaders.py:289).
+A chunked dataset answers indexed reads by assembling the chunks it touches; the feeder's fast path
+(``Dataset._array()``) un-chunks it ONCE (native threads, ``skyemb_h5_unchunk_host``) into a contiguous
+cache file next to the source (or under ``$SKYEMB_H5_CACHE``) and memory-maps that.
 
 If ``h5py`` is importable it is NOT used: one code path everywhere keeps results reproducible.
 """
 from __future__ import annotations
 
+import json
+import os
 import struct
+import tempfile
 
 import numpy as np
 
@@ -29,15 +40,104 @@ class H5LiteError(IOError):
 
 # ------------------------------------------------------------------------------------------ reader
 class Dataset:
-    def __init__(self, name, shape, dtype, offset, fileobj_path, inline=None):
+    def __init__(self, name, shape, dtype, offset, fileobj_path, inline=None, chunks=None, btree=None, reader=None):
         self.name, self.shape, self.dtype = name, tuple(shape), np.dtype(dtype)
         self._offset, self._path, self._inline = offset, fileobj_path, inline
+        self.chunks = tuple(chunks) if chunks is not None else None      # None: contiguous / compact
+        self._btree, self._reader = btree, reader
         self._mm = None
+        self._table = None
 
+    # -- chunked layout ---------------------------------------------------------------------------------------------
+    def chunk_table(self):
+        """(addresses int64 [n], element offsets int64 [n, rank]) of every stored chunk (v1 B-tree, node type 1)."""
+        if self._table is None:
+            addr, off = [], []
+            if self._btree not in (None, UNDEF):
+                self._reader._walk_chunk_btree(self._btree, len(self.shape), int(np.prod(self.chunks)) * self.dtype.itemsize,
+                                               addr, off)
+            self._table = (np.asarray(addr, dtype=np.int64), np.asarray(off, dtype=np.int64).reshape(len(addr), len(self.shape)))
+        return self._table
+
+    def _cache_path(self):
+        root = os.environ.get("SKYEMB_H5_CACHE")
+        base = f".{os.path.basename(self._path)}.{self.name}.contig"
+        for d in ([root] if root else []) + [os.path.dirname(os.path.abspath(self._path)), tempfile.gettempdir()]:
+            if d and os.path.isdir(d) and os.access(d, os.W_OK):
+                return os.path.join(d, base)
+        raise H5LiteError(f"no writable directory for the contiguous cache of {self._path}:{self.name}")
+
+    def _unchunk(self):
+        """Contiguous row-major copy of a chunked dataset in a cache file (rebuilt when the source changes)."""
+        from ._lib import check, lib
+        st = os.stat(self._path)
+        stamp = {"size": st.st_size, "mtime_ns": st.st_mtime_ns, "shape": list(self.shape), "dtype": self.dtype.str,
+                 "chunks": list(self.chunks)}
+        path = self._cache_path()
+        meta = path + ".json"
+        nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        if os.path.exists(path) and os.path.exists(meta) and os.path.getsize(path) == nbytes:
+            try:
+                if json.load(open(meta)) == stamp:
+                    return np.memmap(path, dtype=self.dtype, mode="r", shape=self.shape)
+            except (OSError, ValueError):
+                pass
+        addr, off = self.chunk_table()
+        tmp = f"{path}.{os.getpid()}.tmp"
+        out = np.memmap(tmp, dtype=self.dtype, mode="w+", shape=self.shape)      # holes (never-written chunks) read as 0
+        src = np.memmap(self._path, dtype=np.uint8, mode="r")
+        cd = np.asarray(self.chunks, dtype=np.int64)
+        dd = np.asarray(self.shape, dtype=np.int64)
+        check(lib().skyemb_h5_unchunk_host(src.ctypes.data, src.size, addr.ctypes.data, np.ascontiguousarray(off).ctypes.data,
+                                           len(addr), len(self.shape), cd.ctypes.data, dd.ctypes.data, self.dtype.itemsize,
+                                           out.ctypes.data, min(16, os.cpu_count() or 1)), "skyemb_h5_unchunk_host")
+        out.flush()
+        del out, src
+        os.replace(tmp, path)
+        with open(meta, "w") as fh:
+            json.dump(stamp, fh)
+        return np.memmap(path, dtype=self.dtype, mode="r", shape=self.shape)
+
+    def _read_chunked(self, idx):
+        """Indexed read of a chunked dataset without the cache: only the chunks the request touches are read.  ``idx``
+        selects along axis 0 (int, slice or integer array); trailing axes are returned whole."""
+        n = self.shape[0]
+        if isinstance(idx, tuple):
+            return self._read_chunked(idx[0])[(slice(None),) + tuple(idx[1:])] if not isinstance(idx[0], (int, np.integer)) \
+                else self._read_chunked(idx[0])[tuple(idx[1:])]
+        scalar = isinstance(idx, (int, np.integer))
+        rows = np.arange(n)[idx] if not scalar else np.asarray([idx + n if idx < 0 else idx])
+        rows = np.atleast_1d(np.asarray(rows, dtype=np.int64))
+        if rows.size and (rows.min() < 0 or rows.max() >= n):
+            raise IndexError(f"index out of range for axis 0 with size {n}")
+        out = np.zeros((rows.size,) + self.shape[1:], self.dtype)
+        addr, off = self.chunk_table()
+        if rows.size and len(addr):
+            c0 = self.chunks[0]
+            want = {}                                           # axis-0 chunk block -> [(position in out, row inside block)]
+            for pos, r in enumerate(rows.tolist()):
+                want.setdefault(r // c0, []).append((pos, r % c0))
+            sel = np.nonzero(np.isin(off[:, 0] // c0, list(want)))[0]
+            csize = int(np.prod(self.chunks)) * self.dtype.itemsize
+            with open(self._path, "rb") as fh:
+                for ci in sel.tolist():
+                    fh.seek(int(addr[ci]))
+                    chunk = np.frombuffer(fh.read(csize), dtype=self.dtype).reshape(self.chunks)
+                    o = off[ci]
+                    ext = [min(self.chunks[d], self.shape[d] - int(o[d])) for d in range(1, len(self.shape))]
+                    dst_sl = tuple(slice(int(o[d]), int(o[d]) + ext[d - 1]) for d in range(1, len(self.shape)))
+                    src_sl = tuple(slice(0, e) for e in ext)
+                    for pos, rin in want[int(o[0]) // c0]:
+                        out[(pos,) + dst_sl] = chunk[(rin,) + src_sl]
+        return out[0] if scalar else out
+
+    # -- array access -----------------------------------------------------------------------------------------------
     def _array(self):
         if self._mm is None:
             if self._inline is not None:
                 self._mm = np.frombuffer(self._inline, dtype=self.dtype).reshape(self.shape)
+            elif self.chunks is not None:
+                self._mm = self._unchunk() if int(np.prod(self.shape)) else np.zeros(self.shape, self.dtype)
             elif self._offset == UNDEF or int(np.prod(self.shape)) == 0:
                 self._mm = np.zeros(self.shape, self.dtype)  # never written: fill value 0
             else:
@@ -48,10 +148,15 @@ class Dataset:
         return self.shape[0]
 
     def __getitem__(self, idx):
+        # small 1-D chunked datasets (ra, dec, labels) are assembled from their chunks; image-like ones go through the
+        # contiguous cache: h5py's automatic chunks hold ~128 rows x a sliver of the bands / pixels, so ONE cutout touches
+        # ~160 chunks (10 MB) -- per-item chunk reads would be hundreds of times the useful bytes
+        if self.chunks is not None and self._mm is None and len(self.shape) == 1:
+            return self._read_chunked(idx)
         return np.array(self._array()[idx])  # copy, like h5py (callers mutate: utils/dataloaders.py:294)
 
     def __array__(self, dtype=None, copy=None):
-        a = np.asarray(self._array())
+        a = np.asarray(self._array()) if self.chunks is None or self._mm is not None else self._read_chunked(slice(None))
         return a.astype(dtype) if dtype is not None else a
 
 
@@ -66,14 +171,15 @@ class File:
             self._buf = fh.read(1 << 20)  # metadata of these files lives in the first MiB
             self._fh_size = fh.seek(0, 2)
         self._datasets = {}
+        self._far = None
         self._parse()
 
     # -- low level
     def _read(self, off, n):
         if off + n > len(self._buf):
-            with open(self.path, "rb") as fh:
-                fh.seek(off)
-                return fh.read(n)
+            if self._far is None:                  # chunk B-tree nodes are spread over the whole file: map it once
+                self._far = np.memmap(self.path, dtype=np.uint8, mode="r")
+            return self._far[off:off + n].tobytes()
         return self._buf[off:off + n]
 
     def _u(self, off, n):
@@ -136,6 +242,28 @@ class File:
                     e = child + 8 + j * 40
                     yield self._u(e, 8), self._u(e + 8, 8)
 
+    def _walk_chunk_btree(self, addr, rank, chunk_bytes, out_addr, out_off):
+        """v1 B-tree, node type 1 (raw data chunks): key = {chunk size u32, filter mask u32, rank+1 offsets u64}."""
+        if self._read(addr, 4) != b"TREE":
+            raise H5LiteError("bad chunk B-tree signature")
+        ntype, level, used = self._u(addr + 4, 1), self._u(addr + 5, 1), self._u(addr + 6, 2)
+        if ntype != 1:
+            raise H5LiteError("unexpected B-tree node type for a chunked dataset")
+        ksize = 8 + 8 * (rank + 1)
+        node = self._read(addr + 24, used * (ksize + 8) + ksize)
+        for i in range(used):
+            p = i * (ksize + 8)
+            size, fmask = struct.unpack("<II", node[p:p + 8])
+            offs = struct.unpack("<" + "Q" * (rank + 1), node[p + 8:p + ksize])
+            child = struct.unpack("<Q", node[p + ksize:p + ksize + 8])[0]
+            if level > 0:
+                self._walk_chunk_btree(child + self._base, rank, chunk_bytes, out_addr, out_off)
+            else:
+                if fmask != 0 or size != chunk_bytes:
+                    raise NotImplementedError("filtered (compressed) chunks are not supported")
+                out_addr.append(child + self._base)
+                out_off.append(offs[:rank])
+
     def _messages(self, addr):
         ver = self._u(addr, 1)
         if ver != 1:
@@ -187,15 +315,25 @@ class File:
                 elif cls == 0:
                     n = struct.unpack("<H", d[2:4])[0]
                     layout = ("compact", bytes(d[4:4 + n]), n)
+                elif cls == 2:
+                    nd = d[2]                                  # dimensionality = rank + 1 (last: element size)
+                    bt = struct.unpack("<Q", d[3:11])[0]
+                    dims = struct.unpack("<" + "I" * nd, d[11:11 + 4 * nd])
+                    layout = ("chunked", bt, dims)
                 else:
-                    raise NotImplementedError(f"dataset {name!r} is chunked/filtered: hdf5_lite reads contiguous datasets "
-                                              "only (the reference writes them with create_dataset(name, shape, dtype))")
+                    raise NotImplementedError(f"dataset {name!r}: data layout class {cls} is not supported")
             elif mtype == 0x000B:
                 raise NotImplementedError(f"dataset {name!r} uses a filter pipeline (compression)")
         if shape is None or layout is None or dtype is None:
             return None  # a sub-group or an unsupported type: not part of the schema
         if layout[0] == "compact":
             return Dataset(name, shape, dtype, None, self.path, inline=layout[1])
+        if layout[0] == "chunked":
+            bt, dims = layout[1], layout[2]
+            if len(dims) != len(shape) + 1 or dims[-1] != np.dtype(dtype).itemsize:
+                raise H5LiteError(f"dataset {name!r}: inconsistent chunk dimensions {dims} for shape {shape}")
+            return Dataset(name, shape, dtype, None, self.path, chunks=dims[:-1], btree=bt if bt == UNDEF else bt + self._base,
+                           reader=self)
         a = layout[1]
         return Dataset(name, shape, dtype, a if a == UNDEF else a + self._base, self.path)
 
@@ -246,13 +384,68 @@ def _dtype_msg(dt):
     raise TypeError(f"hdf5_lite cannot write dtype {dt}")
 
 
-def write_datasets(path, datasets: dict):
-    """Create an HDF5 file with root-level contiguous datasets (h5py-readable, 'earliest' format).
-    ``datasets`` maps name -> ndarray (written little-endian, C order)."""
+CHUNK_K = 32          # "indexed storage internal node K" a version-0 superblock implies: <= 64 entries per chunk B-tree node
+
+
+def _chunk_blobs(a, cs):
+    """(element offsets, bytes) of every chunk of array ``a`` cut into chunks of shape ``cs`` (C order of the chunk
+    grid; edge chunks are stored whole, zero padded -- as the HDF5 library does)."""
+    grid = [-(-a.shape[d] // cs[d]) for d in range(a.ndim)]
+    out = []
+    for flat in range(int(np.prod(grid))):
+        g = np.unravel_index(flat, grid)
+        off = [int(g[d]) * cs[d] for d in range(a.ndim)]
+        blk = np.zeros(cs, a.dtype)
+        sl = tuple(slice(off[d], min(off[d] + cs[d], a.shape[d])) for d in range(a.ndim))
+        blk[tuple(slice(0, s_.stop - s_.start) for s_ in sl)] = a[sl]
+        out.append((off, blk.astype(a.dtype.newbyteorder("<"), copy=False).tobytes()))
+    return out
+
+
+def _chunk_btree(entries, rank, chunk_bytes, alloc):
+    """v1 B-tree over ``entries`` = [(offsets, address)]; ``alloc(nbytes) -> address`` reserves file space.  Returns
+    (root address, [(address, node bytes)])."""
+    ksize = 8 + 8 * (rank + 1)
+    node_bytes = 24 + (2 * CHUNK_K + 1) * ksize + 2 * CHUNK_K * 8
+
+    def key(offsets):
+        return struct.pack("<II", chunk_bytes, 0) + struct.pack("<" + "Q" * (rank + 1), *offsets, 0)
+    nodes = []
+    level = 0
+    items = [(off, addr) for off, addr in entries]            # (first key offsets, child address)
+    last_off = entries[-1][0]
+    while True:
+        groups = [items[i:i + 2 * CHUNK_K] for i in range(0, len(items), 2 * CHUNK_K)]
+        addrs = [alloc(node_bytes) for _ in groups]
+        nxt = []
+        for gi, grp in enumerate(groups):
+            left = addrs[gi - 1] if gi > 0 else UNDEF
+            right = addrs[gi + 1] if gi + 1 < len(groups) else UNDEF
+            b = b"TREE" + struct.pack("<BBHQQ", 1, level, len(grp), left, right)
+            for off, child in grp:
+                b += key(off) + struct.pack("<Q", child)
+            b += key(groups[gi + 1][0][0] if gi + 1 < len(groups) else last_off)     # final key: the next node's first chunk
+            b += b"\0" * (node_bytes - len(b))
+            nodes.append((addrs[gi], b))
+            nxt.append((grp[0][0], addrs[gi]))
+        if len(groups) == 1:
+            return addrs[0], nodes
+        items, level = nxt, level + 1
+
+
+def write_datasets(path, datasets: dict, chunks: dict | None = None):
+    """Create an HDF5 file with root-level datasets (h5py-readable, 'earliest' format).  ``datasets`` maps name ->
+    ndarray (written little-endian, C order).  Names listed in ``chunks`` (name -> chunk shape) are written CHUNKED and
+    resizable along axis 0 -- the layout ``create_dataset(k, shape, maxshape=(None, ...))`` + ``resize`` produces in the
+    reference's ETL (data_processing/2_create_h5_files.py:70-81); the others contiguous."""
+    chunks = dict(chunks or {})
     names = sorted(datasets)
     if len(names) > 8:
         raise ValueError("hdf5_lite writes at most 8 root datasets (one symbol-table node)")
     arrays = {n: np.ascontiguousarray(datasets[n]) for n in names}
+    for n, cs in chunks.items():
+        if n not in arrays or len(cs) != arrays[n].ndim or min(cs) < 1:
+            raise ValueError(f"bad chunk shape {cs} for dataset {n!r}")
     # ---- layout plan ------------------------------------------------------------------------
     sb_size = 24 + 32 + 40           # superblock v0 + root symbol table entry
     root_ohdr = sb_size               # 96
@@ -275,21 +468,56 @@ def write_datasets(path, datasets: dict):
     snod = heap_daddr + len(heap_data)
     snod_size = 8 + 2 * K_leaf * 40
     p = snod + snod_size
-    ohdr_addr, ohdr_bytes = {}, {}
+
+    def layout_msg(n, addr):
+        a = arrays[n]
+        if n in chunks:
+            body = struct.pack("<BBBQ", 3, 2, a.ndim + 1, addr) + struct.pack("<" + "I" * (a.ndim + 1), *chunks[n], a.dtype.itemsize)
+            return _msg(0x0008, body)
+        return _msg(0x0008, struct.pack("<BBQQ", 3, 1, addr, a.nbytes))
+
+    def header_msgs(n, addr):
+        a = arrays[n]
+        if n in chunks:      # resizable along axis 0: dataspace v1 with maximum dimensions (flags bit 0)
+            space = struct.pack("<BBB5x", 1, a.ndim, 1) + struct.pack("<" + "Q" * a.ndim, *a.shape) + \
+                struct.pack("<" + "Q" * a.ndim, UNDEF, *a.shape[1:])
+        else:
+            space = struct.pack("<BBB5x", 1, a.ndim, 0) + struct.pack("<" + "Q" * a.ndim, *a.shape)
+        fill = struct.pack("<BBBB", 2, 3 if n in chunks else 2, 0, 0)
+        return _msg(0x0001, space) + _msg(0x0003, _dtype_msg(a.dtype), flags=1) + _msg(0x0005, fill) + layout_msg(n, addr)
+    ohdr_addr = {}
+    for n in names:
+        ohdr_addr[n] = p
+        p += 16 + len(header_msgs(n, 0))
+    data_addr, chunk_plan = {}, {}
+    p = (p + 4095) // 4096 * 4096     # page-align raw data (friendlier to mmap / O_DIRECT readers)
+    data_start = p
+    blobs = []                        # (address, bytes) in file order
+
+    def alloc(nbytes):
+        nonlocal p
+        a_ = p
+        p += (nbytes + 7) // 8 * 8
+        return a_
     for n in names:
         a = arrays[n]
-        space = struct.pack("<BBB5x", 1, a.ndim, 0) + struct.pack("<" + "Q" * a.ndim, *a.shape)
-        fill = struct.pack("<BBBB", 2, 2, 0, 0)
-        msgs = _msg(0x0001, space) + _msg(0x0003, _dtype_msg(a.dtype), flags=1) + _msg(0x0005, fill) + \
-            _msg(0x0008, struct.pack("<BBQQ", 3, 1, 0, a.nbytes))  # address patched below
-        ohdr_addr[n] = p
-        ohdr_bytes[n] = msgs
-        p += 16 + len(msgs)
-    data_addr = {}
-    p = (p + 4095) // 4096 * 4096     # page-align raw data (friendlier to mmap / O_DIRECT readers)
-    for n in names:
-        data_addr[n] = p
-        p += (arrays[n].nbytes + 7) // 8 * 8
+        if n in chunks:
+            if a.size == 0:
+                data_addr[n] = UNDEF
+                continue
+            cs = tuple(int(c) for c in chunks[n])
+            chunk_bytes = int(np.prod(cs)) * a.dtype.itemsize
+            entries = []
+            for off, raw in _chunk_blobs(a, cs):
+                addr = alloc(chunk_bytes)
+                blobs.append((addr, raw))
+                entries.append((off, addr))
+            root, nodes = _chunk_btree(entries, a.ndim, chunk_bytes, alloc)
+            blobs.extend(nodes)
+            data_addr[n] = root
+        else:
+            data_addr[n] = alloc(a.nbytes)
+            blobs.append((data_addr[n], a.astype(a.dtype.newbyteorder("<"), copy=False).tobytes()))
     eof = p
     # ---- emit ---------------------------------------------------------------------------------
     with open(path, "wb") as fh:
@@ -313,25 +541,43 @@ def write_datasets(path, datasets: dict):
         sn += b"\0" * (snod_size - len(sn))
         fh.write(sn)
         for n in names:
-            a = arrays[n]
-            msgs = ohdr_bytes[n]
-            # patch the layout address (last message: 8-byte header + version, class, then address)
-            lay = _msg(0x0008, struct.pack("<BBQQ", 3, 1, data_addr[n], a.nbytes))
-            msgs = msgs[:-len(lay)] + lay
+            msgs = header_msgs(n, data_addr[n])
             assert fh.tell() == ohdr_addr[n]
             fh.write(struct.pack("<BBHII4x", 1, 0, 4, 1, len(msgs)) + msgs)
-        fh.write(b"\0" * (data_addr[names[0]] - fh.tell()) if names else b"")
-        for n in names:
-            a = arrays[n]
-            assert fh.tell() == data_addr[n]
-            fh.write(a.astype(a.dtype.newbyteorder("<"), copy=False).tobytes())
-            fh.write(b"\0" * (-a.nbytes % 8))
+        fh.write(b"\0" * (data_start - fh.tell()))
+        for addr, raw in sorted(blobs, key=lambda t: t[0]):
+            fh.write(b"\0" * (addr - fh.tell()))
+            assert fh.tell() == addr
+            fh.write(raw)
+        fh.write(b"\0" * (eof - fh.tell()))
         assert fh.tell() == eof
 
 
-def make_synthetic_cutouts(path, n=4096, channels=5, size=64, seed=1234, nan_fraction=0.0, with_labels=False):
+def h5py_guess_chunk(shape, itemsize):
+    """The chunk shape h5py picks for ``create_dataset(shape=(0, ...), maxshape=(None, ...))`` without ``chunks=`` (its
+    ``filters.guess_chunk``: unlimited axes count as 1024, target 16 KiB * 2**log10(size / 1 MiB) clipped to
+    [8 KiB, 1 MiB], axes halved in turn until the chunk is within 50 % of the target)."""
+    import math
+    chunks = [1024 if i == 0 else max(int(x), 1) for i, x in enumerate(shape)]
+    dset_size = float(np.prod(chunks)) * itemsize
+    target = 16384.0 * (2 ** math.log10(dset_size / (1024.0 * 1024)))
+    target = min(max(target, 8192.0), 1048576.0)
+    idx = 0
+    while True:
+        nbytes = float(np.prod(chunks)) * itemsize
+        if (nbytes < target or abs(nbytes - target) / target < 0.5) and nbytes < 1048576.0:
+            break
+        if int(np.prod(chunks)) == 1:
+            break
+        chunks[idx % len(chunks)] = int(math.ceil(chunks[idx % len(chunks)] / 2.0))
+        idx += 1
+    return tuple(int(c) for c in chunks)
+
+
+def make_synthetic_cutouts(path, n=4096, channels=5, size=64, seed=1234, nan_fraction=0.0, with_labels=False, chunked=False):
     """Synthetic cutout file in the reference schema: N(0,1) pixels clipped at -3,
-    ra ~ U(0,360), dec ~ U(-90,90); ``nan_fraction`` of the (sample, channel) planes set to NaN."""
+    ra ~ U(0,360), dec ~ U(-90,90); ``nan_fraction`` of the (sample, channel) planes set to NaN.  ``chunked=True`` writes
+    every dataset resizable + chunked with h5py's automatic chunk shapes, like the reference's combined files."""
     rng = np.random.default_rng(seed)
     cut = rng.standard_normal((n, channels, size, size), dtype=np.float32)
     np.maximum(cut, -3.0, out=cut)
@@ -344,5 +590,5 @@ def make_synthetic_cutouts(path, n=4096, channels=5, size=64, seed=1234, nan_fra
         d["zspec"] = rng.uniform(0, 2, n).astype(np.float32)
         d["zspec_err"] = np.full(n, 0.01, np.float32)
         d["class"] = rng.integers(0, 3, n).astype(np.int64)
-    write_datasets(path, d)
+    write_datasets(path, d, chunks={k: h5py_guess_chunk((0,) + v.shape[1:], v.dtype.itemsize) for k, v in d.items()} if chunked else None)
     return path

@@ -7,21 +7,25 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _make(tmp_path, n=300, size=72, nan_fraction=0.05):
+def _make(tmp_path, n=300, size=72, nan_fraction=0.05, chunked=False):
     from sky_embeddings_amd import hdf5_lite
     rng = np.random.default_rng(3)
     cut = (rng.standard_normal((n, 5, size, size), dtype=np.float32) * 3).astype(np.float32)   # values below -3 exist
     cut[rng.random((n, 5)) < nan_fraction] = np.nan
     path = str(tmp_path / "cutouts.h5")
+    chunks = None
+    if chunked:     # what the reference's ETL writes: resizable datasets with h5py's automatic chunk shapes
+        chunks = {"cutouts": hdf5_lite.h5py_guess_chunk((0, 5, size, size), 4), "ra": (1024,), "dec": (1024,)}
     hdf5_lite.write_datasets(path, {"cutouts": cut, "ra": rng.uniform(0, 360, n).astype(np.float32),
-                                    "dec": rng.uniform(-90, 90, n).astype(np.float32)})
+                                    "dec": rng.uniform(-90, 90, n).astype(np.float32)}, chunks=chunks)
     return path, n
 
 
-def test_feeder_matches_per_item_dataset(tmp_path):
+@pytest.mark.parametrize("chunked", [False, True])
+def test_feeder_matches_per_item_dataset(tmp_path, chunked):
     from sky_embeddings_amd.feeder import CutoutFeeder
     from sky_embeddings_amd.utils.dataloaders import H5Dataset
-    path, n = _make(tmp_path)
+    path, n = _make(tmp_path, chunked=chunked)
     ds = H5Dataset(path, img_size=64, patch_size=16, num_channels=5, max_mask_ratio=None)
     fd = CutoutFeeder(path, batch_size=32, img_size=64, shuffle=False, drop_last=False, depth=2, threads=3, epochs=2)
     assert len(fd) == (n + 31) // 32

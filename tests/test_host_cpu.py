@@ -279,3 +279,61 @@ def test_feeder_batch_count_is_equal_on_every_rank():
         per_rank = [(n // world) // B for _ in range(world)]
         longest = len(np.arange(n)[0::world])
         assert len(set(per_rank)) == 1 and per_rank[0] * B <= n // world <= longest
+
+
+def test_hdf5_lite_chunked_resizable_datasets(tmp_path, monkeypatch):
+    """The layout the reference's ETL writes (create_dataset(..., maxshape=(None, ...)) + resize: chunked, v1 chunk B-tree,
+    h5py's automatic chunk shapes): ragged edge chunks, one-, two- and three-level B-trees, never-written datasets,
+    indexed reads from the chunks, the one-time un-chunk into the contiguous cache (native threads) and its invalidation."""
+    monkeypatch.setenv("SKYEMB_H5_CACHE", str(tmp_path / "cache"))
+    (tmp_path / "cache").mkdir()
+    assert hdf5_lite.h5py_guess_chunk((0, 5, 64, 64), 4) == (128, 1, 8, 16)       # h5py filters.guess_chunk by hand
+    assert hdf5_lite.h5py_guess_chunk((0,), 4) == (1024,)
+    rng = np.random.default_rng(0)
+    cut = rng.standard_normal((301, 5, 64, 64), dtype=np.float32)                 # 301 rows: ragged last chunk block
+    cut[3, 2] = np.nan
+    ra = rng.random(301).astype(np.float32)
+    big = np.arange(70001, dtype=np.int32)                                        # 4376 chunks of 16: a three-level B-tree
+    odd = rng.standard_normal((37, 7, 9)).astype(np.float64)                      # chunks that divide no axis
+    empty = np.zeros((0, 5, 8, 8), np.float32)
+    path = str(tmp_path / "chunked.h5")
+    hdf5_lite.write_datasets(path, {"cutouts": cut, "ra": ra, "big": big, "odd": odd, "empty": empty, "dec": ra[::-1].copy()},
+                             chunks={"cutouts": hdf5_lite.h5py_guess_chunk((0, 5, 64, 64), 4), "ra": (1024,), "big": (16,),
+                                     "odd": (5, 4, 4), "empty": (16, 1, 8, 8)})
+    with hdf5_lite.File(path) as f:
+        ds = f["cutouts"]
+        assert ds.shape == cut.shape and ds.chunks == (128, 1, 8, 16) and f["dec"].chunks is None
+        addr, off = ds.chunk_table()
+        assert len(addr) == 3 * 5 * 8 * 4 and len(set(addr.tolist())) == len(addr)
+        # indexed reads straight from the chunks (no cache yet)
+        assert np.array_equal(ds._read_chunked(7), cut[7], equal_nan=True)
+        assert np.array_equal(ds._read_chunked([300, 0, 129, 128]), cut[[300, 0, 129, 128]], equal_nan=True)
+        assert np.array_equal(ds._read_chunked(slice(120, 140, 3)), cut[120:140:3], equal_nan=True)
+        assert np.array_equal(ds._read_chunked(-1), cut[-1])
+        with pytest.raises(IndexError):
+            ds._read_chunked(301)
+        assert np.array_equal(np.asarray(f["big"]), big) and np.array_equal(f["big"][[70000, 5, 4095, 4096]], big[[70000, 5, 4095, 4096]])
+        assert np.array_equal(np.asarray(f["odd"]), odd) and np.array_equal(f["odd"][11], odd[11])
+        assert f["empty"].shape == (0, 5, 8, 8) and np.asarray(f["empty"]).size == 0
+        assert np.array_equal(np.asarray(f["ra"]), ra) and np.array_equal(f["ra"][5:9], ra[5:9])
+        # the feeder's view: un-chunked once into the cache, then a plain memmap
+        arr = ds._array()
+        assert isinstance(arr, np.memmap) and np.array_equal(arr, cut, equal_nan=True)
+        assert np.array_equal(ds[17], cut[17]) and np.array_equal(ds[[4, 3]], cut[[4, 3]], equal_nan=True)
+    cache = [p for p in os.listdir(tmp_path / "cache") if p.endswith(".contig")]
+    assert len(cache) >= 1
+    # a second open reuses the cache; rewriting the source invalidates it
+    with hdf5_lite.File(path) as f:
+        assert np.array_equal(f["cutouts"]._array(), cut, equal_nan=True)
+    cut2 = cut + 1.0
+    hdf5_lite.write_datasets(path, {"cutouts": cut2}, chunks={"cutouts": (128, 1, 8, 16)})
+    with hdf5_lite.File(path) as f:
+        assert np.array_equal(f["cutouts"]._array(), cut2, equal_nan=True)
+    # synthetic generator in the chunked flavour + the per-item dataset semantics on top of it
+    from sky_embeddings_amd.utils.dataloaders import H5Dataset
+    syn = hdf5_lite.make_synthetic_cutouts(str(tmp_path / "syn_chunked.h5"), n=40, seed=3, chunked=True)
+    ref = hdf5_lite.make_synthetic_cutouts(str(tmp_path / "syn_contig.h5"), n=40, seed=3)
+    a, b = H5Dataset(syn, 64, 16, 5, None), H5Dataset(ref, 64, 16, 5, None)
+    for i in (0, 13, 39):
+        xa, xb = a[i], b[i]
+        assert torch.equal(xa[0], xb[0]) and torch.equal(xa[2], xb[2])
