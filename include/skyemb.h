@@ -126,6 +126,12 @@ int skyemb_colsum(const void *X, int dtype, int64_t ldx, int M, int N, float *ou
  * lands on, dec_tab i32 [B,1+keep] = its decoder_pos_embed row. */
 int skyemb_random_mask_from_noise(const float *noise, int B, int L, int keep, int64_t *ids_restore, float *mask,
                                   int32_t *ids_keep, int32_t *dec_dst, int32_t *dec_tab, void *stream);
+/* SimMIM mask generator on the device (replaces utils/dataloaders.py:197-219 MaskGenerator.__call__, which runs per item in
+ * the loader workers): per sample ratio = ratio_u[b] * max_ratio, count = ceil(L * ratio); per channel the `count` patches
+ * with the smallest noise[b, c, :] are masked (a uniformly random subset, like randperm(L)[:count]); out_mask float 0 / 1
+ * [B, C, grid*p, grid*p].  noise [B, C, L] and ratio_u [B] are uniform [0, 1) draws supplied by the caller. */
+int skyemb_simmim_mask_from_noise(const float *noise, const float *ratio_u, double max_ratio, int B, int C, int L, int grid, int p,
+                                  float *out_mask, void *stream);
 
 /* utils/mim_vit.py:385-392 + the im2row half of timm PatchEmbed (:206,402): for every kept
  * patch (b, ids_keep[b,j]) write the row  out[b*keep + j, c*p*p + py*p + px] =

@@ -503,3 +503,19 @@ class Trainer:
         for k in self.no_decay:
             adamw_step(self.st[k], grads[k], self.m[k], self.v[k], self.t, lr, 0.0)
         return loss, pred, mask_o, grads
+
+
+def simmim_mask_from_noise(noise, ratio_u, max_ratio, patch_size):
+    """utils/dataloaders.py:197-219 (MaskGenerator.__call__) driven by explicit uniform draws: per sample
+    ratio = u * max_ratio, count = int(ceil(tensor(L * ratio))); per channel the `count` patches with the smallest noise are
+    masked (== randperm(L)[:count] in distribution; ties by index); upsampled to pixels.  -> float [B, C, H, W]."""
+    B, C, L = noise.shape
+    grid = int(round(L ** 0.5))
+    out = torch.zeros(B, C, L)
+    for b in range(B):
+        count = int(torch.ceil(torch.tensor(L * (float(ratio_u[b]) * max_ratio))).item())
+        for c in range(C):
+            order = torch.argsort(noise[b, c], stable=True)
+            out[b, c, order[:count]] = 1
+    out = out.view(B, C, grid, grid)
+    return out.repeat_interleave(patch_size, dim=2).repeat_interleave(patch_size, dim=3).contiguous()

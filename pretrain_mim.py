@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from sky_embeddings_amd import distributed as sdist
+from sky_embeddings_amd import ops
 from utils.dataloaders import build_h5_dataloader
 from utils.mim_vit import build_model
 from utils.misc import parseArguments
@@ -87,16 +88,17 @@ def main(args):
             n_train = len(f['cutouts'])
         sampler = sdist.DistributedIndexSampler(n_train, rank, world, shuffle=True, seed=1234)
     dataloader_train = build_h5_dataloader(train_file, shuffle=True, sampler=sampler, **common)
-    # MAE mode on a contiguous HDF5 file takes the fast path: the batched HDF5->HBM feeder (no per-item python) feeding
+    # Training takes the fast path: the batched HDF5->HBM feeder (no per-item python; chunked files un-chunked once) feeding
     # the HIP-graph TrainStep (forward + staged backward, gradient all-reduce overlapped, fused AdamW, cosine LR).  The
     # per-item loader above still serves SimMIM mask generation, ragged final batches and validation.
-    fast = max_mask_ratio is None and os.environ.get("SKYEMB_FAST_TRAIN", "1") != "0"
+    fast = os.environ.get("SKYEMB_FAST_TRAIN", "1") != "0"
     train_step = None
     if fast:
         from sky_embeddings_amd.feeder import CutoutFeeder
         from sky_embeddings_amd.train_step import TrainStep
+        # SimMIM mode: the per-channel patch masks are drawn on the device inside the step (max_mask_ratio)
         train_step = TrainStep(model.module.engine, optimizer, lr_scheduler, common['batch_size'], mask_ratio=mask_ratio,
-                               world_size=world)
+                               world_size=world, max_mask_ratio=max_mask_ratio)
     dataloader_val = build_h5_dataloader(os.path.join(data_dir, config['DATA']['val_data_file']), shuffle=True, **common)
     if rank == 0:
         print('The training set consists of %i cutouts.' % (len(dataloader_train.dataset)))
@@ -120,10 +122,17 @@ def main(args):
                                   rank=rank, world_size=world, drop_last=world > 1)
         for samples, masks, ra_decs in loader:
             if fast and samples.shape[0] == common['batch_size']:
-                loss = train_step(samples)
+                loss = train_step(samples, None, ra_decs)
                 losses_cp['train_loss'].append(loss.detach().clone())
             else:
                 samples = samples.to(device, non_blocking=True)
+                if fast and max_mask_ratio is not None:
+                    # a ragged last batch of the feeder in SimMIM mode: draw its masks with the same device generator
+                    eng_cfg = model.module.engine.cfg
+                    masks = torch.empty_like(samples)
+                    ops.simmim_mask_from_noise(torch.rand(samples.shape[0], eng_cfg.in_chans, eng_cfg.num_patches, device=device),
+                                               torch.rand(samples.shape[0], device=device), max_mask_ratio, eng_cfg.grid,
+                                               eng_cfg.patch_size, masks)
                 # forward + backward, then the RCCL gradient all-reduce, then AdamW (run_iter's order)
                 model.train(True)
                 loss, _, _ = model(samples, ra_dec=ra_decs, mask_ratio=mask_ratio, mask=masks)

@@ -60,6 +60,7 @@ PROTOTYPES = {
     "skyemb_gemm_group_launch": (c_i32, [c_vp, ctypes.POINTER(GemmGroupInfo), c_vp]),
     "skyemb_colsum": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "skyemb_random_mask_from_noise": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "skyemb_simmim_mask_from_noise": (c_i32, [c_vp, c_vp, ctypes.c_double, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "skyemb_patch_gather": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32,
                                     c_f32, c_vp]),
     "skyemb_patch_gather_bwd_pmv": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,

@@ -41,6 +41,43 @@ __global__ __launch_bounds__(256) void mask_kernel(const float *__restrict__ noi
     }
 }
 
+
+// ---- utils/dataloaders.py:197-219 (MaskGenerator.__call__) on the device ------------------------------------------------------
+// per sample: ratio = u * max_ratio, count = ceil(L * ratio); per channel an independent uniformly random subset of `count`
+// patches is masked (the reference takes randperm(L)[:count]; here: the `count` smallest of L iid uniform noise values --
+// the same distribution, ties broken by index), expanded to pixels.  One wave per (sample, channel); out is float 0 / 1.
+__global__ __launch_bounds__(256) void simmim_mask_kernel(const float *__restrict__ noise, const float *__restrict__ ratio_u,
+                                                          double max_ratio, int BC, int C, int L, int grid, int p,
+                                                          float *__restrict__ out) {
+    extern __shared__ float sn[];   // [4][L] noise, then [4][L] mask bytes as floats
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bc = blockIdx.x * 4 + wave;
+    if (bc >= BC) return;
+    float *row = sn + wave * 2 * L, *mk = row + L;
+    for (int i = lane; i < L; i += 64) row[i] = noise[(int64_t)bc * L + i];
+    __builtin_amdgcn_wave_barrier();
+    const int b = bc / C;
+    // int(torch.ceil(torch.tensor(token_count * mask_ratio))): product in double, rounded to fp32, then ceil
+    const int count = (int)ceilf((float)((double)L * ((double)ratio_u[b] * max_ratio)));
+    for (int i = lane; i < L; i += 64) {
+        const float v = row[i];
+        int rank = 0;
+        for (int j = 0; j < L; ++j) {
+            const float u = row[j];
+            rank += (u < v || (u == v && j < i)) ? 1 : 0;
+        }
+        mk[i] = rank < count ? 1.0f : 0.0f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int H = grid * p;
+    float *o = out + (int64_t)bc * H * H;
+    for (int e = lane * 4; e < H * H; e += 256) {
+        const int y = e / H, x = e - y * H;                    // 4 consecutive pixels stay inside one patch (p % 4 == 0)
+        const float m = mk[(y / p) * grid + x / p];
+        *(float4 *)(o + e) = make_float4(m, m, m, m);
+    }
+}
+
 // ---- utils/mim_vit.py:385-392 + im2row for Conv2d(k=s=p) --------------------------------------
 // grid = B*keep rows; each thread moves 4 consecutive px of one (c, py)
 // pmask (SimMIM, utils/mim_vit.py:394-399; NULL in MAE mode): x = x * (1 - mask) + pmv * mask after the NaN fill
@@ -201,6 +238,17 @@ extern "C" int skyemb_random_mask_from_noise(const float *noise, int B, int L, i
     hipLaunchKernelGGL(mask_kernel, dim3((B + 3) / 4), dim3(256), (size_t)4 * L * sizeof(float), (hipStream_t)stream, noise,
                        B, L, keep, ids_restore, mask, ids_keep, dec_dst, dec_tab);
     SKY_LAUNCH_CHECK("skyemb_random_mask_from_noise");
+    return 0;
+}
+
+
+extern "C" int skyemb_simmim_mask_from_noise(const float *noise, const float *ratio_u, double max_ratio, int B, int C, int L, int grid,
+                                             int p, float *out_mask, void *stream) {
+    SKY_CHECK_ARG(noise && ratio_u && out_mask && B > 0 && C > 0 && L == grid * grid && L <= 4096 && p > 0 && p % 4 == 0 &&
+                  max_ratio >= 0.0 && max_ratio <= 1.0, "skyemb_simmim_mask_from_noise: bad arguments (L=%d grid=%d p=%d)", L, grid, p);
+    hipLaunchKernelGGL(simmim_mask_kernel, dim3((B * C + 3) / 4), dim3(256), (size_t)8 * L * sizeof(float), (hipStream_t)stream, noise,
+                       ratio_u, max_ratio, B * C, C, L, grid, p, out_mask);
+    SKY_LAUNCH_CHECK("skyemb_simmim_mask_from_noise");
     return 0;
 }
 

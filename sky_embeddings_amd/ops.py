@@ -96,6 +96,13 @@ def random_mask_from_noise(noise, keep, ids_restore, mask, ids_keep, dec_dst=Non
                                               _p(dec_dst), _p(dec_tab), _stream()), "skyemb_random_mask_from_noise")
 
 
+def simmim_mask_from_noise(noise, ratio_u, max_ratio, grid, p, out_mask):
+    """Per-channel random patch masks for SimMIM (utils/dataloaders.py:197-219) from uniform draws: noise [B,C,L], ratio_u [B]."""
+    B, C, L = noise.shape
+    check(lib().skyemb_simmim_mask_from_noise(_p(noise), _p(ratio_u), max_ratio, B, C, L, grid, p, _p(out_mask), _stream()),
+          "skyemb_simmim_mask_from_noise")
+
+
 def patch_gather(imgs, pmv, ids_keep, out, p, keep, pixel_mean, pixel_std):
     B, C, H, W = imgs.shape
     check(lib().skyemb_patch_gather(_p(imgs), _p(pmv), _p(ids_keep), _p(out), dtype_code(out.dtype), B, C, H, W, p,

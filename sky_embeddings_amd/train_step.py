@@ -33,7 +33,7 @@ class TrainStep:
                  use_graph: bool = True, process_group=None, world_size: int = 1, warmup_iters: int = 2,
                  staged: bool | None = None, n_encoder_groups: int = 3, bucket_elems: int = 32 * 1024 * 1024,
                  wgrad_overlap: bool | None = None, optimizer_overlap: bool | None = None, grad_comm: str | None = None,
-                 external_noise: bool = False):
+                 external_noise: bool = False, max_mask_ratio: float | None = None):
         self.engine, self.optimizer, self.scheduler = engine, optimizer, scheduler
         self.mask_ratio = mask_ratio
         self.world_size = world_size
@@ -46,6 +46,12 @@ class TrainStep:
         # SimMIM mode (SimMIMEngine): the per-pixel mask and the RA/Dec pairs are step inputs too
         self.simmim = bool(cfg.simmim)
         self.pixel_mask = torch.zeros_like(self.imgs) if self.simmim else None
+        # SimMIM masks generated on the device inside the step (utils/dataloaders.py:197-219 moved out of the loader workers):
+        # with max_mask_ratio set, callers hand over cutouts (+ RA/Dec) only
+        self.max_mask_ratio = max_mask_ratio if self.simmim else None
+        if self.max_mask_ratio is not None:
+            self.mask_noise = torch.zeros(batch_size, cfg.in_chans, cfg.num_patches, device=dev)
+            self.ratio_u = torch.zeros(batch_size, device=dev)
         self.ra_dec = torch.zeros(batch_size, 2, device=dev) if (self.simmim and cfg.ra_dec) else None
         self.loss = None
         self.external_noise = external_noise          # parity tests fill step.noise themselves (same noise on 1 and N ranks)
@@ -117,6 +123,13 @@ class TrainStep:
 
     def _forward(self):
         if self.simmim:
+            if self.max_mask_ratio is not None:
+                if not self.external_noise:
+                    self.mask_noise.uniform_()
+                    self.ratio_u.uniform_()
+                cfg = self.engine.cfg
+                ops.simmim_mask_from_noise(self.mask_noise, self.ratio_u, float(self.max_mask_ratio), cfg.grid, cfg.patch_size,
+                                           self.pixel_mask)
             self.loss, self.pred, self.mask = self.engine.forward_train(self.imgs, mask=self.pixel_mask, ra_dec=self.ra_dec)
             return
         # utils/mim_vit.py:363 draws the masking noise inside forward; keep it inside the step
@@ -128,8 +141,9 @@ class TrainStep:
         """Stage the next minibatch (device or pinned host tensors) into the static input buffers."""
         self.imgs.copy_(imgs, non_blocking=True)
         if self.simmim:
-            assert mask is not None, "SimMIM steps need the per-pixel mask"
-            self.pixel_mask.copy_(mask, non_blocking=True)
+            if self.max_mask_ratio is None:
+                assert mask is not None, "SimMIM steps need the per-pixel mask (or TrainStep(max_mask_ratio=...))"
+                self.pixel_mask.copy_(mask, non_blocking=True)
             if self.ra_dec is not None:
                 self.ra_dec.copy_(ra_dec, non_blocking=True)
 

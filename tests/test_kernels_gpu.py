@@ -471,3 +471,27 @@ def test_gemm_split_k_wgrad(ops, split):
     assert float((outs[0][0].double() - ref).abs().max()) <= 2e-6 * scale
     assert float((outs[0][1].double() - dyr.double().sum(0)).abs().max()) <= 1e-5 * float(dyr.abs().sum(0).max())
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])   # run-to-run deterministic
+
+
+@pytest.mark.parametrize("L,p,C,max_ratio", [(64, 8, 5, 0.9), (16, 16, 9, 0.6), (64, 16, 5, 0.6), (256, 4, 2, 1.0)])
+def test_simmim_mask_from_noise_matches_oracle(L, p, C, max_ratio):
+    """Device MaskGenerator (utils/dataloaders.py:197-219): per-sample ratio, ceil(L * ratio) patches per channel, an
+    independent uniformly random subset per channel, expanded to pixels -- bit-equal to the oracle on the same draws,
+    including tied noise values and the ratio extremes."""
+    from oracle import mae_oracle as mo
+    from sky_embeddings_amd import ops
+    B = 7
+    g = torch.Generator().manual_seed(L + C)
+    noise = torch.rand(B, C, L, generator=g)
+    noise[0, 0, :] = 0.5                                   # all tied: the first `count` patches are masked
+    noise[1, 1, 3] = noise[1, 1, 9]
+    u = torch.rand(B, generator=g)
+    u[2], u[3] = 0.0, 0.999999
+    ref = mo.simmim_mask_from_noise(noise, u, max_ratio, p)
+    grid = int(round(L ** 0.5))
+    out = torch.empty(B, C, grid * p, grid * p, device="cuda")
+    ops.simmim_mask_from_noise(noise.cuda(), u.cuda(), max_ratio, grid, p, out)
+    assert torch.equal(out.cpu(), ref)
+    per_channel = out[:, :, ::p, ::p].sum(dim=(2, 3)).cpu()
+    want = torch.tensor([int(np.ceil(np.float32(L * (float(u[b]) * max_ratio)))) for b in range(B)], dtype=torch.float32)
+    assert torch.equal(per_channel, want[:, None].expand(B, C))

@@ -184,3 +184,39 @@ def test_mim19_full_size_step_properties():
         del step, opt, eng
         torch.cuda.empty_cache()
     assert results[0][0] == results[1][0] and torch.equal(results[0][1], results[1][1])
+
+
+def test_simmim_step_with_device_masks_graph_equals_eager():
+    """TrainStep(max_mask_ratio=...): masks drawn on the device inside the step (no loader-side MaskGenerator); HIP-graph
+    replay == eager bit for bit on the same draws, and the masks are the oracle's for those draws."""
+    from oracle import mae_oracle as mo
+    from sky_embeddings_amd.optim import CosineLR, FusedAdamW
+    from sky_embeddings_amd.train_step import TrainStep
+    z, cfg, st, imgs, pmask, ra_dec = load_simmim_case("simmim_tiny_H_radec")
+    B = 8
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, cfg.in_chans, cfg.img_size, cfg.img_size, generator=g).cuda()
+    rd = torch.stack([torch.rand(B, generator=g) * 360, torch.rand(B, generator=g) * 180 - 90], 1).cuda()
+    draws = [(torch.rand(B, cfg.in_chans, cfg.num_patches, generator=g), torch.rand(B, generator=g)) for _ in range(3)]
+    results = []
+    for graph in (False, True):
+        eng = make_engine(cfg, st, torch.bfloat16)
+        opt = FusedAdamW(eng, lr=1e-3)
+        step = TrainStep(eng, opt, CosineLR(opt, 100), B, use_graph=graph, max_mask_ratio=0.9, external_noise=True)
+        for noise, u in draws:
+            step.mask_noise.copy_(noise)
+            step.ratio_u.copy_(u)
+            loss = step(x, None, rd)
+        torch.cuda.synchronize()
+        assert torch.equal(step.pixel_mask.cpu(), mo.simmim_mask_from_noise(draws[-1][0], draws[-1][1], 0.9, cfg.patch_size))
+        results.append((float(loss), eng.store.p.clone()))
+    assert results[0][0] == results[1][0] and torch.equal(results[0][1], results[1][1])
+    # and with its own draws the step trains: three different masks, finite decreasing-ish losses
+    eng = make_engine(cfg, st, torch.bfloat16)
+    opt = FusedAdamW(eng, lr=1e-3)
+    step = TrainStep(eng, opt, CosineLR(opt, 100), B, max_mask_ratio=0.9)
+    masks, losses = [], []
+    for _ in range(3):
+        losses.append(float(step(x, None, rd)))
+        masks.append(step.pixel_mask.clone())
+    assert all(np.isfinite(losses)) and not torch.equal(masks[0], masks[1]) and not torch.equal(masks[1], masks[2])
