@@ -257,6 +257,15 @@ int skyemb_h5_unchunk_host(const void *file_base, int64_t file_bytes, const int6
 int skyemb_clip_crop(const float *src, float *dst, int64_t n_planes, int Hs, int Ws, int size, float lo, float hi,
                      int use_lo, int use_hi, void *stream);
 
+/* Target augmentations of the similarity search (utils/dataloaders.py:14-106 get_augmentations as applied by
+ * utils/eval_fns.py:88-108: per sample the original + A augmented copies): flips, RandomResizedCrop back to S x S
+ * (crop + anti-aliased bilinear resize), brightness factor, additive noise, channels set to NaN -- one launch per batch.
+ *   imgs [B, C, S, S] -> out [B * (1 + A), C, S, S], copy 0 of every sample unchanged
+ *   params [B * (1 + A), 8] = {flip_h, flip_v, crop_top, crop_left, crop_h, crop_w, brightness, sigma} (drawn by the caller)
+ *   nan_mask [B * (1 + A)]: bit c set -> channel c is NaN;  noise [B * (1 + A), C, S, S] standard normal draws or NULL */
+int skyemb_augment(const float *imgs, float *out, const float *params, const int32_t *nan_mask, const float *noise, int B, int C,
+                   int S, int A, void *stream);
+
 /* ------------------------------------------------------ similarity search -
  * utils/similarity.py:98-102: standardise bank rows in place or to `out`:
  * (x - mu) / (sigma + 1e-8). */

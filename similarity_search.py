@@ -5,8 +5,8 @@
 target_features, test_images, test_features).
 
 Differences: figures are not drawn (matplotlib/LaTeX plotting is out of scope, SURVEY.md §2 row 9);
-target augmentation needs torchvision and is therefore off unless ``-aug True`` is given together
-with an available augmentation callable (default here: False).  ``--bank`` (extension) encodes the
+the 64x target augmentation (``-aug True``, the reference's default) runs on the device
+(sky_embeddings_amd.augment: torchvision's parameter draws, one HIP launch per batch).  ``--bank`` (extension) encodes the
 test set ONCE into a resident embedding bank and runs the fused cosine top-k kernel over it
 instead of re-scoring streamed batches (requires -mp True or -ct True, i.e. one vector per sample).
 """
@@ -32,7 +32,7 @@ def parseArguments():
     parser.add_argument("-tgt_fn", "--target_fn", type=str, default='HSC_dud_dwarf_galaxy_calexp_GIRYZ7610_64.h5')
     parser.add_argument("-tst_fn", "--test_fn", type=str, default='HSC_dud_unknown_calexp_GIRYZ7610_64.h5')
     parser.add_argument("-tgt_i", "--target_indices", default='[1,2]')
-    parser.add_argument("-aug", "--augment_targets", type=str, default='False')
+    parser.add_argument("-aug", "--augment_targets", type=str, default='True')
     parser.add_argument("-mp", "--max_pool", type=str, default='True')
     parser.add_argument("-ct", "--cls_token", type=str, default='False')
     parser.add_argument("-snr", "--snr_range", default='[2,7]')

@@ -96,6 +96,11 @@ def random_mask_from_noise(noise, keep, ids_restore, mask, ids_keep, dec_dst=Non
                                               _p(dec_dst), _p(dec_tab), _stream()), "skyemb_random_mask_from_noise")
 
 
+def augment(imgs, out, params, nan_mask, noise, A):
+    B, C, S, _ = imgs.shape
+    check(lib().skyemb_augment(_p(imgs), _p(out), _p(params), _p(nan_mask), _p(noise), B, C, S, A, _stream()), "skyemb_augment")
+
+
 def simmim_mask_from_noise(noise, ratio_u, max_ratio, grid, p, out_mask):
     """Per-channel random patch masks for SimMIM (utils/dataloaders.py:197-219) from uniform draws: noise [B,C,L], ratio_u [B]."""
     B, C, L = noise.shape

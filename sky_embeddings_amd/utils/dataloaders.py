@@ -1,6 +1,7 @@
 """utils/dataloaders.py mirror for the HDF5 cutout path (H5Dataset, MaskGenerator,
-build_h5_dataloader).  The FITS tile sampler and the torchvision augmentations are out of
-scope.
+build_h5_dataloader, get_augmentations).  The augmentation pipeline (utils/dataloaders.py:14-106) is
+``sky_embeddings_amd.augment.Augmenter``: torchvision's parameter draws on the host, the arithmetic in one HIP launch.  The
+FITS tile sampler is out of scope.
 
 Differences from the reference, none of which change a returned value:
   * the file is parsed once and datasets are memory-mapped (hdf5_lite) instead of re-opening
@@ -102,9 +103,11 @@ class H5Dataset(torch.utils.data.Dataset):
         return cutout, mask, ra_dec, labels
 
 
-def get_augmentations(*args, **kwargs):
-    raise NotImplementedError("torchvision-v2 augmentations (utils/dataloaders.py:14-106) are outside the hot path; "
-                              "pass transforms=<callable> explicitly (SURVEY.md §8f rank 1)")
+def get_augmentations(img_size=64, flip=True, crop=True, brightness=0.8, noise=0.01, nan_channels=2):
+    """utils/dataloaders.py:90-106: the target-augmentation pipeline; the returned object maps one [C, H, W] tensor to an
+    augmented copy (like the reference's v2.Compose) and a whole batch to ``1 + A`` copies per sample with ``.batch``."""
+    from ..augment import Augmenter
+    return Augmenter(img_size=img_size, flip=flip, crop=crop, brightness=brightness, noise=noise, nan_channels=nan_channels)
 
 
 def build_h5_dataloader(filename, batch_size, num_workers, patch_size=8, num_channels=5, max_mask_ratio=None,
@@ -112,7 +115,7 @@ def build_h5_dataloader(filename, batch_size, num_workers, patch_size=8, num_cha
                         nan_channels=2, shuffle=True, indices=None, transforms=None, sampler=None):
     """utils/dataloaders.py:134-153 (+ optional ``sampler`` for one-process-per-GPU sharding)."""
     if (transforms is None) and augment:
-        transforms = get_augmentations()
+        transforms = get_augmentations(img_size=img_size, brightness=brightness, noise=noise, nan_channels=nan_channels)
     dataset = H5Dataset(filename, img_size=img_size, patch_size=patch_size, num_channels=num_channels,
                         max_mask_ratio=max_mask_ratio, num_patches=num_patches, label_keys=label_keys,
                         transform=transforms, indices=indices)

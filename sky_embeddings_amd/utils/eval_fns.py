@@ -1,5 +1,5 @@
-"""utils/eval_fns.py mirror: ``mae_latent`` (encode a dataset into the embeddings that are
-searched), ``mae_predict`` (reconstructions), and the bank builder of SURVEY.md §8f rank 1.
+"""utils/eval_fns.py mirror: ``mae_latent`` (encode a dataset into the embeddings that are searched, optionally with the
+target augmentations), ``mae_predict`` (reconstructions), and the bank builder of SURVEY.md §8f rank 1.
 ``ft_predict`` (downstream predictor) is out of scope."""
 from __future__ import annotations
 
@@ -7,80 +7,79 @@ import numpy as np
 import torch
 
 
-def _mod(model):
-    return model.module if hasattr(model, 'module') else model
+def _net(model):
+    return getattr(model, 'module', model)
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1)
 
 
 def mae_predict(model, dataloader, device, mask_ratio, single_batch=True):
-    """utils/eval_fns.py:9-70: (pred_imgs, masked_inputs, orig_imgs) as NHWC numpy arrays."""
-    if not single_batch:
-        print('Predicting on %i batches...' % (len(dataloader)))
+    """utils/eval_fns.py:9-70 -> (pred_imgs, masked_inputs, orig_imgs), NHWC numpy arrays in input units: predictions at
+    the masked pixels, the input elsewhere; ``masked_inputs`` = the input with the masked pixels set to NaN."""
+    net = _net(model)
     model.eval()
-    mod = _mod(model)
-    pred_imgs, mask_imgs, orig_imgs = [], [], []
+    if not single_batch:
+        print(f'Reconstructing {len(dataloader)} batches')
+    out = ([], [], [])
     with torch.no_grad():
         for samples, mask, ra_decs in dataloader:
             samples = samples.to(device, non_blocking=True)
-            loss, pred, mask = model(samples, ra_dec=ra_decs, mask_ratio=mask_ratio, mask=mask)
-            if not mod.simmim:   # MAE: patch rows -> image; SimMIM predictions and masks are images already
-                pred = mod.unpatchify(pred)
-                mask = mask.detach().unsqueeze(-1).repeat(1, 1, mod.patch_embed.patch_size[0] ** 2 * mod.in_chans)
-                mask = mod.unpatchify(mask)
+            _, pred, mask = model(samples, ra_dec=ra_decs, mask_ratio=mask_ratio, mask=mask)
+            if net.simmim:
+                pred = pred.clone()                     # image-shaped already (SimMIM head + PixelShuffle index map)
             else:
-                pred = pred.clone()
-            pred = mod.denorm_imgs(samples, pred)
-            pred = torch.einsum('nchw->nhwc', pred).detach().clone()
-            mask = torch.einsum('nchw->nhwc', mask).detach()
-            samples = torch.einsum('nchw->nhwc', samples)
-            pred[mask == 0] = samples[mask == 0]
-            masked_samples = samples.detach().clone()
-            masked_samples[mask == 1] = torch.nan
-            pred_imgs.append(pred.cpu().numpy())
-            mask_imgs.append(masked_samples.cpu().numpy())
-            orig_imgs.append(samples.cpu().numpy())
+                # per-patch rows -> image; the [B, L] patch mask -> pixel mask through the same un-patchify
+                per_patch = net.patch_embed.patch_size[0] ** 2 * net.in_chans
+                pred = net.unpatchify(pred)
+                mask = net.unpatchify(mask.detach()[:, :, None].expand(-1, -1, per_patch))
+            hidden = _nhwc(mask) == 1
+            orig = _nhwc(samples)
+            recon = torch.where(hidden, _nhwc(net.denorm_imgs(samples, pred)), orig)
+            shown = torch.where(hidden, torch.full_like(orig, float('nan')), orig)
+            for dst, t in zip(out, (recon, shown, orig)):
+                dst.append(t.cpu().numpy())
             if single_batch:
                 break
-    return np.concatenate(pred_imgs), np.concatenate(mask_imgs), np.concatenate(orig_imgs)
+    return tuple(np.concatenate(parts) for parts in out)
 
 
 def mae_latent(model, dataloader, device, n_batches=None, return_images=False, verbose=1, apply_augmentations=False,
                num_augmentations=16, remove_cls=True, augmentations=None):
-    """utils/eval_fns.py:72-140.  ``augmentations`` (callable on a [C,H,W] tensor) replaces the
-    reference's torchvision pipeline, which is not available here."""
-    if n_batches is None:
-        n_batches = len(dataloader)
-    if verbose > 0:
-        print(f'Encoding {min(len(dataloader), n_batches)} batches...')
+    """utils/eval_fns.py:72-140: encoder-only forward of every batch -> latents [N, tokens, D] on the host.  With
+    ``apply_augmentations`` every sample is followed by ``num_augmentations`` augmented copies (flip, resized crop,
+    brightness, noise, NaN channels: utils/dataloaders.py:90-106) and its RA/Dec repeated for each -- produced by ONE
+    device launch per batch (``Augmenter.batch``) instead of the reference's per-copy Python loop.  ``augmentations``
+    overrides the pipeline (an ``Augmenter``, or any callable on one [C, H, W] tensor)."""
+    net = _net(model)
     model.eval()
-    mod = _mod(model)
+    limit = len(dataloader) if n_batches is None else min(n_batches, len(dataloader))
+    if verbose > 0:
+        print(f'Encoding {limit} batches' + (f' (+ {num_augmentations} augmented copies per sample)' if apply_augmentations else ''))
     if apply_augmentations and augmentations is None:
-        raise NotImplementedError("apply_augmentations=True needs augmentations=<callable> (torchvision is absent)")
+        from .dataloaders import get_augmentations
+        augmentations = get_augmentations()         # crops are resized back to the sample's own size
+    keep_from = 0 if (not remove_cls or net.attn_pool) else net.num_extra_tokens
     latents, images = [], []
     with torch.no_grad():
-        for samples, masks, ra_decs in dataloader:
+        for done, (samples, _masks, ra_decs) in enumerate(dataloader, 1):
             if apply_augmentations:
-                aug_s, aug_r = [], []
-                for idx, sample in enumerate(samples):
-                    aug_s.append(sample.unsqueeze(0))
-                    aug_r.append(ra_decs[idx].unsqueeze(0))
-                    for _ in range(num_augmentations):
-                        aug_s.append(augmentations(sample).unsqueeze(0))
-                        aug_r.append(ra_decs[idx].unsqueeze(0))
-                samples, ra_decs = torch.cat(aug_s, dim=0), torch.cat(aug_r, dim=0)
+                copies = 1 + num_augmentations
+                if hasattr(augmentations, 'batch'):
+                    samples = augmentations.batch(samples, num_augmentations)
+                else:   # a plain per-sample callable: original first, then its copies
+                    samples = torch.stack([s if a == 0 else augmentations(s.clone()) for s in samples for a in range(copies)])
+                ra_decs = ra_decs.repeat_interleave(copies, dim=0)
             samples = samples.to(device, non_blocking=True)
-            latent, _, _ = mod.forward_features(samples, ra_dec=ra_decs, mask=None, reshape_out=False)
-            if mod.attn_pool:
-                remove_cls = False
-            if remove_cls:
-                latent = latent[:, mod.num_extra_tokens:]
-            latents.append(latent.detach().cpu())
+            latent = net.forward_features(samples, ra_dec=ra_decs, mask=None, reshape_out=False)[0]
+            latents.append(latent[:, keep_from:].detach().cpu())
             if return_images:
                 images.append(samples.detach().cpu())
-            if len(latents) >= n_batches:
+            if done >= limit:
                 break
-    if return_images:
-        return torch.cat(latents), torch.cat(images)
-    return torch.cat(latents)
+    latents = torch.cat(latents)
+    return (latents, torch.cat(images)) if return_images else latents
 
 
 def build_embedding_bank(model, dataloader, device, pool='max', n_batches=None):
@@ -88,20 +87,16 @@ def build_embedding_bank(model, dataloader, device, pool='max', n_batches=None):
     the patch tokens -- all permutation invariant, so the reference's shuffled token order does not
     matter).  The reference re-encodes every test image per search (utils/similarity.py:81)."""
     model.eval()
-    mod = _mod(model)
+    net = _net(model)
+    reduce = {'cls': lambda t: t[:, 0].clone(), 'max': lambda t: t[:, net.num_extra_tokens:].amax(dim=1),
+              'mean': lambda t: t[:, net.num_extra_tokens:].mean(dim=1)}
+    if pool not in reduce:
+        raise ValueError(pool)
     rows = []
     with torch.no_grad():
-        for i, (samples, masks, ra_decs) in enumerate(dataloader):
-            latent, _, _ = mod.forward_features(samples.to(device, non_blocking=True), reshape_out=False)
-            if pool == 'cls':
-                rows.append(latent[:, 0].clone())
-            elif pool == 'max':
-                rows.append(latent[:, mod.num_extra_tokens:].max(dim=1).values)
-            elif pool == 'mean':
-                rows.append(latent[:, mod.num_extra_tokens:].mean(dim=1))
-            else:
-                raise ValueError(pool)
-            if n_batches is not None and i + 1 >= n_batches:
+        for done, (samples, _masks, ra_decs) in enumerate(dataloader, 1):
+            rows.append(reduce[pool](net.forward_features(samples.to(device, non_blocking=True), ra_dec=ra_decs, reshape_out=False)[0]))
+            if n_batches is not None and done >= n_batches:
                 break
     return torch.cat(rows).contiguous()
 

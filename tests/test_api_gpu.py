@@ -138,6 +138,13 @@ def test_build_model_train_checkpoint_resume_and_search(tmp_path):
     assert pred.shape == (8, 64, 64, 5) and np.isfinite(pred[~np.isnan(orig)]).all()
     lat = mae_latent(model, dl, torch.device("cuda"), n_batches=2, remove_cls=False, verbose=0)
     assert lat.shape == (16, 17, 192)
+    # 4 augmented copies per sample (flip / resized crop / brightness / noise / NaN channels on the device): copy 0 is the
+    # sample itself, so its cls embedding equals the un-augmented one; the copies differ
+    lat_aug, imgs_aug = mae_latent(model, dl, torch.device("cuda"), n_batches=1, remove_cls=False, verbose=0, return_images=True,
+                                   apply_augmentations=True, num_augmentations=4)
+    assert lat_aug.shape == (8 * 5, 17, 192) and imgs_aug.shape == (8 * 5, 5, 64, 64)
+    assert torch.allclose(lat_aug[0::5, 0], lat[:8, 0], atol=3e-2, rtol=3e-2)      # bf16 model, a different batch shape
+    assert not torch.allclose(lat_aug[1, 0], lat_aug[0, 0]) and bool(torch.isfinite(lat_aug).all())
     # reference-shaped streaming search == encode-once bank + fused top-k kernel
     tgt = lat[:5]
     imgs, blat, brd, bsc = mae_simsearch(model, tgt, dl, torch.device("cuda"), metric='cosine', combine='min',

@@ -495,3 +495,42 @@ def test_simmim_mask_from_noise_matches_oracle(L, p, C, max_ratio):
     per_channel = out[:, :, ::p, ::p].sum(dim=(2, 3)).cpu()
     want = torch.tensor([int(np.ceil(np.float32(L * (float(u[b]) * max_ratio)))) for b in range(B)], dtype=torch.float32)
     assert torch.equal(per_channel, want[:, None].expand(B, C))
+
+
+def test_augmentation_kernel_matches_oracle():
+    """Device augmentation pipeline (csrc/augment.hip) vs the torch restatement of torchvision's tensor ops on the same drawn
+    parameters: flips, resized crops of every kind the sampler produces (+ the identity crop and a thin one), brightness,
+    noise, NaN channels, NaN pixels in the source (they spread to the pixels that interpolate from them)."""
+    from oracle import augment_oracle as ao
+    from sky_embeddings_amd.augment import Augmenter
+    B, C, S, A = 5, 5, 64, 16
+    g = torch.Generator().manual_seed(0)
+    imgs = torch.randn(B, C, S, S, generator=g)
+    imgs[1, 2] = float("nan")
+    imgs[3, 0, 10:13, 40:47] = float("nan")
+    aug = Augmenter(img_size=S, seed=11)
+    params, nan_mask = aug.draw(B * (1 + A), C, S)
+    params[3] = torch.tensor([1, 0, 0, 0, S, S, 1.0, 0.0])          # pure horizontal flip
+    params[4] = torch.tensor([0, 1, 5, 9, 51, 55, 1.25, 0.01])
+    params[5] = torch.tensor([1, 1, 0, 12, 64, 52, 0.8, 0.0])
+    nan_mask[3] = 0
+    noise = torch.randn(B * (1 + A), C, S, S, generator=g)
+    ref = ao.augment(imgs, params, nan_mask, noise, A)
+    out = aug.batch(imgs, A, params=params, nan_mask=nan_mask, noise=noise).cpu()
+    assert torch.equal(torch.isnan(out), torch.isnan(ref))
+    assert torch.equal(out[0], imgs[0]) and torch.equal(out[3], imgs[0].flip(-1))
+    err = (torch.nan_to_num(out) - torch.nan_to_num(ref)).abs().max()
+    assert float(err) <= 5e-6 * float(torch.nan_to_num(ref).abs().max()), float(err)
+    # the drawn parameters respect torchvision's ranges
+    h, w = params[:, 4], params[:, 5]
+    assert bool(((h >= 1) & (h <= S) & (w >= 1) & (w <= S)).all()) and bool((params[:, 2] + h <= S).all()) and bool((params[:, 3] + w <= S).all())
+    keep = torch.ones(len(params), dtype=torch.bool)
+    keep[[3, 4, 5]] = False
+    area = (h * w)[keep] / (S * S)
+    assert float(area.min()) > 0.75 and float(area.max()) <= 1.0
+    assert bool(((params[keep, 6] >= 0.8) & (params[keep, 6] <= 1.25)).all()) and bool(((params[keep, 7] >= 0) & (params[keep, 7] <= 0.01)).all())
+    nbits = torch.tensor([bin(int(m)).count("1") for m in nan_mask])
+    assert int(nbits.max()) <= 2 and set(nbits.tolist()) == {0, 1, 2}
+    # drop-in call on one sample: an augmented copy of the same shape
+    one = aug(imgs[0])
+    assert one.shape == imgs[0].shape and not torch.equal(torch.nan_to_num(one), imgs[0])
