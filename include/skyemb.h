@@ -122,10 +122,10 @@ int skyemb_colsum(const void *X, int dtype, int64_t ldx, int M, int N, float *ou
  * (ties -> lower index).  noise [B,L] -> ids_restore i64 [B,L], mask f32 [B,L]
  * (1 = removed), ids_keep i32 [B,keep] (first `keep` of the shuffle, in shuffle order).
  * Optional (NULL to skip) decoder un-shuffle maps for utils/mim_vit.py:446-453, one entry per
- * encoder token (cls first): dec_dst i32 [B,1+keep] = row of the [B,1+L] decoder sequence the token
- * lands on, dec_tab i32 [B,1+keep] = its decoder_pos_embed row. */
+ * encoder token (the n_extra = 1 (cls) or 2 (cls, RA/Dec) extra tokens first): dec_dst i32 [B,n_extra+keep] = row of
+ * the [B,n_extra+L] decoder sequence the token lands on, dec_tab i32 [B,n_extra+keep] = its decoder_pos_embed row. */
 int skyemb_random_mask_from_noise(const float *noise, int B, int L, int keep, int64_t *ids_restore, float *mask,
-                                  int32_t *ids_keep, int32_t *dec_dst, int32_t *dec_tab, void *stream);
+                                  int32_t *ids_keep, int32_t *dec_dst, int32_t *dec_tab, int n_extra, void *stream);
 /* SimMIM mask generator on the device (replaces utils/dataloaders.py:197-219 MaskGenerator.__call__, which runs per item in
  * the loader workers): per sample ratio = ratio_u[b] * max_ratio, count = ceil(L * ratio); per channel the `count` patches
  * with the smallest noise[b, c, :] are masked (a uniformly random subset, like randperm(L)[:count]); out_mask float 0 / 1
@@ -197,7 +197,7 @@ int skyemb_mha_bwd(const void *qkv, const void *dout, void *dqkv, int dtype, int
  * utils/mim_vit.py:446-453: rows of the decoder sequence that hold a mask token:
  * x[b, 1+l, :] = mask_token + dec_pos[1+l] for every l with mask[b,l]==1 (x fp32 [B, 1+L, Dd]). */
 int skyemb_fill_mask_tokens(float *x, const float *mask, const float *mask_token, const float *dec_pos, int B,
-                            int L, int Dd, void *stream);
+                            int L, int Dd, int n_extra, void *stream);
 /* gather fp32 rows: out[i, :] = src[idx[i], :] (also emits a dtype copy when out_lp != NULL) */
 int skyemb_gather_rows(const float *src, const int32_t *idx, float *out, void *out_lp, int dtype, int n_rows,
                        int D, void *stream);

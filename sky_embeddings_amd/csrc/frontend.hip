@@ -10,7 +10,7 @@ namespace {
 __global__ __launch_bounds__(256) void mask_kernel(const float *__restrict__ noise, int B, int L, int keep,
                                                    int64_t *__restrict__ ids_restore, float *__restrict__ mask,
                                                    int32_t *__restrict__ ids_keep, int32_t *__restrict__ dec_dst,
-                                                   int32_t *__restrict__ dec_tab) {
+                                                   int32_t *__restrict__ dec_tab, int E) {
     extern __shared__ float sn[];  // [4][L]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + wave;
@@ -29,15 +29,15 @@ __global__ __launch_bounds__(256) void mask_kernel(const float *__restrict__ noi
         mask[(int64_t)b * L + i] = rank >= keep ? 1.0f : 0.0f;
         if (rank < keep) {
             ids_keep[(int64_t)b * keep + rank] = i;
-            if (dec_dst) {  // encoder token 1+rank of sample b lands on decoder row 1+i (mim_vit.py:448-450)
-                dec_dst[(int64_t)b * (keep + 1) + 1 + rank] = b * (L + 1) + 1 + i;
-                dec_tab[(int64_t)b * (keep + 1) + 1 + rank] = 1 + i;
+            if (dec_dst) {  // encoder token E+rank of sample b lands on decoder row E+i (mim_vit.py:448-450; E extra tokens)
+                dec_dst[(int64_t)b * (keep + E) + E + rank] = b * (L + E) + E + i;
+                dec_tab[(int64_t)b * (keep + E) + E + rank] = E + i;
             }
         }
     }
-    if (dec_dst && lane == 0) {
-        dec_dst[(int64_t)b * (keep + 1)] = b * (L + 1);
-        dec_tab[(int64_t)b * (keep + 1)] = 0;
+    if (dec_dst && lane < E) {   // cls (and RA/Dec) rows keep their place at the front
+        dec_dst[(int64_t)b * (keep + E) + lane] = b * (L + E) + lane;
+        dec_tab[(int64_t)b * (keep + E) + lane] = lane;
     }
 }
 
@@ -152,11 +152,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ X, in
 // ---- utils/mim_vit.py:446-453: rows holding a mask token ----------------------------------------
 __global__ __launch_bounds__(256) void fill_mask_tokens_kernel(float *__restrict__ x, const float *__restrict__ mask,
                                                                const float *__restrict__ mask_token,
-                                                               const float *__restrict__ dec_pos, int L, int Dd) {
+                                                               const float *__restrict__ dec_pos, int L, int Dd, int E) {
     const int b = blockIdx.x / L, l = blockIdx.x % L;
     if (mask[(int64_t)b * L + l] == 0.0f) return;
-    float *dst = x + ((int64_t)b * (L + 1) + 1 + l) * Dd;
-    const float *pos = dec_pos + (int64_t)(1 + l) * Dd;
+    float *dst = x + ((int64_t)b * (L + E) + E + l) * Dd;
+    const float *pos = dec_pos + (int64_t)(E + l) * Dd;
     for (int d = threadIdx.x * 4; d < Dd; d += 1024) {
         const float4 t = *(const float4 *)(mask_token + d), q = *(const float4 *)(pos + d);
         *(float4 *)(dst + d) = make_float4(t.x + q.x, t.y + q.y, t.z + q.z, t.w + q.w);
@@ -233,10 +233,11 @@ extern "C" int skyemb_clip_crop(const float *src, float *dst, int64_t n_planes, 
 
 extern "C" int skyemb_random_mask_from_noise(const float *noise, int B, int L, int keep, int64_t *ids_restore,
                                              float *mask, int32_t *ids_keep, int32_t *dec_dst, int32_t *dec_tab,
-                                             void *stream) {
-    SKY_CHECK_ARG(B > 0 && L > 0 && keep >= 0 && keep <= L && L <= 4096, "skyemb_random_mask_from_noise: bad shape B=%d L=%d keep=%d", B, L, keep);
+                                             int n_extra, void *stream) {
+    SKY_CHECK_ARG(B > 0 && L > 0 && keep >= 0 && keep <= L && L <= 4096 && n_extra >= 1 && n_extra <= 2,
+                  "skyemb_random_mask_from_noise: bad shape B=%d L=%d keep=%d extra=%d", B, L, keep, n_extra);
     hipLaunchKernelGGL(mask_kernel, dim3((B + 3) / 4), dim3(256), (size_t)4 * L * sizeof(float), (hipStream_t)stream, noise,
-                       B, L, keep, ids_restore, mask, ids_keep, dec_dst, dec_tab);
+                       B, L, keep, ids_restore, mask, ids_keep, dec_dst, dec_tab, n_extra);
     SKY_LAUNCH_CHECK("skyemb_random_mask_from_noise");
     return 0;
 }
@@ -308,10 +309,10 @@ extern "C" int skyemb_patch_gather_bwd_pmv(const float *imgs, const int32_t *ids
 }
 
 extern "C" int skyemb_fill_mask_tokens(float *x, const float *mask, const float *mask_token, const float *dec_pos, int B,
-                                       int L, int Dd, void *stream) {
-    SKY_CHECK_ARG(B > 0 && L > 0 && Dd % 4 == 0, "skyemb_fill_mask_tokens: bad shape");
+                                       int L, int Dd, int n_extra, void *stream) {
+    SKY_CHECK_ARG(B > 0 && L > 0 && Dd % 4 == 0 && n_extra >= 1, "skyemb_fill_mask_tokens: bad shape");
     hipLaunchKernelGGL(fill_mask_tokens_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, x, mask, mask_token, dec_pos,
-                       L, Dd);
+                       L, Dd, n_extra);
     SKY_LAUNCH_CHECK("skyemb_fill_mask_tokens");
     return 0;
 }

@@ -101,9 +101,8 @@ class MAEEngine:
     def __init__(self, cfg: MAEConfig, device="cuda", compute_dtype=torch.bfloat16, seed=None):
         if cfg.attn_pool:
             raise NotImplementedError("attn_pool (timm AttentionPoolLatent) is a 'next' row (SURVEY.md §8f)")
-        if (cfg.simmim or cfg.ra_dec) and self._modes == "mae":
-            raise NotImplementedError("simmim=True / ra_dec=True are served by sky_embeddings_amd.simmim_engine.SimMIMEngine "
-                                      "(the RA/Dec token in MAE mode is a 'next' row, SURVEY.md §8f)")
+        if cfg.simmim and self._modes == "mae":
+            raise NotImplementedError("simmim=True is served by sky_embeddings_amd.simmim_engine.SimMIMEngine")
         assert cfg.embed_dim % cfg.num_heads == 0 and cfg.decoder_embed_dim % cfg.decoder_num_heads == 0
         assert cfg.embed_dim % 8 == 0 and cfg.decoder_embed_dim % 8 == 0 and cfg.patch_size % 4 == 0
         self.cfg = cfg
@@ -179,19 +178,20 @@ class MAEEngine:
         if key in self._ws:
             return self._ws[key]
         cfg, dev, T = self.cfg, self.device, self.dtype
-        L, D, Dd, pv = cfg.num_patches, cfg.embed_dim, cfg.decoder_embed_dim, cfg.patch_dim
-        Ne, Nd = 1 + keep, 1 + L
+        L, D, Dd, pv, E = cfg.num_patches, cfg.embed_dim, cfg.decoder_embed_dim, cfg.patch_dim, cfg.num_extra_tokens
+        Ne, Nd = E + keep, E + L            # E extra tokens first: cls (, RA/Dec: utils/mim_vit.py:410-419)
         Me, Md = B * Ne, B * Nd
         f32 = dict(device=dev, dtype=torch.float32)
         lp = dict(device=dev, dtype=T)
         i32 = dict(device=dev, dtype=torch.int32)
         w = {}
+        w["sh"], w["z"], w["dz"] = torch.empty(B, 25, **f32), torch.empty(B, 8, **f32), torch.empty(B, 8, **f32)   # RA/Dec encoder
         w["ids_restore"] = torch.empty(B, L, device=dev, dtype=torch.int64)
         w["mask"] = torch.empty(B, L, **f32)
         w["ids_keep"] = torch.empty(B, keep, **i32)
         w["dec_dst"] = torch.empty(B, Ne, **i32)
         w["dec_tab"] = torch.empty(B, Ne, **i32)
-        w["pe_dst"] = (torch.arange(B, device=dev)[:, None] * Ne + 1 + torch.arange(keep, device=dev)[None, :]).to(torch.int32).contiguous()
+        w["pe_dst"] = (torch.arange(B, device=dev)[:, None] * Ne + E + torch.arange(keep, device=dev)[None, :]).to(torch.int32).contiguous()
         w["patches"] = torch.empty(B * keep, pv, **lp)
         w["latent32"] = torch.empty(Me, D, **f32)
 
@@ -265,23 +265,30 @@ class MAEEngine:
         return w
 
     # ------------------------------------------------------------------ forward pieces
-    def _embed(self, imgs, noise, keep, w):
+    def _embed(self, imgs, noise, keep, w, ra_dec=None):
         """a3-a6: mask from noise, fused normalise/NaN-fill/gather of the kept patches, patch-embed
-        GEMM with bias + positional rows scattered into the token sequence, cls row."""
+        GEMM with bias + positional rows scattered into the token sequence, (RA/Dec token,) cls row."""
         cfg, st = self.cfg, self.store
         B = imgs.shape[0]
-        L, D, pv = cfg.num_patches, cfg.embed_dim, cfg.patch_dim
-        Ne = 1 + keep
-        ops.random_mask_from_noise(noise, keep, w["ids_restore"], w["mask"], w["ids_keep"], w["dec_dst"], w["dec_tab"])
+        L, D, pv, E = cfg.num_patches, cfg.embed_dim, cfg.patch_dim, cfg.num_extra_tokens
+        Ne = E + keep
+        ops.random_mask_from_noise(noise, keep, w["ids_restore"], w["mask"], w["ids_keep"], w["dec_dst"], w["dec_tab"], n_extra=E)
         ops.patch_gather(imgs, st.param("patch_mask_values"), w["ids_keep"], w["patches"], cfg.patch_size, keep,
                          cfg.pixel_mean, cfg.pixel_std)
         x0 = w["xs"][0]
         pos = st.frozen["pos_embed"].view(-1, D)
         ops.gemm(w["patches"], st.lp("patch_embed.proj.weight"), M=B * keep, N=D, K=pv,
-                 bias=st.param("patch_embed.proj.bias"), table=pos[1:], tab_row=w["ids_keep"], ldt=D,
+                 bias=st.param("patch_embed.proj.bias"), table=pos[E:], tab_row=w["ids_keep"], ldt=D,
                  dst_row=w["pe_dst"], out_f32=x0, ldo32=D)
         # cls_token + pos_embed[:, :1] (utils/mim_vit.py:417-419): B tiny row copies (host glue)
         x0.view(B, Ne, D)[:, 0, :] = st.param("cls_token").view(D) + pos[0]
+        if cfg.ra_dec:
+            # LocationEncoder(ra_dec) + pos_embed[:, 1] right behind the cls token (utils/mim_vit.py:410-414)
+            P = st.param
+            ops.radec_token_fwd(ra_dec, P("ra_dec_embed.neural_network.layers.0.weight"),
+                                P("ra_dec_embed.neural_network.layers.0.bias"), P("ra_dec_embed.neural_network.last_layer.weight"),
+                                P("ra_dec_embed.neural_network.last_layer.bias"), pos[1], x0.view(-1)[D:], Ne * D, B, D,
+                                w["sh"], w["z"])
         return x0
 
     def _block_fwd(self, x_in, x_out, bufs, prefix, M, dim, heads, Bsz, N):
@@ -303,12 +310,12 @@ class MAEEngine:
         ops.gemm(bufs["hact"], LP(f"{prefix}.mlp.fc2.weight"), M=M, N=dim, K=hidden, bias=P(f"{prefix}.mlp.fc2.bias"),
                  resid=bufs["xmid"], ldr=dim, out_f32=x_out, ws=self._splitk_ws)
 
-    def _encoder_fwd(self, imgs, noise, keep, w, train):
+    def _encoder_fwd(self, imgs, noise, keep, w, train, ra_dec=None):
         cfg, st = self.cfg, self.store
         B = imgs.shape[0]
-        D, Ne = cfg.embed_dim, 1 + keep
+        D, Ne = cfg.embed_dim, cfg.num_extra_tokens + keep
         Me = B * Ne
-        self._embed(imgs, noise, keep, w)
+        self._embed(imgs, noise, keep, w, ra_dec)
         xs = w["xs"]
         for i in range(cfg.depth):
             if train:
@@ -321,6 +328,12 @@ class MAEEngine:
         return x_last
 
     # ------------------------------------------------------------------ public forward paths
+    def _check_ra_dec(self, imgs, ra_dec):
+        if not self.cfg.ra_dec:
+            return None
+        assert ra_dec is not None and tuple(ra_dec.shape) == (imgs.shape[0], 2), "ra_dec=True models need ra_dec [B,2] (degrees)"
+        return ra_dec.to(device=imgs.device, dtype=torch.float32).contiguous()
+
     def _check_inputs(self, imgs, noise):
         cfg = self.cfg
         assert imgs.is_cuda and imgs.dtype == torch.float32 and imgs.is_contiguous()
@@ -331,35 +344,37 @@ class MAEEngine:
         assert noise.shape == (B, cfg.num_patches) and noise.is_cuda and noise.dtype == torch.float32
         return noise.contiguous()
 
-    def forward_features(self, imgs, mask_ratio=0.0, noise=None):
-        """utils/mim_vit.py:381-438 (MAE mode): -> (latent fp32 [B, 1+keep, D], mask [B,L], ids_restore [B,L])."""
+    def forward_features(self, imgs, mask_ratio=0.0, noise=None, ra_dec=None):
+        """utils/mim_vit.py:381-438 (MAE mode): -> (latent fp32 [B, E+keep, D], mask [B,L], ids_restore [B,L])."""
         cfg = self.cfg
         noise = self._check_inputs(imgs, noise)
+        ra_dec = self._check_ra_dec(imgs, ra_dec)
         B = imgs.shape[0]
         keep = int(cfg.num_patches * (1 - mask_ratio))
         w = self._workspace(B, keep, False)
-        self._encoder_fwd(imgs, noise, keep, w, False)
-        return w["latent32"].view(B, 1 + keep, cfg.embed_dim), w["mask"], w["ids_restore"]
+        self._encoder_fwd(imgs, noise, keep, w, False, ra_dec)
+        return w["latent32"].view(B, cfg.num_extra_tokens + keep, cfg.embed_dim), w["mask"], w["ids_restore"]
 
-    def forward_train(self, imgs, mask_ratio=0.75, noise=None):
+    def forward_train(self, imgs, mask_ratio=0.75, noise=None, ra_dec=None):
         """utils/mim_vit.py:552-559: -> (loss [1] device tensor, pred fp32 view [B, L, pv], mask [B, L]).
         Activations are saved for :meth:`backward`."""
         cfg, st = self.cfg, self.store
         noise = self._check_inputs(imgs, noise)
+        ra_dec = self._check_ra_dec(imgs, ra_dec)
         B = imgs.shape[0]
-        L, D, Dd, pv = cfg.num_patches, cfg.embed_dim, cfg.decoder_embed_dim, cfg.patch_dim
+        L, D, Dd, pv, E = cfg.num_patches, cfg.embed_dim, cfg.decoder_embed_dim, cfg.patch_dim, cfg.num_extra_tokens
         keep = int(L * (1 - mask_ratio))
         assert keep >= 1, "mask_ratio leaves no visible patch"
-        Ne, Nd = 1 + keep, 1 + L
+        Ne, Nd = E + keep, E + L
         Me, Md = B * Ne, B * Nd
         w = self._workspace(B, keep, True)
-        self._encoder_fwd(imgs, noise, keep, w, True)
+        self._encoder_fwd(imgs, noise, keep, w, True, ra_dec)
         # ---- decoder (utils/mim_vit.py:440-467)
         xd = w["xd"]
         dpos = st.frozen["decoder_pos_embed"].view(-1, Dd)
         ops.gemm(w["lat_lp"], st.lp("decoder_embed.weight"), M=Me, N=Dd, K=D, bias=st.param("decoder_embed.bias"),
                  table=dpos, tab_row=w["dec_tab"], ldt=Dd, dst_row=w["dec_dst"], out_f32=xd[0], ldo32=Dd)
-        ops.fill_mask_tokens(xd[0], w["mask"], st.param("mask_token"), dpos, B, L, Dd)
+        ops.fill_mask_tokens(xd[0], w["mask"], st.param("mask_token"), dpos, B, L, Dd, n_extra=E)
         for i in range(cfg.decoder_depth):
             self._block_fwd(xd[i], xd[i + 1], w["dec"][i], f"decoder_blocks.{i}", Md, Dd, cfg.decoder_num_heads, B, Nd)
         ops.layernorm_fwd(xd[-1], st.param("decoder_norm.weight"), st.param("decoder_norm.bias"), w["dlat_lp"],
@@ -368,9 +383,9 @@ class MAEEngine:
                  out_f32=w["pred"])
         # ---- loss + d loss / d pred (utils/mim_vit.py:473-521)
         ops.masked_patch_loss(imgs, w["pred"], w["mask"], w["loss"], w["dpred"], None, self.code, w["loss_ws"],
-                              cfg.patch_size, 1, cfg.pixel_mean, cfg.pixel_std, cfg.norm_pix_loss, cfg.loss_fn != "mse")
+                              cfg.patch_size, E, cfg.pixel_mean, cfg.pixel_std, cfg.norm_pix_loss, cfg.loss_fn != "mse")
         self._last = (imgs, B, keep)
-        return w["loss"], w["pred"][:, 1:, :], w["mask"]
+        return w["loss"], w["pred"][:, E:, :], w["mask"]
 
     # ------------------------------------------------------------------ backward
     def _linear_bwd(self, dy, x_in, wname, bname, M, N, K, w, dx_out=None, dx_act=0, dx_aux=None, wgrad=True):
@@ -517,8 +532,8 @@ class MAEEngine:
         assert self._last is not None, "backward() without forward_train()"
         imgs, B, keep = self._last
         cfg = self.cfg
-        L = cfg.num_patches
-        return imgs, B, keep, 1 + keep, 1 + L, self._ws[(B, keep, True)]
+        L, E = cfg.num_patches, cfg.num_extra_tokens
+        return imgs, B, keep, E + keep, E + L, self._ws[(B, keep, True)]
 
     def backward_decoder(self):
         """Stage 0 of backward: decoder_pred ... decoder_embed (+ mask_token); leaves d latent in w['dln']."""
@@ -536,7 +551,7 @@ class MAEEngine:
             self._block_bwd(w["xd"][i], w["dec"][i], f"decoder_blocks.{i}", Md, Dd, cfg.decoder_num_heads, B, Nd, g,
                             g_lp, w)
         # mask token, decoder_embed (g = d xd[0])
-        ops.rowsum_select(g, Dd, w["mask"], 1, L, Nd, B * L, Dd, w["rs_part"], st.grad("mask_token").view(Dd))
+        ops.rowsum_select(g, Dd, w["mask"], cfg.num_extra_tokens, L, Nd, B * L, Dd, w["rs_part"], st.grad("mask_token").view(Dd))
         ops.gather_rows(g, w["dec_dst"], None, w["dE"], Me, Dd)
         dln_e = w["dln"][:Me * D].view(Me, D)
         self._linear_bwd(w["dE"], w["lat_lp"], "decoder_embed.weight", "decoder_embed.bias", Me, Dd, D, w, dx_out=dln_e)
@@ -566,6 +581,12 @@ class MAEEngine:
         Me = B * Ne
         g = w["g"][:Me * D].view(Me, D)
         ops.rowsum_select(g, D, None, 0, 1, Ne, B, D, w["rs_part"], st.grad("cls_token").view(D))
+        if cfg.ra_dec:
+            G = st.grad
+            ops.radec_token_bwd(g.view(-1)[D:], Ne * D, st.param("ra_dec_embed.neural_network.last_layer.weight"), w["sh"],
+                                w["z"], w["dz"], G("ra_dec_embed.neural_network.layers.0.weight"),
+                                G("ra_dec_embed.neural_network.layers.0.bias"), G("ra_dec_embed.neural_network.last_layer.weight"),
+                                G("ra_dec_embed.neural_network.last_layer.bias"), B, D)
         ops.gather_rows(g, w["pe_dst"], None, w["dT"], B * keep, D)
         self._wgrad(w["dT"], w["patches"], D, pv, B * keep, st.grad("patch_embed.proj.weight"),
                     st.grad("patch_embed.proj.bias"), w)
@@ -601,7 +622,7 @@ class MAEEngine:
         cfg = self.cfg
         L, D, Dd, pv = cfg.num_patches, cfg.embed_dim, cfg.decoder_embed_dim, cfg.patch_dim
         keep = int(L * (1 - mask_ratio))
-        Ne, Nd = 1 + keep, 1 + L
+        Ne, Nd = cfg.num_extra_tokens + keep, cfg.num_extra_tokens + L
         r = cfg.mlp_ratio
 
         def blocks(n, d, depth, heads):

@@ -90,10 +90,10 @@ def colsum(X, M, N, out, ldx=None):
     check(lib().skyemb_colsum(_p(X), code, ldx if ldx is not None else N, M, N, _p(out), _stream()), "skyemb_colsum")
 
 
-def random_mask_from_noise(noise, keep, ids_restore, mask, ids_keep, dec_dst=None, dec_tab=None):
+def random_mask_from_noise(noise, keep, ids_restore, mask, ids_keep, dec_dst=None, dec_tab=None, n_extra=1):
     B, L = noise.shape
     check(lib().skyemb_random_mask_from_noise(_p(noise), B, L, keep, _p(ids_restore), _p(mask), _p(ids_keep),
-                                              _p(dec_dst), _p(dec_tab), _stream()), "skyemb_random_mask_from_noise")
+                                              _p(dec_dst), _p(dec_tab), n_extra, _stream()), "skyemb_random_mask_from_noise")
 
 
 def augment(imgs, out, params, nan_mask, noise, A):
@@ -188,8 +188,8 @@ def mha_bwd(qkv, dout, dqkv, B, N, H, hd):
           "skyemb_mha_bwd")
 
 
-def fill_mask_tokens(x, mask, mask_token, dec_pos, B, L, Dd):
-    check(lib().skyemb_fill_mask_tokens(_p(x), _p(mask), _p(mask_token), _p(dec_pos), B, L, Dd, _stream()),
+def fill_mask_tokens(x, mask, mask_token, dec_pos, B, L, Dd, n_extra=1):
+    check(lib().skyemb_fill_mask_tokens(_p(x), _p(mask), _p(mask_token), _p(dec_pos), B, L, Dd, n_extra, _stream()),
           "skyemb_fill_mask_tokens")
 
 

@@ -52,7 +52,7 @@ class TrainStep:
         if self.max_mask_ratio is not None:
             self.mask_noise = torch.zeros(batch_size, cfg.in_chans, cfg.num_patches, device=dev)
             self.ratio_u = torch.zeros(batch_size, device=dev)
-        self.ra_dec = torch.zeros(batch_size, 2, device=dev) if (self.simmim and cfg.ra_dec) else None
+        self.ra_dec = torch.zeros(batch_size, 2, device=dev) if cfg.ra_dec else None
         self.loss = None
         self.external_noise = external_noise          # parity tests fill step.noise themselves (same noise on 1 and N ranks)
         if grad_comm is None:
@@ -135,7 +135,7 @@ class TrainStep:
         # utils/mim_vit.py:363 draws the masking noise inside forward; keep it inside the step
         if not self.external_noise:
             self.noise.uniform_()
-        self.loss, self.pred, self.mask = self.engine.forward_train(self.imgs, self.mask_ratio, self.noise)
+        self.loss, self.pred, self.mask = self.engine.forward_train(self.imgs, self.mask_ratio, self.noise, ra_dec=self.ra_dec)
 
     def load_batch(self, imgs, mask=None, ra_dec=None):
         """Stage the next minibatch (device or pinned host tensors) into the static input buffers."""
@@ -144,8 +144,8 @@ class TrainStep:
             if self.max_mask_ratio is None:
                 assert mask is not None, "SimMIM steps need the per-pixel mask (or TrainStep(max_mask_ratio=...))"
                 self.pixel_mask.copy_(mask, non_blocking=True)
-            if self.ra_dec is not None:
-                self.ra_dec.copy_(ra_dec, non_blocking=True)
+        if self.ra_dec is not None:
+            self.ra_dec.copy_(ra_dec, non_blocking=True)
 
     def __call__(self, imgs=None, mask=None, ra_dec=None):
         if imgs is not None:

@@ -55,7 +55,7 @@ class _LossBackward(torch.autograd.Function):
 
 class MaskedAutoencoderViT:
     """Masked Autoencoder with VisionTransformer backbone (utils/mim_vit.py:183-559): MAE mode (MAEEngine) and SimMIM
-    mode with the optional RA/Dec token (SimMIMEngine)."""
+    mode (SimMIMEngine), each with the optional RA/Dec token."""
 
     def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=1024, depth=24, num_heads=16,
                  decoder_embed_dim=512, decoder_depth=8, decoder_num_heads=16, mlp_ratio=4., norm_layer=None,
@@ -148,7 +148,7 @@ class MaskedAutoencoderViT:
                 H = W = int(L ** 0.5)
                 latent = latent.permute(0, 2, 1).reshape(B, C, H, W)
             return latent, m, None
-        latent, m, ids = self.engine.forward_features(self._prep(x), mask_ratio=mask_ratio, noise=noise)
+        latent, m, ids = self.engine.forward_features(self._prep(x), mask_ratio=mask_ratio, noise=noise, ra_dec=ra_dec)
         return latent.clone(), m.clone(), ids.clone()
 
     def forward(self, imgs, ra_dec=None, mask_ratio=0.75, mask=None, denorm_out=False, noise=None):
@@ -157,7 +157,7 @@ class MaskedAutoencoderViT:
         if self.simmim:
             loss, pred, m = self.engine.forward_train(self._prep(imgs), mask=mask.to(self.engine.device), ra_dec=ra_dec)
         else:
-            loss, pred, m = self.engine.forward_train(self._prep(imgs), mask_ratio=mask_ratio, noise=noise)
+            loss, pred, m = self.engine.forward_train(self._prep(imgs), mask_ratio=mask_ratio, noise=noise, ra_dec=ra_dec)
         if torch.is_grad_enabled():
             loss = _LossBackward.apply(self._hook, self.engine, loss)
         else:

@@ -127,13 +127,13 @@ def sd_np(sd):
 
 def mae_case(mim_vit, pgwd, name, *, img, patch, C=5, D=64, depth=2, heads=4, Dd=32, ddepth=1, dheads=4,
              norm_pix=True, loss_fn="mse", nan=False, B=4, mask_ratio=0.75, steps=0, seed=0, pixel_mean=0.1,
-             pixel_std=1.3, pmv_rand=False):
+             pixel_std=1.3, pmv_rand=False, ra_dec=False):
     torch.manual_seed(seed)
     model = mim_vit.MaskedAutoencoderViT(img_size=img, patch_size=patch, in_chans=C, embed_dim=D, depth=depth,
                                          num_heads=heads, decoder_embed_dim=Dd, decoder_depth=ddepth,
                                          decoder_num_heads=dheads, mlp_ratio=4,
                                          norm_layer=partial(nn.LayerNorm, eps=1e-6), norm_pix_loss=norm_pix,
-                                         loss_fn=loss_fn, pixel_mean=pixel_mean, pixel_std=pixel_std)
+                                         loss_fn=loss_fn, pixel_mean=pixel_mean, pixel_std=pixel_std, ra_dec=ra_dec)
     with torch.no_grad():
         # make zero-initialised tensors non-trivial so every gradient path is exercised
         g = torch.Generator().manual_seed(seed + 100)
@@ -152,6 +152,10 @@ def mae_case(mim_vit, pgwd, name, *, img, patch, C=5, D=64, depth=2, heads=4, Dd
            "cfg": np.array([img, patch, C, D, depth, heads, Dd, ddepth, dheads, int(norm_pix)], dtype=np.int64),
            "loss_fn": np.array(loss_fn), "pixel_mean": np.float64(pixel_mean), "pixel_std": np.float64(pixel_std)}
     out.update({"state/" + k: v for k, v in sd_np(model.state_dict()).items()})
+    rd = None
+    if ra_dec:      # MAE mode with the RA/Dec token (mim_vit.py:410-414, 446-467): sky positions in degrees
+        rd = torch.stack([torch.rand(B, generator=g) * 360, torch.rand(B, generator=g) * 180 - 90], dim=1)
+        out["ra_dec"] = rd.numpy().copy()
 
     L = (img // patch) ** 2
 
@@ -160,17 +164,17 @@ def mae_case(mim_vit, pgwd, name, *, img, patch, C=5, D=64, depth=2, heads=4, Dd
         torch.manual_seed(s)
         noise = torch.rand(B, L).numpy().copy()
         torch.manual_seed(s)
-        return model(x, mask_ratio=mask_ratio), noise
+        return model(x, ra_dec=rd, mask_ratio=mask_ratio), noise
 
     model.train(True)
     (loss, pred, mask), out["noise"] = fwd(1000)
     torch.manual_seed(1000)
-    _, _, ids_restore = model.forward_features(x, mask_ratio=mask_ratio)
+    _, _, ids_restore = model.forward_features(x, ra_dec=rd, mask_ratio=mask_ratio)
     out.update(loss=loss.detach().numpy().copy(), pred=pred.detach().numpy().copy(), mask=mask.numpy().copy(),
                ids_restore=ids_restore.numpy().copy())
     # encoder-only path (eval_fns.py:115): mask_ratio=0 keeps all tokens, shuffled
     torch.manual_seed(1000)
-    latent, _, ids0 = model.forward_features(x, mask_ratio=0, reshape_out=False)
+    latent, _, ids0 = model.forward_features(x, ra_dec=rd, mask_ratio=0, reshape_out=False)
     out.update(latent_full=latent.detach().numpy().copy(), ids_restore_full=ids0.numpy().copy())
     loss.backward()
     for n, p in model.named_parameters():
@@ -405,6 +409,10 @@ def main():
     only = sys.argv[1:]                      # e.g. `make_golden.py simsearch` regenerates one family
     if "simsearch" in only or not only:
         simsearch_cases(sim)
+    if "mae_radec" in only or not only:
+        # I: MAE mode WITH the RA/Dec token (two extra tokens through encoder and decoder), three optimiser steps
+        mae_case(mim_vit, pgwd, "mae_tiny_I_radec", img=64, patch=16, D=32, heads=2, Dd=32, dheads=2, norm_pix=True, loss_fn="mse",
+                 nan=True, ra_dec=True, seed=12, steps=3)
     if only:
         return
     unit_pieces(mim_vit, pos_embed)

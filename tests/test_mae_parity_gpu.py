@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 from oracle import mae_oracle as mo
 from tests.helpers import load_case, rel_err
 
-CASES = ["mae_tiny_A", "mae_tiny_B_nan", "mae_tiny_C_nonorm", "mae_tiny_D_l1", "mae_tiny_E_p8"]
+CASES = ["mae_tiny_A", "mae_tiny_B_nan", "mae_tiny_C_nonorm", "mae_tiny_D_l1", "mae_tiny_E_p8", "mae_tiny_I_radec"]
 
 
 def make_engine(cfg, state, dtype):
@@ -24,7 +24,7 @@ def make_engine(cfg, state, dtype):
     c = MAEConfig(img_size=cfg.img_size, patch_size=cfg.patch_size, in_chans=cfg.in_chans, embed_dim=cfg.embed_dim,
                   depth=cfg.depth, num_heads=cfg.num_heads, decoder_embed_dim=cfg.decoder_embed_dim,
                   decoder_depth=cfg.decoder_depth, decoder_num_heads=cfg.decoder_num_heads, norm_pix_loss=cfg.norm_pix_loss,
-                  loss_fn=cfg.loss_fn, pixel_mean=cfg.pixel_mean, pixel_std=cfg.pixel_std)
+                  loss_fn=cfg.loss_fn, pixel_mean=cfg.pixel_mean, pixel_std=cfg.pixel_std, ra_dec=cfg.ra_dec)
     eng = MAEEngine(c, device="cuda", compute_dtype=dtype, seed=0)
     eng.load_state_dict(state)
     return eng
@@ -38,7 +38,8 @@ def test_forward_backward_vs_reference_goldens(name, dtype):
     imgs = torch.from_numpy(z["imgs"]).cuda()
     noise = torch.from_numpy(z["noise"]).cuda()
     ratio = float(z["mask_ratio"])
-    loss, pred, mask = eng.forward_train(imgs, ratio, noise)
+    rd = torch.from_numpy(z["ra_dec"]).cuda() if cfg.ra_dec else None      # case I: MAE mode with the RA/Dec token
+    loss, pred, mask = eng.forward_train(imgs, ratio, noise, ra_dec=rd)
     eng.backward()
     torch.cuda.synchronize()
     # integer / index work: bit exact
@@ -52,7 +53,7 @@ def test_forward_backward_vs_reference_goldens(name, dtype):
     nan_in = bool(np.isnan(z["imgs"]).any())
     if nan_in:
         _, _, _, _, _, ref = mo.loss_and_grads(st, torch.from_numpy(z["imgs"]), cfg, ratio, torch.from_numpy(z["noise"]),
-                                               nan_safe=True)
+                                               nan_safe=True, ra_dec=None if rd is None else rd.cpu())
         ref = {k: v.numpy() for k, v in ref.items()}
     else:
         ref = {k[len("grad/"):]: z[k] for k in z.files if k.startswith("grad/")}
@@ -67,12 +68,13 @@ def test_forward_backward_vs_reference_goldens(name, dtype):
             assert float(np.abs(g - r).max()) <= tol, (k, float(np.abs(g - r).max()), scale)
 
 
+@pytest.mark.parametrize("case", ["mae_tiny_A", "mae_tiny_I_radec"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_encoder_only_path(dtype):
-    z, cfg, st = load_case("mae_tiny_A")
+def test_encoder_only_path(dtype, case):
+    z, cfg, st = load_case(case)
     eng = make_engine(cfg, st, dtype)
     imgs, noise = torch.from_numpy(z["imgs"]).cuda(), torch.from_numpy(z["noise"]).cuda()
-    lat, mask, ids = eng.forward_features(imgs, 0.0, noise)
+    lat, mask, ids = eng.forward_features(imgs, 0.0, noise, ra_dec=torch.from_numpy(z["ra_dec"]).cuda() if cfg.ra_dec else None)
     assert np.array_equal(ids.cpu().numpy(), z["ids_restore_full"])
     assert rel_err(lat.cpu().numpy(), z["latent_full"]) < (2e-5 if dtype == torch.float32 else 2e-2)
 
