@@ -290,6 +290,9 @@ int skyemb_cosine_topk(const float *tw, const float *qn, const float *bank, cons
 /* merge `nlists` sorted length-k lists per query (bank chunks, or per-rank results after the
  * RCCL all-gather): in [Q, nlists, k] -> out [Q, k].  `ws` (optional, Q ints) enables the gather + block-sort
  * path used for the many short lists of the bank-streaming kernel (per-query fallback to the tournament). */
+/* out[q] = the k-th largest value of x[q, 0..S) minus one ulp (NaN ranks as -inf): the pruning floor a search derives from
+ * the exact scores of a bank sample (host glue of the build; the reference has no counterpart -- it sorts everything). */
+int skyemb_kth_largest_floor(const float *x, int Q, int S, int k, float *out, void *stream);
 int skyemb_topk_merge(const float *in_s, const int64_t *in_i, int Q, int nlists, int k, float *out_s,
                       int64_t *out_i, void *ws, void *stream);
 

@@ -399,15 +399,58 @@ __global__ __launch_bounds__(1024) void topk_merge_sort_kernel(const float *__re
             keys[off++] = ((unsigned long long)orderable(ps[(int64_t)l * k + e]) << 32) | (unsigned int)(~(unsigned int)ix);
         }
     }
-    int n2 = 1;
-    while (n2 < T) n2 <<= 1;
-    if (n2 < 2) n2 = 2;
-    for (int e = T + tid; e < n2; e += 1024) keys[e] = 0ull;   // worst possible key
     __syncthreads();
     if (bad_s) {
         if (tid == 0) fallback[q] = 1;
         return;
     }
+    // Only the best k of the T gathered entries are wanted: select the k-th largest key first (keys are unique: 8 radix
+    // passes of 8 bits over the 64-bit keys, histograms in LDS), keep the k keys >= it, and sort just those -- instead of a
+    // bitonic sort of all T (thousands with a sample-derived floor: ~80 block-wide stages).
+    int n = T;
+    if (T > k) {
+        __shared__ int hist[258];
+        unsigned long long prefix = 0ull, mask = 0ull;
+        int kth = k;
+        for (int shift = 56; shift >= 0; shift -= 8) {
+            for (int b = tid; b < 256; b += 1024) hist[b] = 0;
+            __syncthreads();
+            for (int e = tid; e < T; e += 1024) {
+                const unsigned long long kx = keys[e];
+                if ((kx & mask) == prefix) atomicAdd(&hist[(int)((kx >> shift) & 255ull)], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int run = 0, b = 255;
+                for (; b > 0; --b) {
+                    if (run + hist[b] >= kth) break;
+                    run += hist[b];
+                }
+                hist[256] = b;
+                hist[257] = kth - run;
+            }
+            __syncthreads();
+            prefix |= (unsigned long long)hist[256] << shift;
+            kth = hist[257];
+            mask |= 255ull << shift;
+            __syncthreads();
+        }
+        // compaction of the k winners into the front of a second region (MERGE_CAP keys are followed by room for 512 more)
+        unsigned long long *win = keys + MERGE_CAP;
+        if (tid == 0) hist[0] = 0;
+        __syncthreads();
+        for (int e = tid; e < T; e += 1024)
+            if (keys[e] >= prefix) win[atomicAdd(&hist[0], 1)] = keys[e];
+        __syncthreads();
+        for (int e = tid; e < k; e += 1024) keys[e] = win[e];
+        n = k;
+    }
+    int n2 = 1;
+    while (n2 < n) n2 <<= 1;
+    if (n2 < 2) n2 = 2;
+    __syncthreads();
+    for (int e = n + tid; e < n2; e += 1024) keys[e] = 0ull;   // worst possible key
+    __syncthreads();
     // bitonic sort, descending
     for (int k2 = 2; k2 <= n2; k2 <<= 1) {
         for (int j = k2 >> 1; j > 0; j >>= 1) {
@@ -423,7 +466,7 @@ __global__ __launch_bounds__(1024) void topk_merge_sort_kernel(const float *__re
         }
     }
     for (int e = tid; e < k; e += 1024) {
-        if (e < T) {
+        if (e < n) {
             const unsigned long long key = keys[e];
             out_s[(int64_t)q * k + e] = unorderable((unsigned int)(key >> 32));
             out_i[(int64_t)q * k + e] = (int64_t)(unsigned int)(~(unsigned int)key);
@@ -442,6 +485,48 @@ __global__ __launch_bounds__(64) void topk_merge_fallback_kernel(const float *__
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (fallback[blockIdx.x] == 0) return;
     tournament_merge(in_s, in_i, nlists, k, out_s, out_i, smem);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// pruning floor: per row of x [Q, S] the k-th largest value, returned one ulp lower (the top-k kernels keep rows STRICTLY
+// above the floor).  One workgroup per row: 4 radix passes of 8 bits over orderable keys, histograms in LDS.
+// Replaces torch.topk on the sample-score matrix (a dozen multi-block top-k / sort launches for a [Q, 25600] matrix).
+__global__ __launch_bounds__(1024) void kth_floor_kernel(const float *__restrict__ x, int S, int kth, float *__restrict__ out) {
+    __shared__ int hist[258];
+    const int tid = threadIdx.x;
+    const float *row = x + (int64_t)blockIdx.x * S;
+    unsigned int prefix = 0, mask = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int b = tid; b < 256; b += 1024) hist[b] = 0;
+        __syncthreads();
+        for (int e = tid; e < S; e += 1024) {
+            float v = row[e];
+            if (!(v == v)) v = -INFINITY;                      // NaN scores rank as -inf (contract)
+            const unsigned int u = __float_as_uint(v);
+            const unsigned int key = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0, b = 255;
+            for (; b > 0; --b) {
+                if (run + hist[b] >= kth) break;
+                run += hist[b];
+            }
+            hist[256] = b;
+            hist[257] = kth - run;
+        }
+        __syncthreads();
+        prefix |= (unsigned int)hist[256] << shift;
+        kth = hist[257];
+        mask |= 255u << shift;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float v = __uint_as_float(prefix ^ ((prefix >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+        out[blockIdx.x] = nextafterf(v, -INFINITY);
+    }
 }
 
 template <int QT, int BT, bool SO, int NW = 4>
@@ -554,11 +639,19 @@ extern "C" int skyemb_cosine_scores(const float *tw, const float *qn, const floa
     SKY_CHECK_ARG(Q > 0 && N > 0 && D > 0 && D % 4 == 0, "skyemb_cosine_scores: bad shape");
     hipStream_t st = (hipStream_t)stream;
     const int nchunks = (int)ceil_div64(N, 128 * 8) < 1 ? 1 : (int)ceil_div64(N, 128 * 8);
-    if (Q <= 16)
-        return launch_topk<16, 256, true>(tw, qn, bank, xn, Q, N, D, 1, eps, 0, (int)ceil_div64(N, 256 * 4), nullptr,
+    if (Q <= 16)   // one 256-row tile per workgroup: a 25,600-row sample gives 100 workgroups (was 25: a quarter of the chip's CUs)
+        return launch_topk<16, 256, true>(tw, qn, bank, xn, Q, N, D, 1, eps, 0, (int)ceil_div64(N, 256), nullptr,
                                           nullptr, scores, st, "skyemb_cosine_scores");
     return launch_topk<64, 128, true>(tw, qn, bank, xn, Q, N, D, 1, eps, 0, nchunks, nullptr, nullptr, scores, st,
                                       "skyemb_cosine_scores");
+}
+
+
+extern "C" int skyemb_kth_largest_floor(const float *x, int Q, int S, int k, float *out, void *stream) {
+    SKY_CHECK_ARG(x && out && Q > 0 && S > 0 && k >= 1 && k <= S, "skyemb_kth_largest_floor: bad arguments (Q=%d S=%d k=%d)", Q, S, k);
+    hipLaunchKernelGGL(kth_floor_kernel, dim3(Q), dim3(1024), 0, (hipStream_t)stream, x, S, k, out);
+    SKY_LAUNCH_CHECK("skyemb_kth_largest_floor");
+    return 0;
 }
 
 extern "C" int skyemb_topk_merge(const float *in_s, const int64_t *in_i, int Q, int nlists, int k, float *out_s,
@@ -571,14 +664,14 @@ extern "C" int skyemb_topk_merge(const float *in_s, const int64_t *in_i, int Q, 
         static bool attr_set = false;
         if (!attr_set) {
             hipError_t e = hipFuncSetAttribute((const void *)topk_merge_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               MERGE_CAP * 8);
+                                               (MERGE_CAP + 512) * 8);
             if (e != hipSuccess) {
                 skyemb_set_error("skyemb_topk_merge: hipFuncSetAttribute: %s", hipGetErrorString(e));
                 return 2;
             }
             attr_set = true;
         }
-        hipLaunchKernelGGL(topk_merge_sort_kernel, dim3(Q), dim3(1024), (size_t)MERGE_CAP * 8, (hipStream_t)stream, in_s, in_i,
+        hipLaunchKernelGGL(topk_merge_sort_kernel, dim3(Q), dim3(1024), (size_t)(MERGE_CAP + 512) * 8, (hipStream_t)stream, in_s, in_i,
                            nlists, k, out_s, out_i, (int *)ws);
         hipLaunchKernelGGL(topk_merge_fallback_kernel, dim3(Q), dim3(64), smem, (hipStream_t)stream, in_s, in_i, nlists, k,
                            out_s, out_i, (const int *)ws);

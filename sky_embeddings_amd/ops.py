@@ -245,6 +245,11 @@ def cosine_topk(tw, qn, bank, xn, k, eps, idx_offset, nchunks, part_s, part_i, t
                                    _p(part_s), _p(part_i), _stream()), "skyemb_cosine_topk")
 
 
+def kth_largest_floor(x, k, out):
+    Q, S = x.shape
+    check(lib().skyemb_kth_largest_floor(_p(x), Q, S, k, _p(out), _stream()), "skyemb_kth_largest_floor")
+
+
 def topk_prefilter_applicable(Q, N, D, k):
     return bool(lib().skyemb_topk_prefilter_applicable(Q, N, D, k))
 

@@ -91,8 +91,9 @@ def pruning_floor(tw, qn, pb: "PreparedBank", k: int, eps: float, sample_rows: i
     sb, sn = pb.sample(sample_rows)
     sc = torch.empty(tw.shape[0], sb.shape[0], device=tw.device)
     ops.cosine_scores(tw, qn, sb, sn, eps, sc)          # [Q, sample] score matrix (small)
-    tau = torch.topk(sc, k, dim=1).values[:, k - 1].contiguous()   # host-glue selection on the sample only
-    return torch.nextafter(tau, torch.full_like(tau, float("-inf")))
+    floor = torch.empty(tw.shape[0], device=tw.device)
+    ops.kth_largest_floor(sc, k, floor)                 # k-th best of the sample, one ulp lower (radix select, one launch)
+    return floor
 
 
 def _prefilter_enabled():
