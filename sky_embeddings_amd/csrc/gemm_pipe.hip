@@ -171,7 +171,18 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
         const int q = nwg >> 3, r = nwg & 7;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
     }
-    const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+    // An XCD's chunk of consecutive tiles walks ONE operand in full and a slice of the other (the 8 L2s are not coherent:
+    // each fetches what its tiles touch).  Row-major tile order makes that full operand B, column-major A: let the SMALLER
+    // operand be the one every L2 fetches whole (PMC, round 2: 12.1 GB of L2-side fetches + writes per step against 4.7 GB
+    // of single-copy bytes, mostly the weight matrices fetched by all eight L2s).
+#ifndef SKY_TILE_ROWMAJOR
+    const int tiles_m = (g.M + BM - 1) / BM;
+    const bool colmajor = g.N > g.M;
+    const int tile_m = colmajor ? wg % tiles_m : wg / tiles_n, tile_n = colmajor ? wg / tiles_m : wg % tiles_n;
+#else
+    const int tile_m = wg / tiles_n, tile_n = wg % tiles_n;
+#endif
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const bf16_t *A = (const bf16_t *)g.A;
     const bf16_t *B = (const bf16_t *)g.B;
     const int KT_all = g.K / BK;
@@ -194,7 +205,7 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
 
     // bias gradient = column sums of the RC A tile, taken by the waves of the first tile column with one extra MFMA
     // per A fragment against a fragment of ones (exact products, fp32 accumulation in k order)
-    const bool do_colsum = !A_KC && g.colsum_a != nullptr && (wg % tiles_n) == 0 && wn == 0;
+    const bool do_colsum = !A_KC && g.colsum_a != nullptr && tile_n == 0 && wn == 0;
     f32x4 cacc[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) cacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};

@@ -393,6 +393,39 @@ def simsearch_cases(sim):
     print("wrote simsearch_driver")
 
 
+
+def maskgen_cases():
+    """utils/dataloaders.py:155-219 (MaskGenerator) executed as is.  The module imports h5py, torchvision and astropy at the
+    top (all absent here, none touched by MaskGenerator): inert module objects stand in for the import statements only.
+    For each seed the first torch.rand(1) after the seed is the generator's ratio draw: the golden pins
+    count = ceil(L * ratio) per channel, the per-channel independence and the pixel up-sampling; the subsets themselves
+    follow torch.randperm's stream, which no device kernel reproduces."""
+    for name in ("torchvision", "torchvision.transforms", "torchvision.transforms.v2", "astropy", "astropy.io", "astropy.io.fits",
+                 "astropy.wcs"):
+        m = types.ModuleType(name)
+        m.disable_beta_transforms_warning = lambda: None
+        m.v2 = m.fits = m.WCS = None
+        sys.modules.setdefault(name, m)
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["astropy"].io = sys.modules["astropy.io"]
+    import importlib
+    dl = importlib.import_module("utils.dataloaders")
+    assert dl.__file__.startswith(REF), dl.__file__
+    out = {}
+    for (size, p, C, mx) in ((64, 8, 5, 0.9), (128, 16, 5, 0.6), (64, 16, 9, 0.9)):
+        gen = dl.MaskGenerator(input_size=size, patch_size=p, max_mask_ratio=mx, num_mask_chans=C)
+        us, masks = [], []
+        for seed in range(40):
+            torch.manual_seed(seed)
+            us.append(float(torch.rand(1)))
+            torch.manual_seed(seed)
+            masks.append(gen().numpy().astype(np.uint8))
+        key = f"mg/{size}_{p}_{C}_{mx}"
+        out[key + "/u"], out[key + "/masks"] = np.array(us, dtype=np.float32), np.stack(masks)
+    np.savez_compressed(os.path.join(OUT, "maskgen.npz"), **out)
+    print("wrote maskgen")
+
+
 def main():
     pgwd = install_standins()
     # this repo ships a drop-in ``utils`` package of the same name: keep it off the path so that the REFERENCE is imported
@@ -409,6 +442,8 @@ def main():
     only = sys.argv[1:]                      # e.g. `make_golden.py simsearch` regenerates one family
     if "simsearch" in only or not only:
         simsearch_cases(sim)
+    if "maskgen" in only or not only:
+        maskgen_cases()
     if "mae_radec" in only or not only:
         # I: MAE mode WITH the RA/Dec token (two extra tokens through encoder and decoder), three optimiser steps
         mae_case(mim_vit, pgwd, "mae_tiny_I_radec", img=64, patch=16, D=32, heads=2, Dd=32, dheads=2, norm_pix=True, loss_fn="mse",

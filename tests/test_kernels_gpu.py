@@ -473,6 +473,25 @@ def test_gemm_split_k_wgrad(ops, split):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])   # run-to-run deterministic
 
 
+def test_simmim_mask_counts_match_reference_mask_generator():
+    """The device MaskGenerator against masks the reference's own class drew (tests/golden/maskgen.npz, made by
+    tests/golden/make_golden.py maskgen): fed the reference's ratio draw, the kernel masks exactly as many patches per
+    channel as the reference did, for every draw of every geometry (incl. mim_19's 128/16/0.6)."""
+    from sky_embeddings_amd import ops
+    from tests.helpers import GOLDEN
+    import os
+    z = np.load(os.path.join(str(GOLDEN), "maskgen.npz"))
+    for key in sorted({k.rsplit("/", 1)[0] for k in z.files}):
+        size, p, C, mx = key.split("/")[1].split("_")
+        size, p, C, mx = int(size), int(p), int(C), float(mx)
+        u, masks = torch.from_numpy(z[key + "/u"]), torch.from_numpy(z[key + "/masks"]).float()
+        grid = size // p
+        noise = torch.rand(len(u), C, grid * grid, generator=torch.Generator().manual_seed(2)).cuda()
+        out = torch.empty(len(u), C, size, size, device="cuda")
+        ops.simmim_mask_from_noise(noise, u.cuda(), mx, grid, p, out)
+        assert torch.equal(out[:, :, ::p, ::p].sum(dim=(2, 3)).cpu(), masks[:, :, ::p, ::p].sum(dim=(2, 3)))
+
+
 @pytest.mark.parametrize("L,p,C,max_ratio", [(64, 8, 5, 0.9), (16, 16, 9, 0.6), (64, 16, 5, 0.6), (256, 4, 2, 1.0)])
 def test_simmim_mask_from_noise_matches_oracle(L, p, C, max_ratio):
     """Device MaskGenerator (utils/dataloaders.py:197-219): per-sample ratio, ceil(L * ratio) patches per channel, an

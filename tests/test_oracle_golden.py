@@ -177,3 +177,26 @@ def test_c_topk_oracle_against_reference_formula():
     s, i = so.cosine_topk_np(q, bank, 7)
     assert i[0].tolist() == [0, 1, 2, 4, 3, -1, -1]
     assert np.isneginf(s[0][5:]).all()
+
+
+def test_mask_generator_oracle_matches_reference_counts():
+    """tests/golden/maskgen.npz holds masks drawn by the reference's own MaskGenerator (utils/dataloaders.py:155-219) and the
+    ratio draw behind each: the oracle driven by that draw must mask the same number of patches in every channel, and the
+    reference's masks must be whole patches, independent per channel."""
+    z = np.load(GOLDEN + "/maskgen.npz")
+    keys = sorted({k.rsplit("/", 1)[0] for k in z.files})
+    assert len(keys) == 3
+    for key in keys:
+        size, p, C, mx = key.split("/")[1].split("_")
+        size, p, C, mx = int(size), int(p), int(C), float(mx)
+        u, masks = torch.from_numpy(z[key + "/u"]), torch.from_numpy(z[key + "/masks"]).float()
+        L = (size // p) ** 2
+        assert masks.shape == (len(u), C, size, size)
+        ours = mo.simmim_mask_from_noise(torch.rand(len(u), C, L, generator=torch.Generator().manual_seed(1)), u, mx, p)
+        patches = masks.view(len(u), C, size // p, p, size // p, p)
+        assert torch.equal(patches, patches[:, :, :, :1, :, :1].expand_as(patches))           # whole patches only
+        ref_count = masks[:, :, ::p, ::p].sum(dim=(2, 3))
+        assert torch.equal(ours[:, :, ::p, ::p].sum(dim=(2, 3)), ref_count)
+        assert bool((ref_count == ref_count[:, :1]).all())                                     # same count in every channel
+        differs = (masks[:, 0] != masks[:, 1]).flatten(1).any(dim=1)
+        assert bool(differs[ref_count[:, 0] > 0].float().mean() > 0.8)                         # channels masked independently
