@@ -370,8 +370,9 @@ def bench_search(args, rank, world, dev):
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
+        st = {}
         for _ in range(iters):
-            s, i = cosine_topk(q, pb, k, world_size=world)
+            s, i = cosine_topk(q, pb, k, world_size=world, stats=st)
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
@@ -392,8 +393,12 @@ def bench_search(args, rank, world, dev):
         kms = ev_time_ms(lambda: ops.cosine_topk(tw, qn, bank, pb.norms, k, 1e-6, lo, nch, ps, pi, thr0), iters)
         bank_bytes = (hi - lo) * D * 4
         kbytes = bank_bytes + (hi - lo) * 4 + Q * D * 4 + Q * nch * k * 12   # bank + row norms + queries + partial lists
-        res[label] = dict(Q=Q, sec=dt, queries_per_sec=Q / dt, kernel_ms=kms, kernel_bytes=kbytes,
-                          kernel_hbm_gbs=kbytes / kms / 1e6,
+        # `sec` is the path cosine_topk took (st["path"]); kernel_* time the EXACT kernel on the same inputs -- the whole
+        # job for Q <= 16, and for many queries the single-stage path the two-stage one replaced (and falls back to)
+        res[label] = dict(Q=Q, sec=dt, queries_per_sec=Q / dt, path=st.get("path"), redone=st.get("redone"),
+                          effective_tflops=2.0 * Q * (hi - lo) * D / dt / 1e12,
+                          kernel="cosine_topk_stream_kernel" if Q <= 16 else "cosine_topk_kernel<64,256,8> (exact, single stage)",
+                          kernel_ms=kms, kernel_bytes=kbytes, kernel_hbm_gbs=kbytes / kms / 1e6,
                           kernel_tflops=2.0 * Q * (hi - lo) * D / kms / 1e9, checksum=int(i.sum().item() % (1 << 31)))
     return res, (queries, w, bank)
 

@@ -8,7 +8,8 @@ Reads ``configs/<model_name>.ini``, builds the model / optimiser / scheduler
 (``utils.mim_vit.build_model``), streams HDF5 cutouts, runs ``run_iter`` per batch, evaluates the
 validation loss every ``verbose_iters``, checkpoints ``models/<model_name>.pth.tar`` every
 ``cp_time`` minutes in the reference's format (batch_iters, losses, optimizer, lr_scheduler, model).
-Plots and the sklearn linear probe of the reference are out of scope.
+The linear-probe validation hook (``lp_class_data_file`` / ``lp_regress_data_file`` / ``lp_combine``) runs on rank 0; plots are
+out of scope.
 """
 import configparser
 import os
@@ -23,11 +24,11 @@ from sky_embeddings_amd import ops
 from utils.dataloaders import build_h5_dataloader
 from utils.mim_vit import build_model
 from utils.misc import parseArguments
-from utils.pretrain_fns import run_iter
+from utils.pretrain_fns import linear_probe, run_iter
 
 
 def _mean(vals):
-    return float(torch.stack([v.float().reshape(()) for v in vals]).mean()) if vals else float("nan")
+    return float(torch.stack([torch.as_tensor(v, dtype=torch.float32).reshape(()).cpu() for v in vals]).mean()) if vals else float("nan")
 
 
 def save_checkpoint(model_filename, cur_iter, losses, optimizer, lr_scheduler, model):
@@ -103,6 +104,9 @@ def main(args):
     if rank == 0:
         print('The training set consists of %i cutouts.' % (len(dataloader_train.dataset)))
 
+    lp_files = {key: os.path.join(data_dir, config['DATA'][key]) if key in config['DATA'] else None
+                for key in ('lp_class_data_file', 'lp_regress_data_file')}
+    lp_combine = config['DATA'].get('lp_combine', 'central')
     total_batch_iters = int(float(config['TRAINING']['total_batch_iters']))
     if rank == 0:
         print('Training the network with a batch size of %i per GPU ...' % (dataloader_train.batch_size))
@@ -149,6 +153,10 @@ def main(args):
                                                                          mode='val')
                     if i >= 200:
                         break
+                probing = rank == 0 and any(lp_files.values())
+                if probing:     # the encoder is replicated: rank 0's probe is every rank's
+                    linear_probe(model, losses_cp, device, dataloader_val, lp_files['lp_class_data_file'],
+                                 lp_files['lp_regress_data_file'], combine=lp_combine)
                 for k in list(losses_cp.keys()):
                     losses[k].append(_mean(losses_cp[k]))
                 losses['batch_iters'].append(cur_iter)
@@ -156,6 +164,14 @@ def main(args):
                     print('\nBatch Iterations: %i/%i ' % (cur_iter, total_batch_iters))
                     print('Losses:\n\tTraining Dataset\n\t\tTotal Loss: %0.3f' % (losses['train_loss'][-1]))
                     print('\tValidation Dataset\n\t\tTotal Loss: %0.3f' % (losses['val_loss'][-1]))
+                    if probing:
+                        print('Linear Probing Results:')
+                        if lp_files['lp_class_data_file']:
+                            print('\tClassification Accuracy:\n\t\tTraining: %0.3f, Validation: %0.3f' %
+                                  (losses['train_lp_acc'][-1], losses['val_lp_acc'][-1]))
+                        if lp_files['lp_regress_data_file']:
+                            print('\tRegression R2\n\t\tTraining: %0.3f, Validation: %0.3f' %
+                                  (losses['train_lp_r2'][-1], losses['val_lp_r2'][-1]))
                 losses_cp = defaultdict(list)
             cur_iter += 1
             if (time.time() - cp_start_time) >= args.cp_time * 60:

@@ -1,4 +1,4 @@
-"""utils/misc.py mirror (only what the hot path uses: SURVEY.md §2 row 8)."""
+"""utils/misc.py mirror (what the hot path and its validation hooks use: SURVEY.md §2 row 8)."""
 import argparse
 
 import numpy as np
@@ -47,3 +47,20 @@ def h5_snr(h5_path, n_central_pix=8, batch_size=5000, num_samples=None):
             end = min(num_samples, i + batch_size)
             snr_vals.append(calculate_snr(np.asarray(cut[i:end]), n_central_pix))
     return np.concatenate(snr_vals)
+
+
+def central_indices(grid, n):
+    """utils/misc.py:68-97: (row, col) index pairs of the central sqrt(n) x sqrt(n) block of a 2-D grid, row-major."""
+    side = int(n ** 0.5)
+    if side * side != n:
+        raise ValueError("n must be a perfect square to form a square patch of pixels.")
+    rows = np.arange(side) + grid.shape[0] // 2 - side // 2
+    cols = np.arange(side) + grid.shape[1] // 2 - side // 2
+    return np.stack(np.meshgrid(rows, cols, indexing="ij"), axis=-1).reshape(-1, 2)
+
+
+def select_centre(latent, n_patches):
+    """utils/misc.py:99-117: the central ``n_patches`` patch tokens of [b, L, features] (L a square number, raster order)."""
+    side = int(latent.shape[1] ** 0.5)
+    ij = central_indices(np.empty((side, side)), n_patches)
+    return latent[:, ij[:, 0] * side + ij[:, 1]]

@@ -178,6 +178,7 @@ def test_pretrain_entry_point_runs(tmp_path, mode):
     hdf5_lite.make_synthetic_cutouts(str(dd / "synthetic_cutouts_GRIZY_64_train.h5"), n=64 if mode == "mae" else 70, seed=1234,
                                      chunked=mode == "simmim", nan_fraction=0.0 if mode == "mae" else 0.05)
     hdf5_lite.make_synthetic_cutouts(str(dd / "synthetic_cutouts_GRIZY_64_val.h5"), n=16, seed=4321)
+    hdf5_lite.make_synthetic_cutouts(str(dd / "probe.h5"), n=60, seed=99, with_labels=True)
     # a private copy of the ini with a short schedule, in a scratch checkout layout
     work = tmp_path / "work"
     (work / "configs").mkdir(parents=True)
@@ -185,6 +186,8 @@ def test_pretrain_entry_point_runs(tmp_path, mode):
     if mode == "simmim":
         cfg["ARCHITECTURE"].update(model_type="simmim", patch_size="8", embed_dim="96", ra_dec="True")
         cfg["TRAINING"].update(loss_fn="L1", max_mask_ratio="0.9")
+    else:   # the linear-probe validation hook of the reference's loop (pretrain_mim.py:189-192)
+        cfg["DATA"].update(lp_class_data_file="probe.h5", lp_regress_data_file="probe.h5", lp_combine="pool")
     with open(work / "configs" / "mim_t.ini", "w") as fh:
         cfg.write(fh)
     for name in ("pretrain_mim.py",):
@@ -200,6 +203,7 @@ def test_pretrain_entry_point_runs(tmp_path, mode):
     assert set(ck) == {"batch_iters", "losses", "optimizer", "lr_scheduler", "model"}
     if mode == "mae":
         assert len(ck["model"]) == 255 - 0 and ck["batch_iters"] >= 5 and len(ck["losses"]["val_loss"]) >= 1
+        assert "Linear Probing Results:" in out.stdout and len(ck["losses"]["val_lp_acc"]) >= 1 and len(ck["losses"]["val_lp_r2"]) >= 1
     else:
         assert "decoder.0.weight" in ck["model"] and ck["batch_iters"] >= 12 and np.isfinite(ck["losses"]["train_loss"]).all()
 
@@ -241,7 +245,7 @@ def test_simmim_radec_model_through_the_module_api(tmp_path):
     assert pred.shape == orig.shape == (8, 64, 64, 5)
 
 
-@pytest.mark.parametrize("case", ["mae_tiny_A", "mae_tiny_B_nan"])
+@pytest.mark.parametrize("case", ["mae_tiny_A", "mae_tiny_B_nan", "mae_tiny_I_radec"])
 def test_downstream_vit_forward_features_matches_reference_goldens(case):
     """utils.vit.VisionTransformer.forward_features (utils/vit.py:344-388: input norm, NaN fill, patch embed + positions,
     cls token, Blocks, final norm, tokens in raster order) is line for line the encoder half of the reference's
@@ -254,19 +258,57 @@ def test_downstream_vit_forward_features_matches_reference_goldens(case):
     z, cfg, state = load_case(case)
     c = MAEConfig(img_size=cfg.img_size, patch_size=cfg.patch_size, in_chans=cfg.in_chans, embed_dim=cfg.embed_dim, depth=cfg.depth,
                   num_heads=cfg.num_heads, decoder_embed_dim=cfg.decoder_embed_dim, decoder_depth=cfg.decoder_depth,
-                  decoder_num_heads=cfg.decoder_num_heads, pixel_mean=cfg.pixel_mean, pixel_std=cfg.pixel_std)
+                  decoder_num_heads=cfg.decoder_num_heads, pixel_mean=cfg.pixel_mean, pixel_std=cfg.pixel_std, ra_dec=cfg.ra_dec)
     vit = VisionTransformer(c, "cuda", torch.float32)
     vit.load_encoder_state(state)
     imgs = torch.from_numpy(z["imgs"].copy())
-    tok, m, ids = vit.forward_features(imgs.cuda())
+    ra_dec = torch.from_numpy(z["ra_dec"].copy()) if cfg.ra_dec else None     # utils/vit.py:374-378: token after cls
+    E = 2 if cfg.ra_dec else 1
+    tok, m, ids = vit.forward_features(imgs.cuda(), ra_dec=ra_dec)
     assert m is None and ids is None
     ref, restore = z["latent_full"], z["ids_restore_full"]
     expected = ref.copy()
-    expected[:, 1:] = np.take_along_axis(ref[:, 1:], restore[:, :, None], axis=1)      # patch l sits at shuffled position restore[l]
+    expected[:, E:] = np.take_along_axis(ref[:, E:], restore[:, :, None], axis=1)      # patch l sits at shuffled position restore[l]
     assert tok.shape == expected.shape and rel_err(tok.cpu().numpy(), expected) < 2e-5
     grid = cfg.img_size // cfg.patch_size
-    img_like, _, _ = vit.forward_features(imgs.cuda(), reshape_out=True)
+    img_like, _, _ = vit.forward_features(imgs.cuda(), ra_dec=ra_dec, reshape_out=True)
     assert img_like.shape == (imgs.shape[0], cfg.embed_dim, grid, grid)
-    assert torch.equal(img_like, tok[:, 1:].permute(0, 2, 1).reshape(imgs.shape[0], cfg.embed_dim, grid, grid))
+    assert torch.equal(img_like, tok[:, E:].permute(0, 2, 1).reshape(imgs.shape[0], cfg.embed_dim, grid, grid))
     with pytest.raises(NotImplementedError):
         vit.train(True)
+
+
+def test_linear_probe_hook_on_hip_embeddings(tmp_path):
+    """utils/pretrain_fns.py:52-159: the linear-probe validation hook on embeddings from the HIP encoder.  The labels are a
+    function of the cutout brightness, which even a randomly initialised encoder keeps linearly decodable: the probe has to
+    beat chance clearly; every ``combine`` mode gives the documented feature shape."""
+    from collections import defaultdict
+    from sky_embeddings_amd import hdf5_lite
+    from sky_embeddings_amd.utils.dataloaders import build_h5_dataloader
+    from sky_embeddings_amd.utils.mim_vit import build_model
+    from sky_embeddings_amd.utils.pretrain_fns import get_embeddings, linear_probe
+    rng = np.random.default_rng(5)
+    n = 240
+    level = rng.uniform(-1.0, 1.0, n).astype(np.float32)
+    cut = (rng.standard_normal((n, 5, 64, 64), dtype=np.float32) * 0.3 + level[:, None, None, None]).astype(np.float32)
+    path = str(tmp_path / "labelled.h5")
+    hdf5_lite.write_datasets(path, {"cutouts": cut, "ra": rng.uniform(0, 360, n).astype(np.float32),
+                                    "dec": rng.uniform(-90, 90, n).astype(np.float32),
+                                    "class": np.digitize(level, [-0.33, 0.33]).astype(np.int64), "zspec": (level + 1.0).astype(np.float32)})
+    cfg = _tiny_ini(tmp_path)
+    cfg["TRAINING"]["compute_dtype"] = "f32"
+    torch.manual_seed(0)
+    model, *_ = build_model(cfg, str(tmp_path / "none.pth.tar"), torch.device("cuda"), build_optimizer=True)
+    template = build_h5_dataloader(path, batch_size=8, num_workers=0, patch_size=16, num_channels=5, img_size=64, shuffle=False)
+    cp = defaultdict(list)
+    linear_probe(model, cp, "cuda", template, class_data_path=path, regress_data_path=path, combine="pool")
+    assert set(cp) == {"train_lp_acc", "val_lp_acc", "train_lp_r2", "val_lp_r2"}
+    assert cp["val_lp_acc"][0] > 0.6 and cp["train_lp_acc"][0] > 0.6          # 3 classes: chance = 1/3
+    assert cp["val_lp_r2"][0] > 0.5
+    D, L = model.module.engine.cfg.embed_dim, 16
+    for combine, width in (("token", D), ("flatten", L * D), ("pool", D), ("centralpool", D), ("central", 4 * D), ("mean", D)):
+        x, y = get_embeddings(path, model, "cuda", template, y_label="zspec", combine=combine, remove_cls=combine != "token")
+        assert x.shape == (n, width) and y.shape == (n,), combine
+        assert np.allclose(x.mean(axis=0), 0, atol=1e-3)                          # standard-scaled features
+    x, _ = get_embeddings(path, model, "cuda", template, combine="none")
+    assert x.shape == (n, L, D) and abs(float(x.mean())) < 1e-3 and abs(float(x.std()) - 1) < 1e-3

@@ -337,3 +337,16 @@ def test_hdf5_lite_chunked_resizable_datasets(tmp_path, monkeypatch):
     for i in (0, 13, 39):
         xa, xb = a[i], b[i]
         assert torch.equal(xa[0], xb[0]) and torch.equal(xa[2], xb[2])
+
+
+def test_select_centre_picks_the_central_block():
+    """utils/misc.py:68-117: central sqrt(n) x sqrt(n) block of the raster-ordered patch grid (hand-checked cases)."""
+    from sky_embeddings_amd.utils.misc import central_indices, select_centre
+    lat = np.arange(2 * 64 * 3).reshape(2, 64, 3)                      # 8 x 8 grid
+    got = select_centre(lat, 4)
+    assert got.shape == (2, 4, 3) and np.array_equal(got[0, :, 0] // 3, [27, 28, 35, 36])      # rows 3-4, cols 3-4
+    assert np.array_equal(select_centre(lat, 16)[1, :, 0] // 3 - 64, [r * 8 + c for r in range(2, 6) for c in range(2, 6)])
+    assert np.array_equal(select_centre(np.arange(16).reshape(1, 16, 1), 4)[0, :, 0], [5, 6, 9, 10])   # 4 x 4 grid
+    assert np.array_equal(central_indices(np.empty((5, 5)), 1), [[2, 2]])
+    with pytest.raises(ValueError):
+        central_indices(np.empty((8, 8)), 3)
