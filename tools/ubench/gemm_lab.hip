@@ -262,6 +262,7 @@ int main(int argc, char **argv) {
     if (getenv("LAB_KSWEEP")) {
         // time vs K at fixed M, N: the intercept is the launch + prologue + epilogue cost, the slope the k-loop
         const int epi = atoi(getenv("LAB_KSWEEP"));
+        const int bkc = getenv("LAB_BKC") ? atoi(getenv("LAB_BKC")) : 1;      // 0: B operand row-contiguous (the dgrad layout)
         for (int code : codes) {
             int bm, bn;
             tile_dims(code, bm, bn);
@@ -271,7 +272,7 @@ int main(int argc, char **argv) {
                 float t768 = 0, t1536 = 0;
                 for (int K : {64, 256, 768, 1536}) {
                     if ((size_t)mn.first * K > max_a || (size_t)mn.second * K > max_b) continue;
-                    Shape s{"k", mn.first, mn.second, K, 1, 1, 1, epi};
+                    Shape s{"k", mn.first, mn.second, K, 1, bkc, 1, epi};
                     const float t = time_us(s, code, 1);
                     printf("  K%d:%.1f", K, t);
                     if (K == 768) t768 = t;
