@@ -300,8 +300,9 @@ int skyemb_topk_merge(const float *in_s, const int64_t *in_i, int Q, int nlists,
  * a proven error bound keeps, per query, only the rows whose score could still reach its top-k; the survivors are
  * re-scored with the contract's fp32 fma chain.  Results are bit-identical to skyemb_cosine_topk + skyemb_topk_merge.
  * Replaces the same reference code as skyemb_cosine_topk (utils/similarity.py:18-35,149-172).
- *   skyemb_bank16_prepare   once per bank / weights: bank16 = fp16 rows scaled by 2^-e_i (skyemb_bank16_bytes(N, D) bytes),
- *                           rowp = 4 floats per row {xn 2^-e, ||x'||_2, 2^-e, xn}, skyemb_bank16_rowp_rows(N) rows (whole tiles)
+ *   skyemb_bank16_prepare   once per bank / weights: bank16 = fp16 rows scaled by 2^-e_i, rowp = 4 floats per row
+ *                           {xn 2^-e, ||x'||_2, 2^-e, xn}; BOTH hold skyemb_bank16_rowp_rows(N) rows (N rounded up to whole
+ *                           tiles: the search kernel reads whole tiles), i.e. skyemb_bank16_bytes(N, D) bytes of bank16
  *   skyemb_cosine_topk_prefiltered   whole pipeline on `stream`; out_s / out_i [Q, k] final lists; redo[q] != 0 marks a query
  *                           whose answer could not be certified (too many near-ties, candidate overflow, fewer than k
  *                           finite rows): the caller runs those through skyemb_cosine_topk.  thr0 as in skyemb_cosine_topk

@@ -42,7 +42,8 @@ typedef __attribute__((address_space(3))) void lvoid_t;
 constexpr int QT = 128, BT = 256, BK = 32, NW = 8, NT = NW * 64;   // queries x bank rows per tile, k-step, waves
 constexpr int A_BYTES = QT * BK * 2, B_BYTES = BT * BK * 2, STAGE = 2 * A_BYTES + B_BYTES;   // hi + lo + bank = 32 KiB
 constexpr int NSTAGE = 4, AHEAD = NSTAGE - 1;   // 96 KiB of LDS-DMA in flight per CU: one workgroup per CU has to cover the
-                                                 // L2 latency alone (a 2 x 64 KiB ring ran at 23 GB/s per CU: 2.8 us per k-step)
+                                                 // L2 latency alone (a 2 x 64 KiB ring ran at 23 GB/s per CU: 2.8 us per k-step);
+                                                 // NSTAGE is a power of two: stage s lives in buffer s & (NSTAGE - 1)
 constexpr int NI = (2 * QT + BT) / 16 / NW;     // LDS-DMA instructions per wave per stage (one = 16 rows x 64 B)
 constexpr int GQ = 5;                     // query tiles (hi + lo = 384 KiB each at D = 768) kept hot in an XCD's L2
 constexpr int RESCORE_MAX = 256;          // K': candidates re-scored exactly per query
@@ -63,8 +64,11 @@ __global__ __launch_bounds__(256) void bank16_kernel(const float *__restrict__ b
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= N) {
-        // padding up to a whole bank tile: ||x'|| = NaN makes the candidate test fail for every query
-        if (row < rows_padded && lane == 0) rowp[row] = make_float4(0.f, NAN, 0.f, 0.f);
+        // padding up to a whole bank tile: zeros, and ||x'|| = NaN makes the candidate test fail for every query
+        if (row < rows_padded) {
+            for (int d = lane * 4; d < D; d += 256) *(uint2 *)(bank16 + row * D + d) = make_uint2(0u, 0u);
+            if (lane == 0) rowp[row] = make_float4(0.f, NAN, 0.f, 0.f);
+        }
         return;
     }
     const float *x = bank + row * D;
@@ -112,7 +116,15 @@ __global__ __launch_bounds__(256) void query16_kernel(const float *__restrict__ 
                                                        float eps_a) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= Q) return;
+    if (q >= Q) {
+        // rows up to a whole query tile (the grid covers them): zeros; their test parameters let no pair pass
+        if (q < (Q + QT - 1) / QT * QT)
+            for (int d = lane * 4; d < D; d += 256) {
+                *(uint2 *)(qh + (int64_t)q * D + d) = make_uint2(0u, 0u);
+                *(uint2 *)(ql + (int64_t)q * D + d) = make_uint2(0u, 0u);
+            }
+        return;
+    }
     const float *x = tw + (int64_t)q * D;
     float mx = 0.f;
     for (int d = lane * 4; d < D; d += 256) {
@@ -157,18 +169,16 @@ __device__ __forceinline__ int swz(int r) {
     const int g = (r >> 2) & 3;
     return (((g ^ (g >> 1)) & 1) << 1) | (g >> 1);          // g = 0,1,2,3 -> 0,2,3,1
 }
-template <int R>
-__device__ __forceinline__ void issue_rows(const half_t *__restrict__ X, int64_t ld, int64_t r0, int64_t rows, int k0, char *sbase,
-                                           int wave, int lane) {
-    constexpr int PER_WAVE = R / 16 / NW;
-    const int rr = lane >> 2, cs = (lane & 3) ^ swz(rr);
-#pragma unroll
-    for (int j = 0; j < PER_WAVE; ++j) {
-        const int rows16 = (wave * PER_WAVE + j) * 16;
-        int64_t gr = r0 + rows16 + rr;
-        gr = gr < rows ? gr : rows - 1;          // rows past the edge feed pairs that the epilogue ignores
-        glds16(X + gr * ld + k0 + cs * 8, sbase + rows16 * 64);
-    }
+// All three operand arrays are padded to whole tiles (query16_kernel / bank16_kernel), so a piece's address is a
+// workgroup-uniform base (tile row, k-step: scalar registers) plus ONE per-lane 32-bit offset that never changes.  The
+// instruction is written out (SGPR-base form, LDS destination in M0): left to the compiler, every piece's 64-bit vector
+// address was hoisted out of the loop into registers the accumulators and fragments need (spills inside the k-loop).
+__device__ __forceinline__ void glds16_sbase(const void *base_uniform, unsigned int lane_off, char *lds_wave_base) {
+    const unsigned int dst = (unsigned int)(uintptr_t)(lvoid_t *)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(lane_off), "s"(base_uniform), "s"(dst)
+                 : "memory", "m0");
 }
 __device__ __forceinline__ half8 frag(const char *sbase, int rbase, int lane) {
     const int r = rbase + (lane & 15);
@@ -190,8 +200,27 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
                                                        const half_t *__restrict__ bank16, const float4 *__restrict__ rowp,
                                                        const float4 *__restrict__ qpar, int Q, int64_t N, int D, int t0, int t1,
                                                        int cap, int *__restrict__ cnt, int *__restrict__ cand_i,
-                                                       float *__restrict__ cand_d) {
+                                                       float *__restrict__ cand_d
+#ifdef PF_STAMP
+                                                       , unsigned long long *__restrict__ dbg
+#endif
+                                                       ) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef PF_STAMP
+    unsigned int seg[5] = {0, 0, 0, 0, 0};
+    unsigned long long tprev;
+    auto stamp = [&](int which) {
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (which >= 0) seg[which] += (unsigned int)(t - tprev);
+        tprev = t;
+    };
+#define STAMP(w) stamp(w)
+#else
+#define STAMP(w)
+#endif
     float4 *spar = (float4 *)(smem + NSTAGE * STAGE);        // [QT] test parameters of the item's queries
     float4 *srow = spar + QT;                                 // [BT] constants of the item's bank rows
     const int tid = threadIdx.x, lane = tid & 63;
@@ -225,141 +254,250 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
         qt = __builtin_amdgcn_readfirstlane(g * GQ + within);
         t = __builtin_amdgcn_readfirstlane(t0 + tt * 8 + xcd);
     };
-    // the stage being issued runs one k-step ahead of the one being computed, across item boundaries
-    int n_iss = 0, kt_iss = 0, qt_iss, t_iss;
-    item_of(0, qt_iss, t_iss);
-    auto issue_next = [&](int buf) {
-        char *sa = smem + buf * STAGE;
-        const int k0 = kt_iss * BK;
-        issue_rows<QT>(qh, D, (int64_t)qt_iss * QT, Q, k0, sa, wave, lane);
-        issue_rows<QT>(ql, D, (int64_t)qt_iss * QT, Q, k0, sa + A_BYTES, wave, lane);
-        issue_rows<BT>(bank16, D, (int64_t)t_iss * BT, N, k0, sa + 2 * A_BYTES, wave, lane);
-        if (++kt_iss == KT) {
-            kt_iss = 0;
-            if (++n_iss < my_items) item_of(n_iss, qt_iss, t_iss);
+    // ---- issue cursor: the stage being requested runs AHEAD k-steps in front of the one being read, across item boundaries.
+    // Each wave owns four 1 KiB pieces of a stage: rows [16 wave, +16) of the hi and of the lo query image, rows
+    // [32 wave, +32) of the bank tile.  Their addresses are three running scalar pointers (64 bytes further per k-step,
+    // re-based when the cursor enters a new item) plus one per-lane offset that never changes: a k-step's address work is a
+    // handful of scalar adds (recomputing bases from the tile numbers cost ~80 scalar instructions per k-step and wave).
+    static_assert(QT / 16 / NW == 1 && BT / 16 / NW == 2, "piece ownership below assumes 128 x 256 tiles on 8 waves");
+    const unsigned int lane_off = (unsigned int)((lane >> 2) * D * 2 + (((lane & 3) ^ swz(lane >> 2)) << 4));
+    int n_iss = 0, kt_iss = 0;
+    int qt_cur, t_cur, qt_nxt = 0, t_nxt = 0;                // the item being multiplied / the one the issue cursor has entered
+    item_of(0, qt_cur, t_cur);
+    const char *ph, *pl, *pb;
+    auto rebase = [&](int qt, int t) {
+        const int64_t qoff = ((int64_t)qt * QT + wave * 16) * D * 2;
+        ph = (const char *)qh + qoff;
+        pl = (const char *)ql + qoff;
+        pb = (const char *)bank16 + ((int64_t)t * BT + wave * 32) * D * 2;
+    };
+    rebase(qt_cur, t_cur);
+    const int bank_piece2 = 16 * D * 2;                      // second bank piece: 16 rows further
+    // half 0: the two query pieces; half 1: the two bank pieces, then the cursor moves on
+    auto issue_half = [&](int buf, int half) {
+        char *st = smem + buf * STAGE;
+        if (half == 0) {
+            glds16_sbase(ph, lane_off, st + wave * 1024);
+            glds16_sbase(pl, lane_off, st + A_BYTES + wave * 1024);
+        } else {
+            glds16_sbase(pb, lane_off, st + 2 * A_BYTES + wave * 2048);
+            glds16_sbase(pb + bank_piece2, lane_off, st + 2 * A_BYTES + wave * 2048 + 1024);
+            ph += BK * 2; pl += BK * 2; pb += BK * 2;
+            if (++kt_iss == KT) {
+                kt_iss = 0;
+                if (++n_iss < my_items) {
+                    item_of(n_iss, qt_nxt, t_nxt);
+                    rebase(qt_nxt, t_nxt);
+                }
+            }
         }
     };
 
     f32x4 acc[4][4];
-    int qt = 0, t = 0, buf = 0;
+    half8 fh[4], fl[4], fb[4];
+    const bool late = wave >= 4;                             // wave-uniform (SGPR)
     const int steps = my_items * KT;
 #pragma unroll
     for (int p = 0; p < AHEAD; ++p)
-        if (p < steps) issue_next(p);
-    int s = 0;
-    for (int n = 0; n < my_items; ++n) {
-      item_of(n, qt, t);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      for (int kt = 0; kt < KT; ++kt, ++s, buf = buf + 1 < NSTAGE ? buf + 1 : 0) {
-        // stage s has landed (this wave's pieces); up to AHEAD - 1 younger stages stay in flight.  (The ordinary loads of
-        // the per-item constants below are younger still: they can only make this wait stricter, never weaker.)
-        const int rem = steps - 1 - s;
-        if (rem >= 2) wait_vmcnt<2 * NI>();
-        else if (rem == 1) wait_vmcnt<NI>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();                          // ... everybody's; and the buffer of step s - 1 is free
-        if (kt == 0) {
-            // test parameters of the item's 128 queries (2 KiB) and constants of its 256 rows (4 KiB) go to LDS by the same
-            // DMA path, issued BEFORE this step's stage: two steps on they are older than everything a counted wait leaves
-            // in flight, so they have landed long before the item's epilogue (KT >= 4).  Both arrays are padded to whole
-            // tiles with entries no pair can pass (init_state_kernel / bank16_kernel).
-            if (wave < 2) glds16((const char *)(qpar + (int64_t)qt * QT) + wave * 1024 + lane * 16, (char *)spar + wave * 1024);
-            else if (wave < 6) glds16((const char *)(rowp + (int64_t)t * BT) + (wave - 2) * 1024 + lane * 16, (char *)srow + (wave - 2) * 1024);
+        if (p < steps) {
+            issue_half(p, 0);
+            issue_half(p, 1);
         }
-        const char *sa = smem + buf * STAGE, *sl = sa + A_BYTES, *sb = sa + 2 * A_BYTES;
-        {
-            half8 fh[4], fl[4], fb[4];
+
+    auto zero_acc = [&]() {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                fh[i] = frag(sa, wm * 64 + i * 16, lane);
-                fl[i] = frag(sl, wm * 64 + i * 16, lane);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    auto read_frags = [&](int b) {
+#ifdef PF_NOREAD
+        return;
+#endif
+        const char *sa = smem + b * STAGE, *sl = sa + A_BYTES, *sb = sa + 2 * A_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fh[i] = frag(sa, wm * 64 + i * 16, lane);
+            fl[i] = frag(sl, wm * 64 + i * 16, lane);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = frag(sb, wn * 64 + j * 16, lane);
+    };
+    // the four LDS-DMA instructions of the next stage cost ~100+ issue cycles each: they go BETWEEN the MFMAs (whose execution
+    // covers them), not in front of them
+    // two of the wave's four LDS-DMA pieces of a k-step are requested between the MFMAs (whose execution covers their
+    // issue cost), the other two in the wave's read phase
+    auto multiply = [&](bool issue, int ibuf, int half) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i == 1) {
+                __builtin_amdgcn_sched_barrier(0);
+#ifndef PF_NODMA
+                if (issue) issue_half(ibuf, half);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
             }
+#ifndef PF_NOMFMA
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = frag(sb, wn * 64 + j * 16, lane);
-            // the four LDS-DMA instructions of the next stage cost ~100+ issue cycles each: they go BETWEEN the MFMAs (whose
-            // execution covers them), not in front of them
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[i], fb[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+#else
+            acc[i][0][0] += (float)fh[i][0] + (float)fl[i][1] + (float)fb[i][2];
+#endif
+        }
+    };
+    auto item_epilogue = [&](int qt, int t) {
+        // ---- epilogue of the item: lane holds queries 4*(lane>>4)+r (r = 0..3) x bank row (lane & 15) per 16x16 block.
+        // All 64 tests of the lane are branch-free (a bit mask); only lanes that found something enter the append path.
+        float4 rp[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (i == 1) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (s + AHEAD < steps) issue_next(buf >= 1 ? buf - 1 : NSTAGE - 1);   // (s + AHEAD) % NSTAGE == (buf - 1) mod NSTAGE
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+        for (int j = 0; j < 4; ++j) rp[j] = srow[wn * 64 + j * 16 + (lane & 15)];
+        unsigned int mlo = 0, mhi = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float4 p = spar[wm * 64 + i * 16 + 4 * (lane >> 4) + r];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[i], fb[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[i], fb[j], acc[i][j], 0, 0, 0);
+                    const float rhs = fmaf(p.x, rp[j].x, p.y * rp[j].z);
+                    const float lhs = fmaf(p.z, rp[j].y, acc[i][j][r]);
+                    const int e = (i * 4 + r) * 4 + j;
+                    const unsigned int bit = lhs >= rhs ? (1u << (e & 31)) : 0u;
+                    if (e < 32) mlo |= bit; else mhi |= bit;
                 }
             }
-        }
-        if (kt == KT - 1) {
-            // ---- epilogue of the item: lane holds queries 4*(lane>>4)+r (r = 0..3) x bank row (lane & 15) per 16x16 block.
-            // All 64 tests of the lane are branch-free (a bit mask); only lanes that found something enter the append path.
-            float4 rp[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) rp[j] = srow[wn * 64 + j * 16 + (lane & 15)];
-            unsigned int mlo = 0, mhi = 0;
+#if defined(PF_NOMFMA) || defined(PF_NOREAD) || defined(PF_NODMA) || defined(PF_NOAPPEND)
+        asm volatile("" ::"v"(mlo), "v"(mhi));      // experiment builds: the tests are computed, nothing is appended
+        mlo = mhi = 0;
+#endif
+        if (TAKE_ALL) {
+            // first slice: every (query, row) pair of the slice is a candidate, slot = row within the slice (no counters);
+            // pairs that fail even the open test (NaN) are stored as -inf and dropped by the select step
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float4 p = spar[wm * 64 + i * 16 + 4 * (lane >> 4) + r];
+                    const int q = qt * QT + wm * 64 + i * 16 + 4 * (lane >> 4) + r;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float rhs = fmaf(p.x, rp[j].x, p.y * rp[j].z);
-                        const float lhs = fmaf(p.z, rp[j].y, acc[i][j][r]);
+                        const int64_t row = (int64_t)t * BT + wn * 64 + j * 16 + (lane & 15);
                         const int e = (i * 4 + r) * 4 + j;
-                        const unsigned int bit = lhs >= rhs ? (1u << (e & 31)) : 0u;
-                        if (e < 32) mlo |= bit; else mhi |= bit;
+                        const bool pass = ((e < 32 ? mlo : mhi) >> (e & 31)) & 1u;
+                        if (q < Q && row < N) {
+                            const int64_t o = (int64_t)q * cap + (row - (int64_t)t0 * BT);
+                            cand_i[o] = (int)row;
+                            cand_d[o] = pass ? acc[i][j][r] : -INFINITY;
+                        }
                     }
                 }
-            if (TAKE_ALL) {
-                // first slice: every (query, row) pair of the slice is a candidate, slot = row within the slice (no counters);
-                // pairs that fail even the open test (NaN) are stored as -inf and dropped by the select step
+        } else if (mlo | mhi) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < 4; ++r) {
+                    const int e0 = (i * 4 + r) * 4;
+                    if (((e0 < 32 ? mlo : mhi) >> (e0 & 31)) & 15u) {
                         const int q = qt * QT + wm * 64 + i * 16 + 4 * (lane >> 4) + r;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int64_t row = (int64_t)t * BT + wn * 64 + j * 16 + (lane & 15);
-                            const int e = (i * 4 + r) * 4 + j;
-                            const bool pass = ((e < 32 ? mlo : mhi) >> (e & 31)) & 1u;
-                            if (q < Q && row < N) {
-                                const int64_t o = (int64_t)q * cap + (row - (int64_t)t0 * BT);
-                                cand_i[o] = (int)row;
-                                cand_d[o] = pass ? acc[i][j][r] : -INFINITY;
-                            }
-                        }
-                    }
-            } else if (mlo | mhi) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int e0 = (i * 4 + r) * 4;
-                        if (((e0 < 32 ? mlo : mhi) >> (e0 & 31)) & 15u) {
-                            const int q = qt * QT + wm * 64 + i * 16 + 4 * (lane >> 4) + r;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (((e0 < 32 ? mlo : mhi) >> ((e0 + j) & 31)) & 1u) {
-                                    const int pos = atomicAdd(cnt + q, 1);
-                                    if (pos < cap) {
-                                        cand_i[(int64_t)q * cap + pos] = t * BT + wn * 64 + j * 16 + (lane & 15);
-                                        cand_d[(int64_t)q * cap + pos] = acc[i][j][r];
-                                    }
+                        for (int j = 0; j < 4; ++j)
+                            if (((e0 < 32 ? mlo : mhi) >> ((e0 + j) & 31)) & 1u) {
+                                const int pos = atomicAdd(cnt + q, 1);
+                                if (pos < cap) {
+                                    cand_i[(int64_t)q * cap + pos] = t * BT + wn * 64 + j * 16 + (lane & 15);
+                                    cand_d[(int64_t)q * cap + pos] = acc[i][j][r];
                                 }
-                        }
+                            }
                     }
-            }
-            // (spar / srow are refilled one barrier later at the earliest: after every wave has left this block)
+                }
         }
-      }
+    };
+    // the k-step of its item that this wave multiplies next / that the current step reads
+    int kt_c = 0, kt_s = 0;
+    zero_acc();
+    auto multiply_stage = [&](bool issue, int ibuf, int half) {
+        multiply(issue, ibuf, half);
+        if (++kt_c == KT) {
+            item_epilogue(qt_cur, t_cur);
+            zero_acc();
+            kt_c = 0;
+            qt_cur = qt_nxt;          // (the issue cursor entered the next item AHEAD steps ago, and enters the one after it only later: KT > AHEAD)
+            t_cur = t_nxt;
+        }
+    };
+    auto landed = [&](int s) {
+        // stage s has landed (this wave's pieces); up to AHEAD - 1 younger stages stay in flight.  (The LDS-DMA of the per-item
+        // constants is younger still: it can only make this wait stricter, never weaker.)
+        const int rem = steps - 1 - s;
+        if (rem >= 2) wait_vmcnt<2 * NI>();
+        else if (rem == 1) wait_vmcnt<NI>();
+        else wait_vmcnt<0>();
+    };
+    auto item_constants = [&]() {
+        // after P1 of an item's first step: test parameters of its 128 queries (2 KiB) and constants of its 256 rows (4 KiB) go
+        // to LDS by the same DMA path (by then every wave's current item is this one).  The late group's epilogue of the
+        // PREVIOUS item (which reads spar / srow) ran between P0 and P1.  Three steps on they are older than everything a
+        // counted wait leaves in flight, so they have landed before the item's epilogue (KT >= 4).  Both arrays are padded
+        // to whole tiles with entries no pair can pass (init_state_kernel / bank16_kernel).  (Written-out DMA like the stages:
+        // the compiler, seeing an LDS-DMA it cannot tell apart from the ring's, would drain the whole ring with vmcnt(0) in
+        // front of the epilogue's reads of spar / srow.)
+        if (kt_s == 0) {
+            if (wave < 2) glds16_sbase((const char *)(qpar + (int64_t)qt_cur * QT) + wave * 1024, lane * 16, (char *)spar + wave * 1024);
+            else if (wave < 6) glds16_sbase((const char *)(rowp + (int64_t)t_cur * BT) + (wave - 2) * 1024, lane * 16, (char *)srow + (wave - 2) * 1024);
+        }
+        kt_s = kt_s + 1 < KT ? kt_s + 1 : 0;
+    };
+    STAMP(-1);
+    if (!late) {
+        for (int s = 0; s < steps; ++s) {
+            const bool issue = s + AHEAD < steps;
+            const int ibuf = (s + AHEAD) & (NSTAGE - 1);
+            landed(s);
+            STAMP(0);
+            __builtin_amdgcn_s_barrier();                                  // P0(s)
+            STAMP(1);
+            read_frags(s & (NSTAGE - 1));
+            if (issue) {
+                issue_half(ibuf, 0);
+                issue_half(ibuf, 1);
+            }
+            STAMP(2);
+            __builtin_amdgcn_s_barrier();                                  // P1(s)
+            STAMP(3);
+            item_constants();
+            multiply_stage(false, 0, 0);
+            STAMP(4);
+        }
+    } else {
+        for (int s = 0; s < steps; ++s) {
+            const bool issue = s + AHEAD < steps;
+            const int ibuf = (s + AHEAD) & (NSTAGE - 1);
+            landed(s);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the fragment reads of stage s-1 are out of its buffer
+            STAMP(0);
+            __builtin_amdgcn_s_barrier();                                  // P0(s)
+            STAMP(1);
+            if (s > 0) multiply_stage(false, 0, 0);
+            STAMP(4);
+            __builtin_amdgcn_s_barrier();                                  // P1(s)
+            STAMP(3);
+            item_constants();
+            read_frags(s & (NSTAGE - 1));
+            if (issue) {
+                issue_half(ibuf, 0);
+                issue_half(ibuf, 1);
+            }
+            STAMP(2);
+        }
+        multiply_stage(false, 0, 0);                                       // the last stage (+ its item epilogue)
     }
+#ifdef PF_STAMP
+    if (lane == 0)
+        for (int i = 0; i < 5; ++i) atomicAdd(dbg + (late ? 8 : 0) + i, (unsigned long long)seg[i]);
+    if (lane == 0 && wave == 0) atomicAdd(dbg + 16, (unsigned long long)steps);
+#endif
 }
 
 // ---- between phases: new threshold, compaction; last phase: pick the candidates to re-score ---------------------------------
@@ -606,8 +744,9 @@ int64_t carve(char *base, int Q, int D, int cap, Workspace *w) {
         return p;
     };
     char *p;
-    p = take((int64_t)Q * D * 2); if (w) w->qh = (half_t *)p;
-    p = take((int64_t)Q * D * 2); if (w) w->ql = (half_t *)p;
+    const int64_t Qp = (Q + QT - 1) / QT * QT;               // the fp16 query images are padded to whole tiles
+    p = take(Qp * D * 2); if (w) w->qh = (half_t *)p;
+    p = take(Qp * D * 2); if (w) w->ql = (half_t *)p;
     p = take((int64_t)Q * 16); if (w) w->qbase = (float4 *)p;
     p = take((int64_t)((Q + QT - 1) / QT * QT) * 16); if (w) w->qpar = (float4 *)p;
     p = take((int64_t)Q * 4); if (w) w->tau = (float *)p;
@@ -629,7 +768,7 @@ extern "C" int skyemb_topk_prefilter_applicable(int Q, int64_t N, int D, int k) 
 }
 static int skyemb_topk_prefilter_cap(int k) { return k <= 128 ? 4096 : 8192; }
 
-extern "C" int64_t skyemb_bank16_bytes(int64_t N, int D) { return N * D * 2; }
+extern "C" int64_t skyemb_bank16_bytes(int64_t N, int D) { return ceil_div64(N, BT) * BT * D * 2; }   // whole tiles of BT rows
 
 extern "C" int64_t skyemb_bank16_rowp_rows(int64_t N) { return ceil_div64(N, BT) * BT; }
 
@@ -657,7 +796,8 @@ extern "C" int skyemb_cosine_topk_prefiltered(const float *tw, const float *qn, 
     Workspace w;
     carve((char *)ws, Q, D, cap, &w);
     const float eps_a = (float)(eps_a_of(D) * (1.0 + 1e-6));
-    hipLaunchKernelGGL(query16_kernel, dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, st, tw, qn, Q, D, w.qh, w.ql, w.qbase, eps_a);
+    hipLaunchKernelGGL(query16_kernel, dim3((unsigned)(((Q + QT - 1) / QT * QT + 3) / 4)), dim3(256), 0, st, tw, qn, Q, D, w.qh, w.ql,
+                       w.qbase, eps_a);
     const int T = (int)ceil_div64(N, BT);
     // phases: [0, first) is taken whole unless a floor came in; then slices ending at 1/32, 1/8, 1/2 and all of the tiles
     int first = (int)(cap / 2 / BT);                           // rows of the take-everything slice <= cap / 2
@@ -688,12 +828,30 @@ extern "C" int skyemb_cosine_topk_prefiltered(const float *tw, const float *qn, 
         if (p == 0 && thr0) continue;                          // a valid floor is as good as the first slice
         if (t1 <= t0) continue;
         if (t1 > T) t1 = T;
+#ifdef PF_STAMP
+        static unsigned long long *dbg = nullptr;
+        if (!dbg) { hipMalloc(&dbg, 32 * 8); }
+        hipMemsetAsync(dbg, 0, 32 * 8, st);
+#define PF_DBG , dbg
+#else
+#define PF_DBG
+#endif
         if (p == 0)
             hipLaunchKernelGGL(prefilter_kernel<true>, dim3(256), dim3(NT), smem1, st, w.qh, w.ql, (const half_t *)bank16,
-                               (const float4 *)rowp, w.qpar, Q, N, D, t0, t1, cap, w.cnt, w.cand_i, w.cand_d);
+                               (const float4 *)rowp, w.qpar, Q, N, D, t0, t1, cap, w.cnt, w.cand_i, w.cand_d PF_DBG);
         else
             hipLaunchKernelGGL(prefilter_kernel<false>, dim3(256), dim3(NT), smem1, st, w.qh, w.ql, (const half_t *)bank16,
-                               (const float4 *)rowp, w.qpar, Q, N, D, t0, t1, cap, w.cnt, w.cand_i, w.cand_d);
+                               (const float4 *)rowp, w.qpar, Q, N, D, t0, t1, cap, w.cnt, w.cand_i, w.cand_d PF_DBG);
+#ifdef PF_STAMP
+        {
+            unsigned long long h[32];
+            hipStreamSynchronize(st);
+            hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+            const double n = (double)h[16] * 4.0;     // steps summed over workgroups x 4 waves per group
+            fprintf(stderr, "[stamp] phase %d steps/wg %.0f | early: wait %.0f P0 %.0f read+issue %.0f P1 %.0f mult %.0f | late: wait %.0f P0 %.0f read+issue %.0f P1 %.0f mult %.0f (cycles of s_memtime per k-step)\n",
+                    p, (double)h[16] / 256.0, h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[8] / n, h[9] / n, h[10] / n, h[11] / n, h[12] / n);
+        }
+#endif
         const int final = t1 == T;
         hipLaunchKernelGGL(select_kernel, dim3((unsigned)Q), dim3(256), smem_sel, st, Q, k, cap, eps, w.qbase, (const float4 *)rowp,
                            w.cnt, w.cand_i, w.cand_d, w.qpar, w.tau, w.overflow, final, w.sel_i, w.nsel, w.bound);

@@ -255,10 +255,13 @@ def topk_prefilter_applicable(Q, N, D, k):
 
 
 def bank16_prepare(bank, xn):
-    """fp16 image of the bank for the prefiltered many-query top-k: (bank16 [N, D] half, rowp [N, 4] float)."""
+    """fp16 image of the bank for the prefiltered many-query top-k: (bank16 [rows, D] half, rowp [rows, 4] float), both
+    padded to whole tiles of rows (``skyemb_bank16_rowp_rows``; ``skyemb_bank16_bytes`` is the image's size)."""
     N, D = bank.shape
-    bank16 = torch.empty(N, D, device=bank.device, dtype=torch.float16)
-    rowp = torch.empty(lib().skyemb_bank16_rowp_rows(N), 4, device=bank.device, dtype=torch.float32)   # whole tiles of rows
+    rows = lib().skyemb_bank16_rowp_rows(N)
+    assert lib().skyemb_bank16_bytes(N, D) == rows * D * 2
+    bank16 = torch.empty(rows, D, device=bank.device, dtype=torch.float16)
+    rowp = torch.empty(rows, 4, device=bank.device, dtype=torch.float32)
     check(lib().skyemb_bank16_prepare(_p(bank), _p(xn), N, D, _p(bank16), _p(rowp), _stream()), "skyemb_bank16_prepare")
     return bank16, rowp
 
