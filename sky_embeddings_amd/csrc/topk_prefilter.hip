@@ -47,6 +47,8 @@ constexpr int NSTAGE = 4, AHEAD = NSTAGE - 1;   // 96 KiB of LDS-DMA in flight p
 constexpr int NI = (2 * QT + BT) / 16 / NW;     // LDS-DMA instructions per wave per stage (one = 16 rows x 64 B)
 constexpr int GQ = 5;                     // query tiles (hi + lo = 384 KiB each at D = 768) kept hot in an XCD's L2
 constexpr int RESCORE_MAX = 256;          // K': candidates re-scored exactly per query
+constexpr int SCAP = 2048;                // candidates of one item staged in LDS (8 bytes each)
+constexpr int PF_GRID = 256;              // persistent workgroups of the stage-1 launch (one per CU)
 
 __device__ __forceinline__ void glds16(const void *src, char *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gvoid_t *)src, (lvoid_t *)lds_wave_base, 16, 0, 0);
@@ -195,16 +197,21 @@ __device__ __forceinline__ void wait_vmcnt() {
 // Work items: bank tile t of [t0, t1) x query tile; bank tiles are dealt to the XCDs (t - t0) % 8 == blockIdx.x % 8, and an
 // XCD walks its items group-of-GQ-query-tiles outermost, then bank tile, then query tile: the GQ query tiles stay in its
 // L2 while its bank tiles stream through once per group.  The LDS ring never drains between items.
-template <bool TAKE_ALL>
+// MODE 0: first slice, every pair is stored (slot = row)   1: candidates appended to the per-query lists directly (returning
+// global atomics: the short early phases, whose loose thresholds pass several per cent of the pairs)   2: candidates staged
+// in LDS and flushed to the workgroup's own region (the long late phases)
+template <int MODE>
 __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict__ qh, const half_t *__restrict__ ql,
                                                        const half_t *__restrict__ bank16, const float4 *__restrict__ rowp,
                                                        const float4 *__restrict__ qpar, int Q, int64_t N, int D, int t0, int t1,
-                                                       int cap, int *__restrict__ cnt, int *__restrict__ cand_i,
-                                                       float *__restrict__ cand_d
+                                                       int cap, int *__restrict__ cnt, int *__restrict__ cand_i, float *__restrict__ cand_d,
+                                                       uint4 *__restrict__ wg_list, int *__restrict__ wg_count, int capw,
+                                                       int *__restrict__ overflow
 #ifdef PF_STAMP
                                                        , unsigned long long *__restrict__ dbg
 #endif
                                                        ) {
+    constexpr bool TAKE_ALL = MODE == 0, STAGED = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef PF_STAMP
     unsigned int seg[5] = {0, 0, 0, 0, 0};
@@ -223,6 +230,8 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
 #endif
     float4 *spar = (float4 *)(smem + NSTAGE * STAGE);        // [QT] test parameters of the item's queries
     float4 *srow = spar + QT;                                 // [BT] constants of the item's bank rows
+    uint2 *stg = (uint2 *)(srow + BT);                        // [SCAP] candidates of the item being finished: {q_local << 8 | row_local, dot^}
+    int *stg_n = (int *)(stg + SCAP);                         // their number (may exceed SCAP: the excess was flagged, not stored)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;                 // 2 x 4 waves: 64 queries x 64 rows each
@@ -234,7 +243,10 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
     const int KT = D / BK;
     // this workgroup's items: local, local + nlocal, ...
     const int my_items = items > local ? (items - local + nlocal - 1) / nlocal : 0;
-    if (my_items == 0) return;
+    if (my_items == 0) {
+        if (MODE == 2 && threadIdx.x == 0) wg_count[blockIdx.x] = 0;
+        return;
+    }
 
     auto item_of = [&](int n, int &qt, int &t) {            // n-th item of this workgroup -> (query tile, bank tile)
         const int idx = local + n * nlocal;
@@ -393,36 +405,84 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
                         }
                     }
                 }
+        } else if (!STAGED) {
+            if (mlo | mhi) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int e0 = (i * 4 + r) * 4;
+                        if (((e0 < 32 ? mlo : mhi) >> (e0 & 31)) & 15u) {
+                            const int q = qt * QT + wm * 64 + i * 16 + 4 * (lane >> 4) + r;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (((e0 < 32 ? mlo : mhi) >> ((e0 + j) & 31)) & 1u) {
+                                    const int pos = atomicAdd(cnt + q, 1);
+                                    if (pos < cap) {
+                                        cand_i[(int64_t)q * cap + pos] = t * BT + wn * 64 + j * 16 + (lane & 15);
+                                        cand_d[(int64_t)q * cap + pos] = acc[i][j][r];
+                                    }
+                                }
+                        }
+                    }
+            }
         } else if (mlo | mhi) {
+            // Candidates go to a list in LDS (slot from an LDS counter: no global atomic, no wait on the vector-memory
+            // counter that the LDS-DMA ring lives on -- a returning global atomic per candidate cost ~750 cycles per k-step).
+            // The workgroup flushes the list to its OWN region of wg_list with plain stores (flush_item); bucket_kernel sorts
+            // the regions into the per-query lists afterwards.
+            // (kbase goes through an empty asm: derived from it inside the epilogue, the 64 keys of a lane cannot be hoisted out
+            // of the k-loop into registers the accumulators and fragments need)
+            int kbase = ((wm * 64 + 4 * (lane >> 4)) << 8) | (wn * 64 + (lane & 15));
+            asm volatile("" : "+v"(kbase));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int e0 = (i * 4 + r) * 4;
                     if (((e0 < 32 ? mlo : mhi) >> (e0 & 31)) & 15u) {
-                        const int q = qt * QT + wm * 64 + i * 16 + 4 * (lane >> 4) + r;
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             if (((e0 < 32 ? mlo : mhi) >> ((e0 + j) & 31)) & 1u) {
-                                const int pos = atomicAdd(cnt + q, 1);
-                                if (pos < cap) {
-                                    cand_i[(int64_t)q * cap + pos] = t * BT + wn * 64 + j * 16 + (lane & 15);
-                                    cand_d[(int64_t)q * cap + pos] = acc[i][j][r];
-                                }
+                                const int key = kbase + (((i * 16 + r) << 8) | (j * 16));      // q_local << 8 | row_local
+                                const int slot = atomicAdd(stg_n, 1);
+                                if (slot < SCAP) stg[slot] = make_uint2((unsigned int)key, __float_as_uint(acc[i][j][r]));
+                                else overflow[qt * QT + (key >> 8)] = 1;     // more than the staging list holds: the query is re-run exactly
                             }
                     }
                 }
         }
     };
+    // the staged candidates of item (qt, t) -> this workgroup's region of wg_list (16 bytes each: query, row, dot^)
+    int wpos = 0;
+    auto flush_item = [&](int qt, int t) {
+        int n = *stg_n;      // (a plain LDS read: a volatile one became a FLAT load, whose vmcnt(0) drained the LDS-DMA ring once per item)
+        n = __builtin_amdgcn_readfirstlane(n < SCAP ? n : SCAP);
+        uint4 *dst = wg_list + (int64_t)blockIdx.x * capw;
+        for (int e = tid; e < n; e += NT) {
+            const uint2 c = stg[e];
+            const int q = qt * QT + (int)(c.x >> 8), row = t * BT + (int)(c.x & 255u);
+#ifdef PF_NOFLUSHSTORE
+            asm volatile("" ::"v"(q), "v"(row), "v"(c.y));
+            continue;
+#endif
+            if (wpos + e < capw) dst[wpos + e] = make_uint4((unsigned int)q, (unsigned int)row, c.y, 0u);
+            else overflow[q] = 1;                                          // region full: the query is re-run exactly
+        }
+        wpos = wpos + n < capw ? wpos + n : capw;
+    };
     // the k-step of its item that this wave multiplies next / that the current step reads
-    int kt_c = 0, kt_s = 0;
+    int kt_c = 0, kt_s = 0, qt_done = 0, t_done = 0;
     zero_acc();
+    if (tid == 0) *stg_n = 0;                                 // (the first append is many barriers away)
     auto multiply_stage = [&](bool issue, int ibuf, int half) {
         multiply(issue, ibuf, half);
         if (++kt_c == KT) {
             item_epilogue(qt_cur, t_cur);
             zero_acc();
             kt_c = 0;
+            qt_done = qt_cur;         // (flushed after the next P1, when both groups have finished the item)
+            t_done = t_cur;
             qt_cur = qt_nxt;          // (the issue cursor entered the next item AHEAD steps ago, and enters the one after it only later: KT > AHEAD)
             t_cur = t_nxt;
         }
@@ -435,7 +495,7 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
         else if (rem == 1) wait_vmcnt<NI>();
         else wait_vmcnt<0>();
     };
-    auto item_constants = [&]() {
+    auto item_constants = [&](int s_now) {
         // after P1 of an item's first step: test parameters of its 128 queries (2 KiB) and constants of its 256 rows (4 KiB) go
         // to LDS by the same DMA path (by then every wave's current item is this one).  The late group's epilogue of the
         // PREVIOUS item (which reads spar / srow) ran between P0 and P1.  Three steps on they are older than everything a
@@ -446,6 +506,10 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
         if (kt_s == 0) {
             if (wave < 2) glds16_sbase((const char *)(qpar + (int64_t)qt_cur * QT) + wave * 1024, lane * 16, (char *)spar + wave * 1024);
             else if (wave < 6) glds16_sbase((const char *)(rowp + (int64_t)t_cur * BT) + (wave - 2) * 1024, lane * 16, (char *)srow + (wave - 2) * 1024);
+            // ... and the item finished one step ago (early group) / in this step's first phase (late group) is flushed
+            if (STAGED && s_now > 0) flush_item(qt_done, t_done);
+        } else if (kt_s == 1) {
+            if (STAGED && tid == 0) *stg_n = 0;         // a barrier after the flush's reads, two before the next item's first append
         }
         kt_s = kt_s + 1 < KT ? kt_s + 1 : 0;
     };
@@ -466,7 +530,7 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
             STAMP(2);
             __builtin_amdgcn_s_barrier();                                  // P1(s)
             STAMP(3);
-            item_constants();
+            item_constants(s);
             multiply_stage(false, 0, 0);
             STAMP(4);
         }
@@ -480,10 +544,11 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
             __builtin_amdgcn_s_barrier();                                  // P0(s)
             STAMP(1);
             if (s > 0) multiply_stage(false, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // staged candidates of a finished item are in LDS
             STAMP(4);
             __builtin_amdgcn_s_barrier();                                  // P1(s)
             STAMP(3);
-            item_constants();
+            item_constants(s);
             read_frags(s & (NSTAGE - 1));
             if (issue) {
                 issue_half(ibuf, 0);
@@ -493,11 +558,34 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
         }
         multiply_stage(false, 0, 0);                                       // the last stage (+ its item epilogue)
     }
+    if (STAGED) {
+        __syncthreads();                                                    // both groups are done with the last item
+        flush_item(qt_done, t_done);
+        if (tid == 0) wg_count[blockIdx.x] = wpos;
+    }
 #ifdef PF_STAMP
     if (lane == 0)
         for (int i = 0; i < 5; ++i) atomicAdd(dbg + (late ? 8 : 0) + i, (unsigned long long)seg[i]);
     if (lane == 0 && wave == 0) atomicAdd(dbg + 16, (unsigned long long)steps);
 #endif
+}
+
+// ---- the workgroups' candidate regions -> the per-query lists (slot from the query's counter; a count past `cap` marks the
+// query as overflowed in select_kernel).  grid = (chunks, PF_GRID)
+__global__ __launch_bounds__(256) void bucket_kernel(const uint4 *__restrict__ wg_list, const int *__restrict__ wg_count, int capw,
+                                                     int cap, int *__restrict__ cnt, int *__restrict__ cand_i,
+                                                     float *__restrict__ cand_d) {
+    const int n = wg_count[blockIdx.y];
+    const uint4 *src = wg_list + (int64_t)blockIdx.y * capw;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        const uint4 c = src[e];
+        const int q = (int)c.x;
+        const int pos = atomicAdd(cnt + q, 1);
+        if (pos < cap) {
+            cand_i[(int64_t)q * cap + pos] = (int)c.y;
+            cand_d[(int64_t)q * cap + pos] = __uint_as_float(c.z);
+        }
+    }
 }
 
 // ---- between phases: new threshold, compaction; last phase: pick the candidates to re-score ---------------------------------
@@ -733,7 +821,9 @@ struct Workspace {
     half_t *qh, *ql;
     float4 *qbase, *qpar;
     float *tau, *bound, *cand_d;
-    int *cnt, *overflow, *cand_i, *sel_i, *nsel;
+    int *cnt, *overflow, *cand_i, *sel_i, *nsel, *wg_count;
+    uint4 *wg_list;
+    int capw;
 };
 inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 int64_t carve(char *base, int Q, int D, int cap, Workspace *w) {
@@ -757,6 +847,11 @@ int64_t carve(char *base, int Q, int D, int cap, Workspace *w) {
     p = take((int64_t)Q * RESCORE_MAX * 4); if (w) w->sel_i = (int *)p;
     p = take((int64_t)Q * cap * 4); if (w) w->cand_i = (int *)p;
     p = take((int64_t)Q * cap * 4); if (w) w->cand_d = (float *)p;
+    // stage 1 writes each workgroup's candidates to a region of its own: a few hundred candidates per query and phase in all,
+    // dealt evenly over the workgroups; a full region flags the queries it had to drop
+    const int capw = Q * 4 > 8192 ? Q * 4 : 8192;
+    p = take((int64_t)PF_GRID * capw * 16); if (w) { w->wg_list = (uint4 *)p; w->capw = capw; }
+    p = take((int64_t)PF_GRID * 4); if (w) w->wg_count = (int *)p;
     return off;
 }
 
@@ -799,7 +894,7 @@ extern "C" int skyemb_cosine_topk_prefiltered(const float *tw, const float *qn, 
     hipLaunchKernelGGL(query16_kernel, dim3((unsigned)(((Q + QT - 1) / QT * QT + 3) / 4)), dim3(256), 0, st, tw, qn, Q, D, w.qh, w.ql,
                        w.qbase, eps_a);
     const int T = (int)ceil_div64(N, BT);
-    // phases: [0, first) is taken whole unless a floor came in; then slices ending at 1/32, 1/8, 1/2 and all of the tiles
+    // phases: [0, first) is taken whole unless a floor came in; then slices ending at 1/128, 1/32, 1/8, 1/2 and all of the tiles
     int first = (int)(cap / 2 / BT);                           // rows of the take-everything slice <= cap / 2
     if (first < 1) first = 1;
     if (first > T) first = T;
@@ -808,10 +903,11 @@ extern "C" int skyemb_cosine_topk_prefiltered(const float *tw, const float *qn, 
     hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((Q_padded + 255) / 256)), dim3(256), 0, st, Q, Q_padded, thr0, w.qbase, eps,
                        w.qpar, w.tau, w.cnt, w.overflow, (int)first_rows);
     static bool attr_set = false;
-    constexpr int smem1 = NSTAGE * STAGE + (QT + BT) * 16;
+    constexpr int smem1 = NSTAGE * STAGE + (QT + BT) * 16 + SCAP * 8 + 16;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)prefilter_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem1);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)prefilter_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem1);
+        hipError_t e = hipFuncSetAttribute((const void *)prefilter_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem1);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)prefilter_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem1);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)prefilter_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem1);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8192 * 4 + 272 * 4);
         if (e != hipSuccess) {
@@ -820,10 +916,12 @@ extern "C" int skyemb_cosine_topk_prefiltered(const float *tw, const float *qn, 
         }
         attr_set = true;
     }
-    int ends[5] = {first, T / 32, T / 8, T / 2, T};
+    // (the slice right after the first one meets a threshold that still passes ~5 % of the pairs -- k of the ~2000 rows seen --
+    // so it is kept short and appends directly; from then on a workgroup's candidates fit its staging list and region)
+    int ends[6] = {first, T / 128, T / 32, T / 8, T / 2, T};
     int t0 = 0;
     const size_t smem_sel = (size_t)2 * cap * 4 + 272 * 4;
-    for (int p = 0; p < 5; ++p) {
+    for (int p = 0; p < 6; ++p) {
         int t1 = ends[p];
         if (p == 0 && thr0) continue;                          // a valid floor is as good as the first slice
         if (t1 <= t0) continue;
@@ -836,18 +934,31 @@ extern "C" int skyemb_cosine_topk_prefiltered(const float *tw, const float *qn, 
 #else
 #define PF_DBG
 #endif
-        if (p == 0)
-            hipLaunchKernelGGL(prefilter_kernel<true>, dim3(256), dim3(NT), smem1, st, w.qh, w.ql, (const half_t *)bank16,
-                               (const float4 *)rowp, w.qpar, Q, N, D, t0, t1, cap, w.cnt, w.cand_i, w.cand_d PF_DBG);
-        else
-            hipLaunchKernelGGL(prefilter_kernel<false>, dim3(256), dim3(NT), smem1, st, w.qh, w.ql, (const half_t *)bank16,
-                               (const float4 *)rowp, w.qpar, Q, N, D, t0, t1, cap, w.cnt, w.cand_i, w.cand_d PF_DBG);
+#define PF_ARGS w.qh, w.ql, (const half_t *)bank16, (const float4 *)rowp, w.qpar, Q, N, D, t0, t1, cap, w.cnt, w.cand_i, w.cand_d, \
+                w.wg_list, w.wg_count, w.capw, w.overflow PF_DBG
+        if (p == 0) {
+            hipLaunchKernelGGL(prefilter_kernel<0>, dim3(PF_GRID), dim3(NT), smem1, st, PF_ARGS);
+        } else if (p == 1) {
+            hipLaunchKernelGGL(prefilter_kernel<1>, dim3(PF_GRID), dim3(NT), smem1, st, PF_ARGS);
+        } else {
+            hipLaunchKernelGGL(prefilter_kernel<2>, dim3(PF_GRID), dim3(NT), smem1, st, PF_ARGS);
+            hipLaunchKernelGGL(bucket_kernel, dim3(8, PF_GRID), dim3(256), 0, st, (const uint4 *)w.wg_list, (const int *)w.wg_count,
+                               w.capw, cap, w.cnt, w.cand_i, w.cand_d);
+        }
+#undef PF_ARGS
 #ifdef PF_STAMP
         {
             unsigned long long h[32];
             hipStreamSynchronize(st);
             hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
             const double n = (double)h[16] * 4.0;     // steps summed over workgroups x 4 waves per group
+            if (p >= 2) {
+                int hc[PF_GRID];
+                hipMemcpy(hc, w.wg_count, sizeof(hc), hipMemcpyDeviceToHost);
+                long tot = 0; int mx = 0;
+                for (int i = 0; i < PF_GRID; ++i) { tot += hc[i]; if (hc[i] > mx) mx = hc[i]; }
+                fprintf(stderr, "[stamp] phase %d staged candidates: total %ld (%.1f per query), max per workgroup %d of %d\n", p, tot, (double)tot / Q, mx, w.capw);
+            }
             fprintf(stderr, "[stamp] phase %d steps/wg %.0f | early: wait %.0f P0 %.0f read+issue %.0f P1 %.0f mult %.0f | late: wait %.0f P0 %.0f read+issue %.0f P1 %.0f mult %.0f (cycles of s_memtime per k-step)\n",
                     p, (double)h[16] / 256.0, h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[8] / n, h[9] / n, h[10] / n, h[11] / n, h[12] / n);
         }
