@@ -40,11 +40,12 @@ typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 
 constexpr int QT = 128, BT = 256, BK = 32, NW = 8, NT = NW * 64;   // queries x bank rows per tile, k-step, waves
-constexpr int A_BYTES = QT * BK * 2, B_BYTES = BT * BK * 2, STAGE = 2 * A_BYTES + B_BYTES;   // hi + lo + bank = 32 KiB
+constexpr int A_BYTES = QT * BK * 2, B_BYTES = BT * BK * 2;
+constexpr int stage_bytes(bool lo) { return (lo ? 2 : 1) * A_BYTES + B_BYTES; }   // hi (+ lo) + bank = 24 / 32 KiB
+constexpr int pieces(bool lo) { return ((lo ? 2 : 1) * QT + BT) / 16 / NW; }     // LDS-DMA instructions per wave per stage (one = 16 rows x 64 B)
 constexpr int NSTAGE = 4, AHEAD = NSTAGE - 1;   // 96 KiB of LDS-DMA in flight per CU: one workgroup per CU has to cover the
                                                  // L2 latency alone (a 2 x 64 KiB ring ran at 23 GB/s per CU: 2.8 us per k-step);
                                                  // NSTAGE is a power of two: stage s lives in buffer s & (NSTAGE - 1)
-constexpr int NI = (2 * QT + BT) / 16 / NW;     // LDS-DMA instructions per wave per stage (one = 16 rows x 64 B)
 constexpr int GQ = 5;                     // query tiles (hi + lo = 384 KiB each at D = 768) kept hot in an XCD's L2
 constexpr int RESCORE_MAX = 256;          // K': candidates re-scored exactly per query
 constexpr int SCAP = 2048;                // candidates of one item staged in LDS (8 bytes each)
@@ -54,8 +55,10 @@ __device__ __forceinline__ void glds16(const void *src, char *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gvoid_t *)src, (lvoid_t *)lds_wave_base, 16, 0, 0);
 }
 
-__host__ __device__ inline double eps_a_of(int D) {
-    return 0x1p-11 + 0x1p-21 + 6.06 * D * 0x1p-24 + 2.0 * sqrt((double)D) * 0x1p-27;
+// lo: the query enters as hi + lo (see the header); without lo its own fp16 rounding (2^-11 relative, + the cross term) joins
+// the row's
+__host__ __device__ inline double eps_a_of(int D, bool lo) {
+    return (lo ? 0x1p-11 + 0x1p-21 : 0x1p-10 + 0x1p-21) + 6.06 * D * 0x1p-24 + 2.0 * sqrt((double)D) * 0x1p-27;
 }
 
 // ---- preparation --------------------------------------------------------------------------------------------------
@@ -200,7 +203,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // MODE 0: first slice, every pair is stored (slot = row)   1: candidates appended to the per-query lists directly (returning
 // global atomics: the short early phases, whose loose thresholds pass several per cent of the pairs)   2: candidates staged
 // in LDS and flushed to the workgroup's own region (the long late phases)
-template <int MODE>
+template <int MODE, bool LO>
 __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict__ qh, const half_t *__restrict__ ql,
                                                        const half_t *__restrict__ bank16, const float4 *__restrict__ rowp,
                                                        const float4 *__restrict__ qpar, int Q, int64_t N, int D, int t0, int t1,
@@ -212,6 +215,7 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
 #endif
                                                        ) {
     constexpr bool TAKE_ALL = MODE == 0, STAGED = MODE == 2;
+    constexpr int STAGE = stage_bytes(LO), NI = pieces(LO), B_OFF = (LO ? 2 : 1) * A_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef PF_STAMP
     unsigned int seg[5] = {0, 0, 0, 0, 0};
@@ -290,10 +294,10 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
         char *st = smem + buf * STAGE;
         if (half == 0) {
             glds16_sbase(ph, lane_off, st + wave * 1024);
-            glds16_sbase(pl, lane_off, st + A_BYTES + wave * 1024);
+            if (LO) glds16_sbase(pl, lane_off, st + A_BYTES + wave * 1024);
         } else {
-            glds16_sbase(pb, lane_off, st + 2 * A_BYTES + wave * 2048);
-            glds16_sbase(pb + bank_piece2, lane_off, st + 2 * A_BYTES + wave * 2048 + 1024);
+            glds16_sbase(pb, lane_off, st + B_OFF + wave * 2048);
+            glds16_sbase(pb + bank_piece2, lane_off, st + B_OFF + wave * 2048 + 1024);
             ph += BK * 2; pl += BK * 2; pb += BK * 2;
             if (++kt_iss == KT) {
                 kt_iss = 0;
@@ -326,11 +330,11 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
 #ifdef PF_NOREAD
         return;
 #endif
-        const char *sa = smem + b * STAGE, *sl = sa + A_BYTES, *sb = sa + 2 * A_BYTES;
+        const char *sa = smem + b * STAGE, *sl = sa + A_BYTES, *sb = sa + B_OFF;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             fh[i] = frag(sa, wm * 64 + i * 16, lane);
-            fl[i] = frag(sl, wm * 64 + i * 16, lane);
+            if (LO) fl[i] = frag(sl, wm * 64 + i * 16, lane);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[j] = frag(sb, wn * 64 + j * 16, lane);
@@ -353,10 +357,10 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[i], fb[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[i], fb[j], acc[i][j], 0, 0, 0);
+                if (LO) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[i], fb[j], acc[i][j], 0, 0, 0);
             }
 #else
-            acc[i][0][0] += (float)fh[i][0] + (float)fl[i][1] + (float)fb[i][2];
+            acc[i][0][0] += (float)fh[i][0] + (float)fb[i][2];
 #endif
         }
     };
@@ -890,7 +894,10 @@ extern "C" int skyemb_cosine_topk_prefiltered(const float *tw, const float *qn, 
     hipStream_t st = (hipStream_t)stream;
     Workspace w;
     carve((char *)ws, Q, D, cap, &w);
-    const float eps_a = (float)(eps_a_of(D) * (1.0 + 1e-6));
+    // one fp16 pass (hi only) by default: half the matrix work, 3/4 of the LDS-DMA bytes, intervals ~1.6x wider -- on
+    // embedding-like data a few dozen more candidates per query.  SKYEMB_PREFILTER_LO=1 keeps the hi + lo passes.
+    static const bool use_lo = []() { const char *e = getenv("SKYEMB_PREFILTER_LO"); return e && e[0] == '1'; }();
+    const float eps_a = (float)(eps_a_of(D, use_lo) * (1.0 + 1e-6));
     hipLaunchKernelGGL(query16_kernel, dim3((unsigned)(((Q + QT - 1) / QT * QT + 3) / 4)), dim3(256), 0, st, tw, qn, Q, D, w.qh, w.ql,
                        w.qbase, eps_a);
     const int T = (int)ceil_div64(N, BT);
@@ -903,11 +910,13 @@ extern "C" int skyemb_cosine_topk_prefiltered(const float *tw, const float *qn, 
     hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((Q_padded + 255) / 256)), dim3(256), 0, st, Q, Q_padded, thr0, w.qbase, eps,
                        w.qpar, w.tau, w.cnt, w.overflow, (int)first_rows);
     static bool attr_set = false;
-    constexpr int smem1 = NSTAGE * STAGE + (QT + BT) * 16 + SCAP * 8 + 16;
+    const int smem1 = NSTAGE * stage_bytes(use_lo) + (QT + BT) * 16 + SCAP * 8 + 16;
+    constexpr int smem_max = NSTAGE * stage_bytes(true) + (QT + BT) * 16 + SCAP * 8 + 16;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)prefilter_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem1);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)prefilter_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem1);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)prefilter_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem1);
+        hipError_t e = hipSuccess;
+#define PF_ATTR(M, L) if (e == hipSuccess) e = hipFuncSetAttribute((const void *)prefilter_kernel<M, L>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_max)
+        PF_ATTR(0, false); PF_ATTR(1, false); PF_ATTR(2, false); PF_ATTR(0, true); PF_ATTR(1, true); PF_ATTR(2, true);
+#undef PF_ATTR
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8192 * 4 + 272 * 4);
         if (e != hipSuccess) {
@@ -936,15 +945,21 @@ extern "C" int skyemb_cosine_topk_prefiltered(const float *tw, const float *qn, 
 #endif
 #define PF_ARGS w.qh, w.ql, (const half_t *)bank16, (const float4 *)rowp, w.qpar, Q, N, D, t0, t1, cap, w.cnt, w.cand_i, w.cand_d, \
                 w.wg_list, w.wg_count, w.capw, w.overflow PF_DBG
+#define PF_LAUNCH(M)                                                                                          \
+    do {                                                                                                      \
+        if (use_lo) hipLaunchKernelGGL((prefilter_kernel<M, true>), dim3(PF_GRID), dim3(NT), smem1, st, PF_ARGS); \
+        else hipLaunchKernelGGL((prefilter_kernel<M, false>), dim3(PF_GRID), dim3(NT), smem1, st, PF_ARGS);     \
+    } while (0)
         if (p == 0) {
-            hipLaunchKernelGGL(prefilter_kernel<0>, dim3(PF_GRID), dim3(NT), smem1, st, PF_ARGS);
+            PF_LAUNCH(0);
         } else if (p == 1) {
-            hipLaunchKernelGGL(prefilter_kernel<1>, dim3(PF_GRID), dim3(NT), smem1, st, PF_ARGS);
+            PF_LAUNCH(1);
         } else {
-            hipLaunchKernelGGL(prefilter_kernel<2>, dim3(PF_GRID), dim3(NT), smem1, st, PF_ARGS);
+            PF_LAUNCH(2);
             hipLaunchKernelGGL(bucket_kernel, dim3(8, PF_GRID), dim3(256), 0, st, (const uint4 *)w.wg_list, (const int *)w.wg_count,
                                w.capw, cap, w.cnt, w.cand_i, w.cand_d);
         }
+#undef PF_LAUNCH
 #undef PF_ARGS
 #ifdef PF_STAMP
         {
