@@ -39,10 +39,14 @@ typedef __attribute__((ext_vector_type(8))) _Float16 half8;
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 
-constexpr int QT = 128, BT = 256, BK = 32, NW = 8, NT = NW * 64;   // queries x bank rows per tile, k-step, waves
-constexpr int A_BYTES = QT * BK * 2, B_BYTES = BT * BK * 2;
-constexpr int stage_bytes(bool lo) { return (lo ? 2 : 1) * A_BYTES + B_BYTES; }   // hi (+ lo) + bank = 24 / 32 KiB
-constexpr int pieces(bool lo) { return ((lo ? 2 : 1) * QT + BT) / 16 / NW; }     // LDS-DMA instructions per wave per stage (one = 16 rows x 64 B)
+constexpr int BT = 256, BK = 32, NW = 8, NT = NW * 64;   // bank rows per tile, k-step, waves
+// queries per tile: 256 with one fp16 pass (hi), 128 with two (hi + lo) -- 16 KiB of query rows per k-step either way, but the
+// 256 x 256 tile does twice the products per byte brought into LDS (the LDS-DMA rate, not the matrix cores, bounds the kernel)
+constexpr int qtile(bool lo) { return lo ? 128 : 256; }
+constexpr int QPAD = 256;                                // every per-query array is padded to this many rows
+constexpr int B_BYTES = BT * BK * 2, Q_BYTES = 256 * BK * 2;
+constexpr int stage_bytes(bool) { return Q_BYTES + B_BYTES; }            // query rows (hi, or hi + lo) + bank rows = 32 KiB
+constexpr int pieces(bool) { return (Q_BYTES + B_BYTES) / 1024 / NW; }   // LDS-DMA instructions per wave per stage (one = 16 rows x 64 B)
 constexpr int NSTAGE = 4, AHEAD = NSTAGE - 1;   // 96 KiB of LDS-DMA in flight per CU: one workgroup per CU has to cover the
                                                  // L2 latency alone (a 2 x 64 KiB ring ran at 23 GB/s per CU: 2.8 us per k-step);
                                                  // NSTAGE is a power of two: stage s lives in buffer s & (NSTAGE - 1)
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(256) void query16_kernel(const float *__restrict__ 
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= Q) {
         // rows up to a whole query tile (the grid covers them): zeros; their test parameters let no pair pass
-        if (q < (Q + QT - 1) / QT * QT)
+        if (q < (Q + QPAD - 1) / QPAD * QPAD)
             for (int d = lane * 4; d < D; d += 256) {
                 *(uint2 *)(qh + (int64_t)q * D + d) = make_uint2(0u, 0u);
                 *(uint2 *)(ql + (int64_t)q * D + d) = make_uint2(0u, 0u);
@@ -185,10 +189,11 @@ __device__ __forceinline__ void glds16_sbase(const void *base_uniform, unsigned 
                  : "v"(lane_off), "s"(base_uniform), "s"(dst)
                  : "memory", "m0");
 }
-__device__ __forceinline__ half8 frag(const char *sbase, int rbase, int lane) {
-    const int r = rbase + (lane & 15);
-    const int c = (lane >> 4) ^ swz(r);
-    return *(const half8 *)(sbase + r * 64 + (c << 4));
+// fragment of 16 rows from row `rbase` (a multiple of 16: swz(rbase + l) == swz(l)): every fragment of a lane sits at
+// rbase * 64 + ONE per-lane constant, frag_lane(lane) -- an immediate offset on a single address register
+__device__ __forceinline__ int frag_lane(int lane) { return (lane & 15) * 64 + ((((lane >> 4) ^ swz(lane & 15))) << 4); }
+__device__ __forceinline__ half8 frag(const char *sbase, int rbase, int lane_c) {
+    return *(const half8 *)(sbase + rbase * 64 + lane_c);
 }
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -215,7 +220,8 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
 #endif
                                                        ) {
     constexpr bool TAKE_ALL = MODE == 0, STAGED = MODE == 2;
-    constexpr int STAGE = stage_bytes(LO), NI = pieces(LO), B_OFF = (LO ? 2 : 1) * A_BYTES;
+    constexpr int QT = qtile(LO), MI = QT / 2 / 16;        // queries per tile; 16-row query fragments per wave (the wave's half of the tile)
+    constexpr int STAGE = stage_bytes(LO), NI = pieces(LO), A_BYTES = QT * BK * 2, B_OFF = Q_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef PF_STAMP
     unsigned int seg[5] = {0, 0, 0, 0, 0};
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
     int *stg_n = (int *)(stg + SCAP);                         // their number (may exceed SCAP: the excess was flagged, not stored)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;                 // 2 x 4 waves: 64 queries x 64 rows each
+    const int wm = wave >> 2, wn = wave & 3;                 // 2 x 4 waves: QT / 2 queries x 64 rows each
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, nlocal = gridDim.x >> 3;
     const int T = t1 - t0, Tx = xcd < T ? (T - xcd + 7) / 8 : 0;
     const int nqt = (Q + QT - 1) / QT;
@@ -275,14 +281,14 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
     // [32 wave, +32) of the bank tile.  Their addresses are three running scalar pointers (64 bytes further per k-step,
     // re-based when the cursor enters a new item) plus one per-lane offset that never changes: a k-step's address work is a
     // handful of scalar adds (recomputing bases from the tile numbers cost ~80 scalar instructions per k-step and wave).
-    static_assert(QT / 16 / NW == 1 && BT / 16 / NW == 2, "piece ownership below assumes 128 x 256 tiles on 8 waves");
+    static_assert(BT / 16 / NW == 2 && Q_BYTES / 1024 / NW == 2, "piece ownership below: two query and two bank pieces per wave");
     const unsigned int lane_off = (unsigned int)((lane >> 2) * D * 2 + (((lane & 3) ^ swz(lane >> 2)) << 4));
     int n_iss = 0, kt_iss = 0;
     int qt_cur, t_cur, qt_nxt = 0, t_nxt = 0;                // the item being multiplied / the one the issue cursor has entered
     item_of(0, qt_cur, t_cur);
     const char *ph, *pl, *pb;
     auto rebase = [&](int qt, int t) {
-        const int64_t qoff = ((int64_t)qt * QT + wave * 16) * D * 2;
+        const int64_t qoff = ((int64_t)qt * QT + wave * (QT / NW)) * D * 2;   // LO: 16 rows of hi and of lo; else 32 rows of hi
         ph = (const char *)qh + qoff;
         pl = (const char *)ql + qoff;
         pb = (const char *)bank16 + ((int64_t)t * BT + wave * 32) * D * 2;
@@ -293,8 +299,9 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
     auto issue_half = [&](int buf, int half) {
         char *st = smem + buf * STAGE;
         if (half == 0) {
-            glds16_sbase(ph, lane_off, st + wave * 1024);
+            glds16_sbase(ph, lane_off, st + wave * (QT / NW) * 64);
             if (LO) glds16_sbase(pl, lane_off, st + A_BYTES + wave * 1024);
+            else glds16_sbase(ph + bank_piece2, lane_off, st + wave * 2048 + 1024);      // rows 16..31 of the wave's 32
         } else {
             glds16_sbase(pb, lane_off, st + B_OFF + wave * 2048);
             glds16_sbase(pb + bank_piece2, lane_off, st + B_OFF + wave * 2048 + 1024);
@@ -309,8 +316,8 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
         }
     };
 
-    f32x4 acc[4][4];
-    half8 fh[4], fl[4], fb[4];
+    f32x4 acc[MI][4];
+    half8 fh[MI], fl[LO ? MI : 1], fb[4];
     const bool late = wave >= 4;                             // wave-uniform (SGPR)
     const int steps = my_items * KT;
 #pragma unroll
@@ -322,22 +329,24 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
 
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     };
+    const int flane = frag_lane(lane);
     auto read_frags = [&](int b) {
 #ifdef PF_NOREAD
         return;
 #endif
-        const char *sa = smem + b * STAGE, *sl = sa + A_BYTES, *sb = sa + B_OFF;
+        // one address register per operand: stage base + the wave's first row + the lane's constant; the rest are immediates
+        const char *sa = smem + b * STAGE + wm * (QT / 2) * 64 + flane, *sb = smem + b * STAGE + B_OFF + wn * 64 * 64 + flane;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            fh[i] = frag(sa, wm * 64 + i * 16, lane);
-            if (LO) fl[i] = frag(sl, wm * 64 + i * 16, lane);
+        for (int i = 0; i < MI; ++i) {
+            fh[i] = frag(sa, i * 16, 0);
+            if (LO) fl[i] = frag(sa + A_BYTES, i * 16, 0);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = frag(sb, wn * 64 + j * 16, lane);
+        for (int j = 0; j < 4; ++j) fb[j] = frag(sb, j * 16, 0);
     };
     // the four LDS-DMA instructions of the next stage cost ~100+ issue cycles each: they go BETWEEN the MFMAs (whose execution
     // covers them), not in front of them
@@ -345,7 +354,7 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
     // issue cost), the other two in the wave's read phase
     auto multiply = [&](bool issue, int ibuf, int half) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MI; ++i) {
             if (i == 1) {
                 __builtin_amdgcn_sched_barrier(0);
 #ifndef PF_NODMA
@@ -360,101 +369,106 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
                 if (LO) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[i], fb[j], acc[i][j], 0, 0, 0);
             }
 #else
-            acc[i][0][0] += (float)fh[i][0] + (float)fb[i][2];
+            acc[i][0][0] += (float)fh[i][0] + (float)fb[i & 3][2];
 #endif
         }
     };
     auto item_epilogue = [&](int qt, int t) {
-        // ---- epilogue of the item: lane holds queries 4*(lane>>4)+r (r = 0..3) x bank row (lane & 15) per 16x16 block.
-        // All 64 tests of the lane are branch-free (a bit mask); only lanes that found something enter the append path.
+        // ---- epilogue of the item: per 16x16 block a lane holds queries 4*(lane>>4)+r (r = 0..3) x bank row (lane & 15).
+        // All 16 MI tests of the lane are branch-free (bit masks: test (i, r, j) is bit (r*4 + j) of half-word i); only lanes
+        // that found something enter the append path.
+        // (the lane coordinates go through an empty asm: everything addressed from them is then computed HERE, once per item,
+        // instead of being hoisted out of the k-loop into registers that the accumulators and fragments need)
+        int l16 = lane & 15, l4 = lane >> 4;
+        asm volatile("" : "+v"(l16), "+v"(l4));
         float4 rp[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rp[j] = srow[wn * 64 + j * 16 + (lane & 15)];
-        unsigned int mlo = 0, mhi = 0;
+        for (int j = 0; j < 4; ++j) rp[j] = srow[wn * 64 + j * 16 + l16];
+        unsigned int msk[MI / 2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int w2 = 0; w2 < MI / 2; ++w2) msk[w2] = 0;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float4 p = spar[wm * 64 + i * 16 + 4 * (lane >> 4) + r];
+                const float4 p = spar[wm * (QT / 2) + i * 16 + 4 * l4 + r];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float rhs = fmaf(p.x, rp[j].x, p.y * rp[j].z);
                     const float lhs = fmaf(p.z, rp[j].y, acc[i][j][r]);
-                    const int e = (i * 4 + r) * 4 + j;
-                    const unsigned int bit = lhs >= rhs ? (1u << (e & 31)) : 0u;
-                    if (e < 32) mlo |= bit; else mhi |= bit;
+                    msk[i >> 1] |= lhs >= rhs ? (1u << ((i & 1) * 16 + r * 4 + j)) : 0u;
                 }
+                // (keeps the scheduler from fetching all 4 MI parameter rows up front: 128 more live registers than there are)
+                if (MI > 4 && r == 3) __builtin_amdgcn_sched_barrier(0);
             }
+        unsigned int any = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < MI / 2; ++w2) any |= msk[w2];
 #if defined(PF_NOMFMA) || defined(PF_NOREAD) || defined(PF_NODMA) || defined(PF_NOAPPEND)
-        asm volatile("" ::"v"(mlo), "v"(mhi));      // experiment builds: the tests are computed, nothing is appended
-        mlo = mhi = 0;
+        asm volatile("" ::"v"(any));                 // experiment builds: the tests are computed, nothing is appended
+        any = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < MI / 2; ++w2) msk[w2] = 0;
 #endif
+        auto passed = [&](int i, int r, int j) -> bool { return (msk[i >> 1] >> ((i & 1) * 16 + r * 4 + j)) & 1u; };
+        auto passed4 = [&](int i, int r) -> bool { return (msk[i >> 1] >> ((i & 1) * 16 + r * 4)) & 15u; };
         if (TAKE_ALL) {
             // first slice: every (query, row) pair of the slice is a candidate, slot = row within the slice (no counters);
             // pairs that fail even the open test (NaN) are stored as -inf and dropped by the select step
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int q = qt * QT + wm * 64 + i * 16 + 4 * (lane >> 4) + r;
+                    const int q = qt * QT + wm * (QT / 2) + i * 16 + 4 * l4 + r;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int64_t row = (int64_t)t * BT + wn * 64 + j * 16 + (lane & 15);
-                        const int e = (i * 4 + r) * 4 + j;
-                        const bool pass = ((e < 32 ? mlo : mhi) >> (e & 31)) & 1u;
+                        const int64_t row = (int64_t)t * BT + wn * 64 + j * 16 + l16;
                         if (q < Q && row < N) {
                             const int64_t o = (int64_t)q * cap + (row - (int64_t)t0 * BT);
                             cand_i[o] = (int)row;
-                            cand_d[o] = pass ? acc[i][j][r] : -INFINITY;
+                            cand_d[o] = passed(i, r, j) ? acc[i][j][r] : -INFINITY;
                         }
                     }
                 }
         } else if (!STAGED) {
-            if (mlo | mhi) {
+            if (any) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int e0 = (i * 4 + r) * 4;
-                        if (((e0 < 32 ? mlo : mhi) >> (e0 & 31)) & 15u) {
-                            const int q = qt * QT + wm * 64 + i * 16 + 4 * (lane >> 4) + r;
+                    for (int r = 0; r < 4; ++r)
+                        if (passed4(i, r)) {
+                            const int q = qt * QT + wm * (QT / 2) + i * 16 + 4 * l4 + r;
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
-                                if (((e0 < 32 ? mlo : mhi) >> ((e0 + j) & 31)) & 1u) {
+                                if (passed(i, r, j)) {
                                     const int pos = atomicAdd(cnt + q, 1);
                                     if (pos < cap) {
-                                        cand_i[(int64_t)q * cap + pos] = t * BT + wn * 64 + j * 16 + (lane & 15);
+                                        cand_i[(int64_t)q * cap + pos] = t * BT + wn * 64 + j * 16 + l16;
                                         cand_d[(int64_t)q * cap + pos] = acc[i][j][r];
                                     }
                                 }
                         }
-                    }
             }
-        } else if (mlo | mhi) {
+        } else if (any) {
             // Candidates go to a list in LDS (slot from an LDS counter: no global atomic, no wait on the vector-memory
             // counter that the LDS-DMA ring lives on -- a returning global atomic per candidate cost ~750 cycles per k-step).
             // The workgroup flushes the list to its OWN region of wg_list with plain stores (flush_item); bucket_kernel sorts
             // the regions into the per-query lists afterwards.
-            // (kbase goes through an empty asm: derived from it inside the epilogue, the 64 keys of a lane cannot be hoisted out
-            // of the k-loop into registers the accumulators and fragments need)
-            int kbase = ((wm * 64 + 4 * (lane >> 4)) << 8) | (wn * 64 + (lane & 15));
-            asm volatile("" : "+v"(kbase));
+            const int kbase = ((wm * (QT / 2) + 4 * l4) << 8) | (wn * 64 + l16);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int e0 = (i * 4 + r) * 4;
-                    if (((e0 < 32 ? mlo : mhi) >> (e0 & 31)) & 15u) {
+                for (int r = 0; r < 4; ++r)
+                    if (passed4(i, r)) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            if (((e0 < 32 ? mlo : mhi) >> ((e0 + j) & 31)) & 1u) {
+                            if (passed(i, r, j)) {
                                 const int key = kbase + (((i * 16 + r) << 8) | (j * 16));      // q_local << 8 | row_local
                                 const int slot = atomicAdd(stg_n, 1);
                                 if (slot < SCAP) stg[slot] = make_uint2((unsigned int)key, __float_as_uint(acc[i][j][r]));
                                 else overflow[qt * QT + (key >> 8)] = 1;     // more than the staging list holds: the query is re-run exactly
                             }
                     }
-                }
         }
     };
     // the staged candidates of item (qt, t) -> this workgroup's region of wg_list (16 bytes each: query, row, dot^)
@@ -508,8 +522,9 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
         // the compiler, seeing an LDS-DMA it cannot tell apart from the ring's, would drain the whole ring with vmcnt(0) in
         // front of the epilogue's reads of spar / srow.)
         if (kt_s == 0) {
-            if (wave < 2) glds16_sbase((const char *)(qpar + (int64_t)qt_cur * QT) + wave * 1024, lane * 16, (char *)spar + wave * 1024);
-            else if (wave < 6) glds16_sbase((const char *)(rowp + (int64_t)t_cur * BT) + (wave - 2) * 1024, lane * 16, (char *)srow + (wave - 2) * 1024);
+            constexpr int QW = QT * 16 / 1024;           // waves that fetch the queries' parameters (1 KiB each); four more fetch the rows'
+            if (wave < QW) glds16_sbase((const char *)(qpar + (int64_t)qt_cur * QT) + wave * 1024, lane * 16, (char *)spar + wave * 1024);
+            else if (wave < QW + 4) glds16_sbase((const char *)(rowp + (int64_t)t_cur * BT) + (wave - QW) * 1024, lane * 16, (char *)srow + (wave - QW) * 1024);
             // ... and the item finished one step ago (early group) / in this step's first phase (late group) is flushed
             if (STAGED && s_now > 0) flush_item(qt_done, t_done);
         } else if (kt_s == 1) {
@@ -838,11 +853,11 @@ int64_t carve(char *base, int Q, int D, int cap, Workspace *w) {
         return p;
     };
     char *p;
-    const int64_t Qp = (Q + QT - 1) / QT * QT;               // the fp16 query images are padded to whole tiles
+    const int64_t Qp = (Q + QPAD - 1) / QPAD * QPAD;          // the fp16 query images are padded to whole tiles
     p = take(Qp * D * 2); if (w) w->qh = (half_t *)p;
     p = take(Qp * D * 2); if (w) w->ql = (half_t *)p;
     p = take((int64_t)Q * 16); if (w) w->qbase = (float4 *)p;
-    p = take((int64_t)((Q + QT - 1) / QT * QT) * 16); if (w) w->qpar = (float4 *)p;
+    p = take(Qp * 16); if (w) w->qpar = (float4 *)p;
     p = take((int64_t)Q * 4); if (w) w->tau = (float *)p;
     p = take((int64_t)Q * 4); if (w) w->bound = (float *)p;
     p = take((int64_t)Q * 4); if (w) w->cnt = (int *)p;
@@ -898,7 +913,7 @@ extern "C" int skyemb_cosine_topk_prefiltered(const float *tw, const float *qn, 
     // embedding-like data a few dozen more candidates per query.  SKYEMB_PREFILTER_LO=1 keeps the hi + lo passes.
     static const bool use_lo = []() { const char *e = getenv("SKYEMB_PREFILTER_LO"); return e && e[0] == '1'; }();
     const float eps_a = (float)(eps_a_of(D, use_lo) * (1.0 + 1e-6));
-    hipLaunchKernelGGL(query16_kernel, dim3((unsigned)(((Q + QT - 1) / QT * QT + 3) / 4)), dim3(256), 0, st, tw, qn, Q, D, w.qh, w.ql,
+    hipLaunchKernelGGL(query16_kernel, dim3((unsigned)(((Q + QPAD - 1) / QPAD * QPAD + 3) / 4)), dim3(256), 0, st, tw, qn, Q, D, w.qh, w.ql,
                        w.qbase, eps_a);
     const int T = (int)ceil_div64(N, BT);
     // phases: [0, first) is taken whole unless a floor came in; then slices ending at 1/128, 1/32, 1/8, 1/2 and all of the tiles
@@ -906,12 +921,12 @@ extern "C" int skyemb_cosine_topk_prefiltered(const float *tw, const float *qn, 
     if (first < 1) first = 1;
     if (first > T) first = T;
     const int64_t first_rows = (int64_t)first * BT < N ? (int64_t)first * BT : N;
-    const int Q_padded = (Q + QT - 1) / QT * QT;
+    const int Q_padded = (Q + QPAD - 1) / QPAD * QPAD;
     hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((Q_padded + 255) / 256)), dim3(256), 0, st, Q, Q_padded, thr0, w.qbase, eps,
                        w.qpar, w.tau, w.cnt, w.overflow, (int)first_rows);
     static bool attr_set = false;
-    const int smem1 = NSTAGE * stage_bytes(use_lo) + (QT + BT) * 16 + SCAP * 8 + 16;
-    constexpr int smem_max = NSTAGE * stage_bytes(true) + (QT + BT) * 16 + SCAP * 8 + 16;
+    const int smem1 = NSTAGE * stage_bytes(use_lo) + (qtile(use_lo) + BT) * 16 + SCAP * 8 + 16;
+    constexpr int smem_max = NSTAGE * stage_bytes(true) + (256 + BT) * 16 + SCAP * 8 + 16;
     if (!attr_set) {
         hipError_t e = hipSuccess;
 #define PF_ATTR(M, L) if (e == hipSuccess) e = hipFuncSetAttribute((const void *)prefilter_kernel<M, L>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_max)
@@ -926,9 +941,14 @@ extern "C" int skyemb_cosine_topk_prefiltered(const float *tw, const float *qn, 
         attr_set = true;
     }
     // (the slice right after the first one meets a threshold that still passes ~5 % of the pairs -- k of the ~2000 rows seen --
-    // so it is kept short and appends directly; from then on a workgroup's candidates fit its staging list and region)
-    int ends[6] = {first, T / 128, T / 32, T / 8, T / 2, T};
+    // so it is kept short, to ~96 k rows or 1/128 of the tiles, and appends directly; from then on the threshold passes ~1 %
+    // or less and a workgroup's candidates fit its staging list and region)
+    int direct_end = (int)ceil_div64((int64_t)96 * k, BT);
+    if (direct_end < T / 128) direct_end = T / 128;
+    if (direct_end < first + 1) direct_end = first + 1;
+    int ends[6] = {first, direct_end, T / 32, T / 8, T / 2, T};
     int t0 = 0;
+    bool thresholded_once = thr0 != nullptr;                   // a caller's floor comes from 256 k sampled rows: tight enough
     const size_t smem_sel = (size_t)2 * cap * 4 + 272 * 4;
     for (int p = 0; p < 6; ++p) {
         int t1 = ends[p];
@@ -952,8 +972,9 @@ extern "C" int skyemb_cosine_topk_prefiltered(const float *tw, const float *qn, 
     } while (0)
         if (p == 0) {
             PF_LAUNCH(0);
-        } else if (p == 1) {
+        } else if (!thresholded_once) {
             PF_LAUNCH(1);
+            thresholded_once = true;
         } else {
             PF_LAUNCH(2);
             hipLaunchKernelGGL(bucket_kernel, dim3(8, PF_GRID), dim3(256), 0, st, (const uint4 *)w.wg_list, (const int *)w.wg_count,
