@@ -198,12 +198,14 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int tiles_n = (g.N + BN - 1) / BN;
-    int wg;
+    // (index arithmetic is unsigned 32-bit on purpose: every workgroup runs it before its first load, and the signed / 64-bit
+    // divisions it used to contain were ~300 scalar instructions of software division)
+    const unsigned int tiles_n = ((unsigned int)g.N + BN - 1) / BN;
+    unsigned int wg;
     {   // XCD-aware tile order (see gemm.hip)
         // (re-mapping the workgroups that share a CU onto horizontally adjacent tiles was measured: no L1 reuse, no gain)
-        const int nwg = ntiles, xcd = tb & 7, local = tb >> 3;
-        const int q = nwg >> 3, r = nwg & 7;
+        const unsigned int nwg = (unsigned int)ntiles, xcd = (unsigned int)tb & 7u, local = (unsigned int)tb >> 3;
+        const unsigned int q = nwg >> 3, r = nwg & 7u;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
     }
     // An XCD's chunk of consecutive tiles walks ONE operand in full and a slice of the other (the 8 L2s are not coherent:
@@ -211,17 +213,23 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
     // operand be the one every L2 fetches whole (PMC, round 2: 12.1 GB of L2-side fetches + writes per step against 4.7 GB
     // of single-copy bytes, mostly the weight matrices fetched by all eight L2s).
 #ifndef SKY_TILE_ROWMAJOR
-    const int tiles_m = (g.M + BM - 1) / BM;
+    const unsigned int tiles_m = ((unsigned int)g.M + BM - 1) / BM;
     const bool colmajor = g.N > g.M;
-    const int tile_m = colmajor ? wg % tiles_m : wg / tiles_n, tile_n = colmajor ? wg / tiles_m : wg % tiles_n;
+    const unsigned int div = colmajor ? tiles_m : tiles_n, quo = wg / div, rem = wg - quo * div;     // one division
+    const int tile_m = (int)(colmajor ? rem : quo), tile_n = (int)(colmajor ? quo : rem);
 #else
-    const int tile_m = wg / tiles_n, tile_n = wg % tiles_n;
+    const unsigned int quo = wg / tiles_n;
+    const int tile_m = (int)quo, tile_n = (int)(wg - quo * tiles_n);
 #endif
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const bf16_t *A = (const bf16_t *)g.A;
     const bf16_t *B = (const bf16_t *)g.B;
     const int KT_all = g.K / BK;
-    const int kt_begin = (int)((int64_t)KT_all * split / S), KT = (int)((int64_t)KT_all * (split + 1) / S) - kt_begin;
+    int kt_begin = 0, KT = KT_all;
+    if (S > 1) {   // K / 64 * 8 < 2^32
+        kt_begin = (int)((unsigned int)KT_all * (unsigned int)split / (unsigned int)S);
+        KT = (int)((unsigned int)KT_all * (unsigned int)(split + 1) / (unsigned int)S) - kt_begin;
+    }
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -391,9 +399,12 @@ template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(const skyemb_gemm_args g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int S = g.split_k > 1 ? g.split_k : 1;           // split-K factor (host-resolved)
-    const int ntiles = gridDim.x / S;
-    const int split = blockIdx.x / ntiles;
-    gemm_pipe_body<BM, BN, A_KC, B_KC, NSTAGE, WM, WN>(g, blockIdx.x - split * ntiles, ntiles, split, S, smem);
+    unsigned int ntiles = gridDim.x, split = 0;
+    if (S > 1) {
+        ntiles = gridDim.x / (unsigned int)S;
+        split = blockIdx.x / ntiles;
+    }
+    gemm_pipe_body<BM, BN, A_KC, B_KC, NSTAGE, WM, WN>(g, (int)(blockIdx.x - split * ntiles), (int)ntiles, (int)split, S, smem);
 }
 
 // Grouped launch: several independent problems in ONE grid (the four weight-gradient GEMMs of a transformer block,
