@@ -221,10 +221,12 @@ int skyemb_masked_patch_loss(const float *imgs, const float *pred, const float *
  * pred_tok fp32 [B*(L+extra), C*p*p] (column c*p*p + py*p + px == PixelShuffle(p) of the Conv1x1 output) with
  * weights w = pixel_mask where the target is not NaN:  loss = sum(w*l) / (sum(w) + 1e-5), optional per-patch
  * normalisation of the target.  Outputs: loss, dpred_tok (dtype, same layout; extra rows zero; may be NULL),
- * pred_img fp32 [B,C,H,W] (the reference's `pred`; may be NULL).  ws: 4*B*L + 4 floats. */
+ * pred_img fp32 [B,C,H,W] (the reference's `pred`; may be NULL).  ws: 4*B*L + 4 floats.
+ * pooled != 0 (attention-pooled models, utils/mim_vit.py:250): pred_tok / dpred_tok are [B, C*H*W], one row per image laid
+ * out like the image (PixelShuffle(img_size) of the head's output); p stays the patch size of the normalisation; extra = 0. */
 int skyemb_simmim_pixel_loss(const float *imgs, const float *pred_tok, const float *pixel_mask, float *loss, void *dpred_tok,
                              int dtype, float *pred_img, float *ws, int B, int C, int H, int W, int p, int extra,
-                             float pixel_mean, float pixel_std, int norm_pix, int loss_l1, void *stream);
+                             float pixel_mean, float pixel_std, int norm_pix, int loss_l1, int pooled, void *stream);
 
 /* ----------------------------------------------------------- optimiser ----
  * torch.optim.AdamW single-tensor update order (utils/mim_vit.py:126-129,
@@ -315,6 +317,17 @@ int skyemb_bank16_prepare(const float *bank, const float *xn, int64_t N, int D, 
 int skyemb_cosine_topk_prefiltered(const float *tw, const float *qn, int Q, const float *bank, const float *xn, const void *bank16,
                                    const float *rowp, int64_t N, int D, int k, float eps, int64_t idx_offset, const float *thr0,
                                    void *ws, int64_t ws_bytes, float *out_s, int64_t *out_i, int *redo, void *stream);
+/* Attention pooling with one learned query (timm AttentionPoolLatent as built at utils/mim_vit.py:246-249 and applied at
+ * :426-427; SimMIM models with attn_pool = True).  q [D] = Wq latent + bq is sample-independent (skyemb_attnpool_q);
+ * kv [B, N, 2, H, hd] is the kv projection's output (compute dtype); fwd: out [B, D] (compute dtype) = softmax(scale q.k) v
+ * per head, prob [B, H, N] fp32 saved for backward; bwd: dkv [B, N, 2, H, hd], dq_part [B, D] fp32 (per-sample dq);
+ * skyemb_attnpool_q_bwd sums dq_part over the batch -> dWq = dq latent^T, dbq = dq, dlatent = Wq^T dq (ws: D floats). */
+int skyemb_attnpool_q(const float *latent, const float *Wq, const float *bq, float *q, int D, void *stream);
+int skyemb_attnpool_fwd(const float *q, const void *kv, int dtype, void *out, float *prob, int B, int N, int H, int hd, void *stream);
+int skyemb_attnpool_bwd(const float *q, const void *kv, int dtype, const void *dout, const float *prob, void *dkv, float *dq_part,
+                        int B, int N, int H, int hd, void *stream);
+int skyemb_attnpool_q_bwd(const float *dq_part, int B, const float *latent, const float *Wq, float *dWq, float *dbq, float *dlatent,
+                          float *ws, int D, void *stream);
 /* plain score matrix for the reference-shaped path with P>1 patches per sample
  * (utils/similarity.py:262-267 combine over patches happens on these): scores [Q, N]. */
 int skyemb_cosine_scores(const float *tw, const float *qn, const float *bank, const float *xn, int Q, int64_t N,

@@ -40,6 +40,7 @@ class MAEConfig:
     pixel_std: float = 1.0
     simmim: bool = False
     ra_dec: bool = False          # RA/Dec token from the LocationEncoder (mim_vit.py:209-216, location_encoder.py)
+    attn_pool: bool = False       # SimMIM only: timm AttentionPoolLatent after the blocks, head up-samples to the image (mim_vit.py:246-250)
     ln_eps: float = 1e-6          # partial(nn.LayerNorm, eps=1e-6), mim_vit.py:565
 
     @property
@@ -145,6 +146,15 @@ def state_layout(cfg: MAEConfig):
     out += [("norm.weight", (D,)), ("norm.bias", (D,))]
     if cfg.simmim:
         up = cfg.patch_size  # build deviation from mim_vit.py:255 (tile_size); identical when H == p*p
+        if cfg.attn_pool:    # mim_vit.py:246-250: one pooled token per image, the head up-samples it to the whole image
+            hid = int(D * cfg.mlp_ratio)
+            out += [("attn_pool.latent", (1, 1, D)), ("attn_pool.q.weight", (D, D)), ("attn_pool.q.bias", (D,)),
+                    ("attn_pool.kv.weight", (2 * D, D)), ("attn_pool.kv.bias", (2 * D,)),
+                    ("attn_pool.proj.weight", (D, D)), ("attn_pool.proj.bias", (D,)),
+                    ("attn_pool.norm.weight", (D,)), ("attn_pool.norm.bias", (D,)),
+                    ("attn_pool.mlp.fc1.weight", (hid, D)), ("attn_pool.mlp.fc1.bias", (hid,)),
+                    ("attn_pool.mlp.fc2.weight", (D, hid)), ("attn_pool.mlp.fc2.bias", (D,))]
+            up = cfg.img_size
         out += [("decoder.0.weight", (up * up * C, D, 1, 1)), ("decoder.0.bias", (up * up * C,))]
     else:
         out += [("decoder_embed.weight", (Dd, D)), ("decoder_embed.bias", (Dd,))]
@@ -172,6 +182,8 @@ def init_state(cfg: MAEConfig, seed: int = 0) -> "OrderedDict[str, torch.Tensor]
             t = torch.from_numpy(sincos_pos_embed(shape[-1], cfg.grid, True, cfg.ra_dec)).float().unsqueeze(0)
         elif name in ("cls_token", "mask_token"):
             t = torch.randn(shape, generator=gen) * 0.02
+        elif name == "attn_pool.latent":       # timm AttentionPoolLatent.init_weights: trunc_normal_tf_(std = dim ** -0.5)
+            t = (torch.randn(shape, generator=gen) * shape[-1] ** -0.5).clamp_(-2 * shape[-1] ** -0.5, 2 * shape[-1] ** -0.5)
         elif name.startswith("ra_dec_embed."):
             # Siren.init_ (location_encoder.py:41-49): first layer U(-1/dim_in, 1/dim_in); last layer
             # U(-sqrt(6/dim_in)/w0, +) with w0 = 1; biases drawn from the same range
@@ -341,6 +353,25 @@ def block(x, st, prefix, num_heads, eps):
     return x
 
 
+def attention_pool_latent(x, st, num_heads, eps, prefix="attn_pool"):
+    """timm.layers.AttentionPoolLatent as the reference builds it (mim_vit.py:246-249: latent_len = 1, qkv_bias, no q/k norm,
+    no positional table, pool_type 'token'): ONE learned query attends over all tokens; then x + Mlp(LayerNorm(x)).
+    x [B, N, D] -> [B, D].  (timm is absent: restated from its published forward, like the Block.)"""
+    B, N, D = x.shape
+    hd = D // num_heads
+    q = F.linear(st[f"{prefix}.latent"].expand(B, -1, -1), st[f"{prefix}.q.weight"], st[f"{prefix}.q.bias"])
+    q = q.reshape(B, 1, num_heads, hd).transpose(1, 2)                                  # [B, H, 1, hd]
+    kv = F.linear(x, st[f"{prefix}.kv.weight"], st[f"{prefix}.kv.bias"]).reshape(B, N, 2, num_heads, hd).permute(2, 0, 3, 1, 4)
+    k, v = kv.unbind(0)                                                                 # [B, H, N, hd]
+    att = ((q * hd ** -0.5) @ k.transpose(-2, -1)).softmax(dim=-1)
+    o = (att @ v).transpose(1, 2).reshape(B, 1, D)
+    o = F.linear(o, st[f"{prefix}.proj.weight"], st[f"{prefix}.proj.bias"])
+    h = layer_norm(o, st[f"{prefix}.norm.weight"], st[f"{prefix}.norm.bias"], eps)
+    h = F.linear(F.gelu(F.linear(h, st[f"{prefix}.mlp.fc1.weight"], st[f"{prefix}.mlp.fc1.bias"])),
+                 st[f"{prefix}.mlp.fc2.weight"], st[f"{prefix}.mlp.fc2.bias"])
+    return (o + h)[:, 0]
+
+
 def forward_features(st, x, cfg: MAEConfig, mask_ratio=0.0, noise=None, mask=None, reshape_out=True, ra_dec=None):
     """mim_vit.py:381-438."""
     B = x.shape[0]
@@ -366,9 +397,12 @@ def forward_features(st, x, cfg: MAEConfig, mask_ratio=0.0, noise=None, mask=Non
     x = torch.cat((cls, x), dim=1)
     for i in range(cfg.depth):
         x = block(x, st, f"blocks.{i}", cfg.num_heads, cfg.ln_eps)
+    if cfg.simmim and cfg.attn_pool:
+        x = attention_pool_latent(x, st, cfg.num_heads, cfg.ln_eps).unsqueeze(1)      # mim_vit.py:426-427
     x = layer_norm(x, st["norm.weight"], st["norm.bias"], cfg.ln_eps)
     if cfg.simmim and reshape_out:
-        x = x[:, E:]
+        if not cfg.attn_pool:
+            x = x[:, E:]
         Bb, L, C = x.shape
         H = W = int(L ** 0.5)
         x = x.permute(0, 2, 1).reshape(Bb, C, H, W)
@@ -380,7 +414,8 @@ def forward_decoder(st, x, ids_restore, cfg: MAEConfig):
     E = cfg.num_extra_tokens
     if cfg.simmim:
         x = F.conv2d(x, st["decoder.0.weight"], st["decoder.0.bias"])
-        return F.pixel_shuffle(x, cfg.patch_size)  # reference: tile_size (== patch_size when H == p*p)
+        # reference: tile_size (== patch_size when H == p*p), img_size behind an attention pool (mim_vit.py:250)
+        return F.pixel_shuffle(x, cfg.img_size if cfg.attn_pool else cfg.patch_size)
     x = F.linear(x, st["decoder_embed.weight"], st["decoder_embed.bias"])
     n_mask = ids_restore.shape[1] + E - x.shape[1]
     mask_tokens = st["mask_token"].repeat(x.shape[0], n_mask, 1)

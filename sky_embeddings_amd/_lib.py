@@ -71,10 +71,14 @@ PROTOTYPES = {
     "skyemb_radec_token_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "skyemb_radec_token_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "skyemb_simmim_pixel_loss": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
-                                         c_f32, c_f32, c_i32, c_i32, c_vp]),
+                                         c_f32, c_f32, c_i32, c_i32, c_i32, c_vp]),
     "skyemb_gather_rows_host": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i32]),
     "skyemb_h5_unchunk_host": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32]),
     "skyemb_augment": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "skyemb_attnpool_q": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    "skyemb_attnpool_fwd": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "skyemb_attnpool_bwd": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "skyemb_attnpool_q_bwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "skyemb_clip_crop": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_f32, c_i32, c_i32, c_vp]),
     "skyemb_layernorm_bwd_blocks": (c_i32, [c_i32]),
     "skyemb_layernorm_bwd_reduce_batch": (c_i32, [c_vp, c_i32, c_i32, c_vp]),

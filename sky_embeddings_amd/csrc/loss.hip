@@ -135,7 +135,7 @@ __device__ __forceinline__ int64_t simmim_pixel(int b, int l, int e, int C, int 
 __global__ __launch_bounds__(256) void simmim_pass1(const float *__restrict__ imgs, const float *__restrict__ pred,
                                                     const float *__restrict__ pmask, float *__restrict__ ws, int C, int H,
                                                     int W, int p, int L, int extra, float mean, float stdv, int norm_pix,
-                                                    int loss_l1) {
+                                                    int loss_l1, int pooled) {
     __shared__ float red[4];
     const int b = blockIdx.x / L, l = blockIdx.x % L;
     const int pv = C * p * p;
@@ -158,13 +158,15 @@ __global__ __launch_bounds__(256) void simmim_pass1(const float *__restrict__ im
         q = block_sum(q, red);
         istd = 1.0f / sqrtf(q / n + 1.0e-6f);
     }
+    // prediction of pixel `pix`: element e of the patch's token row, or -- behind an attention pool, whose one row per image
+    // is up-sampled by PixelShuffle(img_size) -- the row laid out like the image itself
     const float *pr = pred + ((int64_t)b * (L + extra) + extra + l) * pv;
     float s = 0.f, n = 0.f;
     for (int e = threadIdx.x; e < pv; e += 256) {
         const int64_t pix = simmim_pixel(b, l, e, C, H, W, p);
         float t = (imgs[pix] - mean) / stdv;
         if (norm_pix) t = (t - mu) * istd;
-        const float d = t - pr[e];
+        const float d = t - (pooled ? pred[pix] : pr[e]);
         const float w = pmask[pix];
         if (d == d) { s += w * (loss_l1 ? fabsf(d) : d * d); n += w; }
     }
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void simmim_pass2(const float *__restrict__ im
                                                     const float *__restrict__ pmask, const float *__restrict__ ws,
                                                     T *__restrict__ dpred, float *__restrict__ pred_img, int C, int H, int W,
                                                     int p, int L, int extra, float mean, float stdv, int norm_pix,
-                                                    int loss_l1, int BL) {
+                                                    int loss_l1, int BL, int pooled) {
     const int Nd = L + extra;
     const int b = blockIdx.x / Nd, r = blockIdx.x % Nd;
     const int pv = C * p * p;
@@ -193,7 +195,8 @@ __global__ __launch_bounds__(256) void simmim_pass2(const float *__restrict__ im
     const float mu = ws[((int64_t)b * L + l) * 4 + 2], istd = ws[((int64_t)b * L + l) * 4 + 3];
     for (int e = threadIdx.x; e < pv; e += 256) {
         const int64_t pix = simmim_pixel(b, l, e, C, H, W, p);
-        const float pe = pred[off + e];
+        const int64_t at = pooled ? pix : off + e;
+        const float pe = pred[at];
         if (pred_img) pred_img[pix] = pe;
         if (!dpred) continue;
         float t = (imgs[pix] - mean) / stdv;
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(256) void simmim_pass2(const float *__restrict__ im
         const float d = pe - t;
         float g = 0.f;
         if (d == d) g = pmask[pix] * (loss_l1 ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : 2.f * d) * inv;
-        dpred[off + e] = from_f32<T>(g);
+        dpred[at] = from_f32<T>(g);
     }
 }
 
@@ -233,20 +236,21 @@ extern "C" int skyemb_masked_patch_loss(const float *imgs, const float *pred, co
 extern "C" int skyemb_simmim_pixel_loss(const float *imgs, const float *pred_tok, const float *pixel_mask, float *loss,
                                         void *dpred_tok, int dtype, float *pred_img, float *ws, int B, int C, int H, int W,
                                         int p, int extra, float pixel_mean, float pixel_std, int norm_pix, int loss_l1,
-                                        void *stream) {
+                                        int pooled, void *stream) {
     SKY_CHECK_ARG(B > 0 && C > 0 && p > 0 && H % p == 0 && W % p == 0 && extra >= 0 && pixel_mask, "skyemb_simmim_pixel_loss: bad arguments");
+    SKY_CHECK_ARG(!pooled || extra == 0, "skyemb_simmim_pixel_loss: a pooled prediction has one row per image (extra = 0)");
     hipStream_t st = (hipStream_t)stream;
     const int L = (H / p) * (W / p), BL = B * L;
     hipLaunchKernelGGL(simmim_pass1, dim3(BL), dim3(256), 0, st, imgs, pred_tok, pixel_mask, ws, C, H, W, p, L, extra, pixel_mean,
-                       pixel_std, norm_pix, loss_l1);
+                       pixel_std, norm_pix, loss_l1, pooled);
     hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(256), 0, st, ws, loss, BL, 1.0f);   // scale = sum(w) (n/numel*numel)
     if (dpred_tok || pred_img) {
         if (dtype == SKYEMB_BF16)
             hipLaunchKernelGGL(simmim_pass2<bf16_t>, dim3(B * (L + extra)), dim3(256), 0, st, imgs, pred_tok, pixel_mask, ws,
-                               (bf16_t *)dpred_tok, pred_img, C, H, W, p, L, extra, pixel_mean, pixel_std, norm_pix, loss_l1, BL);
+                               (bf16_t *)dpred_tok, pred_img, C, H, W, p, L, extra, pixel_mean, pixel_std, norm_pix, loss_l1, BL, pooled);
         else
             hipLaunchKernelGGL(simmim_pass2<float>, dim3(B * (L + extra)), dim3(256), 0, st, imgs, pred_tok, pixel_mask, ws,
-                               (float *)dpred_tok, pred_img, C, H, W, p, L, extra, pixel_mean, pixel_std, norm_pix, loss_l1, BL);
+                               (float *)dpred_tok, pred_img, C, H, W, p, L, extra, pixel_mean, pixel_std, norm_pix, loss_l1, BL, pooled);
     }
     SKY_LAUNCH_CHECK("skyemb_simmim_pixel_loss");
     return 0;

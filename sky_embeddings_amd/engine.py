@@ -99,8 +99,8 @@ class MAEEngine:
     _modes = "mae"      # SimMIMEngine (simmim_engine.py) handles simmim=True and the RA/Dec token
 
     def __init__(self, cfg: MAEConfig, device="cuda", compute_dtype=torch.bfloat16, seed=None):
-        if cfg.attn_pool:
-            raise NotImplementedError("attn_pool (timm AttentionPoolLatent) is a 'next' row (SURVEY.md §8f)")
+        if cfg.attn_pool and not cfg.simmim:
+            raise ValueError("attn_pool exists in SimMIM mode only (utils/mim_vit.py:244-254, :282)")
         if cfg.simmim and self._modes == "mae":
             raise NotImplementedError("simmim=True is served by sky_embeddings_amd.simmim_engine.SimMIMEngine")
         assert cfg.embed_dim % cfg.num_heads == 0 and cfg.decoder_embed_dim % cfg.decoder_num_heads == 0
@@ -129,6 +129,9 @@ class MAEEngine:
             shape = st.shapes[name]
             if name in ("cls_token", "mask_token"):
                 t = torch.randn(shape, generator=gen) * 0.02
+            elif name == "attn_pool.latent":     # timm AttentionPoolLatent.init_weights: trunc_normal_tf_(std = dim ** -0.5)
+                sd_ = shape[-1] ** -0.5
+                t = (torch.randn(shape, generator=gen) * sd_).clamp_(-2 * sd_, 2 * sd_)
             elif name == "patch_mask_values":
                 t = torch.zeros(shape)
             elif name == "patch_embed.proj.bias" or name.startswith("decoder.0."):

@@ -49,6 +49,16 @@ class MAEConfig:
     def num_extra_tokens(self):
         return 2 if self.ra_dec else 1
 
+    @property
+    def head_up(self):
+        """Up-sampling factor of the SimMIM head (Conv1x1 + PixelShuffle): the patch size, or the whole image behind an
+        attention pool (utils/mim_vit.py:250)."""
+        return self.img_size if self.attn_pool else self.patch_size
+
+    @property
+    def head_dim(self):
+        return self.head_up * self.head_up * self.in_chans
+
 
 # utils/mim_vit.py:561-612 factories.  'tiny' is a build extension (SURVEY.md §0) for the
 # BASELINE.json configs[0] plumbing case: ViT-Tiny encoder (D=192, 3 heads) + MAE default decoder.
@@ -124,7 +134,15 @@ def state_layout(cfg: MAEConfig):
         out += _block(f"blocks.{i}", D, int(D * cfg.mlp_ratio))
     out += [("norm.weight", (D,)), ("norm.bias", (D,))]
     if cfg.simmim:
-        out += [("decoder.0.weight", (p * p * C, D, 1, 1)), ("decoder.0.bias", (p * p * C,))]
+        if cfg.attn_pool:   # timm AttentionPoolLatent (utils/mim_vit.py:246-249): latent_len 1, q / kv / proj, norm, Mlp
+            hid = int(D * cfg.mlp_ratio)
+            out += [("attn_pool.latent", (1, 1, D)), ("attn_pool.q.weight", (D, D)), ("attn_pool.q.bias", (D,)),
+                    ("attn_pool.kv.weight", (2 * D, D)), ("attn_pool.kv.bias", (2 * D,)),
+                    ("attn_pool.proj.weight", (D, D)), ("attn_pool.proj.bias", (D,)),
+                    ("attn_pool.norm.weight", (D,)), ("attn_pool.norm.bias", (D,)),
+                    ("attn_pool.mlp.fc1.weight", (hid, D)), ("attn_pool.mlp.fc1.bias", (hid,)),
+                    ("attn_pool.mlp.fc2.weight", (D, hid)), ("attn_pool.mlp.fc2.bias", (D,))]
+        out += [("decoder.0.weight", (cfg.head_dim, D, 1, 1)), ("decoder.0.bias", (cfg.head_dim,))]
         return out
     out += [("decoder_embed.weight", (Dd, D)), ("decoder_embed.bias", (Dd,))]
     for i in range(cfg.decoder_depth):

@@ -101,6 +101,26 @@ def augment(imgs, out, params, nan_mask, noise, A):
     check(lib().skyemb_augment(_p(imgs), _p(out), _p(params), _p(nan_mask), _p(noise), B, C, S, A, _stream()), "skyemb_augment")
 
 
+def attnpool_q(latent, Wq, bq, q):
+    """q [D] = Wq latent + bq: the sample-independent query of the attention pool (timm AttentionPoolLatent)."""
+    check(lib().skyemb_attnpool_q(_p(latent), _p(Wq), _p(bq), _p(q), q.numel(), _stream()), "skyemb_attnpool_q")
+
+
+def attnpool_fwd(q, kv, out, prob, B, N, H, hd):
+    check(lib().skyemb_attnpool_fwd(_p(q), _p(kv), dtype_code(kv.dtype), _p(out), _p(prob), B, N, H, hd, _stream()), "skyemb_attnpool_fwd")
+
+
+def attnpool_bwd(q, kv, dout, prob, dkv, dq_part, B, N, H, hd):
+    check(lib().skyemb_attnpool_bwd(_p(q), _p(kv), dtype_code(kv.dtype), _p(dout), _p(prob), _p(dkv), _p(dq_part), B, N, H, hd,
+                                    _stream()), "skyemb_attnpool_bwd")
+
+
+def attnpool_q_bwd(dq_part, latent, Wq, dWq, dbq, dlatent, ws):
+    B, D = dq_part.shape
+    check(lib().skyemb_attnpool_q_bwd(_p(dq_part), B, _p(latent), _p(Wq), _p(dWq), _p(dbq), _p(dlatent), _p(ws), D, _stream()),
+          "skyemb_attnpool_q_bwd")
+
+
 def simmim_mask_from_noise(noise, ratio_u, max_ratio, grid, p, out_mask):
     """Per-channel random patch masks for SimMIM (utils/dataloaders.py:197-219) from uniform draws: noise [B,C,L], ratio_u [B]."""
     B, C, L = noise.shape
@@ -145,11 +165,11 @@ def radec_token_bwd(g_rows, row_stride, W1, sh, z, dz_ws, dW0, db0, dW1, db1, B,
 
 
 def simmim_pixel_loss(imgs, pred_tok, pixel_mask, loss, dpred_tok, dtype, pred_img, ws, p, extra, pixel_mean, pixel_std,
-                      norm_pix, loss_l1):
+                      norm_pix, loss_l1, pooled=False):
     B, C, H, W = imgs.shape
     check(lib().skyemb_simmim_pixel_loss(_p(imgs), _p(pred_tok), _p(pixel_mask), _p(loss), _p(dpred_tok), dtype, _p(pred_img),
                                          _p(ws), B, C, H, W, p, extra, pixel_mean, pixel_std, int(norm_pix), int(loss_l1),
-                                         _stream()), "skyemb_simmim_pixel_loss")
+                                         int(pooled), _stream()), "skyemb_simmim_pixel_loss")
 
 
 def layernorm_fwd(x, gamma, beta, y, mean, rstd, M, D, eps, y32=None, dtype=None):

@@ -6,6 +6,11 @@ transformer-block forward / backward, LayerNorm batching and grouped weight-grad
 Sequence layout: Ne = E + L tokens per sample, E = 1 (cls) or 2 (cls, RA/Dec); rows b*Ne + {0: cls, 1: RA/Dec, E + l: patch l}.
 The head runs over all M = B*Ne rows (the E extra rows are ignored by the loss, whose gradient for them is zero): one
 plain GEMM instead of a gather.
+
+``attn_pool = True`` (utils/mim_vit.py:246-250, 426-427): after the blocks, timm's AttentionPoolLatent pools each sample's
+tokens into ONE row (a learned query attends over them; then x + Mlp(LayerNorm(x))), the final norm and the head run on
+[B, D] rows, and the head up-samples each row to the whole image (PixelShuffle(img_size) = the loss kernel's index map with
+one "patch" the size of the image).
 """
 from __future__ import annotations
 
@@ -21,7 +26,7 @@ def simmim_stage_ranges(store, cfg: MAEConfig, n_encoder_groups: int = 3):
     """Backward stages [head, encoder block groups (top first) ..., embedding] -> slices of the flat gradient buffer
     that are final after each (cf. engine.stage_gradient_ranges)."""
     off = store.offsets
-    head0 = off["decoder.0.weight"]
+    head0 = off["attn_pool.latent"] if cfg.attn_pool else off["decoder.0.weight"]    # (layout order: the pool precedes the head)
     ranges = [[(head0, store.n_decay)]]
     bounds = sorted({round(cfg.depth * k / n_encoder_groups) for k in range(n_encoder_groups + 1)}, reverse=True)
     groups = []
@@ -70,12 +75,37 @@ class SimMIMEngine(MAEEngine):
         w["lat_lp"] = torch.empty(M, D, **lp)
         w["lat_mean"], w["lat_rstd"] = torch.empty(M, **f32), torch.empty(M, **f32)
         w["sh"], w["z"], w["dz"] = torch.empty(B, 25, **f32), torch.empty(B, 8, **f32), torch.empty(B, 8, **f32)
+        pool = cfg.attn_pool
+        R = B if pool else M                     # rows the final norm and the head see
+        pvh = cfg.head_dim
+        if pool:
+            H = cfg.num_heads
+            w["ap_x"] = torch.empty(M, D, **lp)                       # block output in the compute dtype (kv projection operand)
+            w["ap_kv"] = torch.empty(M, 2 * D, **lp)
+            w["ap_q"] = torch.empty(D, **f32)
+            w["ap_prob"] = torch.empty(B, H, Ne, **f32)
+            w["ap_o"] = torch.empty(B, D, **lp)
+            w["ap_y"] = torch.empty(B, D, **f32)                      # proj output (residual stream of the pool)
+            w["ap_ln"] = torch.empty(B, D, **lp)
+            w["ap_mean"], w["ap_rstd"] = torch.empty(B, **f32), torch.empty(B, **f32)
+            w["ap_hpre"], w["ap_hact"] = torch.empty(B, hidden, **lp), torch.empty(B, hidden, **lp)
+            w["ap_z"] = torch.empty(B, D, **f32)
+            w["lat_lp"] = torch.empty(B, D, **lp)
+            w["latent32"] = torch.empty(B, D, **f32)
+            w["lat_mean"], w["lat_rstd"] = torch.empty(B, **f32), torch.empty(B, **f32)
         if train:
-            w["pred_tok"] = torch.empty(M, pv, **f32)
+            w["pred_tok"] = torch.empty(R, pvh, **f32)
             w["pred_img"] = torch.empty(B, cfg.in_chans, cfg.img_size, cfg.img_size, **f32)
             w["loss"] = torch.zeros(1, **f32)
             w["loss_ws"] = torch.empty(4 * B * L + 4, **f32)
-            w["dpred"] = torch.empty(M, pv, **lp)
+            w["dpred"] = torch.empty(R, pvh, **lp)
+            if pool:
+                w["ap_gz"], w["ap_gz_lp"] = torch.empty(B, D, **f32), torch.empty(B, D, **lp)
+                w["ap_gy"], w["ap_gy_lp"] = torch.empty(B, D, **f32), torch.empty(B, D, **lp)
+                w["ap_dln"], w["ap_dh"] = torch.empty(B, D, **lp), torch.empty(B, hidden, **lp)
+                w["ap_do"] = torch.empty(B, D, **lp)
+                w["ap_dkv"] = torch.empty(M, 2 * D, **lp)
+                w["ap_dq"], w["ap_dq_ws"] = torch.empty(B, D, **f32), torch.empty(D, **f32)
             w["g"] = torch.empty(M * D, **f32)
             w["g_lp"] = torch.empty(M * D, **lp)
             w["g_lp2"] = torch.empty(M * D, **lp)
@@ -91,7 +121,7 @@ class SimMIMEngine(MAEEngine):
             w["pmv_part"] = torch.empty(B, pv, **f32)
             w["rs_part"] = torch.empty(64, D, **f32)
             w["splitk_ws"] = self._splitk_ws
-            order = [("norm", M, D)]
+            order = [("norm", R, D)] + ([("attn_pool.norm", B, D)] if pool else [])
             for i in reversed(range(cfg.depth)):
                 order += [(f"blocks.{i}.norm2", M, D), (f"blocks.{i}.norm1", M, D)]
             entries = []
@@ -152,9 +182,32 @@ class SimMIMEngine(MAEEngine):
             else:
                 self._block_fwd(xs[i % 2], xs[(i + 1) % 2], w["enc"][0], f"blocks.{i}", M, D, cfg.num_heads, B, Ne)
         x_last = xs[cfg.depth] if train else xs[cfg.depth % 2]
+        if cfg.attn_pool:
+            self._pool_fwd(x_last, w, B, Ne)
+            ops.layernorm_fwd(w["ap_z"], st.param("norm.weight"), st.param("norm.bias"), w["lat_lp"], w["lat_mean"], w["lat_rstd"],
+                              B, D, cfg.ln_eps, y32=w["latent32"])
+            return x_last
         ops.layernorm_fwd(x_last, st.param("norm.weight"), st.param("norm.bias"), w["lat_lp"], w["lat_mean"], w["lat_rstd"],
                           M, D, cfg.ln_eps, y32=w["latent32"])
         return x_last
+
+    def _pool_fwd(self, x_last, w, B, Ne):
+        """timm AttentionPoolLatent (utils/mim_vit.py:426-427): [B*Ne, D] fp32 block output -> w["ap_z"] [B, D] fp32."""
+        cfg, st = self.cfg, self.store
+        D, H = cfg.embed_dim, cfg.num_heads
+        M, hidden = B * Ne, int(D * cfg.mlp_ratio)
+        P, LP = st.param, st.lp
+        ops.cast(x_last, w["ap_x"], M * D)
+        ops.gemm(w["ap_x"], LP("attn_pool.kv.weight"), M=M, N=2 * D, K=D, bias=P("attn_pool.kv.bias"), out=w["ap_kv"])
+        ops.attnpool_q(P("attn_pool.latent"), P("attn_pool.q.weight"), P("attn_pool.q.bias"), w["ap_q"])
+        ops.attnpool_fwd(w["ap_q"], w["ap_kv"], w["ap_o"], w["ap_prob"], B, Ne, H, D // H)
+        ops.gemm(w["ap_o"], LP("attn_pool.proj.weight"), M=B, N=D, K=D, bias=P("attn_pool.proj.bias"), out_f32=w["ap_y"])
+        ops.layernorm_fwd(w["ap_y"], P("attn_pool.norm.weight"), P("attn_pool.norm.bias"), w["ap_ln"], w["ap_mean"], w["ap_rstd"],
+                          B, D, cfg.ln_eps)
+        ops.gemm(w["ap_ln"], LP("attn_pool.mlp.fc1.weight"), M=B, N=hidden, K=D, bias=P("attn_pool.mlp.fc1.bias"), act=ops.ACT_GELU,
+                 out=w["ap_hact"], out2=w["ap_hpre"])
+        ops.gemm(w["ap_hact"], LP("attn_pool.mlp.fc2.weight"), M=B, N=D, K=hidden, bias=P("attn_pool.mlp.fc2.bias"), resid=w["ap_y"],
+                 ldr=D, out_f32=w["ap_z"], ws=self._splitk_ws)
 
     def forward_features(self, imgs, mask_ratio=0.0, noise=None, mask=None, ra_dec=None):
         """utils/mim_vit.py:381-438 (reshape_out=False): -> (latent fp32 [B, E+L, D], mask, None); tokens keep their order."""
@@ -163,6 +216,8 @@ class SimMIMEngine(MAEEngine):
         B = imgs.shape[0]
         w = self._workspace(B, cfg.num_patches, False)
         self._encoder_fwd_simmim(imgs, mask, ra_dec, w, False)
+        if cfg.attn_pool:
+            return w["latent32"].view(B, 1, cfg.embed_dim), mask, None            # one pooled token per image
         return w["latent32"].view(B, cfg.num_extra_tokens + cfg.num_patches, cfg.embed_dim), mask, None
 
     def forward_train(self, imgs, mask=None, ra_dec=None):
@@ -176,9 +231,12 @@ class SimMIMEngine(MAEEngine):
         w = self._workspace(B, L, True)
         self._encoder_fwd_simmim(imgs, mask, ra_dec, w, True)
         # head: Conv1x1 D -> p*p*C per token; PixelShuffle(p) is the loss kernel's index map (utils/mim_vit.py:254-261,469)
-        ops.gemm(w["lat_lp"], st.lp("decoder.0.weight"), M=M, N=pv, K=D, bias=st.param("decoder.0.bias"), out_f32=w["pred_tok"])
+        pool = cfg.attn_pool         # one row per image, laid out like the image (PixelShuffle(img_size), utils/mim_vit.py:250)
+        ops.gemm(w["lat_lp"], st.lp("decoder.0.weight"), M=B if pool else M, N=cfg.head_dim, K=D, bias=st.param("decoder.0.bias"),
+                 out_f32=w["pred_tok"])
         ops.simmim_pixel_loss(imgs, w["pred_tok"], mask, w["loss"], w["dpred"], self.code, w["pred_img"], w["loss_ws"],
-                              cfg.patch_size, E, cfg.pixel_mean, cfg.pixel_std, cfg.norm_pix_loss, cfg.loss_fn != "mse")
+                              cfg.patch_size, 0 if pool else E, cfg.pixel_mean, cfg.pixel_std, cfg.norm_pix_loss, cfg.loss_fn != "mse",
+                              pooled=pool)
         self._last = (imgs, B, L, mask)
         return w["loss"], w["pred_img"], mask
 
@@ -195,11 +253,39 @@ class SimMIMEngine(MAEEngine):
         D, pv = cfg.embed_dim, cfg.patch_dim
         M = B * (cfg.num_extra_tokens + cfg.num_patches)
         self._ln_first = self._ln_count = 0
+        g, g_lp = w["g"][:M * D].view(M, D), w["g_lp"][:M * D].view(M, D)
+        if cfg.attn_pool:
+            self._pool_bwd(w, B, M // B, g, g_lp)
+            self._end_stage(w)
+            return
         dln = w["dln"][:M * D].view(M, D)
         self._linear_bwd(w["dpred"], w["lat_lp"], "decoder.0.weight", "decoder.0.bias", M, pv, D, w, dx_out=dln)
-        g, g_lp = w["g"][:M * D].view(M, D), w["g_lp"][:M * D].view(M, D)
         self._ln_bwd(dln, w["xs"][cfg.depth], "norm", w["lat_mean"], w["lat_rstd"], None, g, g_lp, M, D, w)
         self._end_stage(w)
+
+    def _pool_bwd(self, w, B, Ne, g, g_lp):
+        """Head, final norm and the attention pool, backwards; leaves d(block output) in g (fp32) / g_lp."""
+        cfg, st = self.cfg, self.store
+        D, H = cfg.embed_dim, cfg.num_heads
+        M, hidden = B * Ne, int(D * cfg.mlp_ratio)
+        P, G = st.param, st.grad
+        self._linear_bwd(w["dpred"], w["lat_lp"], "decoder.0.weight", "decoder.0.bias", B, cfg.head_dim, D, w, dx_out=w["ap_dln"])
+        self._ln_bwd(w["ap_dln"], w["ap_z"], "norm", w["lat_mean"], w["lat_rstd"], None, w["ap_gz"], w["ap_gz_lp"], B, D, w)
+        # z = y + fc2(gelu(fc1(ln(y))))
+        self._linear_bwd(w["ap_gz_lp"], w["ap_hact"], "attn_pool.mlp.fc2.weight", "attn_pool.mlp.fc2.bias", B, D, hidden, w,
+                         dx_out=w["ap_dh"], dx_act=ops.ACT_DGELU, dx_aux=w["ap_hpre"])
+        self._linear_bwd(w["ap_dh"], w["ap_ln"], "attn_pool.mlp.fc1.weight", "attn_pool.mlp.fc1.bias", B, hidden, D, w,
+                         dx_out=w["ap_dln"])
+        self._ln_bwd(w["ap_dln"], w["ap_y"], "attn_pool.norm", w["ap_mean"], w["ap_rstd"], w["ap_gz"], w["ap_gy"], w["ap_gy_lp"],
+                     B, D, w)
+        # y = proj(pool(q, kv(x)))
+        self._linear_bwd(w["ap_gy_lp"], w["ap_o"], "attn_pool.proj.weight", "attn_pool.proj.bias", B, D, D, w, dx_out=w["ap_do"])
+        ops.attnpool_bwd(w["ap_q"], w["ap_kv"], w["ap_do"], w["ap_prob"], w["ap_dkv"], w["ap_dq"], B, Ne, H, D // H)
+        ops.attnpool_q_bwd(w["ap_dq"], P("attn_pool.latent"), P("attn_pool.q.weight"), G("attn_pool.q.weight"), G("attn_pool.q.bias"),
+                           G("attn_pool.latent"), w["ap_dq_ws"])
+        self._wgrad(w["ap_dkv"], w["ap_x"], 2 * D, D, M, G("attn_pool.kv.weight"), G("attn_pool.kv.bias"), w)
+        ops.gemm(w["ap_dkv"], st.lp("attn_pool.kv.weight"), M=M, N=D, K=2 * D, a_layout=KC, b_layout=RC, lda=2 * D, ldb=D,
+                 out_f32=g, ldo32=D, out=g_lp, ws=w["splitk_ws"])
 
     def backward_encoder(self, hi=None, lo=0):
         imgs, B, mask, w = self._ctx()

@@ -69,7 +69,7 @@ class MaskedAutoencoderViT:
         self.simmim, self.loss_fn = simmim, loss_fn
         self.pixel_mean, self.pixel_std = pixel_mean, pixel_std
         self.norm_pix_loss, self.in_chans, self.ra_dec = norm_pix_loss, in_chans, ra_dec
-        self.attn_pool = False
+        self.attn_pool = bool(attn_pool) and bool(simmim)       # utils/mim_vit.py:246-254: SimMIM only (:282 for MAE)
         self.num_extra_tokens = 2 if ra_dec else 1
         self.tile_size = img_size // patch_size
         self.patch_embed = _PatchEmbedInfo(self.cfg)
@@ -143,7 +143,8 @@ class MaskedAutoencoderViT:
             latent, m, _ = self.engine.forward_features(self._prep(x), mask=m, ra_dec=ra_dec)
             latent = latent.clone()
             if reshape_out:
-                latent = latent[:, self.num_extra_tokens:]
+                if not self.attn_pool:                       # a pooled latent is one token: [B, D, 1, 1] (utils/mim_vit.py:431-436)
+                    latent = latent[:, self.num_extra_tokens:]
                 B, L, C = latent.shape
                 H = W = int(L ** 0.5)
                 latent = latent.permute(0, 2, 1).reshape(B, C, H, W)

@@ -88,10 +88,31 @@ def install_standins():
             x = x + self.attn(self.norm1(x))
             return x + self.mlp(self.norm2(x))
 
-    class AttentionPoolLatent(nn.Module):  # placeholder: only built when attn_pool=True
-        def __init__(self, *a, **k):
+    class AttentionPoolLatent(nn.Module):
+        """timm.layers.AttentionPoolLatent restated for the arguments the reference passes (mim_vit.py:246-249):
+        latent_len 1, qkv_bias, no q/k norm, no positional table, pool_type 'token'; init: trunc-normal latent (std dim^-0.5)."""
+        def __init__(self, in_features, num_heads=8, mlp_ratio=4.0, norm_layer=nn.LayerNorm):
             super().__init__()
-            raise NotImplementedError
+            dim = in_features
+            self.num_heads, self.head_dim, self.scale = num_heads, dim // num_heads, (dim // num_heads) ** -0.5
+            self.latent = nn.Parameter(torch.zeros(1, 1, dim))
+            self.q = nn.Linear(dim, dim, bias=True)
+            self.kv = nn.Linear(dim, dim * 2, bias=True)
+            self.proj = nn.Linear(dim, dim)
+            self.norm = norm_layer(dim)
+            self.mlp = Mlp(dim, int(dim * mlp_ratio))
+            nn.init.trunc_normal_(self.latent, std=dim ** -0.5, a=-2 * dim ** -0.5, b=2 * dim ** -0.5)
+
+        def forward(self, x):
+            B, N, C = x.shape
+            q = self.q(self.latent.expand(B, -1, -1)).reshape(B, 1, self.num_heads, self.head_dim).transpose(1, 2)
+            kv = self.kv(x).reshape(B, N, 2, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
+            k, v = kv.unbind(0)
+            attn = ((q * self.scale) @ k.transpose(-2, -1)).softmax(dim=-1)
+            x = (attn @ v).transpose(1, 2).reshape(B, 1, C)
+            x = self.proj(x)
+            x = x + self.mlp(self.norm(x))
+            return x[:, 0]
 
     def param_groups_weight_decay(model, weight_decay=1e-5, no_weight_decay_list=()):
         decay, no_decay = [], []
@@ -207,16 +228,16 @@ def mae_case(mim_vit, pgwd, name, *, img, patch, C=5, D=64, depth=2, heads=4, Dd
 
 
 def simmim_case(mim_vit, pgwd, name, *, img=64, patch=8, C=5, D=64, depth=2, heads=4, norm_pix=True, loss_fn="L1",
-                nan=False, ra_dec=False, B=3, steps=0, seed=0, pixel_mean=0.1, pixel_std=1.3):
+                nan=False, ra_dec=False, B=3, steps=0, seed=0, pixel_mean=0.1, pixel_std=1.3, attn_pool=False):
     """SimMIM mode (mim_vit.py:244-264, 394-399, 431-436, 469, 480-493): per-channel pixel masks, encoder over all tokens,
     Conv1x1 + PixelShuffle head.  Geometry has img == patch**2 so that the reference's ``tile_size`` upsampling equals
     the patch size (its head is only shape-valid there)."""
-    assert img == patch * patch
+    assert attn_pool or img == patch * patch
     torch.manual_seed(seed)
     model = mim_vit.MaskedAutoencoderViT(img_size=img, patch_size=patch, in_chans=C, embed_dim=D, depth=depth,
                                          num_heads=heads, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6),
                                          norm_pix_loss=norm_pix, simmim=True, loss_fn=loss_fn, pixel_mean=pixel_mean,
-                                         pixel_std=pixel_std, ra_dec=ra_dec)
+                                         pixel_std=pixel_std, ra_dec=ra_dec, attn_pool=attn_pool)
     g = torch.Generator().manual_seed(seed + 100)
     with torch.no_grad():
         for n, p in model.named_parameters():
@@ -235,7 +256,7 @@ def simmim_case(mim_vit, pgwd, name, *, img=64, patch=8, C=5, D=64, depth=2, hea
     mask = m.repeat_interleave(patch, dim=2).repeat_interleave(patch, dim=3).contiguous()
     radec = torch.stack([torch.rand(B, generator=g) * 360.0, torch.rand(B, generator=g) * 180.0 - 90.0], dim=1) if ra_dec else None
     out = {"imgs": x.numpy().copy(), "pixel_mask": mask.numpy().copy(),
-           "cfg": np.array([img, patch, C, D, depth, heads, int(norm_pix), int(ra_dec)], dtype=np.int64),
+           "cfg": np.array([img, patch, C, D, depth, heads, int(norm_pix), int(ra_dec), int(attn_pool)], dtype=np.int64),
            "loss_fn": np.array(loss_fn), "pixel_mean": np.float64(pixel_mean), "pixel_std": np.float64(pixel_std)}
     if ra_dec:
         out["ra_dec"] = radec.numpy().copy()
@@ -448,6 +469,11 @@ def main():
         # I: MAE mode WITH the RA/Dec token (two extra tokens through encoder and decoder), three optimiser steps
         mae_case(mim_vit, pgwd, "mae_tiny_I_radec", img=64, patch=16, D=32, heads=2, Dd=32, dheads=2, norm_pix=True, loss_fn="mse",
                  nan=True, ra_dec=True, seed=12, steps=3)
+    if "attnpool" in only or not only:
+        # J: SimMIM behind timm's AttentionPoolLatent (mim_vit.py:246-250, 426-427): one pooled token per image, head up-samples
+        # it to the whole image; NaNs, RA/Dec token, three optimiser steps.  (32 x 32 cutouts keep the D x img^2 C head small.)
+        simmim_case(mim_vit, pgwd, "simmim_tiny_J_attnpool", img=32, patch=8, norm_pix=True, loss_fn="L1", nan=True, ra_dec=True,
+                    D=32, heads=2, seed=13, steps=3, attn_pool=True)
     if only:
         return
     unit_pieces(mim_vit, pos_embed)

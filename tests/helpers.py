@@ -32,10 +32,11 @@ def rel_err(a, b):
 def load_simmim_case(name):
     """SimMIM-mode goldens (tests/golden/make_golden.py simmim_case): -> (npz, cfg, state, imgs, pixel_mask, ra_dec|None)."""
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
-    img, patch, C, D, depth, heads, norm_pix, rd = [int(v) for v in z["cfg"]]
+    img, patch, C, D, depth, heads, norm_pix, rd = [int(v) for v in z["cfg"][:8]]
+    pool = len(z["cfg"]) > 8 and bool(z["cfg"][8])                  # attention pooling (case J)
     cfg = mo.config_for("simmim", img_size=img, patch_size=patch, in_chans=C, embed_dim=D, depth=depth, num_heads=heads,
                         norm_pix_loss=bool(norm_pix), loss_fn=str(z["loss_fn"]), pixel_mean=float(z["pixel_mean"]),
-                        pixel_std=float(z["pixel_std"]), ra_dec=bool(rd))
+                        pixel_std=float(z["pixel_std"]), ra_dec=bool(rd), attn_pool=pool)
     state = OrderedDict()
     for name_, _shape in mo.state_layout(cfg):
         state[name_] = torch.from_numpy(z["state/" + name_].copy())

@@ -208,9 +208,11 @@ def test_pretrain_entry_point_runs(tmp_path, mode):
         assert "decoder.0.weight" in ck["model"] and ck["batch_iters"] >= 12 and np.isfinite(ck["losses"]["train_loss"]).all()
 
 
-def test_simmim_radec_model_through_the_module_api(tmp_path):
-    """A SimMIM + RA/Dec configuration (what the reference's shipped inis train) through utils.mim_vit.build_model,
-    the per-item loader with MaskGenerator, run_iter, checkpoint / resume, mae_latent and mae_predict."""
+@pytest.mark.parametrize("attn_pool", [False, True])
+def test_simmim_radec_model_through_the_module_api(tmp_path, attn_pool):
+    """A SimMIM + RA/Dec configuration (what the reference's shipped inis train), and its attention-pooled variant
+    (attn_pool = True: one pooled token per image, utils/mim_vit.py:246-250), through utils.mim_vit.build_model, the per-item
+    loader with MaskGenerator, run_iter, checkpoint / resume, mae_latent and mae_predict."""
     from collections import defaultdict
     from sky_embeddings_amd import hdf5_lite
     from sky_embeddings_amd.utils.dataloaders import build_h5_dataloader
@@ -218,12 +220,13 @@ def test_simmim_radec_model_through_the_module_api(tmp_path):
     from sky_embeddings_amd.utils.mim_vit import build_model
     from sky_embeddings_amd.utils.pretrain_fns import run_iter
     cfg = _tiny_ini(tmp_path, total_iters=20, bs=8)
-    cfg["ARCHITECTURE"].update(model_type="simmim", patch_size="8", img_size="64", embed_dim="96", ra_dec="True")
+    cfg["ARCHITECTURE"].update(model_type="simmim", patch_size="8", img_size="64", embed_dim="96", ra_dec="True",
+                               attn_pool=str(attn_pool))
     cfg["TRAINING"].update(loss_fn="L1", norm_pix_loss="True", max_mask_ratio="0.9", compute_dtype="f32", init_lr="0.0005")
     path = hdf5_lite.make_synthetic_cutouts(str(tmp_path / "c.h5"), n=32, seed=3, nan_fraction=0.05)
     fn = str(tmp_path / "simmim.pth.tar")
     model, losses, cur_iter, opt, sched = build_model(cfg, fn, "cuda", build_optimizer=True)
-    assert model.module.simmim and model.module.num_extra_tokens == 2
+    assert model.module.simmim and model.module.num_extra_tokens == 2 and bool(model.module.attn_pool) == attn_pool
     dl = build_h5_dataloader(path, batch_size=8, num_workers=0, patch_size=8, num_channels=5, max_mask_ratio=0.9, img_size=64,
                              num_patches=model.module.patch_embed.num_patches, shuffle=False)
     lc = defaultdict(list)
@@ -240,9 +243,11 @@ def test_simmim_radec_model_through_the_module_api(tmp_path):
         assert torch.equal(v, model2.module.state_dict()[k]), k
     lat = mae_latent(model, dl, "cuda", n_batches=2, verbose=0, remove_cls=False)
     lat = lat[0] if isinstance(lat, tuple) else lat
-    assert tuple(lat.shape[1:]) == (2 + 64, 96) and bool(torch.isfinite(torch.as_tensor(lat)).all())
+    assert tuple(lat.shape[1:]) == ((1, 96) if attn_pool else (2 + 64, 96)) and bool(torch.isfinite(torch.as_tensor(lat)).all())
     pred, masked, orig = mae_predict(model, dl, "cuda", None)
     assert pred.shape == orig.shape == (8, 64, 64, 5)
+    img_like, _, _ = model.module.forward_features(next(iter(dl))[0].cuda(), ra_dec=next(iter(dl))[2])
+    assert tuple(img_like.shape) == ((8, 96, 1, 1) if attn_pool else (8, 96, 8, 8))       # reshape_out (utils/mim_vit.py:431-436)
 
 
 @pytest.mark.parametrize("case", ["mae_tiny_A", "mae_tiny_B_nan", "mae_tiny_I_radec"])

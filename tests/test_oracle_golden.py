@@ -51,10 +51,11 @@ def test_forward_backward_matches_reference(name):
     assert rel_err(lat.numpy(), z["latent_full"]) < 2e-6
 
 
-@pytest.mark.parametrize("name", ["simmim_tiny_F_l1_nan", "simmim_tiny_G_mse", "simmim_tiny_H_radec"])
+@pytest.mark.parametrize("name", ["simmim_tiny_F_l1_nan", "simmim_tiny_G_mse", "simmim_tiny_H_radec", "simmim_tiny_J_attnpool"])
 def test_simmim_mode_matches_reference(name):
-    """SimMIM mode (per-channel pixel masks, all tokens encoded, Conv1x1 + PixelShuffle head, pixel loss) and the
-    RA/Dec token (spherical harmonics -> Siren -> linear), forward / backward / three AdamW steps."""
+    """SimMIM mode (per-channel pixel masks, all tokens encoded, Conv1x1 + PixelShuffle head, pixel loss), the
+    RA/Dec token (spherical harmonics -> Siren -> linear) and the attention-pooled variant (case J: one pooled token per image,
+    head up-samples to the image), forward / backward / three AdamW steps."""
     z, cfg, st, imgs, pmask, ra_dec = load_simmim_case(name)
     assert [k[len("state/"):] for k in z.files if k.startswith("state/")] == [n for n, _ in mo.state_layout(cfg)]
     loss, pred, _, _, latent, grads = mo.loss_and_grads(st, imgs, cfg, mask=pmask, ra_dec=ra_dec)

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 from tests.helpers import load_simmim_case, rel_err
 
-CASES = ["simmim_tiny_F_l1_nan", "simmim_tiny_G_mse", "simmim_tiny_H_radec"]
+CASES = ["simmim_tiny_F_l1_nan", "simmim_tiny_G_mse", "simmim_tiny_H_radec", "simmim_tiny_J_attnpool"]   # J: attention-pooled
 
 
 def make_engine(cfg, state, dtype):
@@ -19,7 +19,7 @@ def make_engine(cfg, state, dtype):
     from sky_embeddings_amd.simmim_engine import SimMIMEngine
     c = MAEConfig(img_size=cfg.img_size, patch_size=cfg.patch_size, in_chans=cfg.in_chans, embed_dim=cfg.embed_dim,
                   depth=cfg.depth, num_heads=cfg.num_heads, norm_pix_loss=cfg.norm_pix_loss, loss_fn=cfg.loss_fn,
-                  pixel_mean=cfg.pixel_mean, pixel_std=cfg.pixel_std, simmim=True, ra_dec=cfg.ra_dec)
+                  pixel_mean=cfg.pixel_mean, pixel_std=cfg.pixel_std, simmim=True, ra_dec=cfg.ra_dec, attn_pool=cfg.attn_pool)
     eng = SimMIMEngine(c, device="cuda", compute_dtype=dtype, seed=0)
     eng.load_state_dict(state)
     return eng
@@ -45,7 +45,9 @@ def test_simmim_forward_backward_vs_reference_goldens(name, dtype):
         if f32:
             assert float(np.abs(g - r).max()) <= 2e-4 * scale, (k, float(np.abs(g - r).max()), scale)
         else:
-            assert rel_err(g, r) < 8e-2 or float(np.abs(g - r).max()) < 6e-2 * scale, k
+            # (behind the attention pool every layer sees B = 3 rows: weight gradients are sums of three bf16-rounded outer
+            # products instead of hundreds, so their relative noise is larger)
+            assert rel_err(g, r) < (2e-1 if cfg.attn_pool else 8e-2) or float(np.abs(g - r).max()) < 6e-2 * scale, k
     # encoder-only path (utils/eval_fns.py:115 shape: tokens in order, extra tokens first)
     lat, _, _ = eng.forward_features(imgs.cuda(), mask=pmask.cuda(), ra_dec=rd)
     assert rel_err(lat.cpu().numpy(), z["latent"]) < (2e-5 if f32 else 2e-2)
@@ -54,7 +56,7 @@ def test_simmim_forward_backward_vs_reference_goldens(name, dtype):
         assert rel_err(w["sh"].cpu().numpy(), z["sh_features"]) < 2e-6
 
 
-@pytest.mark.parametrize("name", ["simmim_tiny_F_l1_nan", "simmim_tiny_H_radec"])
+@pytest.mark.parametrize("name", ["simmim_tiny_F_l1_nan", "simmim_tiny_H_radec", "simmim_tiny_J_attnpool"])
 def test_simmim_three_optimiser_steps_match_reference(name):
     """forward + backward + fused AdamW + cosine LR, three steps, vs the reference's parameters (mask_token untouched)."""
     from sky_embeddings_amd.optim import CosineLR, FusedAdamW
@@ -81,11 +83,13 @@ def test_simmim_three_optimiser_steps_match_reference(name):
     assert np.array_equal(sd["mask_token"].cpu().numpy(), z["state_after3/mask_token"])
 
 
-def test_simmim_graph_step_equals_eager_and_staged():
-    """TrainStep in SimMIM mode: HIP-graph replay (monolithic and staged) == eager execution, bit for bit."""
+@pytest.mark.parametrize("case", ["simmim_tiny_H_radec", "simmim_tiny_J_attnpool"])
+def test_simmim_graph_step_equals_eager_and_staged(case):
+    """TrainStep in SimMIM mode (plain and attention-pooled): HIP-graph replay (monolithic and staged) == eager execution,
+    bit for bit."""
     from sky_embeddings_amd.optim import CosineLR, FusedAdamW
     from sky_embeddings_amd.train_step import TrainStep
-    z, cfg, st, imgs, pmask, ra_dec = load_simmim_case("simmim_tiny_H_radec")
+    z, cfg, st, imgs, pmask, ra_dec = load_simmim_case(case)
     B = 8
     g = torch.Generator().manual_seed(0)
     x = torch.randn(B, cfg.in_chans, cfg.img_size, cfg.img_size, generator=g).cuda()
