@@ -911,7 +911,8 @@ extern "C" int skyemb_cosine_topk_prefiltered(const float *tw, const float *qn, 
     carve((char *)ws, Q, D, cap, &w);
     // one fp16 pass (hi only) by default: half the matrix work, 3/4 of the LDS-DMA bytes, intervals ~1.6x wider -- on
     // embedding-like data a few dozen more candidates per query.  SKYEMB_PREFILTER_LO=1 keeps the hi + lo passes.
-    static const bool use_lo = []() { const char *e = getenv("SKYEMB_PREFILTER_LO"); return e && e[0] == '1'; }();
+    const char *lo_env = getenv("SKYEMB_PREFILTER_LO");       // (read per call: cheap, and a test can switch it)
+    const bool use_lo = lo_env && lo_env[0] == '1';
     const float eps_a = (float)(eps_a_of(D, use_lo) * (1.0 + 1e-6));
     hipLaunchKernelGGL(query16_kernel, dim3((unsigned)(((Q + QPAD - 1) / QPAD * QPAD + 3) / 4)), dim3(256), 0, st, tw, qn, Q, D, w.qh, w.ql,
                        w.qbase, eps_a);

@@ -147,6 +147,33 @@ def test_prefiltered_topk_certification_failures_fall_back_to_the_exact_kernel()
     assert stats["path"] == "prefiltered" and stats["redone"] >= 2                    # queries 3 and 10 at least
 
 
+def test_prefiltered_candidate_floods_are_flagged_not_lost():
+    """Tens of thousands of rows that all score within the fp16 interval of a query's k-th best, placed where the staged
+    phases (LDS staging list of 2048 candidates per 256 x 256 item, per-workgroup regions) meet them: the lists overflow, the
+    flooded queries are flagged and re-run by the exact kernel, everything stays bit-identical to the oracle."""
+    rng = np.random.default_rng(11)
+    Q, N, D, k = 300, 60000, 128, 50
+    q = rng.standard_normal((Q, D), dtype=np.float32)
+    x = rng.standard_normal((N, D), dtype=np.float32)
+    x[20000:50000] = q[7] + 1e-4 * rng.standard_normal((30000, D)).astype(np.float32)     # 30 000 near-copies of query 7
+    x[52000:56000] = -3.0 * q[200] + 1e-4 * rng.standard_normal((4000, D)).astype(np.float32)   # anti-aligned: never candidates
+    stats = _oracle_equal(q, x, None, k)
+    assert stats["path"] == "prefiltered" and 1 <= stats["redone"] <= 30
+
+
+def test_prefiltered_two_pass_variant_is_bit_exact_too(monkeypatch):
+    """SKYEMB_PREFILTER_LO=1: the first stage multiplies the query as hi + lo fp16 halves (tighter intervals, 128-query tiles);
+    same exact results."""
+    monkeypatch.setenv("SKYEMB_PREFILTER_LO", "1")
+    rng = np.random.default_rng(12)
+    Q, N, D, k = 200, 30000, 256, 100
+    q = rng.standard_normal((Q, D), dtype=np.float32)
+    x = (rng.standard_normal((N, D)) * rng.uniform(0.2, 5.0, size=(N, 1))).astype(np.float32)
+    w = (1.0 / (rng.random(D, dtype=np.float32) + 0.05) ** 2).astype(np.float32)
+    stats = _oracle_equal(q, x, w / w.sum(), k)
+    assert stats["path"] == "prefiltered" and stats["redone"] <= Q // 10
+
+
 def test_prefiltered_equals_exact_kernel_at_mid_size():
     """200k x 256 bank, 512 queries: the two device paths agree bit for bit (no CPU oracle at this size)."""
     import os
