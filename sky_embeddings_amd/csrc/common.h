@@ -88,3 +88,33 @@ __device__ __forceinline__ float wave_max(float v) {
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+// One step of an 8-bit radix select: hist[0..255] holds the bin counts of the keys still in play; finds the bin of the
+// kth largest (largest b with sum_{c >= b} hist[c] >= kth; kth <= total) and leaves hist[256] = b, hist[257] = the rank
+// still wanted inside that bin.  Run by the first wave of the workgroup (tid < 64), four bins per lane, suffix sums by
+// shuffles -- a serial walk over the 256 bins by one thread dominated the select kernels.  Caller: __syncthreads() around it.
+__device__ __forceinline__ void radix_pick_bin(int *hist, int kth, int tid) {
+    if (tid >= 64) return;
+    const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+    int suf = h0 + h1 + h2 + h3;                       // -> inclusive suffix sum over lanes tid..63
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_down(suf, o, 64);
+        if (tid + o < 64) suf += up;
+    }
+    const unsigned long long reach = __ballot(suf >= kth);    // lanes 0..L reach kth (suf is non-increasing in the lane)
+    const int L = reach ? 63 - __builtin_clzll(reach) : 0;
+    if (tid == L) {
+        int run = suf - (h0 + h1 + h2 + h3);                   // keys in the bins above this lane's four
+        int b = 4 * tid + 3;
+        const int hh[4] = {h0, h1, h2, h3};
+#pragma unroll
+        for (int j = 3; j > 0; --j) {
+            if (run + hh[j] >= kth) break;
+            run += hh[j];
+            --b;
+        }
+        hist[256] = b;
+        hist[257] = kth - run;
+    }
+}

@@ -420,15 +420,7 @@ __global__ __launch_bounds__(1024) void topk_merge_sort_kernel(const float *__re
                 if ((kx & mask) == prefix) atomicAdd(&hist[(int)((kx >> shift) & 255ull)], 1);
             }
             __syncthreads();
-            if (tid == 0) {
-                int run = 0, b = 255;
-                for (; b > 0; --b) {
-                    if (run + hist[b] >= kth) break;
-                    run += hist[b];
-                }
-                hist[256] = b;
-                hist[257] = kth - run;
-            }
+            radix_pick_bin(hist, kth, tid);
             __syncthreads();
             prefix |= (unsigned long long)hist[256] << shift;
             kth = hist[257];
@@ -508,15 +500,7 @@ __global__ __launch_bounds__(1024) void kth_floor_kernel(const float *__restrict
             if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
         }
         __syncthreads();
-        if (tid == 0) {
-            int run = 0, b = 255;
-            for (; b > 0; --b) {
-                if (run + hist[b] >= kth) break;
-                run += hist[b];
-            }
-            hist[256] = b;
-            hist[257] = kth - run;
-        }
+        radix_pick_bin(hist, kth, tid);
         __syncthreads();
         prefix |= (unsigned int)hist[256] << shift;
         kth = hist[257];

@@ -625,32 +625,7 @@ __device__ unsigned int radix_kth_largest(const unsigned int *keys, int n, int k
             if ((kx & mask) == prefix) atomicAdd(&hist[(kx >> shift) & 255], 1);
         }
         __syncthreads();
-        if (tid < 64) {
-            // the bin holding the kth largest: largest b with sum_{c >= b} hist[c] >= kth.  One wave, four bins per lane,
-            // suffix sums by shuffles (a serial walk over the 256 bins by one thread was most of this kernel's time)
-            const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
-            int suf = h0 + h1 + h2 + h3;                       // -> inclusive suffix sum over lanes tid..63
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int up = __shfl_down(suf, o, 64);
-                if (tid + o < 64) suf += up;
-            }
-            const unsigned long long reach = __ballot(suf >= kth);    // lanes 0..L reach kth (suf is non-increasing in the lane)
-            const int L = reach ? 63 - __builtin_clzll(reach) : 0;   // (reach != 0 whenever kth <= n, the callers' contract)
-            if (tid == L) {
-                int run = suf - (h0 + h1 + h2 + h3);                   // candidates in the bins above this lane's four
-                int b = 4 * tid + 3;
-                const int hh[4] = {h0, h1, h2, h3};
-#pragma unroll
-                for (int j = 3; j > 0; --j) {
-                    if (run + hh[j] >= kth) break;
-                    run += hh[j];
-                    --b;
-                }
-                hist[256] = b;
-                hist[257] = kth - run;
-            }
-        }
+        radix_pick_bin(hist, kth, tid);
         __syncthreads();
         const int b = hist[256];
         kth = hist[257];
