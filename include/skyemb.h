@@ -256,6 +256,13 @@ int skyemb_gather_rows_host(const void *src, int64_t row_bytes, const int64_t *i
 int skyemb_h5_unchunk_host(const void *file_base, int64_t file_bytes, const int64_t *chunk_addr, const int64_t *chunk_off,
                            int64_t nchunks, int rank, const int64_t *chunk_dims, const int64_t *dset_dims, int elem_size, void *dst,
                            int nthreads);
+/* Survey-tile sampler: FitsDataset.__getitem__ (utils/dataloaders.py:589-654) cuts `cutouts_per_tile` windows out of a
+ * multi-band FITS tile with a python loop (random_cutouts :449-476 / overlapping_cutouts :507-536) and clips them (:618-621).
+ * Here the tile [C, H, W] sits in HBM as the files' own 4-byte words (big_endian[c] != 0: plane c still holds FITS
+ * big-endian floats; a missing band is a plane of NaNs) and ONE launch writes out [n, C, S, S] = tile[:, h0[i]:+S, w0[i]:+S],
+ * decoded and clipped at lo / hi (NaN kept).  h0 / w0: int32 device arrays, window origins (caller guarantees they fit). */
+int skyemb_tile_cutouts(const void *tile, const int *big_endian, int C, int H, int W, const int *h0, const int *w0, int n, int S,
+                        float lo, float hi, int use_lo, int use_hi, float *out, void *stream);
 int skyemb_clip_crop(const float *src, float *dst, int64_t n_planes, int Hs, int Ws, int size, float lo, float hi,
                      int use_lo, int use_hi, void *stream);
 

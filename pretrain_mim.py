@@ -21,7 +21,7 @@ import torch
 
 from sky_embeddings_amd import distributed as sdist
 from sky_embeddings_amd import ops
-from utils.dataloaders import build_h5_dataloader
+from utils.dataloaders import build_fits_dataloader, build_h5_dataloader
 from utils.mim_vit import build_model
 from utils.misc import parseArguments
 from utils.pretrain_fns import linear_probe, run_iter
@@ -74,21 +74,36 @@ def main(args):
         mask_ratio, max_mask_ratio = None, float(config['TRAINING']['max_mask_ratio'])
     else:
         mask_ratio, max_mask_ratio = float(config['TRAINING']['mask_ratio']), None
-    if 'train_data_file' not in config['DATA']:
-        raise NotImplementedError("FITS-tile training (train_data_paths) is out of scope; set [DATA] train_data_file")
+    from_tiles = 'train_data_file' not in config['DATA']      # the reference's shipped MIM configs: survey tiles (train_data_paths)
     num_workers = max(1, min(os.cpu_count() // max(world, 1), 12) - 1)
     common = dict(batch_size=int(config['TRAINING']['batch_size']), num_workers=num_workers,
                   patch_size=int(config['ARCHITECTURE']['patch_size']),
                   num_channels=int(config['ARCHITECTURE']['num_channels']), max_mask_ratio=max_mask_ratio,
                   img_size=int(config['ARCHITECTURE']['img_size']), num_patches=model.module.patch_embed.num_patches)
-    train_file = os.path.join(data_dir, config['DATA']['train_data_file'])
     sampler = None
-    if world > 1:
-        from sky_embeddings_amd.hdf5_lite import File
-        with File(train_file) as f:
-            n_train = len(f['cutouts'])
-        sampler = sdist.DistributedIndexSampler(n_train, rank, world, shuffle=True, seed=1234)
-    dataloader_train = build_h5_dataloader(train_file, shuffle=True, sampler=sampler, **common)
+    train_file = dataloader_train = tile_loader = None
+    if from_tiles:
+        # survey tiles (FITS): every item is one sky patch cut into cutouts_per_tile windows on the GPU
+        # (utils/dataloaders.py:538-654); ranks take every world-th patch, the same number each
+        from utils.misc import str2bool
+        tile_loader = build_fits_dataloader(eval(config['DATA']['train_data_paths']), bands=eval(config['DATA']['bands']),
+                                            min_bands=int(config['DATA']['min_bands']), batch_size=common['batch_size'],
+                                            num_workers=num_workers, patch_size=common['patch_size'], max_mask_ratio=None,
+                                            img_size=common['img_size'], cutouts_per_tile=int(config['DATA']['cutouts_per_tile']),
+                                            use_calexp=str2bool(config['DATA'].get('use_calexp', 'True')), ra_dec=True,
+                                            augment=False, shuffle=True, device=device)
+        tiles = tile_loader.dataset.band_filenames
+        tile_loader.dataset.band_filenames = tiles[rank:len(tiles) // world * world:world]
+        if not tile_loader.dataset.band_filenames:
+            raise SystemExit(f"no survey tiles with the requested bands under {config['DATA']['train_data_paths']}")
+    else:
+        train_file = os.path.join(data_dir, config['DATA']['train_data_file'])
+        if world > 1:
+            from sky_embeddings_amd.hdf5_lite import File
+            with File(train_file) as f:
+                n_train = len(f['cutouts'])
+            sampler = sdist.DistributedIndexSampler(n_train, rank, world, shuffle=True, seed=1234)
+        dataloader_train = build_h5_dataloader(train_file, shuffle=True, sampler=sampler, **common)
     # Training takes the fast path: the batched HDF5->HBM feeder (no per-item python; chunked files un-chunked once) feeding
     # the HIP-graph TrainStep (forward + staged backward, gradient all-reduce overlapped, fused AdamW, cosine LR).  The
     # per-item loader above still serves SimMIM mask generation, ragged final batches and validation.
@@ -102,14 +117,18 @@ def main(args):
                                world_size=world, max_mask_ratio=max_mask_ratio)
     dataloader_val = build_h5_dataloader(os.path.join(data_dir, config['DATA']['val_data_file']), shuffle=True, **common)
     if rank == 0:
-        print('The training set consists of %i cutouts.' % (len(dataloader_train.dataset)))
+        if from_tiles:
+            print('The training set consists of %i sky patches per process, %s cutouts each.' %
+                  (len(tile_loader), config['DATA']['cutouts_per_tile']))
+        else:
+            print('The training set consists of %i cutouts.' % (len(dataloader_train.dataset)))
 
     lp_files = {key: os.path.join(data_dir, config['DATA'][key]) if key in config['DATA'] else None
                 for key in ('lp_class_data_file', 'lp_regress_data_file')}
     lp_combine = config['DATA'].get('lp_combine', 'central')
     total_batch_iters = int(float(config['TRAINING']['total_batch_iters']))
     if rank == 0:
-        print('Training the network with a batch size of %i per GPU ...' % (dataloader_train.batch_size))
+        print('Training the network with a batch size of %i per GPU ...' % (common['batch_size']))
         print('Progress will be displayed every %i batch iterations and the model will be saved every %i minutes.' %
               (args.verbose_iters, args.cp_time))
     losses_cp = defaultdict(list)
@@ -120,18 +139,27 @@ def main(args):
         if sampler is not None:
             sampler.set_epoch(epoch)
         epoch += 1
-        loader = dataloader_train
-        if fast:
+        if from_tiles:
+            np.random.seed(1234 + epoch * world + rank)          # window corners: numpy's global generator, per rank and epoch
+
+            def tile_batches():                                   # pretrain_mim.py:143-150 (get_train_samples, nested batches)
+                for cut, msk, rds in tile_loader:
+                    for b in range(cut.shape[1]):
+                        yield cut[0, b], (msk[0, b] if msk.dim() == 6 else None), rds[0, b]
+            loader = tile_batches()
+        elif fast:
             loader = CutoutFeeder(train_file, common['batch_size'], common['img_size'], device, shuffle=True, seed=1234 + epoch,
                                   rank=rank, world_size=world, drop_last=world > 1)
+        else:
+            loader = dataloader_train
         for samples, masks, ra_decs in loader:
             if fast and samples.shape[0] == common['batch_size']:
                 loss = train_step(samples, None, ra_decs)
                 losses_cp['train_loss'].append(loss.detach().clone())
             else:
                 samples = samples.to(device, non_blocking=True)
-                if fast and max_mask_ratio is not None:
-                    # a ragged last batch of the feeder in SimMIM mode: draw its masks with the same device generator
+                if (fast or from_tiles) and max_mask_ratio is not None:
+                    # (a ragged last batch of the feeder, or tile batches on the eager path) SimMIM masks from the device generator
                     eng_cfg = model.module.engine.cfg
                     masks = torch.empty_like(samples)
                     ops.simmim_mask_from_noise(torch.rand(samples.shape[0], eng_cfg.in_chans, eng_cfg.num_patches, device=device),

@@ -79,6 +79,7 @@ PROTOTYPES = {
     "skyemb_attnpool_fwd": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "skyemb_attnpool_bwd": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "skyemb_attnpool_q_bwd": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    "skyemb_tile_cutouts": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_i32, c_i32, c_vp, c_vp]),
     "skyemb_clip_crop": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_f32, c_i32, c_i32, c_vp]),
     "skyemb_layernorm_bwd_blocks": (c_i32, [c_i32]),
     "skyemb_layernorm_bwd_reduce_batch": (c_i32, [c_vp, c_i32, c_i32, c_vp]),

@@ -228,6 +228,30 @@ __global__ __launch_bounds__(256) void clip_crop_kernel(const float *__restrict_
     }
 }
 
+// Survey-tile sampler (utils/dataloaders.py:449-476 random_cutouts / :507-536 overlapping_cutouts + the clip at :618-621):
+// the whole multi-band tile [C, H, W] is resident in HBM as the 4-byte words of the FITS files (big-endian floats where
+// be[c] != 0: the bytes went from the mapped file to the device untouched); cutout i = tile[:, h0[i] : +S, w0[i] : +S],
+// decoded, clipped (NaN kept: both comparisons are false) -> out [n, C, S, S].
+__global__ __launch_bounds__(256) void tile_cutouts_kernel(const unsigned int *__restrict__ tile, const int *__restrict__ be, int C,
+                                                           int H, int W, const int *__restrict__ h0, const int *__restrict__ w0,
+                                                           int64_t n_out, int S, float lo, float hi, int use_lo, int use_hi,
+                                                           float *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_out; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % S);
+        int64_t t = i / S;
+        const int y = (int)(t % S);
+        t /= S;
+        const int c = (int)(t % C);
+        const int64_t k = t / C;
+        unsigned int u = tile[((int64_t)c * H + h0[k] + y) * W + w0[k] + x];
+        if (be[c]) u = __builtin_bswap32(u);
+        float v = __uint_as_float(u);
+        if (use_lo && v < lo) v = lo;
+        if (use_hi && v > hi) v = hi;
+        out[i] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" int skyemb_clip_crop(const float *src, float *dst, int64_t n_planes, int Hs, int Ws, int size, float lo, float hi,
@@ -239,6 +263,19 @@ extern "C" int skyemb_clip_crop(const float *src, float *dst, int64_t n_planes, 
     hipLaunchKernelGGL(clip_crop_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, n_out, Hs, Ws, size,
                        (Hs - size) / 2, (Ws - size) / 2, lo, hi, use_lo, use_hi);
     SKY_LAUNCH_CHECK("skyemb_clip_crop");
+    return 0;
+}
+
+extern "C" int skyemb_tile_cutouts(const void *tile, const int *big_endian, int C, int H, int W, const int *h0, const int *w0, int n,
+                                   int S, float lo, float hi, int use_lo, int use_hi, float *out, void *stream) {
+    SKY_CHECK_ARG(tile && big_endian && h0 && w0 && out && C > 0 && n > 0 && S > 0 && H >= S && W >= S,
+                  "skyemb_tile_cutouts: bad shape C=%d H=%d W=%d n=%d S=%d", C, H, W, n, S);
+    const int64_t n_out = (int64_t)n * C * S * S;
+    int64_t blocks = ceil_div64(n_out, 256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(tile_cutouts_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned int *)tile,
+                       big_endian, C, H, W, h0, w0, n_out, S, lo, hi, use_lo, use_hi, out);
+    SKY_LAUNCH_CHECK("skyemb_tile_cutouts");
     return 0;
 }
 

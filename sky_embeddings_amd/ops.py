@@ -101,6 +101,15 @@ def augment(imgs, out, params, nan_mask, noise, A):
     check(lib().skyemb_augment(_p(imgs), _p(out), _p(params), _p(nan_mask), _p(noise), B, C, S, A, _stream()), "skyemb_augment")
 
 
+def tile_cutouts(tile, big_endian, h0, w0, S, out, lo=None, hi=None):
+    """out [n, C, S, S] = windows of the HBM-resident survey tile [C, H, W] (4-byte words; big_endian [C] int32 marks planes
+    still in FITS byte order), clipped at lo / hi (NaN kept)."""
+    C, H, W = tile.shape
+    check(lib().skyemb_tile_cutouts(_p(tile), _p(big_endian), C, H, W, _p(h0), _p(w0), h0.numel(), S,
+                                    0.0 if lo is None else float(lo), 0.0 if hi is None else float(hi), int(lo is not None),
+                                    int(hi is not None), _p(out), _stream()), "skyemb_tile_cutouts")
+
+
 def attnpool_q(latent, Wq, bq, q):
     """q [D] = Wq latent + bq: the sample-independent query of the attention pool (timm AttentionPoolLatent)."""
     check(lib().skyemb_attnpool_q(_p(latent), _p(Wq), _p(bq), _p(q), q.numel(), _stream()), "skyemb_attnpool_q")

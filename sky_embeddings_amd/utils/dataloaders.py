@@ -1,7 +1,9 @@
-"""utils/dataloaders.py mirror for the HDF5 cutout path (H5Dataset, MaskGenerator,
-build_h5_dataloader, get_augmentations).  The augmentation pipeline (utils/dataloaders.py:14-106) is
-``sky_embeddings_amd.augment.Augmenter``: torchvision's parameter draws on the host, the arithmetic in one HIP launch.  The
-FITS tile sampler is out of scope.
+"""utils/dataloaders.py mirror: the HDF5 cutout path (H5Dataset, MaskGenerator, build_h5_dataloader, get_augmentations) and
+the survey-tile path the reference's shipped MIM configs train from (``train_data_paths``: find_HSC_bands, load_fits_bands,
+random / overlapping cutouts, FitsDataset, build_fits_dataloader).  The augmentation pipeline (utils/dataloaders.py:14-106)
+is ``sky_embeddings_amd.augment.Augmenter``: torchvision's parameter draws on the host, the arithmetic in one HIP launch.
+The tile sampler keeps the whole multi-band tile in HBM (the FITS bytes go to the device as they are) and cuts all of a
+tile's windows with one launch; FITS access is ``sky_embeddings_amd.fits_lite`` (astropy is not a dependency).
 
 Differences from the reference, none of which change a returned value:
   * the file is parsed once and datasets are memory-mapped (hdf5_lite) instead of re-opening
@@ -123,6 +125,212 @@ def build_h5_dataloader(filename, batch_size, num_workers, patch_size=8, num_cha
                                        sampler=sampler, num_workers=num_workers, pin_memory=torch.cuda.is_available())
 
 
-def build_fits_dataloader(*args, **kwargs):
-    raise NotImplementedError("FITS tile streaming (utils/dataloaders.py:538-654) needs astropy and survey tiles: out "
-                              "of scope (SURVEY.md §2 row 5); use train_data_file = <cutouts>.h5")
+# ---------------------------------------------------------------------------------------------------------------
+# survey tiles (FITS): utils/dataloaders.py:330-654
+# ---------------------------------------------------------------------------------------------------------------
+def find_HSC_bands(fits_paths, bands, min_bands=2, verbose=1, use_calexp=True):
+    """utils/dataloaders.py:330-379: [[file of band 0, file of band 1, ...], ...] per sky patch with at least ``min_bands`` of
+    the bands present ('None' where a band is missing).  File names: ``[calexp-]<...>-<band>-<tract>-<patch>.fits``."""
+    import glob
+    import os
+    per_patch = {}
+    for root in fits_paths:
+        for path in sorted(glob.glob(os.path.join(root, "*.fits"))):
+            name = os.path.basename(path)
+            if name.startswith("calexp-") != bool(use_calexp):
+                continue
+            parts = name.split("-")
+            if len(parts) < 3 or parts[-3] not in bands:
+                continue
+            per_patch.setdefault("-".join(parts[-2:]), {})[parts[-3]] = path
+    out = [[found.get(b, "None") for b in bands] for found in per_patch.values()
+           if sum(b in found for b in bands) >= min_bands]
+    if verbose:
+        print(f"Found {len(out)} patches with at least {min_bands} of the {bands} bands.")
+    return out
+
+
+def load_fits_bands(patch_filenames, return_wc=False):
+    """utils/dataloaders.py:381-447 on the host: -> (float array [C, H, W] with NaN planes for missing / unreadable bands,
+    pix_to_radec or None).  (The sampler below does not go through this function: it sends the raw bytes to the GPU.)"""
+    from .. import fits_lite
+    planes, shape, pix_to_radec = [], None, None
+    for fn in patch_filenames:
+        img = None
+        if fn != "None":
+            try:
+                hdu = fits_lite.read_image_hdu(fn, 1)
+                img = hdu.array()
+                shape = shape or img.shape
+                if return_wc and pix_to_radec is None:
+                    wcs = fits_lite.TanSipWCS(hdu.header)
+                    pix_to_radec = lambda x, y, _w=wcs: _w.all_pix2world(x, y, 0)     # noqa: E731 (reference: dataloaders.py:430-433)
+            except Exception as e:                      # the reference carries on with a NaN plane (dataloaders.py:437-440)
+                print(f"Error opening {fn}: {e}")
+        planes.append(img)
+    return np.stack([np.full(shape, np.nan) if p is None else p for p in planes]), pix_to_radec
+
+
+def generate_overlap_coords(img_shape, cutout_size, overlap):
+    """utils/dataloaders.py:478-505: top-left corners of a regular grid of windows with the given overlap, plus windows
+    flush with the bottom / right edges when the step does not divide the tile."""
+    H, W = img_shape
+    step = int(cutout_size * (1 - overlap))
+    rows, cols = range(0, H - cutout_size + 1, step), range(0, W - cutout_size + 1, step)
+    coords = [(i, j) for i in rows for j in cols]
+    if H % step != 0:
+        coords += [(H - cutout_size, j) for j in cols]
+    if W % step != 0:
+        coords += [(i, W - cutout_size) for i in rows]
+    if H % step != 0 and W % step != 0:
+        coords.append((H - cutout_size, W - cutout_size))
+    return coords
+
+
+def random_cutouts(input_array, img_size, n_cutouts, pix_to_radec=None):
+    """utils/dataloaders.py:449-476 (host arrays; numpy's global generator draws the corners, rows first)."""
+    C, H, W = input_array.shape
+    hs = np.random.randint(0, H - img_size + 1, size=n_cutouts)
+    ws = np.random.randint(0, W - img_size + 1, size=n_cutouts)
+    out = np.stack([input_array[:, h:h + img_size, w:w + img_size] for h, w in zip(hs, ws)])
+    if pix_to_radec is None:
+        return out
+    ra, dec = pix_to_radec(hs + img_size // 2, ws + img_size // 2)
+    return out, np.vstack((ra, dec)).T
+
+
+def overlapping_cutouts(input_array, img_size, overlap, pix_to_radec=None):
+    """utils/dataloaders.py:507-536."""
+    coords = generate_overlap_coords(input_array.shape[1:], img_size, overlap)
+    out = np.stack([input_array[:, h:h + img_size, w:w + img_size] for h, w in coords])
+    if pix_to_radec is None:
+        return out
+    ra, dec = pix_to_radec([h + img_size // 2 for h, _ in coords], [w + img_size // 2 for _, w in coords])
+    return out, np.vstack((ra, dec)).T
+
+
+class FitsDataset(torch.utils.data.Dataset):
+    """utils/dataloaders.py:538-654: item = one sky patch -> (cutouts [M, batch, C, S, S], masks, ra_dec [M, batch, 2]) with
+    M = cutouts_per_tile // batch_size.  Same constructor, same draws (numpy's global generator for the window corners, rows
+    first; the reference's MaskGenerator semantics for the masks), same clip; the work is laid out for the GPU:
+
+    * every band file is memory-mapped and its pixel bytes are copied to HBM as they are (big-endian floats, 70 MB per
+      4k x 4k band; a nine-band tile is 0.6 GB of 288); missing or unreadable bands are NaN planes;
+    * ONE launch (``skyemb_tile_cutouts``) decodes, cuts and clips all windows of the tile; the per-channel patch masks come
+      from the device generator (``skyemb_simmim_mask_from_noise``);
+    * RA / Dec of the window centres: ``fits_lite.TanSipWCS`` on the host (a few thousand points), with the reference's
+      argument order (row index as x, column index as y: dataloaders.py:430-433, 472).
+
+    ``transform`` (a per-tensor callable) is applied to the whole [n, C, S, S] stack like the reference does.  The returned
+    tensors live on ``device``; DataLoader workers are not used (num_workers is accepted and ignored)."""
+
+    def __init__(self, fits_paths, patch_size=8, max_mask_ratio=None, bands=('G', 'R', 'I', 'Z', 'Y'), min_bands=5, img_size=64,
+                 cutouts_per_tile=1024, batch_size=64, ra_dec=False, transform=None, pixel_min=-3., pixel_max=None,
+                 use_calexp=True, use_overlap=False, overlap=0.5, device="cuda"):
+        self.fits_paths, self.bands = fits_paths, list(bands)
+        self.img_size, self.patch_size, self.cutouts_per_tile, self.batch_size = img_size, patch_size, cutouts_per_tile, batch_size
+        self.ra_dec, self.transform, self.pixel_min, self.pixel_max = ra_dec, transform, pixel_min, pixel_max
+        self.use_calexp, self.use_overlap, self.overlap = use_calexp, use_overlap, overlap
+        self.max_mask_ratio = max_mask_ratio
+        self.device = torch.device(device)
+        self.band_filenames = find_HSC_bands(fits_paths, self.bands, min_bands, use_calexp=use_calexp)
+        self.mask_generator = None if max_mask_ratio is None else MaskGenerator(
+            input_size=img_size, patch_size=patch_size, max_mask_ratio=max_mask_ratio, num_mask_chans=len(self.bands))
+
+    def __len__(self):
+        return len(self.band_filenames)
+
+    def _tile_to_device(self, filenames):
+        """-> (tile uint32-view tensor [C, H, W] on the device, big_endian int32 [C], header of the first readable band)."""
+        from .. import fits_lite
+        hdus = []
+        for fn in filenames:
+            hdu = None
+            if fn != "None":
+                try:
+                    hdu = fits_lite.read_image_hdu(fn, 1)
+                except Exception as e:
+                    print(f"Error opening {fn}: {e}")
+            hdus.append(hdu)
+        ref = next((h for h in hdus if h is not None), None)
+        if ref is None:
+            raise RuntimeError(f"no readable band among {filenames}")
+        H, W = ref.shape
+        tile = torch.empty(len(hdus), H, W, dtype=torch.float32, device=self.device)
+        be = torch.zeros(len(hdus), dtype=torch.int32)
+        for c, h in enumerate(hdus):
+            if h is None or h.shape != (H, W):
+                tile[c].fill_(float("nan"))
+            elif h.bitpix == -32 and h.bscale == 1.0 and h.bzero == 0.0:
+                # the file's bytes, reinterpreted: no host pass over the pixels (the kernel swaps the byte order)
+                raw = torch.from_numpy(np.asarray(h.raw).view(np.int32))
+                tile[c].view(torch.int32).copy_(raw, non_blocking=True)
+                be[c] = 1
+            else:                                      # integer / double / scaled images: decoded on the host
+                tile[c].copy_(torch.from_numpy(np.ascontiguousarray(h.array(), dtype=np.float32)))
+        return tile, be.to(self.device), ref.header
+
+    def __getitem__(self, idx):
+        from .. import fits_lite, ops
+        S, B = self.img_size, self.batch_size
+        tile, be, header = self._tile_to_device(self.band_filenames[idx])
+        C, H, W = tile.shape
+        if self.use_overlap:
+            coords = generate_overlap_coords((H, W), S, self.overlap)
+            hs, ws = np.array([c[0] for c in coords]), np.array([c[1] for c in coords])
+        else:
+            hs = np.random.randint(0, H - S + 1, size=self.cutouts_per_tile)
+            ws = np.random.randint(0, W - S + 1, size=self.cutouts_per_tile)
+        n = len(hs)
+        cutouts = torch.empty(n, C, S, S, device=self.device)
+        ops.tile_cutouts(tile, be, torch.from_numpy(hs.astype(np.int32)).to(self.device), torch.from_numpy(ws.astype(np.int32)).to(self.device),
+                         S, cutouts, lo=self.pixel_min, hi=self.pixel_max)
+        if self.transform is not None:
+            cutouts = self.transform(cutouts)
+        M = n // B
+        out = [cutouts[:M * B].reshape(M, B, C, S, S)]
+        if self.mask_generator is not None:
+            grid = S // self.patch_size
+            masks = torch.empty(M * B, C, S, S, device=self.device)
+            ops.simmim_mask_from_noise(torch.rand(M * B, C, grid * grid, device=self.device), torch.rand(M * B, device=self.device),
+                                       self.max_mask_ratio, grid, self.patch_size, masks)
+            out.append(masks.reshape(M, B, C, S, S))
+        else:
+            out.append(torch.zeros(M, B, device=self.device))
+        if self.ra_dec:
+            wcs = fits_lite.TanSipWCS(header)
+            ra, dec = wcs.all_pix2world(hs + S // 2, ws + S // 2, 0)      # (row, column) as (x, y), like the reference
+            rd = torch.from_numpy(np.vstack((ra, dec)).T.astype(np.float32))[:M * B].reshape(M, B, 2)
+            out.append(rd.to(self.device))
+        return tuple(out)
+
+
+class _TileLoader:
+    """What ``DataLoader(dataset, batch_size=1, shuffle=...)`` yields for a FitsDataset -- every tensor with a leading
+    dimension of 1 (the reference's loop indexes it away: pretrain_mim.py:143-150) -- without worker processes: the items
+    are device tensors."""
+
+    def __init__(self, dataset, shuffle):
+        self.dataset, self.shuffle = dataset, shuffle
+        self.batch_size, self.num_workers = 1, 0
+
+    def __len__(self):
+        return len(self.dataset)
+
+    def __iter__(self):
+        order = np.random.permutation(len(self.dataset)) if self.shuffle else np.arange(len(self.dataset))
+        for i in order:
+            yield tuple(t.unsqueeze(0) for t in self.dataset[int(i)])
+
+
+def build_fits_dataloader(fits_paths, bands, min_bands, batch_size, num_workers, patch_size=8, max_mask_ratio=None, img_size=64,
+                          cutouts_per_tile=1024, use_calexp=True, augment=False, brightness=0.8, noise=0.01, nan_channels=2,
+                          shuffle=True, ra_dec=True, transforms=None, use_overlap=False, overlap=0.5, device="cuda"):
+    """utils/dataloaders.py:108-132."""
+    if transforms is None and augment:
+        # (an Augmenter maps a [n, C, S, S] stack to one augmented copy of every cutout: one launch for the whole tile)
+        transforms = get_augmentations(img_size=img_size, flip=True, crop=True, brightness=brightness, noise=noise, nan_channels=nan_channels)
+    dataset = FitsDataset(fits_paths, patch_size=patch_size, max_mask_ratio=max_mask_ratio, bands=bands, min_bands=min_bands,
+                          img_size=img_size, cutouts_per_tile=cutouts_per_tile, batch_size=batch_size, ra_dec=ra_dec,
+                          transform=transforms, use_calexp=use_calexp, use_overlap=use_overlap, overlap=overlap, device=device)
+    return _TileLoader(dataset, shuffle)

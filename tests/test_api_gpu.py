@@ -317,3 +317,32 @@ def test_linear_probe_hook_on_hip_embeddings(tmp_path):
         assert np.allclose(x.mean(axis=0), 0, atol=1e-3)                          # standard-scaled features
     x, _ = get_embeddings(path, model, "cuda", template, combine="none")
     assert x.shape == (n, L, D) and abs(float(x.mean())) < 1e-3 and abs(float(x.std()) - 1) < 1e-3
+
+
+def test_pretrain_entry_point_trains_from_survey_tiles(tmp_path):
+    """python pretrain_mim.py <ini> with ``train_data_paths`` (what the reference's shipped MIM configs use: survey tiles in FITS,
+    pretrain_mim.py:88-103): tiles -> HBM -> windows cut on the device -> the HIP-graph step (SimMIM + RA/Dec token)."""
+    from sky_embeddings_amd import hdf5_lite
+    from tests.test_feeder_gpu import _make_tiles
+    dd = tmp_path / "data"
+    tiles = dd / "pdr3_dud"
+    tiles.mkdir(parents=True)
+    _make_tiles(str(tiles), n_patches=2, missing=())
+    hdf5_lite.make_synthetic_cutouts(str(dd / "synthetic_cutouts_GRIZY_64_val.h5"), n=16, seed=4321)
+    work = tmp_path / "work"
+    (work / "configs").mkdir(parents=True)
+    cfg = _tiny_ini(tmp_path, total_iters=10)
+    del cfg["DATA"]["train_data_file"]
+    cfg["DATA"].update(train_data_paths=repr([str(tiles)]), bands="['G','R','I','Z','Y']", min_bands="5", cutouts_per_tile="48", use_calexp="True")
+    cfg["ARCHITECTURE"].update(model_type="simmim", patch_size="8", embed_dim="96", ra_dec="True")
+    cfg["TRAINING"].update(loss_fn="L1", max_mask_ratio="0.9")
+    with open(work / "configs" / "mim_t.ini", "w") as fh:
+        cfg.write(fh)
+    for name in ("pretrain_mim.py", "utils", "sky_embeddings_amd"):
+        os.symlink(os.path.join(ROOT, name), work / name)
+    out = subprocess.run([sys.executable, str(work / "pretrain_mim.py"), "mim_t", "-v", "4", "-ct", "0.001", "-dd", str(dd)],
+                         cwd=str(work), env=dict(os.environ, PYTHONPATH=str(work)), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "Training complete." in out.stdout and "sky patches per process" in out.stdout
+    ck = torch.load(str(work / "models" / "mim_t.pth.tar"), map_location="cpu", weights_only=False)
+    assert ck["batch_iters"] >= 10 and np.isfinite(ck["losses"]["train_loss"]).all()

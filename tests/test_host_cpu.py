@@ -350,3 +350,58 @@ def test_select_centre_picks_the_central_block():
     assert np.array_equal(central_indices(np.empty((5, 5)), 1), [[2, 2]])
     with pytest.raises(ValueError):
         central_indices(np.empty((8, 8)), 3)
+
+
+_WCS_HDR = {"CTYPE1": "RA---TAN-SIP", "CTYPE2": "DEC--TAN-SIP", "CRPIX1": 120.5, "CRPIX2": 131.0, "CRVAL1": 150.1, "CRVAL2": 2.2,
+            "CD1_1": -4.66e-5, "CD1_2": 1.0e-7, "CD2_1": -2.0e-7, "CD2_2": 4.66e-5, "A_ORDER": 2, "B_ORDER": 2, "A_2_0": 1.5e-7,
+            "A_1_1": -3e-8, "B_0_2": 2e-7, "B_1_1": 5e-8}
+
+
+def test_fits_lite_round_trip_and_world_coordinates(tmp_path):
+    """fits_lite (the astropy-free access layer of the survey-tile path, utils/dataloaders.py:417-433): image HDU 1 of a file
+    it wrote comes back bit for bit (float32 with NaNs; int16 with BSCALE / BZERO), header values keep their types, the raw
+    view is big-endian; TAN-SIP pixel -> sky agrees with the oracle's independent formulation and with the obvious cases."""
+    from oracle import tile_oracle as to
+    from sky_embeddings_amd import fits_lite
+    rng = np.random.default_rng(0)
+    img = rng.standard_normal((37, 53)).astype(np.float32)
+    img[3, 4] = np.nan
+    p = fits_lite.write_image_fits(str(tmp_path / "calexp-HSC-G-9813-4,3.fits"), img, _WCS_HDR)
+    h = fits_lite.read_image_hdu(p, 1)
+    assert h.shape == (37, 53) and h.raw.dtype == np.dtype(">f4") and h.bitpix == -32
+    assert np.array_equal(h.array().view(np.uint32), img.view(np.uint32))
+    assert h.header["CTYPE1"] == "RA---TAN-SIP" and h.header["A_ORDER"] == 2 and abs(h.header["CD1_1"] + 4.66e-5) < 1e-18
+    ints = rng.integers(-3000, 3000, (9, 11)).astype(np.int16)
+    p2 = fits_lite.write_image_fits(str(tmp_path / "i.fits"), ints, {"BSCALE": 0.5, "BZERO": 100.0}, bitpix=16)
+    assert np.array_equal(fits_lite.read_image_hdu(p2, 1).array(), ints * 0.5 + 100.0)
+    with pytest.raises(IndexError):
+        fits_lite.read_image_hdu(p, 3)
+    w = fits_lite.TanSipWCS(h.header)
+    x, y = np.array([0, 100.5, 119.5, 4000, 17]), np.array([0, 3000, 130.0, 4100, 999.25])
+    ra, dec = w.all_pix2world(x, y, 0)
+    ra2, dec2 = to.tan_sip_pix2world(_WCS_HDR, x, y, 0)
+    assert np.abs(ra - ra2).max() < 1e-11 and np.abs(dec - dec2).max() < 1e-11
+    assert abs(ra[2] - 150.1) < 1e-12 and abs(dec[2] - 2.2) < 1e-12                      # the reference pixel
+    plain = dict(_WCS_HDR, CTYPE1="RA---TAN", CTYPE2="DEC--TAN", CD1_2=0.0, CD2_1=0.0)
+    r, d = fits_lite.TanSipWCS(plain).all_pix2world(np.array([119.5, 119.5, 120.5]), np.array([130.0, 131.0, 130.0]), 0)
+    assert abs((d[1] - d[0]) - 4.66e-5) < 1e-9                                           # one row up = one pixel scale north
+    assert abs((r[2] - r[0]) * np.cos(np.deg2rad(2.2)) + 4.66e-5) < 1e-9                 # one column right = one pixel scale west
+    with pytest.raises(NotImplementedError):
+        fits_lite.TanSipWCS(dict(plain, CTYPE1="RA---SIN"))
+
+
+def test_tile_file_discovery_and_overlap_grid(tmp_path):
+    """find_HSC_bands (utils/dataloaders.py:330-379) and generate_overlap_coords (:478-505), hand-checked."""
+    from sky_embeddings_amd.utils.dataloaders import find_HSC_bands, generate_overlap_coords
+    for name in ("calexp-HSC-G-9813-4,3.fits", "calexp-HSC-R-9813-4,3.fits", "calexp-HSC-I-9813-4,3.fits", "calexp-HSC-G-9813-5,3.fits",
+                 "HSC-G-9813-4,3.fits", "calexp-HSC-Q-9813-4,3.fits", "notes.txt", "ab.fits"):
+        (tmp_path / name).write_bytes(b"")
+    got = find_HSC_bands([str(tmp_path)], ["G", "R", "I"], min_bands=2, verbose=0)
+    assert len(got) == 1 and [os.path.basename(f) for f in got[0]] == ["calexp-HSC-G-9813-4,3.fits", "calexp-HSC-R-9813-4,3.fits",
+                                                                        "calexp-HSC-I-9813-4,3.fits"]
+    got = find_HSC_bands([str(tmp_path)], ["G", "Y"], min_bands=1, verbose=0)
+    assert sorted(g[1] for g in got) == ["None", "None"] and len(got) == 2
+    assert [os.path.basename(g[0]) for g in find_HSC_bands([str(tmp_path)], ["G"], 1, 0, use_calexp=False)] == ["HSC-G-9813-4,3.fits"]
+    c = generate_overlap_coords((10, 11), 4, 0.5)                  # step 2: rows 0..6, cols 0..6; W % 2 != 0 -> a right-edge column
+    assert c[:4] == [(0, 0), (0, 2), (0, 4), (0, 6)] and (6, 7) in c and (0, 7) in c and len(c) == 16 + 4
+    assert generate_overlap_coords((8, 8), 4, 0.0) == [(0, 0), (0, 4), (4, 0), (4, 4)]
