@@ -1,6 +1,8 @@
 // Attention core for short sequences (N <= 32 tokens) in bf16: ONE wavefront per (sample, head), every
-// product on v_mfma_f32_32x32x16_bf16, operands loaded straight from HBM into MFMA fragments (16-byte row
-// loads; 2-byte gathers for the operands that are contracted over the token index), no LDS staging.
+// product on v_mfma_f32_32x32x16_bf16, operands loaded straight from HBM into MFMA fragments (16-byte row loads).  The
+// operands that are contracted over the TOKEN index are the same rows transposed: 2-byte global gathers (8 per fragment), or
+// -- head dim 32, the 17-token decoder sequences -- the wave parks its row fragments in LDS and reads them back with
+// ds_read_b64_tr_b16 (two per fragment).
 //
 // Orientation trick (cdna_hip_programming.md, "an accumulator tile as the next MFMA's operand"): a 32x32 result has its
 // column on the lane and its rows in the 16 registers, so it is directly the operand of a product that sums over its
@@ -49,6 +51,29 @@ __device__ __forceinline__ bf16x8 pack_regs(const f32x16 &x, int s) {
     for (int e = 0; e < 8; ++e) f[e] = (bf16_t)x[8 * s + e];
     return f;
 }
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
+// a wave's [32 tokens][HD] operand parked in LDS, rows PITCH = HD + 8 elements apart (16 bytes of padding spread the four
+// token rows of a transposing read over the banks)
+template <int HD>
+__device__ __forceinline__ void park_rows(bf16_t *tile, const bf16x8 (&f)[HD / 16], int r, int g) {
+#pragma unroll
+    for (int s = 0; s < HD / 16; ++s) *(bf16x8 *)(tile + r * (HD + 8) + 16 * s + 8 * g) = f[s];
+}
+// transposed fragment out of a parked operand: lane (r, g) gets X[token pi(s, g, e)][32 blk + r], e = 0..7 -- two runs of four
+// consecutive tokens, each one ds_read_b64_tr_b16 (16 lanes x 8 bytes = 4 token rows x 16 columns, transposed in flight)
+template <int HD>
+__device__ __forceinline__ bf16x8 tok_frag_lds(const bf16_t *tile, int blk, int r, int g, int s) {
+    const int i = r & 15, q = i >> 2, p = i & 3;
+    const int col0 = 32 * blk + (r & 16) + 4 * p;
+    const int t0 = 16 * s + 4 * g;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)(tile + (t0 + q) * (HD + 8) + col0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)(tile + (t0 + 8 + q) * (HD + 8) + col0));
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
 // store the [d][token] result tile: lane (token r, g) owns d = 8 q + 4 g + 0..3 for q = 0..3
 template <int HD>
 __device__ __forceinline__ void store_tile(bf16_t *dst_row, const f32x16 &t, int blk, int g, float scale) {
@@ -63,6 +88,11 @@ template <int HD>
 __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out, int B,
                                                            int N, int H) {
     constexpr int KS = HD / 16, NB = (HD + 31) / 32;
+    // PARK: transposed operands through LDS (see the file header).  Measured: pays for the decoder's 17-token sequences
+    // (hd 32: 7.2 -> 6.3 us forward, 16.8 -> 14.9 us backward); the encoder's 5-token sequences gather only 5 of the 8
+    // elements and lose more to the LDS footprint (residency) than they gain (hd 64: 11.0 -> 12.1 us backward)
+    constexpr bool PARK = HD == 32;
+    __shared__ __attribute__((aligned(16))) bf16_t park[PARK ? 4 : 1][PARK ? 32 * (HD + 8) : 8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int head = blockIdx.x * 4 + wave;
     if (head >= B * H) return;
@@ -79,11 +109,20 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t *__restr
         qf[s] = row_frag(qb, rs, r, g, s, N);
         kf[s] = row_frag(kb, rs, r, g, s, N);
     }
+    if constexpr (PARK) {
+        bf16x8 vf[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) vf[s] = row_frag(vb, rs, r, g, s, N);
+        park_rows<HD>(park[wave], vf, r, g);
+        __builtin_amdgcn_wave_barrier();
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int blk = 0; blk < NB; ++blk)
-            vt[s][blk] = s < NS ? tok_frag(vb, rs, 32 * blk + r, 32 * blk + r < HD, g, s, N) : zero8();
+        for (int blk = 0; blk < NB; ++blk) {
+            if constexpr (PARK) vt[s][blk] = s < NS ? tok_frag_lds<HD>(park[wave], blk, r, g, s) : zero8();
+            else vt[s][blk] = s < NS ? tok_frag(vb, rs, 32 * blk + r, 32 * blk + r < HD, g, s, N) : zero8();
+        }
 
     f32x16 st;
 #pragma unroll
@@ -127,7 +166,9 @@ template <int HD>
 __global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
                                                            bf16_t *__restrict__ dqkv, int B, int N, int H) {
     constexpr int KS = HD / 16, NB = (HD + 31) / 32;
+    constexpr bool PARK = HD == 32;                                                 // see mha_fwd_mfma_kernel
     __shared__ float stats[4][3][32];
+    __shared__ __attribute__((aligned(16))) bf16_t park[PARK ? 4 : 1][3][PARK ? 32 * (HD + 8) : 8];      // K, Q, dO of each wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int head = blockIdx.x * 4 + wave;
     if (head >= B * H) return;
@@ -147,6 +188,11 @@ __global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(const bf16_t *__restr
         kf[s] = row_frag(kb, rs, r, g, s, N);
         vf[s] = row_frag(vb, rs, r, g, s, N);
         of[s] = row_frag(ob, D, r, g, s, N);
+    }
+    if constexpr (PARK) {
+        park_rows<HD>(park[wave][0], kf, r, g);
+        park_rows<HD>(park[wave][1], qf, r, g);
+        park_rows<HD>(park[wave][2], of, r, g);
     }
     f32x16 st, sn, dpt, dpn;     // scores / dP with (rows j, col i) and with (rows i, col j)
 #pragma unroll
@@ -213,9 +259,19 @@ __global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(const bf16_t *__restr
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             if (s < NS) {
-                tq = mfma32(tok_frag(kb, rs, dcol, dok, g, s, N), dst_f[s], tq);   // dQ^T[d][i] = sum_j K[j][d] dS[i][j]
-                tk = mfma32(tok_frag(qb, rs, dcol, dok, g, s, N), dsn_f[s], tk);   // dK^T[d][j] = sum_i Q[i][d] dS[i][j]
-                tv = mfma32(tok_frag(ob, D, dcol, dok, g, s, N), pn_f[s], tv);     // dV^T[d][j] = sum_i dO[i][d] P[i][j]
+                bf16x8 kt, qt, ot;
+                if constexpr (PARK) {
+                    kt = tok_frag_lds<HD>(park[wave][0], blk, r, g, s);
+                    qt = tok_frag_lds<HD>(park[wave][1], blk, r, g, s);
+                    ot = tok_frag_lds<HD>(park[wave][2], blk, r, g, s);
+                } else {
+                    kt = tok_frag(kb, rs, dcol, dok, g, s, N);
+                    qt = tok_frag(qb, rs, dcol, dok, g, s, N);
+                    ot = tok_frag(ob, D, dcol, dok, g, s, N);
+                }
+                tq = mfma32(kt, dst_f[s], tq);   // dQ^T[d][i] = sum_j K[j][d] dS[i][j]
+                tk = mfma32(qt, dsn_f[s], tk);   // dK^T[d][j] = sum_i Q[i][d] dS[i][j]
+                tv = mfma32(ot, pn_f[s], tv);    // dV^T[d][j] = sum_i dO[i][d] P[i][j]
             }
         }
         if (r < N) {
