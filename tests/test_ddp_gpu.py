@@ -29,7 +29,7 @@ def _make(dev, B, world, **kw):
     cfg = config_for("tiny", img_size=64, patch_size=16, in_chans=5, embed_dim=192)
     eng = MAEEngine(cfg, device=dev, compute_dtype=torch.bfloat16, seed=1)
     opt = FusedAdamW(eng, lr=LR, betas=(0.9, 0.95), weight_decay=0.05)
-    step = TrainStep(eng, opt, CosineLR(opt, 100), B, world_size=world, external_noise=True, n_encoder_groups=3, **kw)
+    step = TrainStep(eng, opt, CosineLR(opt, 100), B, world_size=world, external_noise=True, **kw)        # default staging: 6 encoder groups with N > 1, 3 with one rank
     return eng, step
 
 
