@@ -182,6 +182,14 @@ __device__ __forceinline__ int swz(int r) {
 // workgroup-uniform base (tile row, k-step: scalar registers) plus ONE per-lane 32-bit offset that never changes.  The
 // instruction is written out (SGPR-base form, LDS destination in M0): left to the compiler, every piece's 64-bit vector
 // address was hoisted out of the loop into registers the accumulators and fragments need (spills inside the k-loop).
+// the lane index, recomputed where it is used (volatile asm: neither hoisted nor spilled).  In the k-loop's once-per-item paths
+// a value kept alive from the kernel's entry gets spilled, and its reload -- a scratch load the compiler waits for with
+// vmcnt(0) -- drains the LDS-DMA ring.
+__device__ __forceinline__ int lane_now() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 __device__ __forceinline__ void glds16_sbase(const void *base_uniform, unsigned int lane_off, char *lds_wave_base) {
     const unsigned int dst = (unsigned int)(uintptr_t)(lvoid_t *)lds_wave_base;
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
@@ -379,8 +387,8 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
         // that found something enter the append path.
         // (the lane coordinates go through an empty asm: everything addressed from them is then computed HERE, once per item,
         // instead of being hoisted out of the k-loop into registers that the accumulators and fragments need)
-        int l16 = lane & 15, l4 = lane >> 4;
-        asm volatile("" : "+v"(l16), "+v"(l4));
+        const int ln = lane_now();
+        const int l16 = ln & 15, l4 = ln >> 4;
         float4 rp[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) rp[j] = srow[wn * 64 + j * 16 + l16];
@@ -474,6 +482,7 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
     // the staged candidates of item (qt, t) -> this workgroup's region of wg_list (16 bytes each: query, row, dot^)
     int wpos = 0;
     auto flush_item = [&](int qt, int t) {
+        const int tid = wave * 64 + lane_now();
         int n = *stg_n;      // (a plain LDS read: a volatile one became a FLAT load, whose vmcnt(0) drained the LDS-DMA ring once per item)
         n = __builtin_amdgcn_readfirstlane(n < SCAP ? n : SCAP);
         uint4 *dst = wg_list + (int64_t)blockIdx.x * capw;
@@ -523,8 +532,9 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
         // front of the epilogue's reads of spar / srow.)
         if (kt_s == 0) {
             constexpr int QW = QT * 16 / 1024;           // waves that fetch the queries' parameters (1 KiB each); four more fetch the rows'
-            if (wave < QW) glds16_sbase((const char *)(qpar + (int64_t)qt_cur * QT) + wave * 1024, lane * 16, (char *)spar + wave * 1024);
-            else if (wave < QW + 4) glds16_sbase((const char *)(rowp + (int64_t)t_cur * BT) + (wave - QW) * 1024, lane * 16, (char *)srow + (wave - QW) * 1024);
+            const unsigned int l16b = (unsigned int)lane_now() * 16u;
+            if (wave < QW) glds16_sbase((const char *)(qpar + (int64_t)qt_cur * QT) + wave * 1024, l16b, (char *)spar + wave * 1024);
+            else if (wave < QW + 4) glds16_sbase((const char *)(rowp + (int64_t)t_cur * BT) + (wave - QW) * 1024, l16b, (char *)srow + (wave - QW) * 1024);
             // ... and the item finished one step ago (early group) / in this step's first phase (late group) is flushed
             if (STAGED && s_now > 0) flush_item(qt_done, t_done);
         } else if (kt_s == 1) {
