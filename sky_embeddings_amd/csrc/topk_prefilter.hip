@@ -724,8 +724,33 @@ __global__ __launch_bounds__(256) void select_kernel(int Q, int k, int cap, floa
         }
         return;
     }
-    // ---- final: the RESCORE_MAX largest U
+    // ---- final.  Only candidates whose interval reaches the k-th largest LOWER bound L_k can be among the k best: at least k
+    // candidates have an exact score >= L_k (each score is >= its own L), so the k-th best exact score is >= L_k, and whoever
+    // has U < L_k is out.  When those needed fit the re-score quota (the rule on embedding-like data: k plus a few dozen), only
+    // they are re-scored and the answer is certified by construction (bound = -inf) -- half the exact stage's HBM traffic.
     int *so = sel_i + (int64_t)q * RESCORE_MAX;
+    if (n >= k && n > 0) {
+        const unsigned int lk = radix_kth_largest(kL, n, k, hist, tid, 256);
+        if (unorderable(lk) > -INFINITY) {            // (k finite lower bounds exist; U = +inf / NaN-turned-inf rows always qualify)
+            if (tid == 0) hist[0] = 0;
+            __syncthreads();
+            int mine = 0;
+            for (int e = tid; e < n; e += 256) mine += kU[e] >= lk ? 1 : 0;
+            if (mine) atomicAdd(&hist[0], mine);
+            __syncthreads();
+            const int need = hist[0];
+            __syncthreads();
+            if (need <= RESCORE_MAX) {
+                if (tid == 0) hist[0] = 0;
+                __syncthreads();
+                for (int e = tid; e < n; e += 256)
+                    if (kU[e] >= lk) so[atomicAdd(&hist[0], 1)] = ci[e];
+                if (tid == 0) { nsel[q] = need; bound[q] = -INFINITY; }
+                return;
+            }
+        }
+    }
+    // ---- otherwise: the RESCORE_MAX largest U
     if (n <= RESCORE_MAX) {
         for (int e = tid; e < n; e += 256) so[e] = ci[e];
         if (tid == 0) { nsel[q] = n; bound[q] = -INFINITY; }
