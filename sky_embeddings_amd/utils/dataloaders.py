@@ -233,6 +233,8 @@ class FitsDataset(torch.utils.data.Dataset):
         self.use_calexp, self.use_overlap, self.overlap = use_calexp, use_overlap, overlap
         self.max_mask_ratio = max_mask_ratio
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.band_filenames = find_HSC_bands(fits_paths, self.bands, min_bands, use_calexp=use_calexp)
         self.mask_generator = None if max_mask_ratio is None else MaskGenerator(
             input_size=img_size, patch_size=patch_size, max_mask_ratio=max_mask_ratio, num_mask_chans=len(self.bands))
@@ -308,10 +310,12 @@ class FitsDataset(torch.utils.data.Dataset):
 class _TileLoader:
     """What ``DataLoader(dataset, batch_size=1, shuffle=...)`` yields for a FitsDataset -- every tensor with a leading
     dimension of 1 (the reference's loop indexes it away: pretrain_mim.py:143-150) -- without worker processes: the items
-    are device tensors."""
+    are device tensors.  With ``prefetch`` the NEXT tile is read, uploaded and cut on a side stream by a background thread
+    while the caller trains on the current one (a nine-band 4k x 4k tile is 0.6 GB of host reads and H2D: tens of
+    milliseconds, about as long as the training steps its cutouts feed)."""
 
-    def __init__(self, dataset, shuffle):
-        self.dataset, self.shuffle = dataset, shuffle
+    def __init__(self, dataset, shuffle, prefetch=True):
+        self.dataset, self.shuffle, self.prefetch = dataset, shuffle, prefetch
         self.batch_size, self.num_workers = 1, 0
 
     def __len__(self):
@@ -319,18 +323,52 @@ class _TileLoader:
 
     def __iter__(self):
         order = np.random.permutation(len(self.dataset)) if self.shuffle else np.arange(len(self.dataset))
-        for i in order:
-            yield tuple(t.unsqueeze(0) for t in self.dataset[int(i)])
+        if not self.prefetch or len(order) < 2 or self.dataset.device.type != "cuda":
+            for i in order:
+                yield tuple(t.unsqueeze(0) for t in self.dataset[int(i)])
+            return
+        import queue
+        import threading
+        dev = self.dataset.device
+        side = torch.cuda.Stream(device=dev)
+        q = queue.Queue(maxsize=1)                      # one tile ahead: two tiles resident
+
+        def produce():
+            try:
+                torch.cuda.set_device(dev)
+                for i in order:
+                    with torch.cuda.stream(side):
+                        item = self.dataset[int(i)]
+                        done = torch.cuda.Event()
+                        done.record(side)
+                    q.put((item, done))
+                q.put(None)
+            except BaseException as e:                  # surfaces in the consumer
+                q.put(e)
+
+        threading.Thread(target=produce, daemon=True).start()
+        while True:
+            got = q.get()
+            if got is None:
+                return
+            if isinstance(got, BaseException):
+                raise got
+            item, done = got
+            main = torch.cuda.current_stream(dev)
+            main.wait_event(done)
+            for t in item:
+                t.record_stream(main)                   # allocated on the side stream, consumed on the caller's
+            yield tuple(t.unsqueeze(0) for t in item)
 
 
 def build_fits_dataloader(fits_paths, bands, min_bands, batch_size, num_workers, patch_size=8, max_mask_ratio=None, img_size=64,
                           cutouts_per_tile=1024, use_calexp=True, augment=False, brightness=0.8, noise=0.01, nan_channels=2,
-                          shuffle=True, ra_dec=True, transforms=None, use_overlap=False, overlap=0.5, device="cuda"):
-    """utils/dataloaders.py:108-132."""
+                          shuffle=True, ra_dec=True, transforms=None, use_overlap=False, overlap=0.5, device="cuda", prefetch=True):
+    """utils/dataloaders.py:108-132 (+ ``device`` / ``prefetch``: see _TileLoader)."""
     if transforms is None and augment:
         # (an Augmenter maps a [n, C, S, S] stack to one augmented copy of every cutout: one launch for the whole tile)
         transforms = get_augmentations(img_size=img_size, flip=True, crop=True, brightness=brightness, noise=noise, nan_channels=nan_channels)
     dataset = FitsDataset(fits_paths, patch_size=patch_size, max_mask_ratio=max_mask_ratio, bands=bands, min_bands=min_bands,
                           img_size=img_size, cutouts_per_tile=cutouts_per_tile, batch_size=batch_size, ra_dec=ra_dec,
                           transform=transforms, use_calexp=use_calexp, use_overlap=use_overlap, overlap=overlap, device=device)
-    return _TileLoader(dataset, shuffle)
+    return _TileLoader(dataset, shuffle, prefetch)

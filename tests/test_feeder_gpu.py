@@ -119,8 +119,13 @@ def test_tile_sampler_matches_oracle(tmp_path):
         assert bool((per_channel == per_channel[:, :, :1]).all())                        # same count in every channel of a sample
     loader = build_fits_dataloader([str(tmp_path)], ["G", "R", "I", "Z", "Y"], 4, batch_size=16, num_workers=3, patch_size=8,
                                    max_mask_ratio=None, img_size=64, cutouts_per_tile=40, shuffle=False, ra_dec=True)
-    items = list(loader)
+    np.random.seed(5)
+    items = [tuple(t.clone() for t in it) for it in loader]                               # next tile prefetched on a side stream
     assert len(items) == 2 and items[0][0].shape == (1, 2, 16, 5, 64, 64) and items[0][1].shape == (1, 2, 16) and items[0][2].shape == (1, 2, 16, 2)
+    loader.prefetch = False
+    np.random.seed(5)
+    for a, b in zip(items, loader):                                                        # same draws, same tensors without it
+        assert torch.equal(torch.nan_to_num(a[0], nan=-77.0), torch.nan_to_num(b[0], nan=-77.0)) and torch.equal(a[2], b[2])
     over = FitsDataset([str(tmp_path)], bands=["G", "R", "I", "Z", "Y"], min_bands=4, img_size=64, batch_size=8, use_overlap=True, overlap=0.5)
     cut, masks = over[0]
     from sky_embeddings_amd.utils.dataloaders import generate_overlap_coords
