@@ -264,9 +264,26 @@ class FitsDataset(torch.utils.data.Dataset):
             if h is None or h.shape != (H, W):
                 tile[c].fill_(float("nan"))
             elif h.bitpix == -32 and h.bscale == 1.0 and h.bzero == 0.0:
-                # the file's bytes, reinterpreted: no host pass over the pixels (the kernel swaps the byte order)
-                raw = torch.from_numpy(np.asarray(h.raw).view(np.int32))
-                tile[c].view(torch.int32).copy_(raw, non_blocking=True)
+                # the file's bytes as they are (the kernel swaps the byte order): native threads copy the mapped band into a
+                # pinned buffer (pageable -> device copies run at ~4 GB/s, this path at the host's memcpy rate), two buffers
+                # in turn so that the copy of one band overlaps the H2D of the previous one
+                slot = self._pin_slot = 1 - getattr(self, "_pin_slot", 1)
+                pins = self.__dict__.setdefault("_pins", [None, None])
+                evs = self.__dict__.setdefault("_pin_events", [None, None])
+                if pins[slot] is None or pins[slot].numel() != H * W:
+                    pins[slot] = torch.empty(H * W, dtype=torch.int32).pin_memory()
+                if evs[slot] is not None:
+                    evs[slot].synchronize()                    # the H2D that last read this buffer has finished
+                rows = getattr(self, "_row_idx", None)
+                if rows is None or len(rows) != H:
+                    rows = self._row_idx = np.arange(H, dtype=np.int64)
+                raw = np.asarray(h.raw)
+                from .._lib import check, lib
+                check(lib().skyemb_gather_rows_host(raw.ctypes.data, W * 4, rows.ctypes.data, H, H, pins[slot].data_ptr(), 16),
+                      "skyemb_gather_rows_host")
+                tile[c].view(torch.int32).view(-1).copy_(pins[slot], non_blocking=True)
+                evs[slot] = torch.cuda.Event()
+                evs[slot].record(torch.cuda.current_stream(self.device))
                 be[c] = 1
             else:                                      # integer / double / scaled images: decoded on the host
                 tile[c].copy_(torch.from_numpy(np.ascontiguousarray(h.array(), dtype=np.float32)))
