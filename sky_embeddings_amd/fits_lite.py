@@ -11,8 +11,10 @@
   (Shupe et al. 2005).  ``all_pix2world(x, y, origin)`` has astropy's argument meaning.
 * ``write_image_fits``: writer for the same subset (tests, synthetic tiles).
 
-Tile-compressed images (``ZIMAGE`` binary tables, what ``fpack`` / astropy ``CompImageHDU`` write) raise
-``NotImplementedError`` by name: funpack such files first.
+Tile-compressed images (``ZIMAGE`` binary tables, what ``fpack`` / astropy ``CompImageHDU`` / the LSST stack write; FITS 4.0
+section 10): the lossless gzip codecs (``GZIP_1``, ``GZIP_2`` = byte-shuffled, ``NOCOMPRESS``) without quantisation are
+decoded on the host (zlib) into a native float32 / integer array; ``RICE_1`` / ``HCOMPRESS_1`` / ``PLIO_1`` and quantised
+floating-point tiles (``ZSCALE`` / ``ZZERO`` columns, dithering) raise ``NotImplementedError`` by name: funpack such files.
 """
 from __future__ import annotations
 
@@ -85,11 +87,17 @@ def _data_bytes(hdr):
 
 
 class ImageHDU:
-    """Header + raw big-endian pixels of one image HDU.  ``raw`` is a read-only memmap [H, W] of the on-disk dtype."""
+    """Header + raw big-endian pixels of one image HDU.  ``raw`` is a read-only memmap [H, W] of the on-disk dtype (or, for a
+    decompressed image, an in-memory big-endian array)."""
 
-    def __init__(self, path, header, offset):
+    def __init__(self, path, header, offset, decoded=None):
         self.path, self.header, self.offset = path, header, offset
         self.bitpix = int(header["BITPIX"])
+        if decoded is not None:
+            self.shape = decoded.shape
+            self.bscale, self.bzero = float(header.get("BSCALE", 1.0)), float(header.get("BZERO", 0.0))
+            self.raw = decoded
+            return
         if int(header.get("NAXIS", 0)) != 2:
             raise NotImplementedError(f"{path}: image HDU with NAXIS = {header.get('NAXIS')} (2-D images only)")
         self.shape = (int(header["NAXIS2"]), int(header["NAXIS1"]))        # FITS axis 1 is the fastest: [rows, columns]
@@ -119,8 +127,7 @@ def read_image_hdu(path, hdu=1) -> ImageHDU:
             pass      # astropy is asked to ignore a missing SIMPLE card too (utils/dataloaders.py:417)
         if index == hdu:
             if hdr.get("ZIMAGE") or (hdr.get("XTENSION") == "BINTABLE" and "ZCMPTYPE" in hdr):
-                raise NotImplementedError(f"{path}: HDU {hdu} is a tile-compressed image ({hdr.get('ZCMPTYPE')}); "
-                                          "decompress it (funpack) -- fits_lite reads plain image HDUs only")
+                return _read_compressed_image(path, hdr, buf, data_pos)
             if index > 0 and hdr.get("XTENSION") != "IMAGE":
                 raise NotImplementedError(f"{path}: HDU {hdu} is a {hdr.get('XTENSION')} extension, not an image")
             return ImageHDU(path, hdr, data_pos)
@@ -128,6 +135,115 @@ def read_image_hdu(path, hdu=1) -> ImageHDU:
         pos = data_pos + (nbytes + BLOCK - 1) // BLOCK * BLOCK
         index += 1
     raise IndexError(f"{path}: no HDU {hdu}")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# tile-compressed images (FITS 4.0 section 10), lossless gzip codecs
+# ---------------------------------------------------------------------------------------------------------------
+def _read_compressed_image(path, hdr, buf, data_pos):
+    import zlib
+    codec = str(hdr.get("ZCMPTYPE", "")).strip()
+    if codec not in ("GZIP_1", "GZIP_2", "NOCOMPRESS"):
+        raise NotImplementedError(f"{path}: tile compression {codec!r} is not supported (lossless GZIP_1 / GZIP_2 only): funpack the file")
+    zbitpix, znaxis = int(hdr["ZBITPIX"]), int(hdr.get("ZNAXIS", 0))
+    if znaxis != 2:
+        raise NotImplementedError(f"{path}: compressed image with ZNAXIS = {znaxis} (2-D images only)")
+    W, H = int(hdr["ZNAXIS1"]), int(hdr["ZNAXIS2"])
+    tw, th = int(hdr.get("ZTILE1", W)), int(hdr.get("ZTILE2", 1))
+    nfields, row_bytes, nrows = int(hdr["TFIELDS"]), int(hdr["NAXIS1"]), int(hdr["NAXIS2"])
+    cols, off = {}, 0
+    import re
+    widths = {"L": 1, "B": 1, "I": 2, "J": 4, "K": 8, "E": 4, "D": 8, "A": 1}
+    for k in range(1, nfields + 1):
+        m = re.match(r"\s*(\d*)([PQ])?([A-Z])", str(hdr[f"TFORM{k}"]))
+        if not m:
+            raise ValueError(f"{path}: TFORM{k} = {hdr[f'TFORM{k}']!r}")
+        repeat = int(m.group(1)) if m.group(1) else 1
+        name = str(hdr.get(f"TTYPE{k}", "")).strip()
+        if m.group(2):                                   # variable-length array: (length, heap offset) descriptor
+            cols[name] = (off, m.group(2))
+            off += repeat * (16 if m.group(2) == "Q" else 8)
+        else:
+            cols[name] = (off, m.group(3))
+            off += repeat * widths[m.group(3)]
+    if zbitpix < 0 and ("ZSCALE" in cols or str(hdr.get("ZQUANTIZ", "NONE")).strip().upper() not in ("NONE", "")):
+        raise NotImplementedError(f"{path}: quantised floating-point tiles ({hdr.get('ZQUANTIZ')}) are not supported: funpack the file")
+    if "COMPRESSED_DATA" not in cols and "GZIP_COMPRESSED_DATA" not in cols:
+        raise NotImplementedError(f"{path}: compressed image table without a COMPRESSED_DATA column")
+    heap = data_pos + int(hdr.get("THEAP", row_bytes * nrows))
+    dt = np.dtype(_BITPIX_DTYPE[zbitpix])
+    out = np.empty((H, W), dtype=dt)
+    tiles_x = (W + tw - 1) // tw
+    table = np.asarray(buf[data_pos:data_pos + row_bytes * nrows]).reshape(nrows, row_bytes)
+
+    def descriptor(row, col):
+        o, kind = cols[col]
+        n = 16 if kind == "Q" else 8
+        vals = np.frombuffer(table[row, o:o + n].tobytes(), dtype=">i8" if kind == "Q" else ">i4")
+        return int(vals[0]), int(vals[1])
+
+    for t in range(nrows):
+        ty, tx = divmod(t, tiles_x)
+        h, w = min(th, H - ty * th), min(tw, W - tx * tw)
+        nbytes = h * w * dt.itemsize
+        length, ptr, col = 0, 0, None
+        for col in ("COMPRESSED_DATA", "GZIP_COMPRESSED_DATA", "UNCOMPRESSED_DATA"):
+            if col in cols:
+                length, ptr = descriptor(t, col)
+                if length > 0:
+                    break
+        chunk = bytes(buf[heap + ptr:heap + ptr + length * (dt.itemsize if col == "UNCOMPRESSED_DATA" else 1)])
+        if col == "UNCOMPRESSED_DATA" or codec == "NOCOMPRESS":
+            raw = chunk
+        else:
+            raw = zlib.decompress(chunk, 15 + 32)              # zlib or gzip wrapper
+            if codec == "GZIP_2" and col == "COMPRESSED_DATA":     # byte planes, most significant first -> pixels
+                raw = np.frombuffer(raw, dtype=np.uint8).reshape(dt.itemsize, h * w).T.tobytes()
+        if len(raw) != nbytes:
+            raise ValueError(f"{path}: tile {t} decompressed to {len(raw)} bytes, expected {nbytes}")
+        out[ty * th:ty * th + h, tx * tw:tx * tw + w] = np.frombuffer(raw, dtype=dt).reshape(h, w)
+    image_hdr = dict(hdr)
+    image_hdr["BITPIX"] = zbitpix
+    for key in ("BSCALE", "BZERO"):
+        if "Z" + key in hdr:
+            image_hdr[key] = hdr["Z" + key]
+    return ImageHDU(path, image_hdr, None, decoded=out)
+
+
+def write_compressed_image_fits(path, image, header=None, codec="GZIP_2", tile_rows=1):
+    """Primary HDU + ONE tile-compressed image extension (BINTABLE, COMPRESSED_DATA as 1PB variable-length arrays, row tiles)
+    with a lossless gzip codec -- the layout read back by ``read_image_hdu`` (tests)."""
+    import zlib
+    image = np.asarray(image)
+    assert image.ndim == 2 and codec in ("GZIP_1", "GZIP_2")
+    bitpix = {np.dtype("float32"): -32, np.dtype("float64"): -64, np.dtype("int16"): 16, np.dtype("int32"): 32}[image.dtype]
+    be = image.astype(_BITPIX_DTYPE[bitpix])
+    H, W = image.shape
+    chunks = []
+    for y in range(0, H, tile_rows):
+        raw = be[y:y + tile_rows].tobytes()
+        if codec == "GZIP_2":
+            n = len(raw) // be.itemsize
+            raw = np.frombuffer(raw, dtype=np.uint8).reshape(n, be.itemsize).T.tobytes()
+        chunks.append(zlib.compress(raw, 6))
+    offs = np.cumsum([0] + [len(c) for c in chunks[:-1]])
+    table = b"".join(np.array([len(c), o], dtype=">i4").tobytes() for c, o in zip(chunks, offs))
+    heap = b"".join(chunks)
+    primary = [_card("SIMPLE", True), _card("BITPIX", 8), _card("NAXIS", 0), _card("EXTEND", True)]
+    ext = [_card("XTENSION", "BINTABLE"), _card("BITPIX", 8), _card("NAXIS", 2), _card("NAXIS1", 8), _card("NAXIS2", len(chunks)),
+           _card("PCOUNT", len(heap)), _card("GCOUNT", 1), _card("TFIELDS", 1), _card("TTYPE1", "COMPRESSED_DATA"),
+           _card("TFORM1", f"1PB({max(len(c) for c in chunks)})"), _card("ZIMAGE", True), _card("ZCMPTYPE", codec),
+           _card("ZBITPIX", bitpix), _card("ZNAXIS", 2), _card("ZNAXIS1", W), _card("ZNAXIS2", H), _card("ZTILE1", W),
+           _card("ZTILE2", tile_rows), _card("ZQUANTIZ", "NONE")]
+    for k, v in (header or {}).items():
+        ext.append(_card(k, v))
+    data = table + heap
+    data += b"\0" * (-len(data) % BLOCK)
+    with open(path, "wb") as f:
+        f.write(_header_bytes(primary))
+        f.write(_header_bytes(ext))
+        f.write(data)
+    return path
 
 
 # ---------------------------------------------------------------------------------------------------------------

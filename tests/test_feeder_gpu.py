@@ -58,7 +58,7 @@ def test_feeder_shards_are_disjoint_and_shuffled(tmp_path):
     assert torch.equal(again, ras[0])                                # same seed, same order
 
 
-def _make_tiles(root, n_patches=2, H=200, W=232, bands=("G", "R", "I", "Z", "Y"), missing=((0, "Z"),), int_band=None):
+def _make_tiles(root, n_patches=2, H=200, W=232, bands=("G", "R", "I", "Z", "Y"), missing=((0, "Z"),), int_band=None, gz_band=None):
     """Synthetic survey tiles in the reference's layout (one FITS file per band and patch, image in HDU 1, TAN-SIP header)."""
     from sky_embeddings_amd import fits_lite
     rng = np.random.default_rng(7)
@@ -78,6 +78,9 @@ def _make_tiles(root, n_patches=2, H=200, W=232, bands=("G", "R", "I", "Z", "Y")
                 q = np.round(np.nan_to_num(img) * 100).astype(np.int16)
                 fits_lite.write_image_fits(os.path.join(root, f"calexp-HSC-{b}-{patch}.fits"), q, dict(hdr, BSCALE=0.01, BZERO=0.0), bitpix=16)
                 planes.append((q * 0.01).astype(np.float32))
+            elif gz_band == b:         # a tile-compressed image (lossless gzip, byte-shuffled): decoded on the host
+                fits_lite.write_compressed_image_fits(os.path.join(root, f"calexp-HSC-{b}-{patch}.fits"), img, dict(hdr, CRVAL1=35.3 + k), "GZIP_2", 1)
+                planes.append(img)
             else:
                 fits_lite.write_image_fits(os.path.join(root, f"calexp-HSC-{b}-{patch}.fits"), img, dict(hdr, CRVAL1=35.3 + k))
                 planes.append(img)
@@ -86,12 +89,13 @@ def _make_tiles(root, n_patches=2, H=200, W=232, bands=("G", "R", "I", "Z", "Y")
 
 
 def test_tile_sampler_matches_oracle(tmp_path):
-    """FitsDataset (utils/dataloaders.py:538-654) with the tile resident in HBM: windows, clip, missing band, an integer band,
+    """FitsDataset (utils/dataloaders.py:538-654) with the tile resident in HBM: windows, clip, missing band, an integer band, a
+    gzip-compressed band,
     batch layout and the RA / Dec of the window centres against the CPU restatement for the same numpy draws."""
     import os as _os
     from oracle import tile_oracle as to
     from sky_embeddings_amd.utils.dataloaders import FitsDataset, build_fits_dataloader, load_fits_bands
-    tiles, hdr = _make_tiles(str(tmp_path), int_band="Y")
+    tiles, hdr = _make_tiles(str(tmp_path), int_band="Y", gz_band="G")      # (G is also the band the world coordinates come from)
     ds = FitsDataset([str(tmp_path)], patch_size=8, max_mask_ratio=0.9, bands=["G", "R", "I", "Z", "Y"], min_bands=4, img_size=64,
                      cutouts_per_tile=70, batch_size=16, ra_dec=True)
     assert len(ds) == 2

@@ -405,3 +405,27 @@ def test_tile_file_discovery_and_overlap_grid(tmp_path):
     c = generate_overlap_coords((10, 11), 4, 0.5)                  # step 2: rows 0..6, cols 0..6; W % 2 != 0 -> a right-edge column
     assert c[:4] == [(0, 0), (0, 2), (0, 4), (0, 6)] and (6, 7) in c and (0, 7) in c and len(c) == 16 + 4
     assert generate_overlap_coords((8, 8), 4, 0.0) == [(0, 0), (0, 4), (4, 0), (4, 4)]
+
+
+def test_fits_lite_reads_lossless_tile_compressed_images(tmp_path):
+    """ZIMAGE binary tables with the lossless gzip codecs (FITS 4.0 section 10; what fpack -g / the LSST stack's GZIP_SHUFFLE
+    write) decode to the same pixels and keep the image header; lossy / other codecs are refused by name."""
+    from sky_embeddings_amd import fits_lite
+    rng = np.random.default_rng(1)
+    img = rng.standard_normal((37, 53)).astype(np.float32)
+    img[2, 3] = np.nan
+    for codec in ("GZIP_1", "GZIP_2"):
+        for tile_rows in (1, 5):
+            p = fits_lite.write_compressed_image_fits(str(tmp_path / f"{codec}_{tile_rows}.fits"), img, _WCS_HDR, codec, tile_rows)
+            h = fits_lite.read_image_hdu(p, 1)
+            assert h.shape == (37, 53) and h.bitpix == -32 and h.raw.dtype == np.dtype(">f4")
+            assert np.array_equal(h.array().view(np.uint32), img.view(np.uint32)) and h.header["CTYPE1"] == "RA---TAN-SIP"
+    ints = rng.integers(-5000, 5000, (20, 31)).astype(np.int32)
+    p = fits_lite.write_compressed_image_fits(str(tmp_path / "i.fits"), ints, None, "GZIP_2", 4)
+    assert np.array_equal(fits_lite.read_image_hdu(p, 1).array(), ints)
+    raw = bytearray(open(p, "rb").read())
+    at = raw.index(b"GZIP_2")
+    raw[at:at + 6] = b"RICE_1"
+    (tmp_path / "r.fits").write_bytes(bytes(raw))
+    with pytest.raises(NotImplementedError, match="RICE_1"):
+        fits_lite.read_image_hdu(str(tmp_path / "r.fits"), 1)
