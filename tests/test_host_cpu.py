@@ -429,3 +429,31 @@ def test_fits_lite_reads_lossless_tile_compressed_images(tmp_path):
     (tmp_path / "r.fits").write_bytes(bytes(raw))
     with pytest.raises(NotImplementedError, match="RICE_1"):
         fits_lite.read_image_hdu(str(tmp_path / "r.fits"), 1)
+
+
+def test_host_cutout_functions_match_oracle(tmp_path):
+    """random_cutouts / overlapping_cutouts / load_fits_bands (host mirrors of utils/dataloaders.py:381-536) against the
+    restatement in oracle/tile_oracle.py for the same numpy draws; RA / Dec with the reference's (row, column) -> (x, y) order."""
+    from oracle import tile_oracle as to
+    from sky_embeddings_amd import fits_lite
+    from sky_embeddings_amd.utils.dataloaders import generate_overlap_coords, load_fits_bands, overlapping_cutouts, random_cutouts
+    rng = np.random.default_rng(3)
+    bands = []
+    for b in "GRI":
+        img = rng.standard_normal((90, 120)).astype(np.float32)
+        fits_lite.write_image_fits(str(tmp_path / f"calexp-HSC-{b}-1-2,3.fits"), img, _WCS_HDR)
+        bands.append(img)
+    tile, pix_to_radec = load_fits_bands([str(tmp_path / f"calexp-HSC-{b}-1-2,3.fits") for b in "GR"] + ["None", str(tmp_path / "calexp-HSC-I-1-2,3.fits")],
+                                         return_wc=True)
+    assert tile.shape == (4, 90, 120) and np.isnan(tile[2]).all() and np.array_equal(tile[3].astype(np.float32), bands[2])
+    np.random.seed(9)
+    cut, rd = random_cutouts(tile, 32, 11, pix_to_radec)
+    np.random.seed(9)
+    hs, ws = np.random.randint(0, 90 - 32 + 1, size=11), np.random.randint(0, 120 - 32 + 1, size=11)
+    ref = to.cutouts_np(tile, hs, ws, 32)
+    assert np.array_equal(np.nan_to_num(cut.astype(np.float32), nan=-7), np.nan_to_num(ref, nan=-7))
+    ra, dec = to.tan_sip_pix2world(_WCS_HDR, hs + 16, ws + 16, 0)
+    assert np.allclose(rd, np.vstack((ra, dec)).T, rtol=0, atol=1e-10)
+    over = overlapping_cutouts(tile, 32, 0.5)
+    coords = generate_overlap_coords((90, 120), 32, 0.5)
+    assert over.shape == (len(coords), 4, 32, 32) and np.array_equal(np.nan_to_num(over[-1]), np.nan_to_num(tile[:, 58:90, 88:120]))
