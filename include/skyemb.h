@@ -305,7 +305,7 @@ int skyemb_kth_largest_floor(const float *x, int Q, int S, int k, float *out, vo
 int skyemb_topk_merge(const float *in_s, const int64_t *in_i, int Q, int nlists, int k, float *out_s,
                       int64_t *out_i, void *ws, void *stream);
 
-/* Many-query exact top-k in two stages (Q >= 64): an fp16 matrix-core pass over a half-precision image of the bank with
+/* Many-query exact top-k in two stages (Q >= 17): an fp16 matrix-core pass over a half-precision image of the bank with
  * a proven error bound keeps, per query, only the rows whose score could still reach its top-k; the survivors are
  * re-scored with the contract's fp32 fma chain.  Results are bit-identical to skyemb_cosine_topk + skyemb_topk_merge.
  * Replaces the same reference code as skyemb_cosine_topk (utils/similarity.py:18-35,149-172).

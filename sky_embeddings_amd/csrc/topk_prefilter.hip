@@ -905,7 +905,7 @@ int64_t carve(char *base, int Q, int D, int cap, Workspace *w) {
 
 extern "C" int skyemb_topk_prefilter_applicable(int Q, int64_t N, int D, int k) {
     // the fp16 pass pays from a few query tiles on; the re-score list must leave room above k
-    return Q >= 64 && D % BK == 0 && D >= 4 * BK && D <= 4096 && k >= 1 && k <= RESCORE_MAX - 64 && N >= 8 * BT && N < (1ll << 31);
+    return Q >= 17 && D % BK == 0 && D >= 4 * BK && D <= 4096 && k >= 1 && k <= RESCORE_MAX - 64 && N >= 8 * BT && N < (1ll << 31);
 }
 static int skyemb_topk_prefilter_cap(int k) { return k <= 128 ? 4096 : 8192; }
 
@@ -930,7 +930,7 @@ extern "C" int skyemb_cosine_topk_prefiltered(const float *tw, const float *qn, 
                                               int64_t *out_i, int *redo, void *stream) {
     SKY_CHECK_ARG(tw && qn && bank && xn && bank16 && rowp && ws && out_s && out_i && redo, "skyemb_cosine_topk_prefiltered: null argument");
     SKY_CHECK_ARG(skyemb_topk_prefilter_applicable(Q, N, D, k), "skyemb_cosine_topk_prefiltered: outside the prefiltered subset "
-                  "(Q >= 64, D %% 64 == 0, k <= %d, N >= %d)", RESCORE_MAX - 64, 8 * BT);
+                  "(Q >= 17, D %% 32 == 0, k <= %d, N >= %d)", RESCORE_MAX - 64, 8 * BT);
     const int cap = skyemb_topk_prefilter_cap(k);
     SKY_CHECK_ARG(ws_bytes >= skyemb_topk_prefilter_ws_bytes(Q, D, k), "skyemb_cosine_topk_prefiltered: workspace too small");
     hipStream_t st = (hipStream_t)stream;

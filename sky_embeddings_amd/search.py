@@ -124,7 +124,7 @@ def _local_topk_prefiltered(tw, qn, pb: "PreparedBank", k, eps):
 def cosine_topk(queries: torch.Tensor, bank, k: int, weights: torch.Tensor | None = None, eps: float = 1e-6,
                 process_group=None, world_size: int = 1, prune: bool = True, stats: dict | None = None):
     """-> (scores f32 [Q,k], indices i64 [Q,k]).  ``bank`` is a [N,D] tensor or a PreparedBank
-    (this rank's shard; ``idx_offset`` = first global row of the shard).  Many queries (Q >= 64) take the two-stage
+    (this rank's shard; ``idx_offset`` = first global row of the shard).  More than 16 queries take the two-stage
     path (fp16 matrix-core prefilter with a proven error bound, exact fp32 re-score of the survivors: same results bit
     for bit); SKYEMB_TOPK_PREFILTER=0 keeps every search on the exact fp32 kernels."""
     pb = bank if isinstance(bank, PreparedBank) else PreparedBank(bank, weights)
