@@ -287,21 +287,15 @@ __global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(const bf16_t *__restr
 // 32 < N <= 128 (SimMIM sequences: 65 / 66 tokens): one workgroup per (sample, head), wave s owns token strip
 // [32 s, 32 s + 32) both as QUERY strip (softmax statistics, output / dQ) and as KEY strip (dK, dV).  Same orientation
 // trick per 32x32 tile; the statistics of every query row travel through LDS between the two phases of backward.
+// The head's K, V (forward) or Q, K, V, dO (backward) are staged ONCE in LDS with coalesced 16-byte loads (rows past N
+// zero-filled, pitch HD + 8): row fragments come back as ds_read_b128, the token-contracted (transposed) ones as two
+// ds_read_b64_tr_b16 -- the first version gathered those 2 bytes at a time from global memory, ~300 loads per lane in
+// backward (mim_19: 193 us per layer backward, 49 us forward).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int MAX_NT = 4;
 
 __device__ __forceinline__ bf16x8 row_frag_at(const bf16_t *base, int64_t row_stride, int row, int g, int s, int N) {
     return row < N ? *(const bf16x8 *)(base + (int64_t)row * row_stride + 16 * s + 8 * g) : zero8();
-}
-// lane (r, g): X[token row0 + pi(s,g,e)][dcol]
-__device__ __forceinline__ bf16x8 tok_frag_at(const bf16_t *base, int64_t row_stride, int row0, int dcol, bool dok, int g, int s, int N) {
-    bf16x8 f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int t = row0 + pi_row(s, g, e);
-        f[e] = (dok && t < N) ? base[(int64_t)t * row_stride + dcol] : (bf16_t)0.0f;
-    }
-    return f;
 }
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
@@ -309,11 +303,27 @@ __device__ __forceinline__ f32x16 zero16() {
     for (int e = 0; e < 16; ++e) z[e] = 0.f;
     return z;
 }
+// [rows][HD] of one head -> LDS tile with pitch HD + 8; rows >= N become zeros
+template <int HD>
+__device__ __forceinline__ void stage_rows(bf16_t *tile, const bf16_t *base, int64_t row_stride, int N, int rows, int tid, int nthreads) {
+    constexpr int PR = HD / 8;                            // 16-byte pieces per row
+    for (int p = tid; p < rows * PR; p += nthreads) {
+        const int row = p / PR, c = p - row * PR;
+        *(bf16x8 *)(tile + row * (HD + 8) + 8 * c) = row < N ? *(const bf16x8 *)(base + (int64_t)row * row_stride + 8 * c) : zero8();
+    }
+}
+template <int HD>
+__device__ __forceinline__ bf16x8 row_frag_lds(const bf16_t *tile, int row, int g, int s) {
+    return *(const bf16x8 *)(tile + row * (HD + 8) + 16 * s + 8 * g);
+}
+
+extern __shared__ __attribute__((aligned(16))) bf16_t strip_lds[];
 
 template <int HD, int NT>
 __global__ __launch_bounds__(64 * NT) void mha_fwd_strip_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out, int B,
                                                                 int N, int H) {
-    constexpr int KS = HD / 16, NB = (HD + 31) / 32;
+    constexpr int KS = HD / 16, NB = (HD + 31) / 32, PITCH = HD + 8, ROWS = 32 * NT;
+    bf16_t *kt = strip_lds, *vt = strip_lds + ROWS * PITCH;
     const int lane = threadIdx.x & 63, strip = threadIdx.x >> 6;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     const int D = H * HD;
@@ -323,9 +333,12 @@ __global__ __launch_bounds__(64 * NT) void mha_fwd_strip_kernel(const bf16_t *__
     const int my = 32 * strip + r;                        // this lane's query token
     const float scale = rsqrtf((float)HD);
 
+    stage_rows<HD>(kt, kb, rs, N, ROWS, threadIdx.x, 64 * NT);
+    stage_rows<HD>(vt, vb, rs, N, ROWS, threadIdx.x, 64 * NT);
     bf16x8 qf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) qf[s] = row_frag_at(qb, rs, my, g, s, N);
+    __syncthreads();
     f32x16 st[NT];
     float mx = -INFINITY;
 #pragma unroll
@@ -333,7 +346,7 @@ __global__ __launch_bounds__(64 * NT) void mha_fwd_strip_kernel(const bf16_t *__
         st[t] = zero16();
         if (32 * t < N) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s) st[t] = mfma32(row_frag_at(kb, rs, 32 * t + r, g, s, N), qf[s], st[t]);   // ST[j][i]
+            for (int s = 0; s < KS; ++s) st[t] = mfma32(row_frag_lds<HD>(kt, 32 * t + r, g, s), qf[s], st[t]);   // ST[j][i]
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -355,7 +368,6 @@ __global__ __launch_bounds__(64 * NT) void mha_fwd_strip_kernel(const bf16_t *__
     bf16_t *orow = out + ((int64_t)b * N + my) * D + h * HD;
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) {
-        const int dcol = 32 * blk + r;
         f32x16 ot = zero16();
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -365,7 +377,7 @@ __global__ __launch_bounds__(64 * NT) void mha_fwd_strip_kernel(const bf16_t *__
                     bf16x8 pf;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)(st[t][8 * s + e] * inv);
-                    ot = mfma32(tok_frag_at(vb, rs, 32 * t, dcol, dcol < HD, g, s, N), pf, ot);   // O^T[d][i] += V[j][d] P[i][j]
+                    ot = mfma32(tok_frag_lds<HD>(vt + 32 * t * PITCH, blk, r, g, s), pf, ot);   // O^T[d][i] += V[j][d] P[i][j]
                 }
         if (my < N) store_tile<HD>(orow, ot, blk, g, 1.0f);
     }
@@ -374,8 +386,9 @@ __global__ __launch_bounds__(64 * NT) void mha_fwd_strip_kernel(const bf16_t *__
 template <int HD, int NT>
 __global__ __launch_bounds__(64 * NT) void mha_bwd_strip_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
                                                                 bf16_t *__restrict__ dqkv, int B, int N, int H) {
-    constexpr int KS = HD / 16, NB = (HD + 31) / 32;
+    constexpr int KS = HD / 16, NB = (HD + 31) / 32, PITCH = HD + 8, ROWS = 32 * NT;
     __shared__ float stats[3][32 * MAX_NT];               // per query token: softmax max, 1 / sum, rowsum(P dP)
+    bf16_t *qt = strip_lds, *kt = qt + ROWS * PITCH, *vt = kt + ROWS * PITCH, *dot = vt + ROWS * PITCH;
     const int lane = threadIdx.x & 63, strip = threadIdx.x >> 6;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     const int D = H * HD;
@@ -387,13 +400,19 @@ __global__ __launch_bounds__(64 * NT) void mha_bwd_strip_kernel(const bf16_t *__
     const float scale = rsqrtf((float)HD);
     bf16_t *dq = dqkv + ((int64_t)b * N + my) * rs + h * HD, *dk = dq + D, *dv = dq + 2 * D;
 
+    stage_rows<HD>(qt, qb, rs, N, ROWS, threadIdx.x, 64 * NT);
+    stage_rows<HD>(kt, kb, rs, N, ROWS, threadIdx.x, 64 * NT);
+    stage_rows<HD>(vt, vb, rs, N, ROWS, threadIdx.x, 64 * NT);
+    stage_rows<HD>(dot, ob, D, N, ROWS, threadIdx.x, 64 * NT);
+    __syncthreads();
+
     // ---- phase A: my query strip against every key tile: statistics, dS^T, dQ
     {
         bf16x8 qf[KS], of[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            qf[s] = row_frag_at(qb, rs, my, g, s, N);
-            of[s] = row_frag_at(ob, D, my, g, s, N);
+            qf[s] = row_frag_lds<HD>(qt, my, g, s);
+            of[s] = row_frag_lds<HD>(dot, my, g, s);
         }
         f32x16 st[NT], dpt[NT];
         float mx = -INFINITY;
@@ -404,8 +423,8 @@ __global__ __launch_bounds__(64 * NT) void mha_bwd_strip_kernel(const bf16_t *__
             if (32 * t < N) {
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
-                    st[t] = mfma32(row_frag_at(kb, rs, 32 * t + r, g, s, N), qf[s], st[t]);
-                    dpt[t] = mfma32(row_frag_at(vb, rs, 32 * t + r, g, s, N), of[s], dpt[t]);   // dP^T[j][i]
+                    st[t] = mfma32(row_frag_lds<HD>(kt, 32 * t + r, g, s), qf[s], st[t]);
+                    dpt[t] = mfma32(row_frag_lds<HD>(vt, 32 * t + r, g, s), of[s], dpt[t]);   // dP^T[j][i]
                 }
             }
 #pragma unroll
@@ -441,7 +460,6 @@ __global__ __launch_bounds__(64 * NT) void mha_bwd_strip_kernel(const bf16_t *__
         }
 #pragma unroll
         for (int blk = 0; blk < NB; ++blk) {
-            const int dcol = 32 * blk + r;
             f32x16 tq = zero16();
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -451,7 +469,7 @@ __global__ __launch_bounds__(64 * NT) void mha_bwd_strip_kernel(const bf16_t *__
                         bf16x8 df;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) df[e] = (bf16_t)(st[t][8 * s + e] * (dpt[t][8 * s + e] - rsum));   // dS^T[j][i]
-                        tq = mfma32(tok_frag_at(kb, rs, 32 * t, dcol, dcol < HD, g, s, N), df, tq);   // dQ^T[d][i] += K[j][d] dS[i][j]
+                        tq = mfma32(tok_frag_lds<HD>(kt + 32 * t * PITCH, blk, r, g, s), df, tq);   // dQ^T[d][i] += K[j][d] dS[i][j]
                     }
             if (my < N) store_tile<HD>(dq, tq, blk, g, scale);
         }
@@ -462,8 +480,8 @@ __global__ __launch_bounds__(64 * NT) void mha_bwd_strip_kernel(const bf16_t *__
         bf16x8 kf[KS], vf[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            kf[s] = row_frag_at(kb, rs, my, g, s, N);
-            vf[s] = row_frag_at(vb, rs, my, g, s, N);
+            kf[s] = row_frag_lds<HD>(kt, my, g, s);
+            vf[s] = row_frag_lds<HD>(vt, my, g, s);
         }
         f32x16 tk[NB], tv[NB];
 #pragma unroll
@@ -477,9 +495,8 @@ __global__ __launch_bounds__(64 * NT) void mha_bwd_strip_kernel(const bf16_t *__
             f32x16 sn = zero16(), dpn = zero16();
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const bf16x8 qt = row_frag_at(qb, rs, 32 * t + r, g, s, N), ot = row_frag_at(ob, D, 32 * t + r, g, s, N);
-                sn = mfma32(qt, kf[s], sn);            // S[i][j]: rows i = 32 t + acc_row, col j = my
-                dpn = mfma32(ot, vf[s], dpn);          // dP[i][j]
+                sn = mfma32(row_frag_lds<HD>(qt, 32 * t + r, g, s), kf[s], sn);       // S[i][j]: rows i = 32 t + acc_row, col j = my
+                dpn = mfma32(row_frag_lds<HD>(dot, 32 * t + r, g, s), vf[s], dpn);    // dP[i][j]
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -495,9 +512,8 @@ __global__ __launch_bounds__(64 * NT) void mha_bwd_strip_kernel(const bf16_t *__
                 const bf16x8 pf = pack_regs(sn, s), df = pack_regs(dpn, s);
 #pragma unroll
                 for (int blk = 0; blk < NB; ++blk) {
-                    const int dcol = 32 * blk + r;
-                    tk[blk] = mfma32(tok_frag_at(qb, rs, 32 * t, dcol, dcol < HD, g, s, N), df, tk[blk]);   // dK^T[d][j] += Q[i][d] dS[i][j]
-                    tv[blk] = mfma32(tok_frag_at(ob, D, 32 * t, dcol, dcol < HD, g, s, N), pf, tv[blk]);    // dV^T[d][j] += dO[i][d] P[i][j]
+                    tk[blk] = mfma32(tok_frag_lds<HD>(qt + (32 * t) * PITCH, blk, r, g, s), df, tk[blk]);    // dK^T[d][j] += Q[i][d] dS[i][j]
+                    tv[blk] = mfma32(tok_frag_lds<HD>(dot + (32 * t) * PITCH, blk, r, g, s), pf, tv[blk]);   // dV^T[d][j] += dO[i][d] P[i][j]
                 }
             }
         }
@@ -512,10 +528,23 @@ __global__ __launch_bounds__(64 * NT) void mha_bwd_strip_kernel(const bf16_t *__
 }
 
 template <int HD, int NT>
-void launch_strip(bool bwd, const bf16_t *x, const bf16_t *dout, bf16_t *out, int B, int N, int H, hipStream_t st) {
+int launch_strip(bool bwd, const bf16_t *x, const bf16_t *dout, bf16_t *out, int B, int N, int H, hipStream_t st) {
     const dim3 grid(B * H), block(64 * NT);
-    if (!bwd) hipLaunchKernelGGL((mha_fwd_strip_kernel<HD, NT>), grid, block, 0, st, x, out, B, N, H);
-    else hipLaunchKernelGGL((mha_bwd_strip_kernel<HD, NT>), grid, block, 0, st, x, dout, out, B, N, H);
+    const int smem = (bwd ? 4 : 2) * 32 * NT * (HD + 8) * 2;
+    if (smem > 65536) {
+        static bool attr_set = false;                     // (one per instantiation; only the backward kernel gets this large)
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void *)mha_bwd_strip_kernel<HD, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e != hipSuccess) {
+                skyemb_set_error("skyemb_mha: hipFuncSetAttribute: %s", hipGetErrorString(e));
+                return 2;
+            }
+            attr_set = true;
+        }
+    }
+    if (!bwd) hipLaunchKernelGGL((mha_fwd_strip_kernel<HD, NT>), grid, block, smem, st, x, out, B, N, H);
+    else hipLaunchKernelGGL((mha_bwd_strip_kernel<HD, NT>), grid, block, smem, st, x, dout, out, B, N, H);
+    return 0;
 }
 
 }  // namespace
@@ -529,10 +558,11 @@ int skyemb_mha_mfma_try(bool bwd, const void *qkv, const void *dout, void *out, 
     if (N > 32) {
         const int nt = (N + 31) / 32;
 #define STRIP(HD_, NT_) launch_strip<HD_, NT_>(bwd, x, (const bf16_t *)dout, (bf16_t *)out, B, N, H, st)
-        if (hd == 32) { if (nt == 2) STRIP(32, 2); else if (nt == 3) STRIP(32, 3); else STRIP(32, 4); }
-        else { if (nt == 2) STRIP(64, 2); else if (nt == 3) STRIP(64, 3); else STRIP(64, 4); }
+        int rc;
+        if (hd == 32) rc = nt == 2 ? STRIP(32, 2) : nt == 3 ? STRIP(32, 3) : STRIP(32, 4);
+        else rc = nt == 2 ? STRIP(64, 2) : nt == 3 ? STRIP(64, 3) : STRIP(64, 4);
 #undef STRIP
-        return 0;
+        return rc;
     }
     const dim3 grid((B * H + 3) / 4), block(256);
     if (!bwd) {

@@ -587,7 +587,9 @@ int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
     }
     // measured: the 64x64 tile (3 workgroups per CU) is the best all-round choice at ViT-B sizes; launches with several
     // full rounds of 128x64 tiles (ViT-L token counts) gain ~5 % from the larger tile's lower L2->LDS traffic
-    if (tile == 0 && ceil_div64(g.M, 128) * ceil_div64(g.N, 64) >= 2048) tile = 128064;
+    // (from 4 rounds on with long k-loops: ViT-L data gradients and fc2, 12-19 % in tools/gemm_tune.py --model mim19)
+    const int64_t t12864 = ceil_div64(g.M, 128) * ceil_div64(g.N, 64);
+    if (tile == 0 && (t12864 >= 2048 || (t12864 >= 1024 && g.K >= 1024))) tile = 128064;
     if (tile == 0) tile = 64064;
     int bm, bn;
     tile_dims(tile, bm, bn);
@@ -627,6 +629,12 @@ extern "C" int skyemb_gemm_group_plan(const skyemb_gemm_args *args, int n, int t
         int64_t t12864 = 0;
         for (int i = 0; i < n; ++i) t12864 += ceil_div64(args[i].M, 128) * ceil_div64(args[i].N, 64);
         tile = t12864 >= 320 ? 128064 : 64064;
+        // ViT-L weight gradients (>= 2.5 rounds of 128x128 tiles, K = thousands of token rows): 128x128 (mim_19: 35.8 -> 35.2 ms/step)
+        int64_t t128 = 0;
+        for (int i = 0; i < n; ++i) t128 += ceil_div64(args[i].M, 128) * ceil_div64(args[i].N, 128);
+        if (t128 >= 640) tile = 128128;
+        static const int env_tile = []() { const char *e = getenv("SKYEMB_GROUP_TILE"); return e ? atoi(e) : 0; }();   // experiments
+        if (env_tile) tile = canonical_tile(env_tile);
     }
     SKY_CHECK_ARG(tile == 64064 || tile == 128064 || tile == 128128, "skyemb_gemm_group_plan: tile %d is not built for grouped launches", tile);
     int bm, bn;
