@@ -119,19 +119,27 @@ __global__ __launch_bounds__(256) void pmv_partial_kernel(const float *__restric
                                                           int C, int H, int W, int p, int keep, const float *__restrict__ pmask) {
     const int b = blockIdx.x;
     const int gw = W / p, pv = C * p * p;
-    for (int e = threadIdx.x; e < pv; e += 256) {
-        const int px = e % p, py = (e / p) % p, c = e / (p * p);
-        float acc = 0.f;
-        for (int j = 0; j < keep; ++j) {
+    const int e = blockIdx.y * 256 + threadIdx.x;         // grid (B, ceil(pv / 256)): one patch element per thread
+    if (e >= pv) return;
+    const int px = e % p, py = (e / p) % p, c = e / (p * p);
+    float acc = 0.f;
+    for (int j0 = 0; j0 < keep; j0 += 4) {                // four patches' loads in flight (the sum stays in patch order)
+        float wgt[4], d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u < keep ? j0 + u : keep - 1;
             const int l = ids_keep ? ids_keep[b * keep + j] : j;
             const int y = (l / gw) * p + py, x = (l % gw) * p + px;
             const int64_t pix = (((int64_t)b * C + c) * H + y) * W + x;
             const float v = imgs[pix];
-            const float wgt = v != v ? 1.0f : (pmask ? pmask[pix] : 0.0f);
-            if (wgt != 0.0f) acc += wgt * drows[((int64_t)b * keep + j) * pv + e];
+            wgt[u] = j0 + u >= keep ? 0.0f : v != v ? 1.0f : (pmask ? pmask[pix] : 0.0f);
+            d[u] = drows[((int64_t)b * keep + j) * pv + e];
         }
-        partial[(int64_t)b * pv + e] = acc;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (wgt[u] != 0.0f) acc += wgt[u] * d[u];
     }
+    partial[(int64_t)b * pv + e] = acc;
 }
 
 // ---- column sums: out[n] = sum_m X[m][n]; block = 64 columns x 4 row groups -------------------
@@ -345,7 +353,7 @@ extern "C" int skyemb_patch_gather_bwd_pmv_blend(const float *imgs, const int32_
                                                  const float *drows, float *partial, float *dpmv, int B, int C, int H, int W,
                                                  int p, int keep, void *stream) {
     SKY_CHECK_ARG(B > 0 && C > 0 && p > 0 && keep > 0, "skyemb_patch_gather_bwd_pmv: bad geometry");
-    hipLaunchKernelGGL(pmv_partial_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, imgs, ids_keep, drows, partial, C, H,
+    hipLaunchKernelGGL(pmv_partial_kernel, dim3(B, (C * p * p + 255) / 256), dim3(256), 0, (hipStream_t)stream, imgs, ids_keep, drows, partial, C, H,
                        W, p, keep, pixel_mask);
     SKY_LAUNCH_CHECK("skyemb_patch_gather_bwd_pmv");
     return skyemb_colsum(partial, SKYEMB_F32, (int64_t)C * p * p, B, C * p * p, dpmv, stream);
