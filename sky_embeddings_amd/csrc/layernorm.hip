@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD *__restrict__ dy, 
     }
     for (int row = blockIdx.x * 4 + wave; row < M; row += nblk * 4) {
         const float mu = mean[row], rs = rstd[row];
-        float4 xh[NV], dyv[NV];
+        float4 xh[NV], dyv[NV], gi[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -82,6 +82,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD *__restrict__ dy, 
             if (c < nv) {
                 const float4 xv = *(const float4 *)(x + (int64_t)row * D + 4 * c);
                 dyv[i] = load4<TD>(dy + (int64_t)row * D + 4 * c);
+                // the incoming residual gradient is requested with the row, not after the two reductions (one memory
+                // latency per row instead of two)
+                gi[i] = g_in ? *(const float4 *)(g_in + (int64_t)row * D + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
                 xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
                 const float a0 = dyv[i].x * gam[i].x, a1 = dyv[i].y * gam[i].y, a2 = dyv[i].z * gam[i].z,
                             a3 = dyv[i].w * gam[i].w;
@@ -104,8 +107,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD *__restrict__ dy, 
                 o.w = rs * (dyv[i].w * gam[i].w - m1 - xh[i].w * m2);
                 const int64_t off = (int64_t)row * D + 4 * c;
                 if (g_in) {
-                    const float4 gi = *(const float4 *)(g_in + off);
-                    o.x += gi.x; o.y += gi.y; o.z += gi.z; o.w += gi.w;
+                    o.x += gi[i].x; o.y += gi[i].y; o.z += gi[i].z; o.w += gi[i].w;
                 }
                 *(float4 *)(g_out + off) = o;
                 if (g_lp) store4<T>(g_lp + off, o.x, o.y, o.z, o.w);
