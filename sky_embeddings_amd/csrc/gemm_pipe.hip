@@ -520,11 +520,13 @@ int dispatch(const skyemb_gemm_args &g, hipStream_t st) {
 
 // Launch shapes.  code = variant * 1,000,000 + BM * 1000 + BN; X(variant, BM, BN, NSTAGE, WM, WN).
 // LDS per workgroup = NSTAGE * (BM + BN) * 128 B, which fixes the workgroups per CU (160 KiB): 64x64 x3 = 48 KB -> 3;
-// 128x64 x3 = 72 KB -> 2; 128x128 x3 = 96 KB -> 1, x2 = 64 KB -> 2; 256x128 x3 = 144 KB -> 1.
+// 128x64 x3 = 72 KB -> 2; 128x128 x3 = 96 KB -> 1, x2 = 64 KB -> 2; 256x128 x3 = 144 KB -> 1.  The 128x128 tile ships with the
+// 2-stage ring: two resident workgroups (16 waves) cover each other's barriers, which a third stage did not (ViT-L shapes,
+// tools/ubench/gemm_lab with LAB_VITL=1: [8320 x 3072 x 1024] 93 us on 128x64, 86 us on 128x128 x3, 74 us on 128x128 x2).
 #define SKY_GEMM_PRODUCT_VARIANTS(X) \
     X(0, 64, 64, 3, 2, 2)            \
     X(0, 128, 64, 3, 4, 2)           \
-    X(0, 128, 128, 3, 4, 2)
+    X(0, 128, 128, 2, 4, 2)
 #ifdef SKY_GEMM_LAB   // experiment builds (tools/ubench/gemm_lab.hip): every shape under study
 #define SKY_GEMM_VARIANTS(X) SKY_GEMM_PRODUCT_VARIANTS(X) SKY_GEMM_LAB_VARIANTS(X)
 #else
@@ -588,7 +590,8 @@ int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
     // measured: the 64x64 tile (3 workgroups per CU) is the best all-round choice at ViT-B sizes; launches with several
     // full rounds of 128x64 tiles (ViT-L token counts) gain ~5 % from the larger tile's lower L2->LDS traffic
     // (from 4 rounds on with long k-loops: ViT-L data gradients and fc2, 12-19 % in tools/gemm_tune.py --model mim19)
-    const int64_t t12864 = ceil_div64(g.M, 128) * ceil_div64(g.N, 64);
+    const int64_t t12864 = ceil_div64(g.M, 128) * ceil_div64(g.N, 64), t128 = ceil_div64(g.M, 128) * ceil_div64(g.N, 128);
+    if (tile == 0 && (t128 >= 1024 || (t128 >= 512 && g.K >= 2048))) tile = 128128;   // >= 2 rounds of 2 workgroups per CU
     if (tile == 0 && (t12864 >= 2048 || (t12864 >= 1024 && g.K >= 1024))) tile = 128064;
     if (tile == 0) tile = 64064;
     int bm, bn;
@@ -715,7 +718,7 @@ extern "C" int skyemb_gemm_group_launch(const void *blob_dev, const skyemb_gemm_
     switch (info->tile) {
         case 64064: return group_launch_classes<64, 64, 3, 2, 2>(blob_dev, info->total_blocks, info->class_mask, st);
         case 128064: return group_launch_classes<128, 64, 3, 4, 2>(blob_dev, info->total_blocks, info->class_mask, st);
-        case 128128: return group_launch_classes<128, 128, 3, 4, 2>(blob_dev, info->total_blocks, info->class_mask, st);
+        case 128128: return group_launch_classes<128, 128, 2, 4, 2>(blob_dev, info->total_blocks, info->class_mask, st);
     }
     skyemb_set_error("skyemb_gemm_group_launch: tile %d not built", info->tile);
     return 1;

@@ -13,7 +13,7 @@
     X(2, 128, 128, 2, 2, 2)      \
     X(3, 128, 128, 4, 2, 2)      \
     X(4, 128, 128, 4, 4, 2)      \
-    X(5, 128, 128, 2, 4, 2)      \
+    X(5, 128, 128, 3, 4, 2)      \
     X(0, 256, 128, 3, 4, 2)      \
     X(1, 256, 128, 2, 4, 2)      \
     X(2, 256, 128, 3, 4, 4)      \
@@ -83,8 +83,9 @@ struct Shape {
 int main(int argc, char **argv) {
     const int B = 256, Me = B * 5, Md = B * 17;
     std::vector<Shape> shapes;
-    for (int dec = 0; dec < 2; ++dec) {
-        const int M = dec ? Md : Me, D = dec ? 512 : 768, cnt = dec ? 8 : 12;
+    const bool vitl = getenv("LAB_VITL") != nullptr;      // mim_19: SimMIM ViT-L/16 on 128x128 cutouts, 128 x 65 token rows
+    for (int dec = 0; dec < (vitl ? 1 : 2); ++dec) {
+        const int M = vitl ? 128 * 65 : dec ? Md : Me, D = vitl ? 1024 : dec ? 512 : 768, cnt = vitl ? 24 : dec ? 8 : 12;
         const char *t = dec ? "dec" : "enc";
         static char names[64][32];
         static int ni = 0;
@@ -110,7 +111,12 @@ int main(int argc, char **argv) {
 #undef X
     }
     const int ROT = 6;
-    const size_t max_a = (size_t)Md * 2048, max_b = (size_t)3072 * 4352, max_o = (size_t)Md * 2048;
+    size_t max_a = (size_t)Md * 2048, max_b = (size_t)3072 * 4352, max_o = (size_t)Md * 2048;
+    for (const Shape &s : shapes) {
+        max_a = std::max(max_a, (size_t)s.M * s.K);
+        max_b = std::max(max_b, (size_t)s.N * s.K);
+        max_o = std::max(max_o, (size_t)s.M * s.N);
+    }
     bf16_t *A[ROT], *Bm[ROT], *aux;
     float *o32, *ref, *bias, *resid, *colsum, *ws;
     bf16_t *o16, *o16b;
