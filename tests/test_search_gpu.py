@@ -108,7 +108,8 @@ def _oracle_equal(q, x, w, k, **kw):
 
 
 @pytest.mark.parametrize("Q,N,D,k,weighted", [(64, 2048, 128, 10, True), (130, 21000, 128, 100, True), (300, 60000, 768, 100, False),
-                                              (77, 9000, 192, 150, True), (1000, 30000, 160, 1, True)])
+                                              (77, 9000, 192, 150, True), (1000, 30000, 160, 1, True), (17, 12000, 768, 100, True),
+                                              (33, 5000, 128, 7, False)])
 def test_prefiltered_many_query_topk_is_bit_exact(Q, N, D, k, weighted):
     """Two-stage path (fp16 matrix-core prefilter with a proven bound -> exact fp32 re-score) == oracle, bit for bit:
     ragged query / bank tiles, k up to the re-score quota, duplicates inside and across bank slices."""
