@@ -1,8 +1,8 @@
-// Attention core for short sequences (N <= 32 tokens) in bf16: ONE wavefront per (sample, head), every
-// product on v_mfma_f32_32x32x16_bf16, operands loaded straight from HBM into MFMA fragments (16-byte row loads).  The
-// operands that are contracted over the TOKEN index are the same rows transposed: 2-byte global gathers (8 per fragment), or
-// -- head dim 32, the 17-token decoder sequences -- the wave parks its row fragments in LDS and reads them back with
-// ds_read_b64_tr_b16 (two per fragment).
+// Attention core for short sequences (N <= 32 tokens) in bf16: ONE wavefront per 32-row tile of one head -- one sample, or
+// 32 / N consecutive samples when N <= 16 (their token rows are consecutive rows of the qkv matrix; score entries pairing
+// tokens of different samples are masked) -- every product on v_mfma_f32_32x32x16_bf16, operands loaded straight from HBM
+// into MFMA fragments (16-byte row loads).  The operands that are contracted over the TOKEN index are the same rows
+// transposed: the wave parks its row fragments in LDS and reads them back with ds_read_b64_tr_b16 (two per fragment).
 //
 // Orientation trick (cdna_hip_programming.md, "an accumulator tile as the next MFMA's operand"): a 32x32 result has its
 // column on the lane and its rows in the 16 registers, so it is directly the operand of a product that sums over its
@@ -34,16 +34,6 @@ __device__ __forceinline__ bf16x8 zero8() {
 // row fragment: lane (r, g) holds X[row r][16 s + 8 g + 0..7]  (the A and the B operand maps coincide)
 __device__ __forceinline__ bf16x8 row_frag(const bf16_t *base, int64_t row_stride, int r, int g, int s, int N) {
     return r < N ? *(const bf16x8 *)(base + (int64_t)r * row_stride + 16 * s + 8 * g) : zero8();
-}
-// transposed fragment for a contraction over the token index: lane (r, g) holds X[token pi(s,g,e)][d = dcol]
-__device__ __forceinline__ bf16x8 tok_frag(const bf16_t *base, int64_t row_stride, int dcol, bool dok, int g, int s, int N) {
-    bf16x8 f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int t = pi_row(s, g, e);
-        f[e] = (dok && t < N) ? base[(int64_t)t * row_stride + dcol] : (bf16_t)0.0f;
-    }
-    return f;
 }
 __device__ __forceinline__ bf16x8 pack_regs(const f32x16 &x, int s) {
     bf16x8 f;
@@ -84,45 +74,60 @@ __device__ __forceinline__ void store_tile(bf16_t *dst_row, const f32x16 &t, int
     }
 }
 
+// Sequences of N <= 16 tokens are PACKED: a wave takes P = 32 / N consecutive samples of one head -- their token rows are
+// consecutive rows of the qkv matrix -- as one 32-row tile and masks the score entries that pair tokens of different samples
+// (the encoder's 5-token sequences: 6 samples = 30 of 32 rows per MFMA tile instead of 5, a sixth of the waves).
+struct PackInfo {
+    int b0, h, nrows, inv_n;   // first sample, head, valid rows of the tile, ceil(65536 / N)
+};
+__device__ __forceinline__ PackInfo pack_of(int head, int B, int N, int H) {
+    const int P = N <= 16 ? 32 / N : 1;
+    const int pack = head / H;
+    PackInfo pi;
+    pi.h = head - pack * H;
+    pi.b0 = pack * P;
+    const int ns = B - pi.b0 < P ? B - pi.b0 : P;
+    pi.nrows = ns * N;
+    pi.inv_n = (65536 + N - 1) / N;
+    return pi;
+}
+__device__ __forceinline__ int seq_of(int row, const PackInfo &pi) { return (row * pi.inv_n) >> 16; }   // row / N, exact for row < 32
+
 template <int HD>
 __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out, int B,
-                                                           int N, int H) {
+                                                           int N, int H, int nheads) {
     constexpr int KS = HD / 16, NB = (HD + 31) / 32;
-    // PARK: transposed operands through LDS (see the file header).  Measured: pays for the decoder's 17-token sequences
-    // (hd 32: 7.2 -> 6.3 us forward, 16.8 -> 14.9 us backward); the encoder's 5-token sequences gather only 5 of the 8
-    // elements and lose more to the LDS footprint (residency) than they gain (hd 64: 11.0 -> 12.1 us backward)
-    constexpr bool PARK = HD == 32;
-    __shared__ __attribute__((aligned(16))) bf16_t park[PARK ? 4 : 1][PARK ? 32 * (HD + 8) : 8];
+    // transposed operands through LDS (see the file header)
+    __shared__ __attribute__((aligned(16))) bf16_t park[4][32 * (HD + 8)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int head = blockIdx.x * 4 + wave;
-    if (head >= B * H) return;
-    const int b = head / H, h = head - b * H;
+    if (head >= nheads) return;
+    const PackInfo pk = pack_of(head, B, N, H);
+    const int h = pk.h, NR = pk.nrows;
     const int D = H * HD;
     const int64_t rs = 3 * (int64_t)D;
     const int r = lane & 31, g = lane >> 5;
-    const bf16_t *qb = qkv + (int64_t)b * N * rs + h * HD, *kb = qb + D, *vb = qb + 2 * D;
-    const int NS = N > 16 ? 2 : 1;       // k-steps over the token index
+    const bf16_t *qb = qkv + (int64_t)pk.b0 * N * rs + h * HD, *kb = qb + D, *vb = qb + 2 * D;
+    const int NS = NR > 16 ? 2 : 1;       // k-steps over the token index
+    const int my_seq = r < NR ? seq_of(r, pk) : 0;
 
     bf16x8 qf[KS], kf[KS], vt[2][NB];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        qf[s] = row_frag(qb, rs, r, g, s, N);
-        kf[s] = row_frag(kb, rs, r, g, s, N);
+        qf[s] = row_frag(qb, rs, r, g, s, NR);
+        kf[s] = row_frag(kb, rs, r, g, s, NR);
     }
-    if constexpr (PARK) {
+    {
         bf16x8 vf[KS];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) vf[s] = row_frag(vb, rs, r, g, s, N);
+        for (int s = 0; s < KS; ++s) vf[s] = row_frag(vb, rs, r, g, s, NR);
         park_rows<HD>(park[wave], vf, r, g);
         __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int blk = 0; blk < NB; ++blk) {
-            if constexpr (PARK) vt[s][blk] = s < NS ? tok_frag_lds<HD>(park[wave], blk, r, g, s) : zero8();
-            else vt[s][blk] = s < NS ? tok_frag(vb, rs, 32 * blk + r, 32 * blk + r < HD, g, s, N) : zero8();
-        }
+        for (int blk = 0; blk < NB; ++blk) vt[s][blk] = s < NS ? tok_frag_lds<HD>(park[wave], blk, r, g, s) : zero8();
 
     f32x16 st;
 #pragma unroll
@@ -134,7 +139,8 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t *__restr
     float mx = -INFINITY;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-        st[e] = acc_row(e, g) < N ? st[e] * scale : -INFINITY;
+        const int j = acc_row(e, g);
+        st[e] = (j < NR && seq_of(j, pk) == my_seq) ? st[e] * scale : -INFINITY;
         mx = fmaxf(mx, st[e]);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t *__restr
     for (int e = 0; e < 16; ++e) st[e] *= inv;
 
     bf16x8 pf[2] = {pack_regs(st, 0), pack_regs(st, 1)};
-    bf16_t *orow = out + ((int64_t)b * N + r) * D + h * HD;
+    bf16_t *orow = out + ((int64_t)pk.b0 * N + r) * D + h * HD;
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) {
         f32x16 ot;
@@ -158,42 +164,41 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t *__restr
         for (int e = 0; e < 16; ++e) ot[e] = 0.f;
         ot = mfma32(vt[0][blk], pf[0], ot);                           // O^T[d][i] = sum_j V[j][d] P[i][j]
         if (NS > 1) ot = mfma32(vt[1][blk], pf[1], ot);
-        if (r < N) store_tile<HD>(orow, ot, blk, g, 1.0f);
+        if (r < NR) store_tile<HD>(orow, ot, blk, g, 1.0f);
     }
 }
 
 template <int HD>
 __global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
-                                                           bf16_t *__restrict__ dqkv, int B, int N, int H) {
+                                                           bf16_t *__restrict__ dqkv, int B, int N, int H, int nheads) {
     constexpr int KS = HD / 16, NB = (HD + 31) / 32;
-    constexpr bool PARK = HD == 32;                                                 // see mha_fwd_mfma_kernel
     __shared__ float stats[4][3][32];
-    __shared__ __attribute__((aligned(16))) bf16_t park[PARK ? 4 : 1][3][PARK ? 32 * (HD + 8) : 8];      // K, Q, dO of each wave
+    __shared__ __attribute__((aligned(16))) bf16_t park[4][3][32 * (HD + 8)];      // K, Q, dO of each wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int head = blockIdx.x * 4 + wave;
-    if (head >= B * H) return;
-    const int b = head / H, h = head - b * H;
+    if (head >= nheads) return;
+    const PackInfo pk = pack_of(head, B, N, H);        // packed short sequences: see mha_fwd_mfma_kernel
+    const int h = pk.h, NR = pk.nrows;
     const int D = H * HD;
     const int64_t rs = 3 * (int64_t)D;
     const int r = lane & 31, g = lane >> 5;
-    const bf16_t *qb = qkv + (int64_t)b * N * rs + h * HD, *kb = qb + D, *vb = qb + 2 * D;
-    const bf16_t *ob = dout + (int64_t)b * N * D + h * HD;
-    const int NS = N > 16 ? 2 : 1;
+    const bf16_t *qb = qkv + (int64_t)pk.b0 * N * rs + h * HD, *kb = qb + D, *vb = qb + 2 * D;
+    const bf16_t *ob = dout + (int64_t)pk.b0 * N * D + h * HD;
+    const int NS = NR > 16 ? 2 : 1;
     const float scale = rsqrtf((float)HD);
+    const int my_seq = r < NR ? seq_of(r, pk) : 0;
 
     bf16x8 qf[KS], kf[KS], vf[KS], of[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        qf[s] = row_frag(qb, rs, r, g, s, N);
-        kf[s] = row_frag(kb, rs, r, g, s, N);
-        vf[s] = row_frag(vb, rs, r, g, s, N);
-        of[s] = row_frag(ob, D, r, g, s, N);
+        qf[s] = row_frag(qb, rs, r, g, s, NR);
+        kf[s] = row_frag(kb, rs, r, g, s, NR);
+        vf[s] = row_frag(vb, rs, r, g, s, NR);
+        of[s] = row_frag(ob, D, r, g, s, NR);
     }
-    if constexpr (PARK) {
-        park_rows<HD>(park[wave][0], kf, r, g);
-        park_rows<HD>(park[wave][1], qf, r, g);
-        park_rows<HD>(park[wave][2], of, r, g);
-    }
+    park_rows<HD>(park[wave][0], kf, r, g);
+    park_rows<HD>(park[wave][1], qf, r, g);
+    park_rows<HD>(park[wave][2], of, r, g);
     f32x16 st, sn, dpt, dpn;     // scores / dP with (rows j, col i) and with (rows i, col j)
 #pragma unroll
     for (int e = 0; e < 16; ++e) st[e] = sn[e] = dpt[e] = dpn[e] = 0.f;
@@ -205,10 +210,13 @@ __global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(const bf16_t *__restr
         dpn = mfma32(of[s], vf[s], dpn);
     }
     // ---- column-i orientation: softmax statistics, P^T, rowsum, dS^T
+    bool same[16];                             // register row (token j, or i below) belongs to this lane's sample
     float mx = -INFINITY;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-        st[e] = acc_row(e, g) < N ? st[e] * scale : -INFINITY;
+        const int j = acc_row(e, g);
+        same[e] = j < NR && seq_of(j, pk) == my_seq;
+        st[e] = same[e] ? st[e] * scale : -INFINITY;
         mx = fmaxf(mx, st[e]);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -240,41 +248,32 @@ __global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(const bf16_t *__restr
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int i = acc_row(e, g);
-        const float p = (r < N && i < N) ? __expf(sn[e] * scale - stats[wave][0][i]) * stats[wave][1][i] : 0.f;
+        const float p = (r < NR && same[e]) ? __expf(sn[e] * scale - stats[wave][0][i]) * stats[wave][1][i] : 0.f;
         pn[e] = p;
         sn[e] = p * (dpn[e] - stats[wave][2][i]);                     // dS[i][j]
     }
 
-    bf16_t *dq = dqkv + ((int64_t)b * N + r) * rs + h * HD, *dk = dq + D, *dv = dq + 2 * D;
+    bf16_t *dq = dqkv + ((int64_t)pk.b0 * N + r) * rs + h * HD, *dk = dq + D, *dv = dq + 2 * D;
     bf16x8 dst_f[2] = {pack_regs(st, 0), pack_regs(st, 1)};           // dS^T, k = j
     bf16x8 dsn_f[2] = {pack_regs(sn, 0), pack_regs(sn, 1)};           // dS,   k = i
     bf16x8 pn_f[2] = {pack_regs(pn, 0), pack_regs(pn, 1)};            // P,    k = i
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) {
-        const int dcol = 32 * blk + r;
-        const bool dok = dcol < HD;
         f32x16 tq, tk, tv;
 #pragma unroll
         for (int e = 0; e < 16; ++e) tq[e] = tk[e] = tv[e] = 0.f;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             if (s < NS) {
-                bf16x8 kt, qt, ot;
-                if constexpr (PARK) {
-                    kt = tok_frag_lds<HD>(park[wave][0], blk, r, g, s);
-                    qt = tok_frag_lds<HD>(park[wave][1], blk, r, g, s);
-                    ot = tok_frag_lds<HD>(park[wave][2], blk, r, g, s);
-                } else {
-                    kt = tok_frag(kb, rs, dcol, dok, g, s, N);
-                    qt = tok_frag(qb, rs, dcol, dok, g, s, N);
-                    ot = tok_frag(ob, D, dcol, dok, g, s, N);
-                }
+                const bf16x8 kt = tok_frag_lds<HD>(park[wave][0], blk, r, g, s);
+                const bf16x8 qt = tok_frag_lds<HD>(park[wave][1], blk, r, g, s);
+                const bf16x8 ot = tok_frag_lds<HD>(park[wave][2], blk, r, g, s);
                 tq = mfma32(kt, dst_f[s], tq);   // dQ^T[d][i] = sum_j K[j][d] dS[i][j]
                 tk = mfma32(qt, dsn_f[s], tk);   // dK^T[d][j] = sum_i Q[i][d] dS[i][j]
                 tv = mfma32(ot, pn_f[s], tv);    // dV^T[d][j] = sum_i dO[i][d] P[i][j]
             }
         }
-        if (r < N) {
+        if (r < NR) {
             store_tile<HD>(dq, tq, blk, g, scale);
             store_tile<HD>(dk, tk, blk, g, scale);
             store_tile<HD>(dv, tv, blk, g, 1.0f);
@@ -564,13 +563,15 @@ int skyemb_mha_mfma_try(bool bwd, const void *qkv, const void *dout, void *out, 
 #undef STRIP
         return rc;
     }
-    const dim3 grid((B * H + 3) / 4), block(256);
+    const int P = N <= 16 ? 32 / N : 1;                   // samples packed into one wave's 32-row tile
+    const int nheads = ((B + P - 1) / P) * H;
+    const dim3 grid((nheads + 3) / 4), block(256);
     if (!bwd) {
-        if (hd == 32) hipLaunchKernelGGL(mha_fwd_mfma_kernel<32>, grid, block, 0, st, x, (bf16_t *)out, B, N, H);
-        else hipLaunchKernelGGL(mha_fwd_mfma_kernel<64>, grid, block, 0, st, x, (bf16_t *)out, B, N, H);
+        if (hd == 32) hipLaunchKernelGGL(mha_fwd_mfma_kernel<32>, grid, block, 0, st, x, (bf16_t *)out, B, N, H, nheads);
+        else hipLaunchKernelGGL(mha_fwd_mfma_kernel<64>, grid, block, 0, st, x, (bf16_t *)out, B, N, H, nheads);
     } else {
-        if (hd == 32) hipLaunchKernelGGL(mha_bwd_mfma_kernel<32>, grid, block, 0, st, x, (const bf16_t *)dout, (bf16_t *)out, B, N, H);
-        else hipLaunchKernelGGL(mha_bwd_mfma_kernel<64>, grid, block, 0, st, x, (const bf16_t *)dout, (bf16_t *)out, B, N, H);
+        if (hd == 32) hipLaunchKernelGGL(mha_bwd_mfma_kernel<32>, grid, block, 0, st, x, (const bf16_t *)dout, (bf16_t *)out, B, N, H, nheads);
+        else hipLaunchKernelGGL(mha_bwd_mfma_kernel<64>, grid, block, 0, st, x, (const bf16_t *)dout, (bf16_t *)out, B, N, H, nheads);
     }
     return 0;
 }

@@ -209,7 +209,8 @@ def test_layernorm_bwd_batched_reduce(ops):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cfg", [(3, 5, 12, 64), (2, 17, 16, 32), (2, 66, 2, 64), (4, 5, 4, 16), (1, 65, 3, 8),
                                  (2, 32, 3, 32), (5, 16, 2, 64), (3, 1, 2, 32), (7, 31, 5, 64),
-                                 (2, 65, 4, 32), (1, 100, 2, 32), (3, 33, 2, 32), (2, 97, 3, 32), (2, 64, 2, 64)])
+                                 (2, 65, 4, 32), (1, 100, 2, 32), (3, 33, 2, 32), (2, 97, 3, 32), (2, 64, 2, 64),
+                                 (8, 5, 3, 64), (7, 3, 2, 32), (13, 5, 2, 32), (9, 2, 1, 64), (4, 11, 2, 32), (3, 10, 3, 64)])
 def test_attention(ops, dtype, cfg):
     B, N, H, hd = cfg
     D = H * hd
