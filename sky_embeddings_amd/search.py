@@ -132,6 +132,12 @@ def cosine_topk(queries: torch.Tensor, bank, k: int, weights: torch.Tensor | Non
     Q, D = q.shape
     N = pb.bank.shape[0]
     assert D == pb.bank.shape[1]
+    if k < 1:
+        raise ValueError(f"cosine_topk: k = {k}")
+    if world_size == 1 and k > N:
+        raise ValueError(f"cosine_topk: k = {k} exceeds the {N} rows of the bank")
+    if Q == 0:                                      # nothing to search for (an empty target list): empty result, no launch
+        return (torch.empty(0, k, device=q.device), torch.empty(0, k, device=q.device, dtype=torch.int64))
     tw, qn = prepare_queries(q, pb.weights)
     if _prefilter_enabled() and ops.topk_prefilter_applicable(Q, N, D, k):
         out_s, out_i, n_redo = _local_topk_prefiltered(tw, qn, pb, k, eps)

@@ -194,3 +194,16 @@ def test_prefiltered_equals_exact_kernel_at_mid_size():
         del os.environ["SKYEMB_TOPK_PREFILTER"]
     assert st["path"] == "exact"
     assert torch.equal(i1, i2) and torch.equal(s1, s2)
+
+
+def test_degenerate_search_inputs():
+    """No queries -> empty lists; k outside [1, rows of the bank] -> ValueError (nothing is launched)."""
+    from sky_embeddings_amd import search
+    bank = torch.randn(50, 64, device="cuda")
+    s, i = search.cosine_topk(torch.empty(0, 64, device="cuda"), bank, 5)
+    assert s.shape == (0, 5) and i.shape == (0, 5) and i.dtype == torch.int64
+    s, i = search.cosine_topk(torch.randn(3, 64, device="cuda"), bank, 50)            # k == N: every row, best first
+    assert torch.isfinite(s).all() and sorted(i[0].tolist()) == list(range(50))
+    for k in (0, 51):
+        with pytest.raises(ValueError):
+            search.cosine_topk(torch.randn(3, 64, device="cuda"), bank, k)
