@@ -591,7 +591,7 @@ int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
     // full rounds of 128x64 tiles (ViT-L token counts) gain ~5 % from the larger tile's lower L2->LDS traffic
     // (from 4 rounds on with long k-loops: ViT-L data gradients and fc2, 12-19 % in tools/gemm_tune.py --model mim19)
     const int64_t t12864 = ceil_div64(g.M, 128) * ceil_div64(g.N, 64), t128 = ceil_div64(g.M, 128) * ceil_div64(g.N, 128);
-    if (tile == 0 && (t128 >= 1024 || (t128 >= 512 && g.K >= 2048))) tile = 128128;   // >= 2 rounds of 2 workgroups per CU
+    if (tile == 0 && (t128 >= 1024 || (t128 >= 512 && g.K >= 1024))) tile = 128128;   // >= 2 rounds of 2 workgroups per CU
     if (tile == 0 && (t12864 >= 2048 || (t12864 >= 1024 && g.K >= 1024))) tile = 128064;
     if (tile == 0) tile = 64064;
     int bm, bn;
@@ -611,6 +611,41 @@ int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
         if (S < 1) S = 1;
     }
     g.split_k = S;
+    // Row tail: with two 128x128 workgroups per CU a launch has 512 slots per round, and a few tiles more than whole rounds
+    // (ViT-L: 65 row blocks of 128 token rows -> 520 / 1560 / 2080 tiles) cost a round of their own on 8-32 CUs while the
+    // rest of the chip idles.  The row blocks that fill whole rounds go as one launch; the remaining rows as a second,
+    // finely split launch (64x64 tiles, split-K) that is over in a fraction of a round.
+    static const bool tail_on = []() { const char *e = getenv("SKYEMB_GEMM_TAIL"); return !(e && e[0] == '0'); }();
+    if (tail_on && tile == 128128 && S == 1 && g.a_layout == SKYEMB_KC && g.ws && !g.dst_row && !g.tab_row && !g.colsum_a) {
+        const int64_t R = ceil_div64(g.M, 128), C = ceil_div64(g.N, 128), slots = 512;
+        const int64_t full = (R * C / slots) * slots;                 // tiles in whole rounds
+        const int64_t Rm = full / C;                                  // row blocks of the main launch
+        const int64_t tail_tiles = (R - Rm) * C;
+        // (measured on the ViT-L shapes: 118 -> 92 us at one round + 8 tiles; nothing gained at three or four rounds)
+        if (Rm >= 1 && Rm < R && tail_tiles <= 64 && full - Rm * C < C && full <= 2 * slots) {
+            const int64_t r0 = Rm * 128;
+            skyemb_gemm_args gm = g, gt = g;
+            gm.M = (int)r0;
+            gt.M = g.M - (int)r0;
+            gt.A = (const char *)g.A + r0 * g.lda * 2;
+            if (g.out) gt.out = (char *)g.out + r0 * g.ldo * 2;
+            if (g.out2) gt.out2 = (char *)g.out2 + r0 * g.ldo2 * 2;
+            if (g.out_f32) gt.out_f32 = g.out_f32 + r0 * g.ldo32;
+            if (g.resid) gt.resid = g.resid + r0 * g.ldr;
+            if (g.aux) gt.aux = (const char *)g.aux + r0 * g.ldaux * 2;
+            const int64_t t64 = ceil_div64(gt.M, 64) * ceil_div64(gt.N, 64);
+            int St = (int)(768 / t64);
+            if (St > 8) St = 8;
+            if (St > g.K / BK / 4) St = g.K / BK / 4;
+            while (St > 1 && (int64_t)St * ((int64_t)gt.M * gt.N + gt.M) * 4 > g.ws_bytes) --St;
+            if (St < 1) St = 1;
+            gt.tile = 64064;
+            gt.split_k = St;
+            const int rc = dispatch_code(tile, gm, st);
+            if (rc != 0) return rc;
+            return skyemb_gemm_pipe_try(gt, st);
+        }
+    }
     return dispatch_code(tile, g, st);
 }
 

@@ -474,6 +474,41 @@ def test_gemm_split_k_wgrad(ops, split):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])   # run-to-run deterministic
 
 
+@pytest.mark.parametrize("b_layout", [0, 1])
+def test_gemm_row_tail_launch_at_vit_l_token_counts(ops, b_layout, monkeypatch):
+    """8320 token rows (mim_19: 128 x 65) x 1024 columns = 520 tiles of 128x128, one round of 512 plus 8: the dispatcher
+    runs the last 128 rows as a second, split-K launch.  Forward-shaped (bias + fp32 residual) and data-gradient-shaped
+    (row-contiguous weights, dGELU) launches against fp64 matmuls; the residual / aux / output row offsets of the tail
+    launch are what this checks."""
+    M, N, K = 8320, 1024, 2048
+    g = torch.Generator().manual_seed(5 + b_layout)
+    A = torch.randn(M, K, generator=g)
+    Bm = torch.randn(N, K, generator=g) * 0.05
+    bias = torch.randn(N, generator=g)
+    Ar, Br = A.bfloat16().float(), Bm.bfloat16().float()
+    ws = torch.zeros(8 * 1024 * 1024, device=DEV)
+    Ad = dev(A, torch.bfloat16)
+    Bd = dev(Bm.T.contiguous() if not b_layout else Bm, torch.bfloat16)
+    ref = (Ar.double() @ Br.double().T)
+    scale = float(ref.abs().max())
+    if b_layout:      # forward: bias + residual -> fp32
+        resid = torch.randn(M, N, generator=g)
+        out = torch.full((M, N), float("nan"), device=DEV)
+        ops.gemm(Ad, Bd, M=M, N=N, K=K, bias=dev(bias), resid=dev(resid), ldr=N, out_f32=out, ws=ws)
+        want = ref + bias.double() + resid.double()
+        assert float((out.cpu().double() - want).abs().max()) <= 1e-5 * scale
+    else:             # data gradient: dX = dY . W (W row-contiguous) times dGELU(aux) -> bf16
+        aux = torch.randn(M, N, generator=g)
+        out = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        ops.gemm(Ad, Bd, M=M, N=N, K=K, a_layout=ops.KC, b_layout=ops.RC, lda=K, ldb=N, act=ops.ACT_DGELU, aux=dev(aux, torch.bfloat16),
+                 ldaux=N, out=out, ws=ws)
+        x = aux.bfloat16().double()
+        dgelu = 0.5 * (1.0 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5
+        want = ref * dgelu
+        assert float((out.float().cpu().double() - want).abs().max()) <= 1e-2 * scale
+    torch.cuda.synchronize()
+
+
 def test_simmim_mask_counts_match_reference_mask_generator():
     """The device MaskGenerator against masks the reference's own class drew (tests/golden/maskgen.npz, made by
     tests/golden/make_golden.py maskgen): fed the reference's ratio draw, the kernel masks exactly as many patches per
