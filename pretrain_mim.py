@@ -152,6 +152,7 @@ def main(args):
                                   rank=rank, world_size=world, drop_last=world > 1)
         else:
             loader = dataloader_train
+        epoch_start_iter = cur_iter
         for samples, masks, ra_decs in loader:
             if fast and samples.shape[0] == common['batch_size']:
                 loss = train_step(samples, None, ra_decs)
@@ -213,6 +214,10 @@ def main(args):
                     save_checkpoint(model_filename, cur_iter, losses, optimizer, lr_scheduler, model)
                 done = True
                 break
+        if cur_iter == epoch_start_iter:
+            # an epoch without a single batch (fewer cutouts per rank than one batch): the loop would never end
+            raise RuntimeError('the training data yields no batch of %i samples per rank (world size %i)'
+                               % (common['batch_size'], world))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
