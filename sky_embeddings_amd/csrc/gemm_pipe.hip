@@ -670,7 +670,7 @@ extern "C" int skyemb_gemm_group_plan(const skyemb_gemm_args *args, int n, int t
         // ViT-L weight gradients (>= 2.5 rounds of 128x128 tiles, K = thousands of token rows): 128x128 (mim_19: 35.8 -> 35.2 ms/step)
         int64_t t128 = 0;
         for (int i = 0; i < n; ++i) t128 += ceil_div64(args[i].M, 128) * ceil_div64(args[i].N, 128);
-        if (t128 >= 640) tile = 128128;
+        if (t128 >= 400) tile = 128128;
         static const int env_tile = []() { const char *e = getenv("SKYEMB_GROUP_TILE"); return e ? atoi(e) : 0; }();   // experiments
         if (env_tile) tile = canonical_tile(env_tile);
     }
