@@ -526,7 +526,8 @@ int dispatch(const skyemb_gemm_args &g, hipStream_t st) {
 #define SKY_GEMM_PRODUCT_VARIANTS(X) \
     X(0, 64, 64, 3, 2, 2)            \
     X(0, 128, 64, 3, 4, 2)           \
-    X(0, 128, 128, 2, 4, 2)
+    X(0, 128, 128, 2, 4, 2)          \
+    X(2, 256, 128, 3, 4, 4)
 #ifdef SKY_GEMM_LAB   // experiment builds (tools/ubench/gemm_lab.hip): every shape under study
 #define SKY_GEMM_VARIANTS(X) SKY_GEMM_PRODUCT_VARIANTS(X) SKY_GEMM_LAB_VARIANTS(X)
 #else
@@ -591,6 +592,10 @@ int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
     // full rounds of 128x64 tiles (ViT-L token counts) gain ~5 % from the larger tile's lower L2->LDS traffic
     // (from 4 rounds on with long k-loops: ViT-L data gradients and fc2, 12-19 % in tools/gemm_tune.py --model mim19)
     const int64_t t12864 = ceil_div64(g.M, 128) * ceil_div64(g.N, 64), t128 = ceil_div64(g.M, 128) * ceil_div64(g.N, 128);
+    // ViT-L token counts, long k-loops or the widest outputs: 256x128 with 16 waves, one workgroup per CU (fc2 forward
+    // [8320 x 1024 x 4096]: 91 -> 84 us, fc1 forward [8320 x 4096 x 1024]: 128 -> 120 us; the [8320 x 3072 x 1024] launch is
+    // better off with two 128x128 workgroups per CU overlapping each other's prologue and epilogue: 73 vs 80 us)
+    if (tile == 0 && g.a_layout == SKYEMB_KC && ((t128 >= 512 && g.K >= 2048) || (t128 >= 2048 && g.N >= 4096))) tile = 2256128;
     if (tile == 0 && (t128 >= 1024 || (t128 >= 512 && g.K >= 1024))) tile = 128128;   // >= 2 rounds of 2 workgroups per CU
     if (tile == 0 && (t12864 >= 2048 || (t12864 >= 1024 && g.K >= 1024))) tile = 128064;
     if (tile == 0) tile = 64064;
@@ -616,14 +621,16 @@ int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
     // rest of the chip idles.  The row blocks that fill whole rounds go as one launch; the remaining rows as a second,
     // finely split launch (64x64 tiles, split-K) that is over in a fraction of a round.
     static const bool tail_on = []() { const char *e = getenv("SKYEMB_GEMM_TAIL"); return !(e && e[0] == '0'); }();
-    if (tail_on && tile == 128128 && S == 1 && g.a_layout == SKYEMB_KC && g.ws && !g.dst_row && !g.tab_row && !g.colsum_a) {
-        const int64_t R = ceil_div64(g.M, 128), C = ceil_div64(g.N, 128), slots = 512;
+    if (tail_on && (tile == 128128 || tile == 2256128) && S == 1 && g.a_layout == SKYEMB_KC && g.ws && !g.dst_row && !g.tab_row &&
+        !g.colsum_a) {
+        const int64_t bm_t = tile == 128128 ? 128 : 256, slots = tile == 128128 ? 512 : 256;   // 256x128: one workgroup per CU
+        const int64_t R = ceil_div64(g.M, bm_t), C = ceil_div64(g.N, 128);
         const int64_t full = (R * C / slots) * slots;                 // tiles in whole rounds
         const int64_t Rm = full / C;                                  // row blocks of the main launch
         const int64_t tail_tiles = (R - Rm) * C;
         // (measured on the ViT-L shapes: 118 -> 92 us at one round + 8 tiles; nothing gained at three or four rounds)
-        if (Rm >= 1 && Rm < R && tail_tiles <= 64 && full - Rm * C < C && full <= 2 * slots) {
-            const int64_t r0 = Rm * 128;
+        if (Rm >= 1 && Rm < R && tail_tiles <= 64 && full - Rm * C < C && (full <= 2 * slots || tile == 2256128)) {
+            const int64_t r0 = Rm * bm_t;
             skyemb_gemm_args gm = g, gt = g;
             gm.M = (int)r0;
             gt.M = g.M - (int)r0;
