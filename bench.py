@@ -505,7 +505,7 @@ def main():
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
         gi = pre["gemm_in_step"]
         kernel = dict(kernel="gemm_pipe_kernel<BM,BN,A_KC,B_KC,3,WM,WN> (forward KC.KC, data gradient KC.RC) + "
-                             "gemm_pipe_group_kernel<128,64,3,4,2,4> (the four weight gradients of a block per launch) "
+                             "gemm_pipe_group_kernel<128,128,2,4,2,4> (encoder) / <128,64,3,4,2,4> (decoder): the four weight gradients of a block per launch "
                              "(+ splitk_reduce_kernel)", **gi)
         if "gemm_probe" in pre:
             kernel["isolated_probe"] = pre["gemm_probe"]
