@@ -311,9 +311,31 @@ __device__ __forceinline__ void stage_rows(bf16_t *tile, const bf16_t *base, int
         *(bf16x8 *)(tile + row * (HD + 8) + 8 * c) = row < N ? *(const bf16x8 *)(base + (int64_t)row * row_stride + 8 * c) : zero8();
     }
 }
+// The LDS tiles hold round_up(N, 4) + 4 rows: the data rows, zero-filled up to the 4-row group, and one all-zero group
+// (rows zrow..zrow+3) that every read past the sequence is redirected to -- 72 rows instead of 96 for the 65-token
+// sequences: with the register budget capped for three waves per SIMD (below) three backward workgroups share a CU.
+struct StripRows {
+    int n4, zrow;      // round_up(N, 4); first row of the zero group
+};
 template <int HD>
-__device__ __forceinline__ bf16x8 row_frag_lds(const bf16_t *tile, int row, int g, int s) {
+__device__ __forceinline__ bf16x8 row_frag_lds(const bf16_t *tile, int row, int g, int s, const StripRows &sr) {
+    row = row < sr.n4 ? row : sr.zrow;
     return *(const bf16x8 *)(tile + row * (HD + 8) + 16 * s + 8 * g);
+}
+// tok_frag_lds for tokens row0 + pi(s, g, e): the two 4-row groups it reads are redirected as wholes
+template <int HD>
+__device__ __forceinline__ bf16x8 tok_frag_strip(const bf16_t *tile, int row0, int blk, int r, int g, int s, const StripRows &sr) {
+    const int i = r & 15, q = i >> 2, p = i & 3;
+    const int col0 = 32 * blk + (r & 16) + 4 * p;
+    int g0 = row0 + 16 * s + 4 * g, g1 = g0 + 8;
+    g0 = g0 < sr.n4 ? g0 : sr.zrow;
+    g1 = g1 < sr.n4 ? g1 : sr.zrow;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)(tile + (g0 + q) * (HD + 8) + col0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)(tile + (g1 + q) * (HD + 8) + col0));
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
 }
 
 extern __shared__ __attribute__((aligned(16))) bf16_t strip_lds[];
@@ -321,7 +343,9 @@ extern __shared__ __attribute__((aligned(16))) bf16_t strip_lds[];
 template <int HD, int NT>
 __global__ __launch_bounds__(64 * NT) void mha_fwd_strip_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out, int B,
                                                                 int N, int H) {
-    constexpr int KS = HD / 16, NB = (HD + 31) / 32, PITCH = HD + 8, ROWS = 32 * NT;
+    constexpr int KS = HD / 16, NB = (HD + 31) / 32, PITCH = HD + 8;
+    const StripRows sr = {(N + 3) & ~3, (N + 3) & ~3};
+    const int ROWS = sr.n4 + 4;
     bf16_t *kt = strip_lds, *vt = strip_lds + ROWS * PITCH;
     const int lane = threadIdx.x & 63, strip = threadIdx.x >> 6;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
@@ -345,7 +369,7 @@ __global__ __launch_bounds__(64 * NT) void mha_fwd_strip_kernel(const bf16_t *__
         st[t] = zero16();
         if (32 * t < N) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s) st[t] = mfma32(row_frag_lds<HD>(kt, 32 * t + r, g, s), qf[s], st[t]);   // ST[j][i]
+            for (int s = 0; s < KS; ++s) st[t] = mfma32(row_frag_lds<HD>(kt, 32 * t + r, g, s, sr), qf[s], st[t]);   // ST[j][i]
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -376,17 +400,19 @@ __global__ __launch_bounds__(64 * NT) void mha_fwd_strip_kernel(const bf16_t *__
                     bf16x8 pf;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)(st[t][8 * s + e] * inv);
-                    ot = mfma32(tok_frag_lds<HD>(vt + 32 * t * PITCH, blk, r, g, s), pf, ot);   // O^T[d][i] += V[j][d] P[i][j]
+                    ot = mfma32(tok_frag_strip<HD>(vt, 32 * t, blk, r, g, s, sr), pf, ot);   // O^T[d][i] += V[j][d] P[i][j]
                 }
         if (my < N) store_tile<HD>(orow, ot, blk, g, 1.0f);
     }
 }
 
 template <int HD, int NT>
-__global__ __launch_bounds__(64 * NT) void mha_bwd_strip_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
+__global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(NT <= 3 ? 3 : 2))) void mha_bwd_strip_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
                                                                 bf16_t *__restrict__ dqkv, int B, int N, int H) {
-    constexpr int KS = HD / 16, NB = (HD + 31) / 32, PITCH = HD + 8, ROWS = 32 * NT;
+    constexpr int KS = HD / 16, NB = (HD + 31) / 32, PITCH = HD + 8;
     __shared__ float stats[3][32 * MAX_NT];               // per query token: softmax max, 1 / sum, rowsum(P dP)
+    const StripRows sr = {(N + 3) & ~3, (N + 3) & ~3};
+    const int ROWS = sr.n4 + 4;
     bf16_t *qt = strip_lds, *kt = qt + ROWS * PITCH, *vt = kt + ROWS * PITCH, *dot = vt + ROWS * PITCH;
     const int lane = threadIdx.x & 63, strip = threadIdx.x >> 6;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
@@ -410,8 +436,8 @@ __global__ __launch_bounds__(64 * NT) void mha_bwd_strip_kernel(const bf16_t *__
         bf16x8 qf[KS], of[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            qf[s] = row_frag_lds<HD>(qt, my, g, s);
-            of[s] = row_frag_lds<HD>(dot, my, g, s);
+            qf[s] = row_frag_lds<HD>(qt, my, g, s, sr);
+            of[s] = row_frag_lds<HD>(dot, my, g, s, sr);
         }
         f32x16 st[NT], dpt[NT];
         float mx = -INFINITY;
@@ -422,8 +448,8 @@ __global__ __launch_bounds__(64 * NT) void mha_bwd_strip_kernel(const bf16_t *__
             if (32 * t < N) {
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
-                    st[t] = mfma32(row_frag_lds<HD>(kt, 32 * t + r, g, s), qf[s], st[t]);
-                    dpt[t] = mfma32(row_frag_lds<HD>(vt, 32 * t + r, g, s), of[s], dpt[t]);   // dP^T[j][i]
+                    st[t] = mfma32(row_frag_lds<HD>(kt, 32 * t + r, g, s, sr), qf[s], st[t]);
+                    dpt[t] = mfma32(row_frag_lds<HD>(vt, 32 * t + r, g, s, sr), of[s], dpt[t]);   // dP^T[j][i]
                 }
             }
 #pragma unroll
@@ -468,7 +494,7 @@ __global__ __launch_bounds__(64 * NT) void mha_bwd_strip_kernel(const bf16_t *__
                         bf16x8 df;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) df[e] = (bf16_t)(st[t][8 * s + e] * (dpt[t][8 * s + e] - rsum));   // dS^T[j][i]
-                        tq = mfma32(tok_frag_lds<HD>(kt + 32 * t * PITCH, blk, r, g, s), df, tq);   // dQ^T[d][i] += K[j][d] dS[i][j]
+                        tq = mfma32(tok_frag_strip<HD>(kt, 32 * t, blk, r, g, s, sr), df, tq);   // dQ^T[d][i] += K[j][d] dS[i][j]
                     }
             if (my < N) store_tile<HD>(dq, tq, blk, g, scale);
         }
@@ -479,8 +505,8 @@ __global__ __launch_bounds__(64 * NT) void mha_bwd_strip_kernel(const bf16_t *__
         bf16x8 kf[KS], vf[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            kf[s] = row_frag_lds<HD>(kt, my, g, s);
-            vf[s] = row_frag_lds<HD>(vt, my, g, s);
+            kf[s] = row_frag_lds<HD>(kt, my, g, s, sr);
+            vf[s] = row_frag_lds<HD>(vt, my, g, s, sr);
         }
         f32x16 tk[NB], tv[NB];
 #pragma unroll
@@ -494,8 +520,8 @@ __global__ __launch_bounds__(64 * NT) void mha_bwd_strip_kernel(const bf16_t *__
             f32x16 sn = zero16(), dpn = zero16();
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                sn = mfma32(row_frag_lds<HD>(qt, 32 * t + r, g, s), kf[s], sn);       // S[i][j]: rows i = 32 t + acc_row, col j = my
-                dpn = mfma32(row_frag_lds<HD>(dot, 32 * t + r, g, s), vf[s], dpn);    // dP[i][j]
+                sn = mfma32(row_frag_lds<HD>(qt, 32 * t + r, g, s, sr), kf[s], sn);       // S[i][j]: rows i = 32 t + acc_row, col j = my
+                dpn = mfma32(row_frag_lds<HD>(dot, 32 * t + r, g, s, sr), vf[s], dpn);    // dP[i][j]
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -511,8 +537,8 @@ __global__ __launch_bounds__(64 * NT) void mha_bwd_strip_kernel(const bf16_t *__
                 const bf16x8 pf = pack_regs(sn, s), df = pack_regs(dpn, s);
 #pragma unroll
                 for (int blk = 0; blk < NB; ++blk) {
-                    tk[blk] = mfma32(tok_frag_lds<HD>(qt + (32 * t) * PITCH, blk, r, g, s), df, tk[blk]);    // dK^T[d][j] += Q[i][d] dS[i][j]
-                    tv[blk] = mfma32(tok_frag_lds<HD>(dot + (32 * t) * PITCH, blk, r, g, s), pf, tv[blk]);   // dV^T[d][j] += dO[i][d] P[i][j]
+                    tk[blk] = mfma32(tok_frag_strip<HD>(qt, 32 * t, blk, r, g, s, sr), df, tk[blk]);    // dK^T[d][j] += Q[i][d] dS[i][j]
+                    tv[blk] = mfma32(tok_frag_strip<HD>(dot, 32 * t, blk, r, g, s, sr), pf, tv[blk]);   // dV^T[d][j] += dO[i][d] P[i][j]
                 }
             }
         }
@@ -529,11 +555,12 @@ __global__ __launch_bounds__(64 * NT) void mha_bwd_strip_kernel(const bf16_t *__
 template <int HD, int NT>
 int launch_strip(bool bwd, const bf16_t *x, const bf16_t *dout, bf16_t *out, int B, int N, int H, hipStream_t st) {
     const dim3 grid(B * H), block(64 * NT);
-    const int smem = (bwd ? 4 : 2) * 32 * NT * (HD + 8) * 2;
+    const int smem = (bwd ? 4 : 2) * (((N + 3) & ~3) + 4) * (HD + 8) * 2;
     if (smem > 65536) {
         static bool attr_set = false;                     // (one per instantiation; only the backward kernel gets this large)
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void *)mha_bwd_strip_kernel<HD, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            hipError_t e = hipFuncSetAttribute((const void *)mha_bwd_strip_kernel<HD, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               4 * (32 * NT + 4) * (HD + 8) * 2);     // the longest sequence of this instance
             if (e != hipSuccess) {
                 skyemb_set_error("skyemb_mha: hipFuncSetAttribute: %s", hipGetErrorString(e));
                 return 2;
