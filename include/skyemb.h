@@ -202,7 +202,7 @@ int skyemb_fill_mask_tokens(float *x, const float *mask, const float *mask_token
 int skyemb_gather_rows(const float *src, const int32_t *idx, float *out, void *out_lp, int dtype, int n_rows,
                        int D, void *stream);
 /* selected row sum (d mask_token, d cls_token): out[d] = sum_i [sel == NULL || sel[i] != 0] src[r(i)*ld + d],
- * r(i) = row0 + (i / inner) * outer_stride + (i % inner), i in [0, n_rows); `partial` fp32 [64, D]. */
+ * r(i) = row0 + (i / inner) * outer_stride + (i % inner), i in [0, n_rows); `partial` fp32 [256, D]. */
 int skyemb_rowsum_select(const float *src, int64_t ld, const float *sel, int row0, int inner, int outer_stride,
                          int n_rows, int D, float *partial, float *out, void *stream);
 

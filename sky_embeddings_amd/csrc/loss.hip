@@ -39,31 +39,68 @@ __global__ __launch_bounds__(256) void loss_pass1(const float *__restrict__ imgs
         if (threadIdx.x == 0) { o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; }
         return;
     }
+    // the patch's target elements are read ONCE into registers (<= 12 per thread: patches up to 3072 values; larger ones
+    // re-read them per pass); same element -> thread mapping and summation order as the three-pass form, so the same bits
+    constexpr int MAXE = 12;
+    const bool cached = pv <= MAXE * 256;
+    float tv[MAXE];
+    if (cached) {
+#pragma unroll
+        for (int u = 0; u < MAXE; ++u) {
+            const int e = threadIdx.x + u * 256;
+            tv[u] = e < pv ? target_elem(imgs, b, l, e, C, H, W, p, mean, stdv) : 0.f;
+        }
+    }
     float mu = 0.f, istd = 1.f;
     if (norm_pix) {
         float s = 0.f, n = 0.f;
-        for (int e = threadIdx.x; e < pv; e += 256) {
-            const float t = target_elem(imgs, b, l, e, C, H, W, p, mean, stdv);
-            if (t == t) { s += t; n += 1.f; }
+        if (cached) {
+#pragma unroll
+            for (int u = 0; u < MAXE; ++u)
+                if (threadIdx.x + u * 256 < pv) { const float t = tv[u]; if (t == t) { s += t; n += 1.f; } }
+        } else {
+            for (int e = threadIdx.x; e < pv; e += 256) {
+                const float t = target_elem(imgs, b, l, e, C, H, W, p, mean, stdv);
+                if (t == t) { s += t; n += 1.f; }
+            }
         }
         s = block_sum(s, red);
         n = block_sum(n, red);
         mu = s / n;
         float q = 0.f;
-        for (int e = threadIdx.x; e < pv; e += 256) {
-            const float t = target_elem(imgs, b, l, e, C, H, W, p, mean, stdv);
-            if (t == t) { const float d = t - mu; q += d * d; }
+        if (cached) {
+#pragma unroll
+            for (int u = 0; u < MAXE; ++u)
+                if (threadIdx.x + u * 256 < pv) { const float t = tv[u]; if (t == t) { const float d = t - mu; q += d * d; } }
+        } else {
+            for (int e = threadIdx.x; e < pv; e += 256) {
+                const float t = target_elem(imgs, b, l, e, C, H, W, p, mean, stdv);
+                if (t == t) { const float d = t - mu; q += d * d; }
+            }
         }
         q = block_sum(q, red);
         istd = 1.0f / sqrtf(q / n + 1.0e-6f);
     }
     const float *pr = pred + ((int64_t)b * (L + extra) + extra + l) * pv;
     float s = 0.f, n = 0.f;
-    for (int e = threadIdx.x; e < pv; e += 256) {
-        float t = target_elem(imgs, b, l, e, C, H, W, p, mean, stdv);
-        if (norm_pix) t = (t - mu) * istd;
-        const float d = t - pr[e];
-        if (d == d) { s += loss_l1 ? fabsf(d) : d * d; n += 1.f; }
+    if (cached) {
+#pragma unroll
+        for (int u = 0; u < MAXE; ++u) {
+            const int e = threadIdx.x + u * 256;
+            if (e < pv) {
+                float t = tv[u];
+                if (norm_pix) t = (t - mu) * istd;
+                const float d = t - pr[e];
+                if (d == d) { s += loss_l1 ? fabsf(d) : d * d; n += 1.f; }
+            }
+        }
+    } else {
+        for (int e = threadIdx.x; e < pv; e += 256) {
+            float t = target_elem(imgs, b, l, e, C, H, W, p, mean, stdv);
+            if (norm_pix) t = (t - mu) * istd;
+            const float d = t - pr[e];
+            if (d == d) { s += loss_l1 ? fabsf(d) : d * d; n += 1.f; }
+        }
     }
     s = block_sum(s, red);
     n = block_sum(n, red);

@@ -255,7 +255,7 @@ class MAEEngine:
             w["dT"] = torch.empty(B * keep, D, **lp)
             w["drows"] = torch.empty(B * keep, pv, **f32)
             w["pmv_part"] = torch.empty(B, pv, **f32)
-            w["rs_part"] = torch.empty(64, max(D, Dd), **f32)
+            w["rs_part"] = torch.empty(256, max(D, Dd), **f32)
             w["splitk_ws"] = self._splitk_ws
             # the four weight-gradient GEMMs of a block as ONE grouped launch (ops.GemmGroup): together they fill the
             # chip, so none needs split-K slabs or a reduce launch.  bf16 path only; pointers are fixed from here on.

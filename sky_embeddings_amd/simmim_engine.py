@@ -119,7 +119,7 @@ class SimMIMEngine(MAEEngine):
             w["dT"] = torch.empty(B * L, D, **lp)
             w["drows"] = torch.empty(B * L, pv, **f32)
             w["pmv_part"] = torch.empty(B, pv, **f32)
-            w["rs_part"] = torch.empty(64, D, **f32)
+            w["rs_part"] = torch.empty(256, D, **f32)
             w["splitk_ws"] = self._splitk_ws
             order = [("norm", R, D)] + ([("attn_pool.norm", B, D)] if pool else [])
             for i in reversed(range(cfg.depth)):

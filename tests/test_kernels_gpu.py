@@ -324,7 +324,7 @@ def test_glue_kernels(ops):
     ops.gather_rows(dev(x.reshape(-1, Dd)), dev(idx), o32, olp, 23, Dd)
     assert torch.equal(o32.cpu(), x.reshape(-1, Dd)[idx.long()])
     assert torch.equal(olp.cpu(), x.reshape(-1, Dd)[idx.long()].bfloat16())
-    part, out = torch.empty(64, Dd, device=DEV), torch.empty(Dd, device=DEV)
+    part, out = torch.empty(256, Dd, device=DEV), torch.empty(Dd, device=DEV)
     ops.rowsum_select(dev(x.reshape(-1, Dd)), Dd, dev(mask.reshape(-1)), 1, L, L + 1, B * L, Dd, part, out)
     assert float((out.cpu() - (x[:, 1:] * mask[:, :, None]).sum((0, 1))).abs().max()) < 1e-5
     ops.rowsum_select(dev(x.reshape(-1, Dd)), Dd, None, 0, 1, L + 1, B, Dd, part, out)
