@@ -148,6 +148,7 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float *__rest
     const float *src = part + (int64_t)blockIdx.y * nblk * D;
     float acc = 0.f;
     if (d < D)
+#pragma unroll 8
         for (int b = rg; b < nblk; b += 32) acc += src[(int64_t)b * D + d];
     red[rg][col] = acc;
     __syncthreads();
@@ -168,8 +169,10 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_batch_kernel(const skyemb_
     if (blockIdx.x * 32 >= it.D) return;
     const float *src = it.part + (int64_t)blockIdx.y * it.nblk * it.D;
     float acc = 0.f;
-    if (d < it.D)
-        for (int b = rg; b < it.nblk; b += 32) acc += src[(int64_t)b * it.D + d];
+    if (d < it.D) {
+#pragma unroll 8
+        for (int b = rg; b < it.nblk; b += 32) acc += src[(int64_t)b * it.D + d];   // (loads in flight; same summation order)
+    }
     red[rg][col] = acc;
     __syncthreads();
     if (rg == 0 && d < it.D) {
@@ -218,8 +221,12 @@ extern "C" int skyemb_layernorm_fwd(const float *x, const float *gamma, const fl
 }
 
 extern "C" int skyemb_layernorm_bwd_blocks(int M) {
+    // one row per wave and pass; about two waves per SIMD, and every wave the SAME number of rows (4352 decoder rows over 512
+    // workgroups left a quarter of the waves with a third row: 544 workgroups x 2 rows; 8320 ViT-L rows: 520 x 4)
     int nb = (M + 3) / 4;
-    return nb < 512 ? (nb < 1 ? 1 : nb) : 512;   // 2 waves per SIMD at M >= 2048 rows
+    if (nb < 1) nb = 1;
+    const int rounds = (nb + 575) / 576;
+    return (nb + rounds - 1) / rounds;
 }
 
 extern "C" int skyemb_layernorm_bwd(const void *dy, int dy_is_f32, int dtype, const float *x, const float *gamma,
