@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t *__restr
 }
 
 template <int HD>
-__global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 32 ? 4 : 2))) void mha_bwd_mfma_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
                                                            bf16_t *__restrict__ dqkv, int B, int N, int H, int nheads) {
     constexpr int KS = HD / 16, NB = (HD + 31) / 32;
     __shared__ float stats[4][3][32];
