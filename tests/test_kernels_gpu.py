@@ -143,7 +143,7 @@ def test_gemm_group_equals_single_launches(ops):
 
 # ------------------------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(20, 64), (1280, 768), (37, 512), (9, 1280), (5, 192)])
+@pytest.mark.parametrize("shape", [(20, 64), (1280, 768), (37, 512), (9, 1280), (5, 192), (8320, 1024), (8197, 256), (4352, 512)])
 def test_layernorm(ops, dtype, shape):
     M, D = shape
     g = torch.Generator().manual_seed(D)
