@@ -519,7 +519,8 @@ int dispatch(const skyemb_gemm_args &g, hipStream_t st) {
 }
 
 // Launch shapes.  code = variant * 1,000,000 + BM * 1000 + BN; X(variant, BM, BN, NSTAGE, WM, WN).
-// LDS per workgroup = NSTAGE * (BM + BN) * 128 B, which fixes the workgroups per CU (160 KiB): 64x64 x3 = 48 KB -> 3;
+// LDS per workgroup = NSTAGE * (BM + BN) * 128 B, which fixes the workgroups per CU (160 KiB): 64x64 x3 = 48 KB -> 3, x2 = 32 KB -> 5
+// (code 6064064, tuned table);
 // 128x64 x3 = 72 KB -> 2, x2 = 48 KB -> 3 (code 6128064: the decoder's [4352 x 2048] launches, tuned table);
 // 128x128 x3 = 96 KB -> 1, x2 = 64 KB -> 2; 256x128 x3 = 144 KB -> 1.  The 128x128 tile ships with the
 // 2-stage ring: two resident workgroups (16 waves) cover each other's barriers, which a third stage did not (ViT-L shapes,
@@ -529,7 +530,8 @@ int dispatch(const skyemb_gemm_args &g, hipStream_t st) {
     X(0, 128, 64, 3, 4, 2)           \
     X(0, 128, 128, 2, 4, 2)          \
     X(2, 256, 128, 3, 4, 4)          \
-    X(6, 128, 64, 2, 4, 2)
+    X(6, 128, 64, 2, 4, 2)           \
+    X(6, 64, 64, 2, 2, 2)
 #ifdef SKY_GEMM_LAB   // experiment builds (tools/ubench/gemm_lab.hip): every shape under study
 #define SKY_GEMM_VARIANTS(X) SKY_GEMM_PRODUCT_VARIANTS(X) SKY_GEMM_LAB_VARIANTS(X)
 #else

@@ -16,7 +16,6 @@
     X(5, 128, 128, 3, 4, 2)      \
     X(0, 256, 128, 3, 4, 2)      \
     X(1, 256, 128, 2, 4, 2)      \
-    X(6, 64, 64, 2, 2, 2)        \
     X(0, 128, 256, 3, 2, 4)      \
     X(1, 128, 256, 2, 2, 4)
 #include "../../sky_embeddings_amd/csrc/gemm_pipe.hip"
