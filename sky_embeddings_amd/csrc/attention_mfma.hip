@@ -341,7 +341,7 @@ __device__ __forceinline__ bf16x8 tok_frag_strip(const bf16_t *tile, int row0, i
 extern __shared__ __attribute__((aligned(16))) bf16_t strip_lds[];
 
 template <int HD, int NT>
-__global__ __launch_bounds__(64 * NT) void mha_fwd_strip_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out, int B,
+__global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(NT <= 3 ? 5 : 3))) void mha_fwd_strip_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out, int B,
                                                                 int N, int H) {
     constexpr int KS = HD / 16, NB = (HD + 31) / 32, PITCH = HD + 8;
     const StripRows sr = {(N + 3) & ~3, (N + 3) & ~3};
