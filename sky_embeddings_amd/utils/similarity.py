@@ -81,8 +81,10 @@ def compute_similarity(target_latent, test_latent, metric='MAE', combine='mean',
     """utils/similarity.py:214-268."""
     largest = metric == 'cosine'
     if n_central_patches is not None:
-        raise NotImplementedError("n_central_patches: the reference calls an un-imported select_centre here "
-                                  "(utils/similarity.py:240, NameError); not supported")
+        # utils/similarity.py:238-240 calls utils.misc.select_centre without importing it (NameError in the reference);
+        # the intended behaviour -- target features from the central patch tokens only -- is what runs here
+        from .misc import select_centre
+        target_latent = select_centre(target_latent, n_central_patches)
     target_latent, feat_weights = determine_target_features(target_latent)
     if not use_weights:
         feat_weights = torch.ones_like(feat_weights)

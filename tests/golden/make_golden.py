@@ -415,6 +415,30 @@ def simsearch_cases(sim):
 
 
 
+def central_cases(sim):
+    """utils/similarity.py:238-240 with n_central_patches: the reference calls utils.misc.select_centre without importing
+    it (NameError).  The golden is made by binding the REFERENCE's own utils.misc.select_centre into the module's namespace
+    -- the import the file lacks -- and running compute_similarity unchanged."""
+    import importlib
+    misc = importlib.import_module("utils.misc")
+    assert misc.__file__.startswith(REF), misc.__file__
+    sim.select_centre = misc.select_centre
+    out = {}
+    g = torch.Generator().manual_seed(23)
+    for (T, L, N, D, n) in ((9, 16, 24, 32, 4), (5, 64, 12, 16, 16), (7, 64, 12, 16, 4)):
+        tgt = torch.randn(T, L, D, generator=g) * 2 + 0.5
+        tst = torch.randn(N, L, D, generator=g)
+        key = f"central/{T}_{L}_{N}_{n}"
+        out[key + "/target"], out[key + "/test"] = tgt.numpy(), tst.numpy()
+        for metric in ("cosine", "MSE", "MAE"):
+            for combine in ("min", "mean", "max"):
+                out[f"{key}/{metric}_{combine}"] = sim.compute_similarity(tgt, tst, metric=metric, combine=combine, use_weights=True,
+                                                                          n_central_patches=n).numpy()
+    del sim.select_centre
+    np.savez_compressed(os.path.join(OUT, "similarity_central.npz"), **out)
+    print("wrote similarity_central")
+
+
 def maskgen_cases():
     """utils/dataloaders.py:155-219 (MaskGenerator) executed as is.  The module imports h5py, torchvision and astropy at the
     top (all absent here, none touched by MaskGenerator): inert module objects stand in for the import statements only.
@@ -463,6 +487,8 @@ def main():
     only = sys.argv[1:]                      # e.g. `make_golden.py simsearch` regenerates one family
     if "simsearch" in only or not only:
         simsearch_cases(sim)
+    if "central" in only or not only:
+        central_cases(sim)
     if "maskgen" in only or not only:
         maskgen_cases()
     if "mae_radec" in only or not only:

@@ -41,3 +41,37 @@ def test_gemm_args_struct_layout_matches_header():
     # offsets a C compiler gives the struct (natural alignment) -- guards against ctypes drift
     assert ctypes.sizeof(_lib.GemmArgs) == 232
     assert _lib.GemmArgs.tile.offset == 192 and _lib.GemmArgs.out_f32.offset == 144 and _lib.GemmArgs.colsum_a.offset == 200
+
+
+def test_integration_md_bindings_match_the_prototypes():
+    """Every `_L.<name>.argtypes = [...]` a maintainer is shown in INTEGRATION.md has the header's parameter count, the
+    same pointer / integer / float kind per position, and every call of that name in the document passes as many values."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    shown = re.findall(r"_L\.(skyemb_[a-z0-9_]+)\.argtypes\s*=\s*\[([^\]]*)\]", text)
+    assert len(shown) >= 5
+    kind = {"vp": "p", "i32": "i", "i64": "i", "f32": "f", "f64": "f"}
+
+    def proto_kind(t):
+        if t in (ctypes.c_float, ctypes.c_double):
+            return "f"
+        if t in (ctypes.c_int32, ctypes.c_int64):
+            return "i"
+        return "p"
+    for name, body in shown:
+        assert name in _lib.PROTOTYPES, f"INTEGRATION.md binds {name}, which include/skyemb.h does not declare"
+        toks = [t.strip() for t in body.split(",") if t.strip()]
+        want = _lib.PROTOTYPES[name][1]
+        assert len(toks) == len(want), f"INTEGRATION.md: {name}.argtypes has {len(toks)} entries, the header {len(want)}"
+        for k, (t, w) in enumerate(zip(toks, want)):
+            assert kind[t] == proto_kind(w), f"INTEGRATION.md: {name} argument {k} is shown as {t}"
+        # calls of the form _L.name( ... ) inside _chk(...): count top-level commas
+        for m in re.finditer(r"_L\." + name + r"\(", text):
+            depth, i, n_args, start = 1, m.end(), 1, m.end()
+            while depth:
+                c = text[i]
+                depth += c in "([" 
+                depth -= c in ")]"
+                n_args += (c == "," and depth == 1)
+                i += 1
+            if text[start:i - 1].strip():
+                assert n_args == len(want), f"INTEGRATION.md: a call of {name} passes {n_args} values, the header takes {len(want)}"

@@ -346,3 +346,20 @@ def test_pretrain_entry_point_trains_from_survey_tiles(tmp_path):
     assert "Training complete." in out.stdout and "sky patches per process" in out.stdout
     ck = torch.load(str(work / "models" / "mim_t.pth.tar"), map_location="cpu", weights_only=False)
     assert ck["batch_iters"] >= 10 and np.isfinite(ck["losses"]["train_loss"]).all()
+
+
+def test_compute_similarity_central_patches_matches_reference_goldens():
+    """n_central_patches (utils/similarity.py:238-240): the reference's own compute_similarity with the select_centre import it
+    lacks supplied by the generator (tests/golden/make_golden.py central_cases)."""
+    from sky_embeddings_amd.utils import similarity as sim
+    z = np.load(os.path.join(GOLDEN, "similarity_central.npz"))
+    keys = sorted({k.rsplit("/", 1)[0] for k in z.files if k.endswith("/target")})
+    assert len(keys) == 3
+    for key in keys:
+        n = int(key.rsplit("_", 1)[1])
+        tgt, tst = torch.from_numpy(z[key + "/target"]).cuda(), torch.from_numpy(z[key + "/test"]).cuda()
+        for metric in ("cosine", "MSE", "MAE"):
+            for combine in ("min", "mean", "max"):
+                s = sim.compute_similarity(tgt, tst, metric=metric, combine=combine, n_central_patches=n).cpu().numpy()
+                ref = z[f"{key}/{metric}_{combine}"]
+                assert np.abs(s - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (key, metric, combine)
