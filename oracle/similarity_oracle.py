@@ -55,10 +55,22 @@ def weighted_MAE(target_feats, test_feats, weights):
     return torch.mean(torch.abs(target_feats - test_feats) * weights / torch.sum(weights), dim=-1)
 
 
-def compute_similarity(target_latent, test_latent, metric="MAE", combine="mean", use_weights=True, n_top_sims=None):
-    """utils/similarity.py:214-268 (``n_central_patches`` omitted: NameError in
-    the reference)."""
+def select_centre(latent, n_patches):
+    """utils/misc.py:68-117: the central sqrt(n) x sqrt(n) block of a raster-ordered square grid of patch tokens."""
+    side, k = int(latent.shape[1] ** 0.5), int(n_patches ** 0.5)
+    assert k * k == n_patches, "n must be a perfect square"
+    r0 = side // 2 - k // 2
+    idx = [(r0 + i) * side + (r0 + j) for i in range(k) for j in range(k)]
+    return latent[:, idx]
+
+
+def compute_similarity(target_latent, test_latent, metric="MAE", combine="mean", use_weights=True, n_top_sims=None,
+                       n_central_patches=None):
+    """utils/similarity.py:214-268.  ``n_central_patches`` (:238-240) raises NameError in the reference (select_centre is
+    not imported there); pinned here by goldens made with that import supplied (similarity_central.npz)."""
     largest = metric == "cosine"
+    if n_central_patches is not None:
+        target_latent = select_centre(target_latent, n_central_patches)
     tgt, w = determine_target_features(target_latent)
     if not use_weights:
         w = torch.ones_like(w)

@@ -186,6 +186,11 @@ def main(args):
                 if probing:     # the encoder is replicated: rank 0's probe is every rank's
                     linear_probe(model, losses_cp, device, dataloader_val, lp_files['lp_class_data_file'],
                                  lp_files['lp_regress_data_file'], combine=lp_combine)
+                    model.train(True)       # the probe leaves the model in eval mode (utils/pretrain_fns.py:62)
+                if world > 1 and any(lp_files.values()):
+                    # the other ranks wait for rank 0's host-side scikit-learn fits HERE, on the host, not inside the next
+                    # step's gradient all-reduce (whose watchdog would abort the job after ten minutes)
+                    sdist.host_barrier()
                 for k in list(losses_cp.keys()):
                     losses[k].append(_mean(losses_cp[k]))
                 losses['batch_iters'].append(cur_iter)

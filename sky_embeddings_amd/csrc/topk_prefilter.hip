@@ -31,6 +31,7 @@
 #include "common.h"
 #include <math.h>
 #include <stdlib.h>
+#include <mutex>
 
 namespace {
 
@@ -88,17 +89,18 @@ __global__ __launch_bounds__(256) void bank16_kernel(const float *__restrict__ b
     }
     mx = wave_max(mx);
     half_t *o = bank16 + row * D;
-    if (!(mx < INFINITY)) {
-        // a row with an infinite element cannot be bounded: fp16 zeros + ||x'|| = inf make every query keep it as a
-        // candidate (U = inf), so the exact stage decides
+    int e = 0;
+    if (mx > 0.f && mx < INFINITY) {
+        (void)frexpf(mx, &e);            // mx = m * 2^e, m in [0.5, 1)
+        e -= 14;                         // mx * 2^-e in [2^13, 2^14)
+    }
+    if (!(mx < INFINITY) || e < -126) {
+        // a row with an infinite element cannot be bounded, and neither can one so small that its scale 2^-e would
+        // overflow (largest |x| below ~2^-113: the fp16 image would be inf / NaN and the row silently lost): fp16 zeros
+        // + ||x'|| = inf make every query keep it as a candidate (U = inf), so the exact stage decides
         for (int d = lane * 4; d < D; d += 256) *(uint2 *)(o + d) = make_uint2(0u, 0u);
         if (lane == 0) rowp[row] = make_float4(xn[row], INFINITY, 1.0f, xn[row]);
         return;
-    }
-    int e = 0;
-    if (mx > 0.f) {
-        (void)frexpf(mx, &e);            // mx = m * 2^e, m in [0.5, 1)
-        e -= 14;                         // mx * 2^-e in [2^13, 2^14)
     }
     const float s = ldexpf(1.0f, -e);
     float ss = 0.f;
@@ -146,6 +148,7 @@ __global__ __launch_bounds__(256) void query16_kernel(const float *__restrict__ 
         (void)frexpf(mx, &e);
         e -= 14;
     }
+    if (e < -126) e = -126;             // keep 2^-e finite; such a query (scale == 2^126) is flagged for the exact path by init_state_kernel
     const float s = ldexpf(1.0f, -e);
     float ss = 0.f;
     for (int d = lane * 4; d < D; d += 256) {
@@ -853,8 +856,10 @@ __global__ void init_state_kernel(int Q, int Q_padded, const float *__restrict__
     const float tau = thr0 ? thr0[q] : -INFINITY;
     tau_q[q] = tau;
     cnt[q] = thr0 ? 0 : first_rows;          // without a floor the first slice is taken whole: slot = row (prefilter_kernel<true>)
-    overflow[q] = 0;
     const float4 qb = qbase[q];
+    // a query whose scale hit the clamp (largest |t w| below ~2^-112) has an fp16 image outside the error bound's
+    // assumptions: answered by the exact kernel (redo), never silently by this path
+    overflow[q] = qb.z >= 0x1p126f ? 1 : 0;
     const float t = tau > -3.0e38f ? tau : -3.0e38f;
     float a = t * qb.x, b = t * eps * qb.z;
     a -= fabsf(a) * 0x1p-20f;
@@ -938,7 +943,8 @@ extern "C" int skyemb_cosine_topk_prefiltered(const float *tw, const float *qn, 
     carve((char *)ws, Q, D, cap, &w);
     // one fp16 pass (hi only) by default: half the matrix work, 3/4 of the LDS-DMA bytes, intervals ~1.6x wider -- on
     // embedding-like data a few dozen more candidates per query.  SKYEMB_PREFILTER_LO=1 keeps the hi + lo passes.
-    const char *lo_env = getenv("SKYEMB_PREFILTER_LO");       // (read per call: cheap, and a test can switch it)
+    // (read per call on purpose: a getenv is a sub-microsecond scan next to a multi-millisecond search, and the tests switch it)
+    const char *lo_env = getenv("SKYEMB_PREFILTER_LO");
     const bool use_lo = lo_env && lo_env[0] == '1';
     const float eps_a = (float)(eps_a_of(D, use_lo) * (1.0 + 1e-6));
     hipLaunchKernelGGL(query16_kernel, dim3((unsigned)(((Q + QPAD - 1) / QPAD * QPAD + 3) / 4)), dim3(256), 0, st, tw, qn, Q, D, w.qh, w.ql,
@@ -952,9 +958,15 @@ extern "C" int skyemb_cosine_topk_prefiltered(const float *tw, const float *qn, 
     const int Q_padded = (Q + QPAD - 1) / QPAD * QPAD;
     hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((Q_padded + 255) / 256)), dim3(256), 0, st, Q, Q_padded, thr0, w.qbase, eps,
                        w.qpar, w.tau, w.cnt, w.overflow, (int)first_rows);
-    static bool attr_set = false;
+    // the dynamic-LDS limit is a per-DEVICE attribute of the function: one flag per device, set under a mutex
+    static std::mutex attr_mutex;
+    static bool attr_done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     const int smem1 = NSTAGE * stage_bytes(use_lo) + (qtile(use_lo) + BT) * 16 + SCAP * 8 + 16;
     constexpr int smem_max = NSTAGE * stage_bytes(true) + (256 + BT) * 16 + SCAP * 8 + 16;
+    std::lock_guard<std::mutex> attr_lock(attr_mutex);
+    bool &attr_set = attr_done[dev & 63];
     if (!attr_set) {
         hipError_t e = hipSuccess;
 #define PF_ATTR(M, L) if (e == hipSuccess) e = hipFuncSetAttribute((const void *)prefilter_kernel<M, L>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_max)

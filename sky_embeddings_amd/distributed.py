@@ -32,6 +32,30 @@ def init_from_env(backend: str | None = None):
     return rank, world, local
 
 
+_HOST_BARRIERS = 0
+
+
+def host_barrier(timeout_s: float = 6 * 3600.0, poll_s: float = 0.05):
+    """Barrier through the rendezvous store instead of a collective: ranks wait on the HOST, so a long rank-0-only
+    phase (the scikit-learn linear probe between training steps) cannot run into the RCCL watchdog that a pending
+    all-reduce or NCCL barrier would trip after its 10-minute default.  No-op in a single process."""
+    global _HOST_BARRIERS
+    if not dist.is_initialized() or dist.get_world_size() <= 1:
+        return
+    import time
+    store = dist.distributed_c10d._get_default_store()
+    key = f"skyemb/host_barrier/{_HOST_BARRIERS}"
+    _HOST_BARRIERS += 1
+    world = dist.get_world_size()
+    arrived = store.add(key, 1)
+    t0 = time.time()
+    while arrived < world:
+        if time.time() - t0 > timeout_s:
+            raise RuntimeError(f"host_barrier: {arrived} of {world} ranks arrived within {timeout_s:.0f} s")
+        time.sleep(poll_s)
+        arrived = store.add(key, 0)
+
+
 def bucket_bounds(n: int, bucket_elems: int):
     """Contiguous [start, end) slices of a flat buffer, each a multiple of 8 elements except the last."""
     bucket_elems = max(8, bucket_elems // 8 * 8)

@@ -62,13 +62,29 @@ class Dataset:
     def _cache_path(self):
         root = os.environ.get("SKYEMB_H5_CACHE")
         base = f".{os.path.basename(self._path)}.{self.name}.contig"
-        for d in ([root] if root else []) + [os.path.dirname(os.path.abspath(self._path)), tempfile.gettempdir()]:
+        home = os.path.dirname(os.path.abspath(self._path))
+        for d in ([root] if root else []) + [home, tempfile.gettempdir()]:
             if d and os.path.isdir(d) and os.access(d, os.W_OK):
+                if d != root and d != home:
+                    # a dataset-sized file in the temp directory is rarely what the operator wants: say so once per dataset
+                    import warnings
+                    warnings.warn(f"hdf5_lite: {home} is read-only, the contiguous copy of {self._path}:{self.name} goes to {d} "
+                                  f"(set SKYEMB_H5_CACHE to choose the directory)", RuntimeWarning, stacklevel=3)
                 return os.path.join(d, base)
         raise H5LiteError(f"no writable directory for the contiguous cache of {self._path}:{self.name}")
 
+    def _cache_valid(self, path, meta, stamp, nbytes):
+        try:
+            return os.path.getsize(path) == nbytes and json.load(open(meta)) == stamp
+        except (OSError, ValueError):
+            return False
+
     def _unchunk(self):
-        """Contiguous row-major copy of a chunked dataset in a cache file (rebuilt when the source changes)."""
+        """Contiguous row-major copy of a chunked dataset in a cache file (rebuilt when the source changes).  Every rank's
+        feeder and every loader worker lands here at the same moment: ONE process builds the copy under an exclusive
+        lock (flock on `<cache>.lock`), the others block on the lock and then find the finished file.  The stamp (.json) is
+        renamed into place BEFORE the data file, so a reader that sees the data file also sees the stamp that describes it."""
+        import fcntl
         from ._lib import check, lib
         st = os.stat(self._path)
         stamp = {"size": st.st_size, "mtime_ns": st.st_mtime_ns, "shape": list(self.shape), "dtype": self.dtype.str,
@@ -76,26 +92,36 @@ class Dataset:
         path = self._cache_path()
         meta = path + ".json"
         nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
-        if os.path.exists(path) and os.path.exists(meta) and os.path.getsize(path) == nbytes:
+        if self._cache_valid(path, meta, stamp, nbytes):
+            return np.memmap(path, dtype=self.dtype, mode="r", shape=self.shape)
+        with open(path + ".lock", "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)                    # released when the file is closed (also if the builder dies)
             try:
-                if json.load(open(meta)) == stamp:
-                    return np.memmap(path, dtype=self.dtype, mode="r", shape=self.shape)
-            except (OSError, ValueError):
-                pass
-        addr, off = self.chunk_table()
-        tmp = f"{path}.{os.getpid()}.tmp"
-        out = np.memmap(tmp, dtype=self.dtype, mode="w+", shape=self.shape)      # holes (never-written chunks) read as 0
-        src = np.memmap(self._path, dtype=np.uint8, mode="r")
-        cd = np.asarray(self.chunks, dtype=np.int64)
-        dd = np.asarray(self.shape, dtype=np.int64)
-        check(lib().skyemb_h5_unchunk_host(src.ctypes.data, src.size, addr.ctypes.data, np.ascontiguousarray(off).ctypes.data,
-                                           len(addr), len(self.shape), cd.ctypes.data, dd.ctypes.data, self.dtype.itemsize,
-                                           out.ctypes.data, min(16, os.cpu_count() or 1)), "skyemb_h5_unchunk_host")
-        out.flush()
-        del out, src
-        os.replace(tmp, path)
-        with open(meta, "w") as fh:
-            json.dump(stamp, fh)
+                if not self._cache_valid(path, meta, stamp, nbytes):      # somebody else may have built it while we waited
+                    addr, off = self.chunk_table()
+                    tmp = f"{path}.{os.getpid()}.tmp"
+                    try:
+                        out = np.memmap(tmp, dtype=self.dtype, mode="w+", shape=self.shape)   # holes (never-written chunks) read as 0
+                        src = np.memmap(self._path, dtype=np.uint8, mode="r")
+                        cd = np.asarray(self.chunks, dtype=np.int64)
+                        dd = np.asarray(self.shape, dtype=np.int64)
+                        check(lib().skyemb_h5_unchunk_host(src.ctypes.data, src.size, addr.ctypes.data,
+                                                           np.ascontiguousarray(off).ctypes.data, len(addr), len(self.shape),
+                                                           cd.ctypes.data, dd.ctypes.data, self.dtype.itemsize, out.ctypes.data,
+                                                           min(16, os.cpu_count() or 1)), "skyemb_h5_unchunk_host")
+                        out.flush()
+                        del out, src
+                        if os.path.exists(path):
+                            os.unlink(path)                     # a stale copy must not be seen next to the new stamp
+                        with open(meta + ".tmp", "w") as fh:
+                            json.dump(stamp, fh)
+                        os.replace(meta + ".tmp", meta)
+                        os.replace(tmp, path)
+                    finally:
+                        if os.path.exists(tmp):
+                            os.unlink(tmp)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
         return np.memmap(path, dtype=self.dtype, mode="r", shape=self.shape)
 
     def _read_chunked(self, idx):

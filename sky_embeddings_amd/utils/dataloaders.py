@@ -298,8 +298,9 @@ class FitsDataset(torch.utils.data.Dataset):
             coords = generate_overlap_coords((H, W), S, self.overlap)
             hs, ws = np.array([c[0] for c in coords]), np.array([c[1] for c in coords])
         else:
-            hs = np.random.randint(0, H - S + 1, size=self.cutouts_per_tile)
-            ws = np.random.randint(0, W - S + 1, size=self.cutouts_per_tile)
+            draw = getattr(self, "rng", None) or np.random      # a loader hands over its own generator (see _TileLoader)
+            hs = draw.randint(0, H - S + 1, size=self.cutouts_per_tile)
+            ws = draw.randint(0, W - S + 1, size=self.cutouts_per_tile)
         n = len(hs)
         cutouts = torch.empty(n, C, S, S, device=self.device)
         ops.tile_cutouts(tile, be, torch.from_numpy(hs.astype(np.int32)).to(self.device), torch.from_numpy(ws.astype(np.int32)).to(self.device),
@@ -339,43 +340,77 @@ class _TileLoader:
         return len(self.dataset)
 
     def __iter__(self):
-        order = np.random.permutation(len(self.dataset)) if self.shuffle else np.arange(len(self.dataset))
+        # One private generator per pass, seeded in the CALLER's thread from numpy's global state (the reference seeds
+        # that one): window corners are then drawn from it, never from the global generator inside the producer thread,
+        # so a run is reproducible whatever else draws from numpy meanwhile -- and prefetching does not change the draws.
+        rng = np.random.RandomState(np.random.randint(0, 2 ** 31 - 1))
+        order = rng.permutation(len(self.dataset)) if self.shuffle else np.arange(len(self.dataset))
+        self.dataset.rng = rng
         if not self.prefetch or len(order) < 2 or self.dataset.device.type != "cuda":
-            for i in order:
-                yield tuple(t.unsqueeze(0) for t in self.dataset[int(i)])
+            try:
+                for i in order:
+                    yield tuple(t.unsqueeze(0) for t in self.dataset[int(i)])
+            finally:
+                self.dataset.rng = None
             return
         import queue
         import threading
         dev = self.dataset.device
         side = torch.cuda.Stream(device=dev)
         q = queue.Queue(maxsize=1)                      # one tile ahead: two tiles resident
+        stop = threading.Event()
+
+        def put(x):
+            while not stop.is_set():
+                try:
+                    q.put(x, timeout=0.1)
+                    return True
+                except queue.Full:
+                    pass
+            return False
 
         def produce():
             try:
                 torch.cuda.set_device(dev)
                 for i in order:
+                    if stop.is_set():
+                        return
                     with torch.cuda.stream(side):
                         item = self.dataset[int(i)]
                         done = torch.cuda.Event()
                         done.record(side)
-                    q.put((item, done))
-                q.put(None)
+                    if not put((item, done)):
+                        return
+                put(None)
             except BaseException as e:                  # surfaces in the consumer
-                q.put(e)
+                put(e)
 
-        threading.Thread(target=produce, daemon=True).start()
-        while True:
-            got = q.get()
-            if got is None:
-                return
-            if isinstance(got, BaseException):
-                raise got
-            item, done = got
-            main = torch.cuda.current_stream(dev)
-            main.wait_event(done)
-            for t in item:
-                t.record_stream(main)                   # allocated on the side stream, consumed on the caller's
-            yield tuple(t.unsqueeze(0) for t in item)
+        th = threading.Thread(target=produce, daemon=True)
+        th.start()
+        try:
+            while True:
+                got = q.get()
+                if got is None:
+                    return
+                if isinstance(got, BaseException):
+                    raise got
+                item, done = got
+                main = torch.cuda.current_stream(dev)
+                main.wait_event(done)
+                for t in item:
+                    t.record_stream(main)                   # allocated on the side stream, consumed on the caller's
+                yield tuple(t.unsqueeze(0) for t in item)
+        finally:
+            # the consumer is done or has abandoned the generator (iteration budget reached, an exception): stop the
+            # producer, free the tile it may be holding and wait for it
+            stop.set()
+            try:
+                while True:
+                    q.get_nowait()
+            except queue.Empty:
+                pass
+            th.join(timeout=30.0)
+            self.dataset.rng = None
 
 
 def build_fits_dataloader(fits_paths, bands, min_bands, batch_size, num_workers, patch_size=8, max_mask_ratio=None, img_size=64,

@@ -176,6 +176,14 @@ def _worker(rank, world, port, tmp):
     dist.all_gather(both, mine_idx)
     allidx = torch.cat(both)
     assert len(mine_idx) == 50 and len(set(allidx.tolist())) == 100
+    # (4) store barrier: rank 1 arrives 0.5 s late, nobody leaves before it has arrived; twice (fresh key per use)
+    import time
+    for late in (1, 0):
+        if rank == late:
+            time.sleep(0.5)
+        t0 = time.time()
+        sdist.host_barrier(timeout_s=60.0)
+        assert rank == late or time.time() - t0 >= 0.3
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
@@ -457,3 +465,31 @@ def test_host_cutout_functions_match_oracle(tmp_path):
     over = overlapping_cutouts(tile, 32, 0.5)
     coords = generate_overlap_coords((90, 120), 32, 0.5)
     assert over.shape == (len(coords), 4, 32, 32) and np.array_equal(np.nan_to_num(over[-1]), np.nan_to_num(tile[:, 58:90, 88:120]))
+
+
+def _open_chunked_worker(args):
+    path, cache = args
+    os.environ["SKYEMB_H5_CACHE"] = cache
+    from sky_embeddings_amd import hdf5_lite as h5
+    with h5.File(path) as f:
+        arr = f["cutouts"]._array()
+        return float(np.nansum(arr[::7])), sorted(os.listdir(cache))
+
+
+def test_hdf5_lite_unchunk_cache_is_built_once_by_concurrent_openers(tmp_path):
+    """Every rank's feeder and every loader worker hits a chunked file at the same moment: the contiguous copy is built under
+    a lock by one of them (no per-process temp copies left behind), the others wait and map the finished file."""
+    import multiprocessing as mp
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    rng = np.random.default_rng(5)
+    cut = rng.standard_normal((260, 5, 16, 16), dtype=np.float32)
+    path = str(tmp_path / "c.h5")
+    hdf5_lite.write_datasets(path, {"cutouts": cut}, chunks={"cutouts": (64, 1, 8, 16)})
+    with mp.get_context("spawn").Pool(4) as pool:
+        res = pool.map(_open_chunked_worker, [(path, str(cache))] * 4)
+    want = float(np.nansum(cut[::7]))
+    assert all(abs(r[0] - want) <= 1e-3 * abs(want) for r in res)
+    left = sorted(os.listdir(cache))
+    assert not [p for p in left if p.endswith(".tmp")], left
+    assert [p for p in left if p.endswith(".contig")] and [p for p in left if p.endswith(".contig.json")]

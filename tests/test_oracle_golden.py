@@ -159,6 +159,19 @@ def test_similarity_matches_reference():
     assert np.array_equal(got, z["std/out"].reshape(-1, 96))
 
 
+def test_similarity_central_patches_matches_reference():
+    z = np.load(f"{GOLDEN}/similarity_central.npz")
+    keys = sorted({k.rsplit("/", 1)[0] for k in z.files if k.endswith("/target")})
+    assert len(keys) == 3
+    for key in keys:
+        n = int(key.rsplit("_", 1)[1])
+        tgt, tst = torch.from_numpy(z[key + "/target"]), torch.from_numpy(z[key + "/test"])
+        for metric in ("cosine", "MSE", "MAE"):
+            for combine in ("min", "mean", "max"):
+                s = so.compute_similarity(tgt, tst, metric=metric, combine=combine, n_central_patches=n)
+                assert np.array_equal(s.numpy(), z[f"{key}/{metric}_{combine}"]), (key, metric, combine)
+
+
 def test_c_topk_oracle_against_reference_formula():
     """The fixed-order C contract stays within fp32 rounding of the reference's torch formula and
     its top-k equals a stable sort of its own scores."""

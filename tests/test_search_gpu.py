@@ -148,6 +148,25 @@ def test_prefiltered_topk_certification_failures_fall_back_to_the_exact_kernel()
     assert stats["path"] == "prefiltered" and stats["redone"] >= 2                    # queries 3 and 10 at least
 
 
+def test_prefiltered_denormal_scale_rows_and_queries_reach_the_exact_stage():
+    """A non-zero bank row whose largest |x| is below ~2^-113 (its power-of-two scale would overflow) scores ~0 exactly and
+    belongs in the top-k of a query whose k-th best score is NEGATIVE; a query that small is answered by the exact kernel.
+    Before the clamp the row's fp16 image was inf / NaN and the row was silently dropped."""
+    rng = np.random.default_rng(17)
+    Q, N, D, k = 40, 6000, 128, 5
+    base = rng.standard_normal(D).astype(np.float32)
+    q = (base + 0.3 * rng.standard_normal((Q, D))).astype(np.float32)
+    x = (-np.abs(rng.uniform(0.5, 2.0, size=(N, 1))) * base + 0.3 * rng.standard_normal((N, D))).astype(np.float32)   # anti-aligned bank
+    tiny = np.float32(2.0 ** -120)
+    x[123] = tiny * rng.standard_normal(D).astype(np.float32)        # denormal-scale rows: exact score ~ 0 > every other row's
+    x[4567] = tiny * np.abs(base)
+    q[9] = np.float32(2.0 ** -125) * q[9]                             # denormal-scale query
+    ref_s, ref_i = so.cosine_topk_np(q, x, k, None)
+    assert (ref_s[0] < 0).sum() >= k - 2 and {123, 4567} <= set(ref_i[0].tolist())    # the case the advisor described
+    stats = _oracle_equal(q, x, None, k)
+    assert stats["path"] == "prefiltered" and stats["redone"] >= 1
+
+
 def test_prefiltered_candidate_floods_are_flagged_not_lost():
     """Tens of thousands of rows that all score within the fp16 interval of a query's k-th best, placed where the staged
     phases (LDS staging list of 2048 candidates per 256 x 256 item, per-workgroup regions) meet them: the lists overflow, the
