@@ -14,6 +14,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 
 namespace {
 
@@ -22,6 +23,18 @@ typedef __attribute__((address_space(3))) void lvoid_t;
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
 
 constexpr int BK = 64;
+
+// -DGEMM_STAMP (tools/ubench/gemm_lab.hip, LAB_STAMP): per-workgroup timeline of a launch.  Wave 0 keeps s_memtime stamps
+// in scalar registers and writes them out after its last store has been acknowledged: nothing is added to the vector-memory
+// queue the k-loop's counted waits rely on.  Slot layout per workgroup (16 x u64): 0 entry, 1 first LDS-DMA issued,
+// 2 first stage landed (after the barrier), 3 k-loop done, 4 tile staged in LDS, 5 last store issued, 6 stores acknowledged,
+// 8 / 9 s_memrealtime (100 MHz, chip-wide) at entry / exit, 10 XCC id.  The product build compiles none of it.
+#ifdef GEMM_STAMP
+__device__ unsigned long long *g_gemm_stamp = nullptr;
+#define GSTAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define GSTAMP(var)
+#endif
 
 __device__ __forceinline__ void glds16(const void *src, char *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gvoid_t *)src, (lvoid_t *)lds_wave_base, 16, 0, 0);
@@ -185,19 +198,31 @@ __device__ __forceinline__ void wait_stages(int rem) {
 // 4x2 on 128x64, 2x2 / 4x2 on 128x128 (64x64 / 32x64 per wave), 4x2 on 256x128 (64x64 per wave).  A wave tile of
 // 64x64 reads 8 fragments for 16 MFMAs (32x32: 4 for 4), i.e. half the LDS read traffic per FLOP.
 // One workgroup's work: tile `tb` of `ntiles` (XCD-aware order), k-range `split` of `S`.
-template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int WM, int WN>
+// WK = 2 ("two wave groups over k"): a ring stage holds TWO consecutive k-tiles and the workgroup has 2 x WM x WN waves; group wk
+// multiplies k-tile wk of every stage into its own accumulators, the two partial tiles are added in LDS on the way to the
+// epilogue (fixed order: even k-tiles + odd k-tiles).  Why: with ONE workgroup per CU (launches of <= 256 tiles: [1280 x 768]
+// outputs) a k-step is one wave's serial chain -- barrier, LDS-DMA issue, fragment reads, 8 MFMAs: 0.29 us whatever the ring
+// depth (K-sweeps with 3 / 4 / 6 / 8 stages all gave 0.29; three co-resident workgroups reach 0.14 per k-step and tile) --
+// and a second wave per SIMD running the same chain on the other half of the stage overlaps it.
+template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int WM, int WN, int WK = 1>
 __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const int tb, const int ntiles, const int split,
                                                const int S, char *smem) {
-    constexpr int NW = WM * WN;
+    constexpr int NWG = WM * WN, NW = NWG * WK;         // waves per k-group / per workgroup
     constexpr int SM = BM / WM, SN = BN / WN;           // rows / columns of the tile owned by one wave
     constexpr int TM = SM / 16, TN = SN / 16;
-    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-    constexpr int NI = (BM + BN) / 8 / NW;              // LDS-DMA instructions per wave per stage
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, SUB = A_BYTES + B_BYTES, STAGE = SUB * WK;
+    constexpr int NI = (BM + BN) / 8 * WK / NW;         // LDS-DMA instructions per wave per stage
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && SM % 16 == 0 && SN % 16 == 0, "tile / wave grid mismatch");
+    static_assert(WK == 1 || (WK == 2 && A_KC), "two k-groups: data paths with a k-contiguous A operand only (no colsum)");
 
+    GSTAMP(st_entry);
+#ifdef GEMM_STAMP
+    const unsigned long long st_real0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
+    const int wk = WK == 1 ? 0 : wave / NWG, wave_g = WK == 1 ? wave : wave % NWG;
+    const int wm = wave_g / WN, wn = wave_g % WN;
     // (index arithmetic is unsigned 32-bit on purpose: every workgroup runs it before its first load, and the signed / 64-bit
     // divisions it used to contain were ~300 scalar instructions of software division)
     const unsigned int tiles_n = ((unsigned int)g.N + BN - 1) / BN;
@@ -224,7 +249,7 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const bf16_t *A = (const bf16_t *)g.A;
     const bf16_t *B = (const bf16_t *)g.B;
-    const int KT_all = g.K / BK;
+    const int KT_all = g.K / (BK * WK);                 // ring stages (WK k-tiles each; the host checks divisibility)
     int kt_begin = 0, KT = KT_all;
     if (S > 1) {   // K / 64 * 8 < 2^32
         kt_begin = (int)((unsigned int)KT_all * (unsigned int)split / (unsigned int)S);
@@ -238,12 +263,15 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto issue = [&](int kt, int buf) {
-        char *sa = smem + buf * STAGE, *sb = sa + A_BYTES;
-        const int k0 = (kt_begin + kt) * BK;
-        if (A_KC) issue_kc<BM, NW>(A, g.lda, m0, g.M, k0, sa, wave, lane);
-        else issue_rc<BM, NW>(A, g.lda, m0, g.M, k0, sa, wave, lane);
-        if (B_KC) issue_kc<BN, NW>(B, g.ldb, n0, g.N, k0, sb, wave, lane);
-        else issue_rc<BN, NW>(B, g.ldb, n0, g.N, k0, sb, wave, lane);
+#pragma unroll
+        for (int j = 0; j < WK; ++j) {                   // every wave takes its share of every k-tile of the stage
+            char *sa = smem + buf * STAGE + j * SUB, *sb = sa + A_BYTES;
+            const int k0 = ((kt_begin + kt) * WK + j) * BK;
+            if (A_KC) issue_kc<BM, NW>(A, g.lda, m0, g.M, k0, sa, wave, lane);
+            else issue_rc<BM, NW>(A, g.lda, m0, g.M, k0, sa, wave, lane);
+            if (B_KC) issue_kc<BN, NW>(B, g.ldb, n0, g.N, k0, sb, wave, lane);
+            else issue_rc<BN, NW>(B, g.ldb, n0, g.N, k0, sb, wave, lane);
+        }
     };
 
     // bias gradient = column sums of the RC A tile, taken by the waves of the first tile column with one extra MFMA
@@ -260,12 +288,19 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
 #pragma unroll
     for (int p = 0; p < AHEAD; ++p)
         if (p < KT) issue(p, p);
+    GSTAMP(st_issued);
+#ifdef GEMM_STAMP
+    unsigned long long st_landed = 0;
+#endif
     int buf = 0;
     for (int kt = 0; kt < KT; ++kt) {
         wait_stages<NI, AHEAD - 1>(KT - 1 - kt);   // stage kt has landed; up to AHEAD-1 younger ones stay in flight
         __builtin_amdgcn_s_barrier();
+#ifdef GEMM_STAMP
+        if (kt == 0) st_landed = __builtin_amdgcn_s_memtime();
+#endif
         if (kt + AHEAD < KT) issue(kt + AHEAD, buf >= 1 ? buf - 1 : NSTAGE - 1);   // (kt+AHEAD) % NSTAGE == (buf-1) mod NSTAGE
-        const char *sa = smem + buf * STAGE, *sb = sa + A_BYTES;
+        const char *sa = smem + buf * STAGE + wk * SUB, *sb = sa + A_BYTES;
 #ifdef SKY_NOMATH   // experiment build: LDS-DMA stream + barriers only
         buf = buf + 1 < NSTAGE ? buf + 1 : 0;
         continue;
@@ -323,6 +358,7 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
         }
         buf = buf + 1 < NSTAGE ? buf + 1 : 0;
     }
+    GSTAMP(st_kloop);
     // ---- epilogue ------------------------------------------------------------------------------------------------
     // The accumulators leave the MFMA with one ROW per lane (16 rows per wave-instruction): stored as they stand, a
     // wave-instruction scatters 64 pieces of 8-16 bytes over 16 rows, and the launch ends in a store phase at ~1.3 TB/s
@@ -340,14 +376,31 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
     }
     constexpr int PITCH = BN * 4 + 16;                   // bytes per tile row in LDS (+16: conflict-free b128 writes)
     __builtin_amdgcn_s_barrier();                        // every wave is done with the fragments of the last stage
+    if (WK == 2) {                                       // partial tile of the odd k-tiles first, the even ones are added to it
+        if (wk == 1) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int r = wm * SM + i * 16 + (lane & 15), c = wn * SN + j * 16 + 4 * (lane >> 4);
-            *(f32x4 *)(smem + r * PITCH + c * 4) = acc[i][j] * g.alpha;
+                for (int j = 0; j < TN; ++j) {
+                    const int r = wm * SM + i * 16 + (lane & 15), c = wn * SN + j * 16 + 4 * (lane >> 4);
+                    *(f32x4 *)(smem + r * PITCH + c * 4) = acc[i][j];
+                }
         }
+        __syncthreads();
+    }
+    if (wk == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wm * SM + i * 16 + (lane & 15), c = wn * SN + j * 16 + 4 * (lane >> 4);
+                f32x4 v = acc[i][j];
+                if (WK == 2) v += *(const f32x4 *)(smem + r * PITCH + c * 4);
+                *(f32x4 *)(smem + r * PITCH + c * 4) = v * g.alpha;
+            }
+    }
     __syncthreads();
+    GSTAMP(st_staged);
     constexpr int PPR = BN / 8, PIECES = BM * PPR;       // pieces (8 columns) per row / per tile
     bf16_t *out = (bf16_t *)g.out;
     bf16_t *out2 = (bf16_t *)g.out2;
@@ -393,10 +446,24 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
         }
         if (out) store8(out + (int64_t)orow * g.ldo + n, v);
     }
+#ifdef GEMM_STAMP
+    {
+        const unsigned long long st_stored = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long st_acked = __builtin_amdgcn_s_memtime();
+        const unsigned long long st_real1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0 && g_gemm_stamp) {
+            unsigned long long *o = g_gemm_stamp + (size_t)blockIdx.x * 16;
+            o[0] = st_entry; o[1] = st_issued; o[2] = st_landed; o[3] = st_kloop; o[4] = st_staged; o[5] = st_stored; o[6] = st_acked;
+            o[8] = st_real0; o[9] = st_real1;
+            o[10] = (unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf);   // HW_REG_XCC_ID, bits 3:0
+        }
+    }
+#endif
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(const skyemb_gemm_args g) {
+template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int WM, int WN, int WK = 1>
+__global__ __launch_bounds__(WM * WN * WK * 64) void gemm_pipe_kernel(const skyemb_gemm_args g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int S = g.split_k > 1 ? g.split_k : 1;           // split-K factor (host-resolved)
     unsigned int ntiles = gridDim.x, split = 0;
@@ -404,7 +471,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(const skyemb_ge
         ntiles = gridDim.x / (unsigned int)S;
         split = blockIdx.x / ntiles;
     }
-    gemm_pipe_body<BM, BN, A_KC, B_KC, NSTAGE, WM, WN>(g, (int)(blockIdx.x - split * ntiles), (int)ntiles, (int)split, S, smem);
+    gemm_pipe_body<BM, BN, A_KC, B_KC, NSTAGE, WM, WN, WK>(g, (int)(blockIdx.x - split * ntiles), (int)ntiles, (int)split, S, smem);
 }
 
 // Grouped launch: several independent problems in ONE grid (the four weight-gradient GEMMs of a transformer block,
@@ -483,23 +550,30 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const skyemb_gemm_ar
     }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int WM, int WN>
+template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int WM, int WN, int WK>
 int launch_n(const skyemb_gemm_args &g, hipStream_t st) {
-    constexpr size_t ring = (size_t)NSTAGE * (BM + BN) * BK * 2, image = (size_t)BM * (BN * 4 + 16);   // k-loop ring / epilogue tile
+    constexpr size_t ring = (size_t)NSTAGE * (BM + BN) * BK * 2 * WK, image = (size_t)BM * (BN * 4 + 16);   // k-loop ring / epilogue tile
     constexpr size_t smem = ring > image ? ring : image;
-    static bool attr_set = false;
-    auto kern = gemm_pipe_kernel<BM, BN, A_KC, B_KC, NSTAGE, WM, WN>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) {
-            skyemb_set_error("skyemb_gemm(pipe): hipFuncSetAttribute(%zu B LDS): %s", smem, hipGetErrorString(e));
-            return 2;
+    auto kern = gemm_pipe_kernel<BM, BN, A_KC, B_KC, NSTAGE, WM, WN, WK>;
+    // the dynamic-LDS limit is an attribute of the function PER DEVICE
+    static std::mutex attr_mutex;
+    static bool attr_done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lock(attr_mutex);
+        if (!attr_done[dev & 63]) {
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) {
+                skyemb_set_error("skyemb_gemm(pipe): hipFuncSetAttribute(%zu B LDS): %s", smem, hipGetErrorString(e));
+                return 2;
+            }
+            attr_done[dev & 63] = true;
         }
-        attr_set = true;
     }
     const int64_t tiles = ceil_div64(g.M, BM) * ceil_div64(g.N, BN);
     const int S = g.split_k > 1 ? g.split_k : 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * S)), dim3(WM * WN * 64), smem, st, g);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * S)), dim3(WM * WN * WK * 64), smem, st, g);
     if (S > 1) {
         int64_t blocks = ceil_div64((int64_t)g.M * g.N / 4, 256);
         if (blocks > 1024) blocks = 1024;
@@ -509,16 +583,26 @@ int launch_n(const skyemb_gemm_args &g, hipStream_t st) {
     return 0;
 }
 
-template <int BM, int BN, int NSTAGE, int WM, int WN>
+template <int BM, int BN, int NSTAGE, int WM, int WN, int WK>
 int dispatch(const skyemb_gemm_args &g, hipStream_t st) {
     const bool a = g.a_layout == SKYEMB_KC, b = g.b_layout == SKYEMB_KC;
-    if (a && b) return launch_n<BM, BN, true, true, NSTAGE, WM, WN>(g, st);
-    if (a && !b) return launch_n<BM, BN, true, false, NSTAGE, WM, WN>(g, st);
-    if (!a && !b) return launch_n<BM, BN, false, false, NSTAGE, WM, WN>(g, st);
-    return launch_n<BM, BN, false, true, NSTAGE, WM, WN>(g, st);
+    if constexpr (WK == 2) {
+        // two k-groups: k-contiguous A, no bias-gradient column sums, an even number of k-tiles
+        if (!a || g.colsum_a || (g.K / BK) % 2 != 0) {
+            skyemb_set_error("skyemb_gemm(pipe): the two-k-group tiles need a k-contiguous A operand and K %% 128 == 0");
+            return 1;
+        }
+        if (b) return launch_n<BM, BN, true, true, NSTAGE, WM, WN, WK>(g, st);
+        return launch_n<BM, BN, true, false, NSTAGE, WM, WN, WK>(g, st);
+    } else {
+        if (a && b) return launch_n<BM, BN, true, true, NSTAGE, WM, WN, WK>(g, st);
+        if (a && !b) return launch_n<BM, BN, true, false, NSTAGE, WM, WN, WK>(g, st);
+        if (!a && !b) return launch_n<BM, BN, false, false, NSTAGE, WM, WN, WK>(g, st);
+        return launch_n<BM, BN, false, true, NSTAGE, WM, WN, WK>(g, st);
+    }
 }
 
-// Launch shapes.  code = variant * 1,000,000 + BM * 1000 + BN; X(variant, BM, BN, NSTAGE, WM, WN).
+// Launch shapes.  code = variant * 1,000,000 + BM * 1000 + BN; X(variant, BM, BN, NSTAGE, WM, WN, WK).
 // LDS per workgroup = NSTAGE * (BM + BN) * 128 B, which fixes the workgroups per CU (160 KiB): 64x64 x3 = 48 KB -> 3, x2 = 32 KB -> 5
 // (code 6064064, tuned table);
 // 128x64 x3 = 72 KB -> 2, x2 = 48 KB -> 3 (code 6128064: the decoder's [4352 x 2048] launches, tuned table);
@@ -526,12 +610,13 @@ int dispatch(const skyemb_gemm_args &g, hipStream_t st) {
 // 2-stage ring: two resident workgroups (16 waves) cover each other's barriers, which a third stage did not (ViT-L shapes,
 // tools/ubench/gemm_lab with LAB_VITL=1: [8320 x 3072 x 1024] 93 us on 128x64, 86 us on 128x128 x3, 74 us on 128x128 x2).
 #define SKY_GEMM_PRODUCT_VARIANTS(X) \
-    X(0, 64, 64, 3, 2, 2)            \
-    X(0, 128, 64, 3, 4, 2)           \
-    X(0, 128, 128, 2, 4, 2)          \
-    X(2, 256, 128, 3, 4, 4)          \
-    X(6, 128, 64, 2, 4, 2)           \
-    X(6, 64, 64, 2, 2, 2)
+    X(0, 64, 64, 3, 2, 2, 1)         \
+    X(0, 128, 64, 3, 4, 2, 1)        \
+    X(0, 128, 128, 2, 4, 2, 1)       \
+    X(2, 256, 128, 3, 4, 4, 1)       \
+    X(6, 128, 64, 2, 4, 2, 1)        \
+    X(6, 64, 64, 2, 2, 2, 1)         \
+    X(9, 64, 64, 3, 2, 2, 2)
 #ifdef SKY_GEMM_LAB   // experiment builds (tools/ubench/gemm_lab.hip): every shape under study
 #define SKY_GEMM_VARIANTS(X) SKY_GEMM_PRODUCT_VARIANTS(X) SKY_GEMM_LAB_VARIANTS(X)
 #else
@@ -539,8 +624,8 @@ int dispatch(const skyemb_gemm_args &g, hipStream_t st) {
 #endif
 
 int dispatch_code(int code, const skyemb_gemm_args &g, hipStream_t st) {
-#define X(V, BM_, BN_, NS, WM_, WN_) \
-    if (code == V * 1000000 + BM_ * 1000 + BN_) return dispatch<BM_, BN_, NS, WM_, WN_>(g, st);
+#define X(V, BM_, BN_, NS, WM_, WN_, WK_) \
+    if (code == V * 1000000 + BM_ * 1000 + BN_) return dispatch<BM_, BN_, NS, WM_, WN_, WK_>(g, st);
     SKY_GEMM_VARIANTS(X)
 #undef X
     skyemb_set_error("skyemb_gemm(pipe): unknown tile code %d", code);
@@ -603,6 +688,15 @@ int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
     if (tile == 0 && (t128 >= 1024 || (t128 >= 512 && g.K >= 1024))) tile = 128128;   // >= 2 rounds of 2 workgroups per CU
     if (tile == 0 && (t12864 >= 2048 || (t12864 >= 1024 && g.K >= 1024))) tile = 128064;
     if (tile == 0) tile = 64064;
+    // At most one 64x64 workgroup per CU: two k-groups of waves in the workgroup instead of an idle second wave slot per
+    // SIMD (tools/ubench/gemm_lab: [1280 x 768] outputs 0.32 -> 0.20 us per k-step; K = 3072: 17.8 -> 14.3 us unsplit, where
+    // the best one-group launch was a 2-way split-K plus its reduce launch).
+    static const bool wk2_on = []() { const char *e = getenv("SKYEMB_GEMM_WK2"); return !(e && e[0] == '0'); }();
+    if (wk2_on && tile == 64064 && g.tile == 0 && g_in.split_k <= 1 && g.a_layout == SKYEMB_KC && !g.colsum_a && (g.K / BK) % 2 == 0 &&
+        g.K / BK >= 4 && ceil_div64(g.M, 64) * ceil_div64(g.N, 64) <= 256) {
+        tile = 9064064;
+        want_split = 1;
+    }
     int bm, bn;
     tile_dims(tile, bm, bn);
     // split-K (deterministic slabs + a reduce launch that applies the epilogue) for launches with too few tiles to

@@ -2,22 +2,29 @@
 // step, standalone (no torch), and checks every variant against a naive fp32 kernel.
 //   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DSKY_GEMM_LAB tools/ubench/gemm_lab.hip -o tools/ubench/gemm_lab
 //   run:   tools/ubench/gemm_lab [codes...]      (default: every compiled variant)
+//   LAB_STAMP=1 (binary built with -DGEMM_STAMP): per-launch timeline of the product's launch shapes as JSON
+//   (profiles/r03_gemm_timeline.json): marker kernel -> GEMM -> marker kernel, s_memtime / s_memrealtime stamps per workgroup.
 // Timing: each (shape, config) is launched over a rotation of 6 operand sets (the weights of six different layers: cold
 // in L2, as in the training step, where a layer's weights were last read a whole step earlier) between two HIP events.
 #define SKY_GEMM_LAB_VARIANTS(X) \
-    X(1, 64, 64, 4, 2, 2)        \
-    X(0, 64, 128, 3, 2, 4)       \
-    X(1, 64, 128, 3, 2, 2)       \
-    X(1, 128, 64, 3, 2, 2)       \
-    X(1, 128, 128, 3, 2, 2)      \
-    X(2, 128, 128, 2, 2, 2)      \
-    X(3, 128, 128, 4, 2, 2)      \
-    X(4, 128, 128, 4, 4, 2)      \
-    X(5, 128, 128, 3, 4, 2)      \
-    X(0, 256, 128, 3, 4, 2)      \
-    X(1, 256, 128, 2, 4, 2)      \
-    X(0, 128, 256, 3, 2, 4)      \
-    X(1, 128, 256, 2, 2, 4)
+    X(1, 64, 64, 4, 2, 2, 1)        \
+    X(7, 64, 64, 6, 2, 2, 1)        \
+    X(8, 64, 64, 8, 2, 2, 1)        \
+    X(0, 64, 128, 3, 2, 4, 1)       \
+    X(1, 64, 128, 3, 2, 2, 1)       \
+    X(1, 128, 64, 3, 2, 2, 1)       \
+    X(1, 128, 128, 3, 2, 2, 1)      \
+    X(2, 128, 128, 2, 2, 2, 1)      \
+    X(3, 128, 128, 4, 2, 2, 1)      \
+    X(4, 128, 128, 4, 4, 2, 1)      \
+    X(5, 128, 128, 3, 4, 2, 1)      \
+    X(0, 256, 128, 3, 4, 2, 1)      \
+    X(1, 256, 128, 2, 4, 2, 1)      \
+    X(0, 128, 256, 3, 2, 4, 1)      \
+    X(1, 128, 256, 2, 2, 4, 1)   \
+    X(10, 64, 64, 2, 2, 2, 2)    \
+    X(11, 64, 64, 4, 2, 2, 2)    \
+    X(9, 128, 128, 2, 4, 2, 2)
 #include "../../sky_embeddings_amd/csrc/gemm_pipe.hip"
 
 #include <stdarg.h>
@@ -67,6 +74,15 @@ __global__ void ref_gemm(const bf16_t *A, const bf16_t *B, int M, int N, int K, 
     out[(int64_t)m * N + n] = acc;
 }
 
+// one wave: s_memrealtime (100 MHz, chip-wide) when it starts and when it ends -- brackets the stamped launch on the stream
+__global__ void marker_kernel(unsigned long long *o) {
+    const unsigned long long a = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        o[0] = a;
+        o[1] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
 __global__ void empty_kernel(float *p) {
     extern __shared__ char sm[];
     if (p == nullptr) sm[threadIdx.x] = 1;
@@ -105,7 +121,7 @@ int main(int argc, char **argv) {
     std::vector<int> codes;
     for (int i = 1; i < argc; ++i) codes.push_back(atoi(argv[i]));
     if (codes.empty()) {
-#define X(V, BM_, BN_, NS, WM_, WN_) codes.push_back(V * 1000000 + BM_ * 1000 + BN_);
+#define X(V, BM_, BN_, NS, WM_, WN_, WK_) codes.push_back(V * 1000000 + BM_ * 1000 + BN_);
         SKY_GEMM_VARIANTS(X)
 #undef X
     }
@@ -164,6 +180,7 @@ int main(int argc, char **argv) {
                 continue;
             Shape s = s0;
             s.epi = 1;
+            if (code / 1000000 >= 9 && !s.a_kc) continue;      // two-k-group tiles: k-contiguous A only
             skyemb_gemm_args g = make_args(s, 0, code, 1);
             g.resid = nullptr; g.bias = nullptr;
             CK(hipMemset(o32, 0xff, (size_t)s.M * s.N * 4));
@@ -203,6 +220,80 @@ int main(int argc, char **argv) {
         CK(hipEventElapsedTime(&ms, e0, e1));
         return ms * 1e3f / iters;
     };
+
+#ifdef GEMM_STAMP
+    if (getenv("LAB_STAMP")) {
+        // timeline of the launches that dominate the step (product tile choice: code 0 = tuned table / heuristic), cold
+        // operands (rotation over six sets, as in the step)
+        const int MAXWG = 4096;
+        unsigned long long *d_st, *d_mk;
+        CK(hipMalloc(&d_st, (size_t)MAXWG * 16 * 8));
+        CK(hipMalloc(&d_mk, 4 * 8));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamp), &d_st, sizeof(d_st)));
+        std::vector<unsigned long long> h((size_t)MAXWG * 16), hm(4);
+        struct Want { const char *what; int M, N, K, a_kc, b_kc, epi; };
+        const Want wants[] = {{"enc.proj.fwd [1280 x 768 x 768] bias + fp32 residual", 1280, 768, 768, 1, 1, 1},
+                              {"enc.qkv.fwd [1280 x 2304 x 768] bias -> bf16", 1280, 2304, 768, 1, 1, 0},
+                              {"dec.fc1.fwd [4352 x 2048 x 512] bias + GELU (two bf16 outputs)", 4352, 2048, 512, 1, 1, 2},
+                              {"enc.fc1.dgrad [1280 x 768 x 3072] data gradient (row-contiguous weights)", 1280, 768, 3072, 1, 0, 0},
+                              {"enc.fc2.dgrad [1280 x 3072 x 768] data gradient + dGELU", 1280, 3072, 768, 1, 0, 3},
+                              {"dec.qkv.fwd [4352 x 1536 x 512] bias -> bf16", 4352, 1536, 512, 1, 1, 0}};
+        printf("{\n \"source\": \"tools/ubench/gemm_lab built with -DGEMM_STAMP -DSKY_GEMM_LAB, LAB_STAMP=1: marker kernel -> launch -> marker kernel on one stream, 24 repetitions over 6 operand sets; medians over repetitions of per-launch figures, medians over workgroups of per-phase figures; times in us (s_memrealtime 100 MHz for spans and gaps, s_memtime shader cycles / measured clock for phases)\",\n \"launches\": [\n");
+        bool first_out = true;
+        for (const Want &wn : wants) {
+            Shape s{"stamp", wn.M, wn.N, wn.K, wn.a_kc, wn.b_kc, 1, wn.epi};
+            std::vector<double> span, gap_in, gap_out, spread, clk, ph[6], evt, xcd_skew;
+            int grid = 0, nsplit = 1;
+            for (int it = 0; it < 26; ++it) {
+                skyemb_gemm_args g = make_args(s, it % ROT, 0, 0);
+                CK(hipMemsetAsync(d_st, 0, (size_t)MAXWG * 16 * 8, 0));
+                marker_kernel<<<1, 64>>>(d_mk);
+                CK(hipEventRecord(e0));
+                if (skyemb_gemm_pipe_try(g, 0) != 0) { fprintf(stderr, "refused: %s\n", g_err); return 1; }
+                CK(hipEventRecord(e1));
+                marker_kernel<<<1, 64>>>(d_mk + 2);
+                CK(hipDeviceSynchronize());
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                CK(hipMemcpy(h.data(), d_st, (size_t)MAXWG * 16 * 8, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(hm.data(), d_mk, 32, hipMemcpyDeviceToHost));
+                if (it < 2) continue;                         // warm-up
+                int n = 0;
+                while (n < MAXWG && h[(size_t)n * 16 + 8]) ++n;
+                grid = n;
+                unsigned long long lo = ~0ull, hi = 0, lo_max = 0;
+                std::vector<double> p[6], c;
+                for (int w = 0; w < n; ++w) {
+                    const unsigned long long *o = &h[(size_t)w * 16];
+                    lo = std::min(lo, o[8]); lo_max = std::max(lo_max, o[8]); hi = std::max(hi, o[9]);
+                    const double cyc_per_us = (double)(o[6] - o[0]) / ((double)(o[9] - o[8]) / 100.0);
+                    c.push_back(cyc_per_us);
+                    for (int k = 0; k < 6; ++k) p[k].push_back((double)(o[k + 1] - o[k]));
+                }
+                auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+                const double cm = med(c);
+                for (int k = 0; k < 6; ++k) ph[k].push_back(med(p[k]) / cm);
+                clk.push_back(cm / 1e3);
+                span.push_back((double)(hi - lo) / 100.0);
+                gap_in.push_back((double)((long long)lo - (long long)hm[1]) / 100.0);
+                gap_out.push_back((double)((long long)hm[2] - (long long)hi) / 100.0);
+                spread.push_back((double)(lo_max - lo) / 100.0);
+                evt.push_back(ms * 1e3);
+            }
+            auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+            printf("%s  {\"launch\": \"%s\", \"workgroups\": %d, \"hip_event_us\": %.2f, \"marker_to_first_workgroup_us\": %.2f, "
+                   "\"first_to_last_workgroup_start_us\": %.2f, \"first_start_to_last_end_us\": %.2f, \"last_end_to_next_kernel_us\": %.2f, "
+                   "\"clock_ghz\": %.3f, \"workgroup_phases_us\": {\"entry_to_ring_issued\": %.2f, \"first_stage_landed\": %.2f, "
+                   "\"k_loop\": %.2f, \"tile_to_lds\": %.2f, \"epilogue_loads_math_stores_issued\": %.2f, \"stores_acknowledged\": %.2f}}",
+                   first_out ? "" : ",\n", wn.what, grid, med(evt), med(gap_in), med(spread), med(span), med(gap_out), med(clk), med(ph[0]), med(ph[1]),
+                   med(ph[2]), med(ph[3]), med(ph[4]), med(ph[5]));
+            first_out = false;
+            (void)nsplit;
+        }
+        printf("\n ]\n}\n");
+        return 0;
+    }
+#endif
     if (getenv("LAB_EMPTY")) {
         for (auto cfg : {std::tuple<int, int, int>{960, 256, 49152}, {2176, 256, 49152}, {480, 512, 73728}, {240, 512, 98304}, {544, 512, 98304}}) {
             const int grid = std::get<0>(cfg), thr = std::get<1>(cfg), lds = std::get<2>(cfg);
