@@ -213,7 +213,7 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, SUB = A_BYTES + B_BYTES, STAGE = SUB * WK;
     constexpr int NI = (BM + BN) / 8 * WK / NW;         // LDS-DMA instructions per wave per stage
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && SM % 16 == 0 && SN % 16 == 0, "tile / wave grid mismatch");
-    static_assert(WK == 1 || (WK == 2 && A_KC), "two k-groups: data paths with a k-contiguous A operand only (no colsum)");
+    static_assert(WK == 1 || WK == 2, "one or two k-groups");
 
     GSTAMP(st_entry);
 #ifdef GEMM_STAMP
@@ -367,14 +367,8 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
     // consecutive pieces of a row: every wave-instruction writes whole 128-byte lines.  The fused inputs (bias, table
     // rows, residual, dGELU operand) are read in the same lane order.
     float *cs_out = S > 1 ? (float *)g.ws + (int64_t)S * g.M * g.N + (int64_t)split * g.M : g.colsum_a;
-    if (!A_KC && do_colsum && lane < 16) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * SM + i * 16 + lane;
-            if (m < g.M) cs_out[m] = cacc[i][0];
-        }
-    }
     constexpr int PITCH = BN * 4 + 16;                   // bytes per tile row in LDS (+16: conflict-free b128 writes)
+    float *cs_lds = (float *)(smem + BM * PITCH);        // (two k-groups) the odd k-tiles' column sums, BM floats behind the image
     __builtin_amdgcn_s_barrier();                        // every wave is done with the fragments of the last stage
     if (WK == 2) {                                       // partial tile of the odd k-tiles first, the even ones are added to it
         if (wk == 1) {
@@ -385,8 +379,21 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
                     const int r = wm * SM + i * 16 + (lane & 15), c = wn * SN + j * 16 + 4 * (lane >> 4);
                     *(f32x4 *)(smem + r * PITCH + c * 4) = acc[i][j];
                 }
+            if (!A_KC && do_colsum && lane < 16) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) cs_lds[wm * SM + i * 16 + lane] = cacc[i][0];
+            }
         }
         __syncthreads();
+    }
+    if (!A_KC && do_colsum && lane < 16 && wk == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * SM + i * 16 + lane;
+            float v = cacc[i][0];
+            if (WK == 2) v += cs_lds[wm * SM + i * 16 + lane];
+            if (m < g.M) cs_out[m] = v;
+        }
     }
     if (wk == 0) {
 #pragma unroll
@@ -481,8 +488,8 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm_pipe_kernel(const skye
 // 1 KC.KC, 2 KC.RC, 4 RC.RC, 8 RC.KC).
 // blob = [int32 n, total_blocks, 6 x pad, start[0..n] (multiples of 8), ...pad to 256 B][n x skyemb_gemm_args]
 constexpr int GROUP_HEADER_BYTES = 256, GROUP_MAX = 32;
-template <int BM, int BN, int NSTAGE, int WM, int WN, int CLASSES>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_group_kernel(const char *__restrict__ blob) {
+template <int BM, int BN, int NSTAGE, int WM, int WN, int CLASSES, int WK = 1>
+__global__ __launch_bounds__(WM * WN * WK * 64) void gemm_pipe_group_kernel(const char *__restrict__ blob) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int *hdr = (const int *)blob;
     const int n = hdr[0];
@@ -493,10 +500,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_group_kernel(const cha
     const int ntiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     if (tb >= ntiles) return;                             // padding up to the next multiple of 8 (keeps tb & 7 == XCD)
     const bool a = g.a_layout == SKYEMB_KC, b = g.b_layout == SKYEMB_KC;   // workgroup-uniform
-    if constexpr (CLASSES & 1) if (a && b) return gemm_pipe_body<BM, BN, true, true, NSTAGE, WM, WN>(g, tb, ntiles, 0, 1, smem);
-    if constexpr (CLASSES & 2) if (a && !b) return gemm_pipe_body<BM, BN, true, false, NSTAGE, WM, WN>(g, tb, ntiles, 0, 1, smem);
-    if constexpr (CLASSES & 4) if (!a && !b) return gemm_pipe_body<BM, BN, false, false, NSTAGE, WM, WN>(g, tb, ntiles, 0, 1, smem);
-    if constexpr (CLASSES & 8) if (!a && b) return gemm_pipe_body<BM, BN, false, true, NSTAGE, WM, WN>(g, tb, ntiles, 0, 1, smem);
+    if constexpr (CLASSES & 1) if (a && b) return gemm_pipe_body<BM, BN, true, true, NSTAGE, WM, WN, WK>(g, tb, ntiles, 0, 1, smem);
+    if constexpr (CLASSES & 2) if (a && !b) return gemm_pipe_body<BM, BN, true, false, NSTAGE, WM, WN, WK>(g, tb, ntiles, 0, 1, smem);
+    if constexpr (CLASSES & 4) if (!a && !b) return gemm_pipe_body<BM, BN, false, false, NSTAGE, WM, WN, WK>(g, tb, ntiles, 0, 1, smem);
+    if constexpr (CLASSES & 8) if (!a && b) return gemm_pipe_body<BM, BN, false, true, NSTAGE, WM, WN, WK>(g, tb, ntiles, 0, 1, smem);
 }
 
 // second launch of a split-K GEMM: v = sum_s slab[s][m][n] (fixed order, alpha already applied), then
@@ -552,7 +559,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const skyemb_gemm_ar
 
 template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int WM, int WN, int WK>
 int launch_n(const skyemb_gemm_args &g, hipStream_t st) {
-    constexpr size_t ring = (size_t)NSTAGE * (BM + BN) * BK * 2 * WK, image = (size_t)BM * (BN * 4 + 16);   // k-loop ring / epilogue tile
+    constexpr size_t ring = (size_t)NSTAGE * (BM + BN) * BK * 2 * WK, image = (size_t)BM * (BN * 4 + 16) + (WK > 1 ? BM * 4 : 0);   // k-loop ring / epilogue tile (+ column sums)
     constexpr size_t smem = ring > image ? ring : image;
     auto kern = gemm_pipe_kernel<BM, BN, A_KC, B_KC, NSTAGE, WM, WN, WK>;
     // the dynamic-LDS limit is an attribute of the function PER DEVICE
@@ -587,19 +594,15 @@ template <int BM, int BN, int NSTAGE, int WM, int WN, int WK>
 int dispatch(const skyemb_gemm_args &g, hipStream_t st) {
     const bool a = g.a_layout == SKYEMB_KC, b = g.b_layout == SKYEMB_KC;
     if constexpr (WK == 2) {
-        // two k-groups: k-contiguous A, no bias-gradient column sums, an even number of k-tiles
-        if (!a || g.colsum_a || (g.K / BK) % 2 != 0) {
-            skyemb_set_error("skyemb_gemm(pipe): the two-k-group tiles need a k-contiguous A operand and K %% 128 == 0");
+        if ((g.K / BK) % 2 != 0) {                          // a ring stage holds two k-tiles
+            skyemb_set_error("skyemb_gemm(pipe): the two-k-group tiles need K %% 128 == 0");
             return 1;
         }
-        if (b) return launch_n<BM, BN, true, true, NSTAGE, WM, WN, WK>(g, st);
-        return launch_n<BM, BN, true, false, NSTAGE, WM, WN, WK>(g, st);
-    } else {
-        if (a && b) return launch_n<BM, BN, true, true, NSTAGE, WM, WN, WK>(g, st);
-        if (a && !b) return launch_n<BM, BN, true, false, NSTAGE, WM, WN, WK>(g, st);
-        if (!a && !b) return launch_n<BM, BN, false, false, NSTAGE, WM, WN, WK>(g, st);
-        return launch_n<BM, BN, false, true, NSTAGE, WM, WN, WK>(g, st);
     }
+    if (a && b) return launch_n<BM, BN, true, true, NSTAGE, WM, WN, WK>(g, st);
+    if (a && !b) return launch_n<BM, BN, true, false, NSTAGE, WM, WN, WK>(g, st);
+    if (!a && !b) return launch_n<BM, BN, false, false, NSTAGE, WM, WN, WK>(g, st);
+    return launch_n<BM, BN, false, true, NSTAGE, WM, WN, WK>(g, st);
 }
 
 // Launch shapes.  code = variant * 1,000,000 + BM * 1000 + BN; X(variant, BM, BN, NSTAGE, WM, WN, WK).
@@ -616,7 +619,8 @@ int dispatch(const skyemb_gemm_args &g, hipStream_t st) {
     X(2, 256, 128, 3, 4, 4, 1)       \
     X(6, 128, 64, 2, 4, 2, 1)        \
     X(6, 64, 64, 2, 2, 2, 1)         \
-    X(9, 64, 64, 3, 2, 2, 2)
+    X(9, 64, 64, 3, 2, 2, 2)         \
+    X(9, 128, 128, 2, 4, 2, 2)
 #ifdef SKY_GEMM_LAB   // experiment builds (tools/ubench/gemm_lab.hip): every shape under study
 #define SKY_GEMM_VARIANTS(X) SKY_GEMM_PRODUCT_VARIANTS(X) SKY_GEMM_LAB_VARIANTS(X)
 #else
@@ -776,10 +780,20 @@ extern "C" int skyemb_gemm_group_plan(const skyemb_gemm_args *args, int n, int t
         int64_t t128 = 0;
         for (int i = 0; i < n; ++i) t128 += ceil_div64(args[i].M, 128) * ceil_div64(args[i].N, 128);
         if (t128 >= 400) tile = 128128;
+        // at most one 128x128 workgroup per CU (the decoder's four weight gradients: 192 tiles, K = 4352 token rows): two k-groups
+        static const int wk2 = []() { const char *e = getenv("SKYEMB_GROUP_WK2"); return e ? atoi(e) : 0; }();
+        if (wk2 && t128 <= 256) {
+            bool even = true;
+            for (int i = 0; i < n; ++i) even = even && (args[i].K / BK) % 2 == 0 && args[i].K >= 4 * BK;
+            if (even) tile = 9128128;
+        }
         static const int env_tile = []() { const char *e = getenv("SKYEMB_GROUP_TILE"); return e ? atoi(e) : 0; }();   // experiments
         if (env_tile) tile = canonical_tile(env_tile);
     }
-    SKY_CHECK_ARG(tile == 64064 || tile == 128064 || tile == 128128, "skyemb_gemm_group_plan: tile %d is not built for grouped launches", tile);
+    SKY_CHECK_ARG(tile == 64064 || tile == 128064 || tile == 128128 || tile == 9128128, "skyemb_gemm_group_plan: tile %d is not built for grouped launches", tile);
+    if (tile == 9128128)
+        for (int i = 0; i < n; ++i)
+            SKY_CHECK_ARG((args[i].K / BK) % 2 == 0, "skyemb_gemm_group_plan: the two-k-group tile needs K %% 128 == 0 (problem %d)", i);
     int bm, bn;
     tile_dims(tile, bm, bn);
     int *hdr = (int *)blob_host;
@@ -821,31 +835,37 @@ extern "C" int skyemb_gemm_group_plan(const skyemb_gemm_args *args, int n, int t
     return 0;
 }
 
-template <int BM, int BN, int NSTAGE, int WM, int WN, int CLASSES>
+template <int BM, int BN, int NSTAGE, int WM, int WN, int CLASSES, int WK = 1>
 static int group_launch_n(const void *blob_dev, int total_blocks, hipStream_t st) {
-    constexpr size_t ring = (size_t)NSTAGE * (BM + BN) * BK * 2, image = (size_t)BM * (BN * 4 + 16);
+    constexpr size_t ring = (size_t)NSTAGE * (BM + BN) * BK * 2 * WK, image = (size_t)BM * (BN * 4 + 16) + (WK > 1 ? BM * 4 : 0);
     constexpr size_t smem = ring > image ? ring : image;
-    static bool attr_set = false;
-    auto kern = gemm_pipe_group_kernel<BM, BN, NSTAGE, WM, WN, CLASSES>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) {
-            skyemb_set_error("skyemb_gemm_group_launch: hipFuncSetAttribute(%zu B LDS): %s", smem, hipGetErrorString(e));
-            return 2;
+    auto kern = gemm_pipe_group_kernel<BM, BN, NSTAGE, WM, WN, CLASSES, WK>;
+    static std::mutex attr_mutex;
+    static bool attr_done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lock(attr_mutex);
+        if (!attr_done[dev & 63]) {
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) {
+                skyemb_set_error("skyemb_gemm_group_launch: hipFuncSetAttribute(%zu B LDS): %s", smem, hipGetErrorString(e));
+                return 2;
+            }
+            attr_done[dev & 63] = true;
         }
-        attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)total_blocks), dim3(WM * WN * 64), smem, st, (const char *)blob_dev);
+    hipLaunchKernelGGL(kern, dim3((unsigned)total_blocks), dim3(WM * WN * WK * 64), smem, st, (const char *)blob_dev);
     SKY_LAUNCH_CHECK("skyemb_gemm_group_launch");
     return 0;
 }
-template <int BM, int BN, int NSTAGE, int WM, int WN>
+template <int BM, int BN, int NSTAGE, int WM, int WN, int WK = 1>
 static int group_launch_classes(const void *blob_dev, int total_blocks, int mask, hipStream_t st) {
     switch (mask) {
-        case 1: return group_launch_n<BM, BN, NSTAGE, WM, WN, 1>(blob_dev, total_blocks, st);
-        case 2: return group_launch_n<BM, BN, NSTAGE, WM, WN, 2>(blob_dev, total_blocks, st);
-        case 4: return group_launch_n<BM, BN, NSTAGE, WM, WN, 4>(blob_dev, total_blocks, st);
-        case 6: return group_launch_n<BM, BN, NSTAGE, WM, WN, 6>(blob_dev, total_blocks, st);
+        case 1: return group_launch_n<BM, BN, NSTAGE, WM, WN, 1, WK>(blob_dev, total_blocks, st);
+        case 2: return group_launch_n<BM, BN, NSTAGE, WM, WN, 2, WK>(blob_dev, total_blocks, st);
+        case 4: return group_launch_n<BM, BN, NSTAGE, WM, WN, 4, WK>(blob_dev, total_blocks, st);
+        case 6: if constexpr (WK == 1) return group_launch_n<BM, BN, NSTAGE, WM, WN, 6, WK>(blob_dev, total_blocks, st); else break;
     }
     skyemb_set_error("skyemb_gemm_group_launch: class mask %d not built", mask);
     return 1;
@@ -859,6 +879,7 @@ extern "C" int skyemb_gemm_group_launch(const void *blob_dev, const skyemb_gemm_
         case 64064: return group_launch_classes<64, 64, 3, 2, 2>(blob_dev, info->total_blocks, info->class_mask, st);
         case 128064: return group_launch_classes<128, 64, 3, 4, 2>(blob_dev, info->total_blocks, info->class_mask, st);
         case 128128: return group_launch_classes<128, 128, 2, 4, 2>(blob_dev, info->total_blocks, info->class_mask, st);
+        case 9128128: return group_launch_classes<128, 128, 2, 4, 2, 2>(blob_dev, info->total_blocks, info->class_mask, st);
     }
     skyemb_set_error("skyemb_gemm_group_launch: tile %d not built", info->tile);
     return 1;

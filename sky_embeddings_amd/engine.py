@@ -481,7 +481,10 @@ class MAEEngine:
         args = [ops.gemm_args(dy, x_in, M=n_out, N=k_in, K=M, a_layout=RC, b_layout=RC, lda=n_out, ldb=k_in,
                               out_f32=st.grad(f"{name}.weight"), colsum_a=st.grad(f"{name}.bias"))
                 for dy, x_in, name, n_out, k_in in self._wgrad_layers(prefix, bufs, M, dim, w)]
-        grp = ops.GemmGroup(args, self.device)
+        # (experiments: SKYEMB_WGRAD_TILE_ENC / _DEC force the grouped launch's tile code for one stack)
+        import os
+        tile = int(os.environ.get("SKYEMB_WGRAD_TILE_DEC" if prefix.startswith("decoder") else "SKYEMB_WGRAD_TILE_ENC", "0"))
+        grp = ops.GemmGroup(args, self.device, tile=tile)
         return grp if grp.ok else None
 
     def _block_bwd(self, x_in, bufs, prefix, M, dim, heads, Bsz, N, g, g_lp, w):

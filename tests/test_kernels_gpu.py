@@ -122,6 +122,38 @@ def test_gemm_two_k_group_tile(ops, b_l, tile, shape):
             ops.gemm(Ad[:, :64].contiguous(), dev(B[:, :64].contiguous(), T), M=M, N=N, K=64, out_f32=out, tile=tile)
 
 
+@pytest.mark.parametrize("tile", [9064064, 9128128])
+def test_gemm_two_k_group_weight_gradients(ops, tile):
+    """Row-contiguous operands (weight-gradient class) on the two-k-group tiles: products and the fused bias-gradient column
+    sums against fp64; four problems as ONE grouped launch give the bits of four single launches on the same tile."""
+    g = torch.Generator().manual_seed(tile % 1000)
+    tokens = 384
+    shapes = [(192, 768), (768, 192), (200, 136), (576, 264)]       # (N_out, K_in); ragged tile edges
+    args, outs, refs, keep = [], [], [], []
+    for n_out, k_in in shapes:
+        dy32, x32 = torch.randn(tokens, n_out, generator=g), torch.randn(tokens, k_in, generator=g)
+        dy, x = dev(dy32, torch.bfloat16), dev(x32, torch.bfloat16)
+        dw1, db1 = torch.full((n_out, k_in), float("nan"), device=DEV), torch.full((n_out,), float("nan"), device=DEV)
+        kw = dict(M=n_out, N=k_in, K=tokens, a_layout=ops.RC, b_layout=ops.RC, lda=n_out, ldb=k_in)
+        ops.gemm(dy, x, out_f32=dw1, colsum_a=db1, split_k=1, tile=tile, **kw)
+        dyr, xr = dy.double().cpu(), x.double().cpu()
+        ref = dyr.T @ xr
+        assert float((dw1.cpu().double() - ref).abs().max()) <= 2e-6 * float((dyr.abs().T @ xr.abs()).max())
+        assert float((db1.cpu().double() - dyr.sum(0)).abs().max()) <= 1e-5 * float(dyr.abs().sum(0).max())
+        dw, db = torch.full((n_out, k_in), float("nan"), device=DEV), torch.full((n_out,), float("nan"), device=DEV)
+        args.append(ops.gemm_args(dy, x, out_f32=dw, colsum_a=db, **kw))
+        keep.append((dy, x))
+        outs.append((dw, db))
+        refs.append((dw1, db1))
+    if tile == 9128128:
+        grp = ops.GemmGroup(args, DEV, tile=tile)
+        assert grp.ok and grp.total_blocks % 8 == 0
+        grp.launch()
+        torch.cuda.synchronize()
+        for (dw, db), (dw1, db1) in zip(outs, refs):
+            assert torch.equal(dw, dw1) and torch.equal(db, db1)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_epilogues(ops, dtype):
     M, N, K = 70, 136, 96
