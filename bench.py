@@ -230,9 +230,53 @@ def bench_pretrain(args, rank, world, dev):
         if args.probe:
             out["gemm_probe"] = gemm_step_probe(B, dtype, dev)
         out["phases"] = hbm_phases(eng, opt, step, B)
+        if world == 1:
+            # a longer timed region beside the driver's (>= 100 steps), HIP events on the launch stream
+            n_long = max(100, args.steps)
+            _, long_ms, _ = timed(step, n_long)
+            out["long_run"] = dict(steps=n_long, ms_per_step=long_ms, images_per_sec=B / long_ms * 1e3)
+            out["staged"] = staged_schedule_price(eng, opt, sched, B, pool, dev, args)
         if world == 1 and not args.skip_feeder:
             out["feeder"] = bench_feeder(args, dev, step, B)
     return out, eng
+
+
+def staged_schedule_price(eng, opt, sched, B, pool, dev, args):
+    """What the N > 1 schedule costs in COMPUTE on one GPU (no 8-GPU node is guaranteed to the driver): the step as 8 stage
+    graphs (decoder, six encoder groups, embedding) with the per-stage gradient casts into the bf16 communication mirror --
+    everything the data-parallel step does except the collectives -- beside the monolithic graph; also with fp32 communication
+    buffers (no casts).  Bytes per stage = what each stage's all-reduce would move."""
+    from sky_embeddings_amd.train_step import TrainStep
+    st = eng.store
+    snap = [t.clone() for t in (st.p, st.m, st.v, st.p_lp)]
+    counters = (opt.step_count, sched.last_epoch)
+    res = {}
+    try:
+        for comm in ("bf16", "f32"):
+            s2 = TrainStep(eng, opt, sched, B, mask_ratio=0.75, use_graph=not args.no_graph, world_size=1, staged=True,
+                           n_encoder_groups=6, grad_comm=comm)
+            for i in range(5):
+                s2(pool[i % 2])
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(50):
+                s2(pool[i % 2])
+            e1.record()
+            e1.synchronize()
+            elem = 2 if comm == "bf16" else 4
+            res[comm] = dict(ms_per_step=e0.elapsed_time(e1) / 50, stages=len(s2.stages),
+                             bytes_per_stage=[sum(e - s for s, e in ranges) * elem for _, ranges in s2.stages])
+            del s2
+    finally:
+        for dst, src in zip((st.p, st.m, st.v, st.p_lp), snap):
+            dst.copy_(src)
+        opt.step_count, sched.last_epoch = counters
+        sched._apply()
+        opt.grad_scale = 1.0
+    res["note"] = ("TrainStep(staged=True, n_encoder_groups=6) at world 1: stage graphs + skyemb_cast launches, no collectives; the "
+                   "8-GPU step = this + the exposed part of the last stages' all-reduce (DESIGN.md §2)")
+    return res
 
 
 def bench_mim19(args, dev):
@@ -392,7 +436,9 @@ def bench_search(args, rank, world, dev):
         thr0 = pruning_floor(tw, qn, pb, k, 1e-6)
         kms = ev_time_ms(lambda: ops.cosine_topk(tw, qn, bank, pb.norms, k, 1e-6, lo, nch, ps, pi, thr0), iters)
         bank_bytes = (hi - lo) * D * 4
-        kbytes = bank_bytes + (hi - lo) * 4 + Q * D * 4 + Q * nch * k * 12   # bank + row norms + queries + partial lists
+        # bank + row norms + queries + the [Q, k] result (the per-wave candidate lists are a few rows each since round 3: a list
+        # ends at its first negative index, the padding behind it is no longer written or read)
+        kbytes = bank_bytes + (hi - lo) * 4 + Q * D * 4 + Q * k * 12
         # `sec` is the path cosine_topk took (st["path"]); kernel_* time the EXACT kernel on the same inputs -- the whole
         # job for Q <= 16, and for many queries the single-stage path the two-stage one replaced (and falls back to)
         res[label] = dict(Q=Q, sec=dt, queries_per_sec=Q / dt, path=st.get("path"), redone=st.get("redone"),
@@ -408,7 +454,7 @@ def pmc_traffic(args):
     correction, + WRITE_SIZE); counters cannot be read from inside the timed process, so this is the profiles/ figure for
     the same workload, or None when the workload differs."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_topk_stream_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_topk_stream_pmc.json")) as f:
             prof = json.load(f)
     except OSError:
         return None
@@ -504,9 +550,9 @@ def main():
         ach = pre["images_per_sec"] / world * executed / 1e12   # per-GPU TFLOP/s, executed FLOPs
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
         gi = pre["gemm_in_step"]
-        kernel = dict(kernel="gemm_pipe_kernel<BM,BN,A_KC,B_KC,3,WM,WN> (forward KC.KC, data gradient KC.RC) + "
-                             "gemm_pipe_group_kernel<128,128,2,4,2,4> (encoder) / <128,64,3,4,2,4> (decoder): the four weight gradients of a block per launch "
-                             "(+ splitk_reduce_kernel)", **gi)
+        kernel = dict(kernel="gemm_pipe_kernel<BM,BN,A_KC,B_KC,NSTAGE,WM,WN,WK> (forward KC.KC, data gradient KC.RC; WK = 2 k-groups of waves "
+                             "on the <= 256-tile launches) + gemm_pipe_group_kernel<128,128,2,4,2,4> (encoder) / <128,64,3,4,2,4> (decoder): the "
+                             "four weight gradients of a block per launch (+ splitk_reduce_kernel)", **gi)
         if "gemm_probe" in pre:
             kernel["isolated_probe"] = pre["gemm_probe"]
         line = {
@@ -534,8 +580,12 @@ def main():
             "phases": pre.get("phases"),
             "feeder": pre.get("feeder"),
         }
+        line["extra"] = {}
         if mim19 is not None:
-            line["extra"] = {"mim_19": mim19}
+            line["extra"]["mim_19"] = mim19
+        for key in ("long_run", "staged"):
+            if key in pre:
+                line["extra"][key] = pre[key]
         if search is not None:
             ql, qs = search["q_large"], search["q_small"]
             line["search"] = {
@@ -545,6 +595,9 @@ def main():
                 "roofline": {"bound": "hbm", "achieved": qs["kernel_hbm_gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": qs["kernel_hbm_gbs"] / PEAK_HBM_GBS, "traffic": pmc_traffic(args),
                              "algorithmic_bytes": qs["kernel_bytes"],
+                             # the whole search as the caller sees it: query preparation, sample floor, bank pass, merge
+                             "frac_end_to_end": qs["kernel_bytes"] / qs["sec"] / 1e9 / PEAK_HBM_GBS,
+                             "frac_end_to_end_q1": search["q1"]["kernel_bytes"] / search["q1"]["sec"] / 1e9 / PEAK_HBM_GBS,
                              "note": "Q=16 bank-streaming launch (HBM-bound regime): (bank shard + queries + partial "
                                      "lists) bytes / kernel time; the Q=10k path: see q_large"},
             }
@@ -560,11 +613,11 @@ def main():
 
 
 def gemm_pmc_traffic():
-    """HBM bytes per GEMM launch (average over the launches of one step) from the committed PMC passes of this round
-    (profiles/r02_gemm_pmc.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), or None."""
+    """HBM-side bytes per GEMM launch (average over the launches of one step) from the committed PMC passes of this round
+    (profiles/r03_mfma_pmc.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), or None."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_gemm_pmc.json")) as f:
-            return json.load(f)["traffic_bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", "r03_mfma_pmc.json")) as f:
+            return json.load(f)["gemm_family_total"]["hbm_side_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         return None
 

@@ -291,7 +291,8 @@ int skyemb_weighted_norms(const float *x, const float *w, float *norms, float *x
  * thr0 (optional, [Q]): a pruning floor per query -- only rows scoring STRICTLY above it are kept.  Any value
  * below the true k-th best score is valid (e.g. nextafter(k-th best of a row sample, -inf)) and leaves
  * the result unchanged while removing most list insertions.
- * sorted by (score desc, index asc); idx = idx_offset + local row.  Then skyemb_topk_merge. */
+ * sorted by (score desc, index asc); idx = idx_offset + local row.  A list with fewer than k rows ends at its first
+ * entry with a NEGATIVE index (score -inf); the slots behind that terminator are unspecified.  Then skyemb_topk_merge. */
 int skyemb_cosine_topk_chunks(int64_t N, int Q, int D, int k);
 int skyemb_cosine_topk(const float *tw, const float *qn, const float *bank, const float *xn, int Q, int64_t N,
                        int D, int k, float eps, int64_t idx_offset, int nchunks, const float *thr0, float *part_s,
@@ -302,6 +303,14 @@ int skyemb_cosine_topk(const float *tw, const float *qn, const float *bank, cons
 /* out[q] = the k-th largest value of x[q, 0..S) minus one ulp (NaN ranks as -inf): the pruning floor a search derives from
  * the exact scores of a bank sample (host glue of the build; the reference has no counterpart -- it sorts everything). */
 int skyemb_kth_largest_floor(const float *x, int Q, int S, int k, float *out, void *stream);
+/* The same floor for Q <= 16 queries in two launches, without the [Q, S] score matrix: exact scores of the S sample rows reduced
+ * on the fly to the maximum of every 16-row tile, then the k-th largest of the S / 16 maxima per query, one ulp lower (the score
+ * of at least k different rows: a valid floor, and within a few ranks of the sample's own k-th best when S / 16 >> k).
+ *   sample [S, D] rows of the bank, sample_norms [S] their weighted norms; ws: Q * ceil(S / 16) floats; floor_out [Q].
+ * Needs D % 64 == 0, D <= 1024, k <= S / 16 <= 2048.  (Build-level helper like skyemb_kth_largest_floor: the reference sorts
+ * every score, utils/similarity.py:18-35.) */
+int skyemb_cosine_sample_floor(const float *tw, const float *qn, const float *sample, const float *sample_norms, int Q, int64_t S,
+                               int D, int k, float eps, float *ws, float *floor_out, void *stream);
 int skyemb_topk_merge(const float *in_s, const int64_t *in_i, int Q, int nlists, int k, float *out_s,
                       int64_t *out_i, void *ws, void *stream);
 

@@ -74,6 +74,73 @@ __global__ __launch_bounds__(256) void wnorm_kernel(const float *__restrict__ x,
     if (n0 + tid < N) norms[n0 + tid] = __fsqrt_rn(acc);
 }
 
+// The same chain for a handful of rows (the queries of a search: N <= 16): the rows are staged in LDS by the whole
+// workgroup (coalesced), then one lane per row walks its row -- the tiled kernel above spends 70 us on 16 rows (one workgroup, two barriers per
+// 32 columns, a serial chain out of LDS).
+template <bool HAS_W, bool HAS_OUT>
+__global__ __launch_bounds__(256) void wnorm_rows_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                         float *__restrict__ norms, float *__restrict__ xw_out, int64_t N, int D) {
+    extern __shared__ __attribute__((aligned(16))) float rows_lds[];    // [N][D + 4]: the rows, + w in the last row
+    const int tid = threadIdx.x, P = D + 4;                              // pitch: lanes of different rows on different banks
+    float *wl = rows_lds + (size_t)N * P;
+    const int d4 = D >> 2;
+    // (four loads in flight per thread before the first LDS write: left to itself the compiler waits for every load in
+    // turn -- twelve dependent memory round trips for 16 rows of 768)
+    const int total = (int)N * d4;
+    for (int e0 = tid; e0 < total; e0 += 4 * 256) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * 256 < total ? e0 + u * 256 : total - 1;
+            const int r = e / d4, c = e - r * d4;
+            v[u] = *(const float4 *)(x + (int64_t)r * D + 4 * c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * 256;
+            if (e < total) {
+                const int r = e / d4, c = e - r * d4;
+                *(float4 *)(rows_lds + (size_t)r * P + 4 * c) = v[u];
+            }
+        }
+    }
+    if (HAS_W)
+        for (int e = tid; e < d4; e += 256) *(float4 *)(wl + 4 * e) = *(const float4 *)(w + 4 * e);
+    __syncthreads();
+    if (tid < N) {
+        const float *row = rows_lds + (size_t)tid * P;
+        float acc = 0.f;
+        // eight float4 groups of the row (and of w) are requested from LDS before the chain consumes them: group by group,
+        // with the `w` / `xw_out` tests inside the loop, every group cost four LDS round trips (18 of the kernel's 21 us)
+        for (int d0 = 0; d0 < D; d0 += 32) {
+            float4 v[8], ww[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int d = d0 + 4 * u < D ? d0 + 4 * u : D - 4;
+                v[u] = *(const float4 *)(row + d);
+                if (HAS_W) ww[u] = *(const float4 *)(wl + d);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int d = d0 + 4 * u;
+                if (d < D) {
+                    const float xs[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float wj = j == 0 ? ww[u].x : j == 1 ? ww[u].y : j == 2 ? ww[u].z : ww[u].w;
+                        o[j] = HAS_W ? __fmul_rn(wj, xs[j]) : xs[j];
+                        acc = fmaf(o[j], xs[j], acc);
+                    }
+                    // (straight to global memory: a store into the LDS rows would order every later LDS read behind it)
+                    if (HAS_OUT) *(float4 *)(xw_out + (int64_t)tid * D + d) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+        norms[tid] = __fsqrt_rn(acc);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float finish_score(float dot, float qn, float xn, float eps) {
     const float den = fmaf(qn, xn, eps);
@@ -360,15 +427,13 @@ __global__ __launch_bounds__(1024) void topk_merge_sort_kernel(const float *__re
     const int64_t *pi = in_i + (int64_t)q * nlists * k;
     if (tid == 0) bad_s = 0;
     __syncthreads();
-    // valid-prefix length of each list (entries are sorted, padding has idx < 0): binary search
+    // valid-prefix length of each list: entries up to the first negative index (what follows it is unspecified -- the
+    // bank-streaming kernel writes one terminator, not k - n padding slots); with a pruning floor a list holds a few rows
     int mycount = 0;
     for (int l = tid; l < nlists; l += 1024) {
-        int lo = 0, hi = k;   // first position with idx < 0
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (pi[(int64_t)l * k + mid] >= 0) lo = mid + 1; else hi = mid;
-        }
-        mycount += lo;
+        int e = 0;
+        while (e < k && pi[(int64_t)l * k + e] >= 0) ++e;
+        mycount += e;
     }
     // block exclusive scan of per-thread counts
     int incl = mycount;
@@ -513,6 +578,141 @@ __global__ __launch_bounds__(1024) void kth_floor_kernel(const float *__restrict
     }
 }
 
+// The same result for S <= 32 K values per row without atomics: every thread keeps its (up to 32) keys in registers and the
+// k-th largest key is found by bisection on the 32-bit key space -- per step one ballot + popcount per register and a
+// 16-value sum through LDS.  (The radix select above spends its first pass adding 25,600 scores, which share a handful of
+// sign / exponent bytes, into three or four LDS words: ~45 us for the [16, 25600] sample matrix of a search, against 0.5 ms
+// for the whole bank pass it prunes.)
+__device__ __forceinline__ int wave_total(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// largest t (searched over bits `top` .. 0 on top of the prefix `t`) with |{key[j] >= t}| >= kth over the NK keys each lane of
+// ONE wave holds in registers: per bit NK compares + ballots (a wave-uniform count, no cross-lane exchange)
+template <int NK>
+__device__ __forceinline__ unsigned int wave_bisect(const unsigned int (&key)[NK], unsigned int t, int top, int kth) {
+    for (int bit = top; bit >= 0; --bit) {
+        const unsigned int cand = t | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < NK; ++j) c += __popcll(__ballot(key[j] >= cand));
+        if (c >= kth) t = cand;
+    }
+    return t;
+}
+__device__ __forceinline__ unsigned int score_key(float v) {
+    if (!(v == v)) v = -INFINITY;                              // NaN scores rank as -inf (contract)
+    const unsigned int u = __float_as_uint(v);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);        // > 0 for every real score (a negative NaN would be 0)
+}
+__device__ __forceinline__ float key_floor(unsigned int t) {
+    return nextafterf(__uint_as_float(t ^ ((t >> 31) ? 0x80000000u : 0xFFFFFFFFu)), -INFINITY);
+}
+
+// S <= 2048 values per row (e.g. the per-tile maxima of a search's row sample): ONE wave per row, every key in registers, no
+// barriers.  ~4 us; the workgroup-wide kernels below need a barrier per bit.
+__global__ __launch_bounds__(64) void kth_floor_wave_kernel(const float *__restrict__ x, int S, int kth, float *__restrict__ out) {
+    const int lane = threadIdx.x;
+    const float *row = x + (int64_t)blockIdx.x * S;
+    unsigned int key[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int e = lane + 64 * i;                           // (clamped, unconditional loads: see the kernel below)
+        const float v = row[e < S ? e : S - 1];
+        key[i] = e < S ? score_key(v) : 0u;
+    }
+    const unsigned int t = wave_bisect<32>(key, 0u, 31, kth);
+    if (lane == 0) out[blockIdx.x] = key_floor(t);
+}
+
+// 2048 < S <= 32 K: every thread of a 1024-thread workgroup keeps its (up to 32) keys in registers; a pivot from a sample
+// (wave 0's first registers: the key of rank m there, m = three times the expected sample rank of the k-th largest + 8) is
+// CHECKED by one count (kth <= |{key >= pivot}| <= CAP); those keys are pooled in LDS and wave 0 finishes on them in registers.
+// A pivot that fails the check falls back to a workgroup-wide bisection, bit by bit, until the keys in play fit the pool.
+// No atomics anywhere: the radix select further down adds 25,600 scores sharing a handful of sign / exponent bytes into
+// three or four LDS words in its first pass.
+__global__ __launch_bounds__(1024) void kth_floor_bisect_kernel(const float *__restrict__ x, int S, int kth, float *__restrict__ out) {
+    constexpr int CAP = 1024, NSUB = 8;
+    __shared__ int part[3][16];
+    __shared__ unsigned int pool[CAP];
+    __shared__ unsigned int pivot_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *row = x + (int64_t)blockIdx.x * S;
+    unsigned int key[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        // every load issued unconditionally (clamped index) and selected afterwards: a load under `if (e < S)` makes the compiler
+        // branch around it and wait for each one in turn
+        const int e = tid + i * 1024;
+        const float v = row[e < S ? e : S - 1];
+        key[i] = e < S ? score_key(v) : 0u;                    // padding: 0, never counted
+    }
+    // per-wave counts of the keys >= thr, their total and this wave's offset among them (buffer b of `part`)
+    auto count_ge = [&](unsigned int thr, int b, int &total, int &before) {
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) c += __popcll(__ballot(key[i] >= thr && key[i] != 0u));
+        if (lane == 0) part[b][wave] = c;
+        __syncthreads();
+        total = before = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const int p = part[b][w]; before += w < wave ? p : 0; total += p; }
+    };
+    if (wave == 0) {
+        unsigned int sub[NSUB];
+        int nsub = 0;
+#pragma unroll
+        for (int i = 0; i < NSUB; ++i) {
+            sub[i] = key[i];
+            const int left = S - i * 1024;
+            nsub += left <= 0 ? 0 : (left < 64 ? left : 64);
+        }
+        const long long m = ((long long)kth * nsub * 3 + S - 1) / S + 8;
+        unsigned int piv = 0u;
+        if (m <= nsub) piv = wave_bisect<NSUB>(sub, 0u, 31, (int)m);
+        if (lane == 0) pivot_s = piv;
+    }
+    __syncthreads();
+    const unsigned int piv = pivot_s;
+    int above, before;
+    count_ge(piv, 2, above, before);
+    unsigned int t = 0u, thr = piv;
+    int bit = 31;
+    if (piv == 0u || above < kth || above > CAP) {
+        above = S;
+        for (; bit >= 0 && above > CAP; --bit) {
+            int tot, unused;
+            count_ge(t | (1u << bit), bit & 1, tot, unused);
+            if (tot >= kth) { t |= 1u << bit; above = tot; }   // (else |{key >= t}| is unchanged)
+        }
+        thr = t;
+        __syncthreads();                                       // part[2]'s readers of the pivot count are long done
+        if (bit >= 0) count_ge(thr, 2, above, before);
+    }
+    if (bit >= 0) {
+        // pool the keys >= thr (kth <= `above` <= CAP): wave w writes behind the waves before it, lanes in ballot order
+        int base = before;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const bool in = key[i] >= thr && key[i] != 0u;
+            const unsigned long long msk = __ballot(in);
+            if (in) pool[(base + __popcll(msk & ((1ull << lane) - 1ull))) & (CAP - 1)] = key[i];
+            base += __popcll(msk);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            unsigned int pk[CAP / 64];
+#pragma unroll
+            for (int j = 0; j < CAP / 64; ++j) pk[j] = pool[lane + 64 * j];
+#pragma unroll
+            for (int j = 0; j < CAP / 64; ++j) pk[j] = lane + 64 * j < above ? pk[j] : 0u;
+            t = wave_bisect<CAP / 64>(pk, t, bit, kth);
+        }
+    }
+    if (tid == 0) out[blockIdx.x] = key_floor(t);
+}
+
 template <int QT, int BT, bool SO, int NW = 4>
 int launch_topk(const float *tw, const float *qn, const float *bank, const float *xn, int Q, int64_t N, int D, int k,
                 float eps, int64_t idx_offset, int nchunks, float *part_s, int64_t *part_i, float *scores, hipStream_t st,
@@ -567,6 +767,16 @@ extern "C" int skyemb_standardise(const float *x, const float *mu, const float *
 extern "C" int skyemb_weighted_norms(const float *x, const float *w, float *norms, float *xw_out, int64_t N, int D,
                                      void *stream) {
     SKY_CHECK_ARG(N > 0 && D > 0 && D % 4 == 0, "skyemb_weighted_norms: bad shape");
+    if (N <= 16 && (size_t)(N + 1) * (D + 4) * 4 <= 64 * 1024 && aligned16(x) && (!w || aligned16(w)) && (!xw_out || aligned16(xw_out))) {
+        const size_t lds = (size_t)(N + 1) * (D + 4) * 4;
+        hipStream_t st = (hipStream_t)stream;
+        if (w && xw_out) hipLaunchKernelGGL((wnorm_rows_kernel<true, true>), dim3(1), dim3(256), lds, st, x, w, norms, xw_out, N, D);
+        else if (w) hipLaunchKernelGGL((wnorm_rows_kernel<true, false>), dim3(1), dim3(256), lds, st, x, w, norms, xw_out, N, D);
+        else if (xw_out) hipLaunchKernelGGL((wnorm_rows_kernel<false, true>), dim3(1), dim3(256), lds, st, x, w, norms, xw_out, N, D);
+        else hipLaunchKernelGGL((wnorm_rows_kernel<false, false>), dim3(1), dim3(256), lds, st, x, w, norms, xw_out, N, D);
+        SKY_LAUNCH_CHECK("skyemb_weighted_norms");
+        return 0;
+    }
     hipLaunchKernelGGL(wnorm_kernel, dim3((unsigned)ceil_div64(N, 256)), dim3(256), 0, (hipStream_t)stream, x, w, norms,
                        xw_out, N, D);
     SKY_LAUNCH_CHECK("skyemb_weighted_norms");
@@ -579,6 +789,9 @@ int skyemb_topk_stream_lists(int64_t N, int D, int k);
 int skyemb_topk_stream_launch(const float *tw, const float *qn, const float *bank, const float *xn, int Q, int64_t N, int D,
                               int k, float eps, int64_t idx_offset, int nlists, float *part_s, int64_t *part_i,
                               const float *thr0, hipStream_t st);
+bool skyemb_scores_stream_applicable(int Q, int64_t N, int D);
+int skyemb_scores_stream_launch(const float *tw, const float *qn, const float *bank, const float *xn, int Q, int64_t N, int D,
+                                float eps, float *scores, hipStream_t st);
 static bool use_stream(int Q, int D, int k) {
     static const bool on = []() { const char *e = getenv("SKYEMB_TOPK_STREAM"); return !(e && e[0] == '0'); }();
     return on && skyemb_topk_stream_applicable(Q, D, k);
@@ -623,6 +836,8 @@ extern "C" int skyemb_cosine_scores(const float *tw, const float *qn, const floa
     SKY_CHECK_ARG(Q > 0 && N > 0 && D > 0 && D % 4 == 0, "skyemb_cosine_scores: bad shape");
     hipStream_t st = (hipStream_t)stream;
     const int nchunks = (int)ceil_div64(N, 128 * 8) < 1 ? 1 : (int)ceil_div64(N, 128 * 8);
+    if (use_stream(Q, D, 1) && skyemb_scores_stream_applicable(Q, N, D))
+        return skyemb_scores_stream_launch(tw, qn, bank, xn, Q, N, D, eps, scores, st);
     if (Q <= 16)   // one 256-row tile per workgroup: a 25,600-row sample gives 100 workgroups (was 25: a quarter of the chip's CUs)
         return launch_topk<16, 256, true>(tw, qn, bank, xn, Q, N, D, 1, eps, 0, (int)ceil_div64(N, 256), nullptr,
                                           nullptr, scores, st, "skyemb_cosine_scores");
@@ -631,9 +846,33 @@ extern "C" int skyemb_cosine_scores(const float *tw, const float *qn, const floa
 }
 
 
+// The pruning floor of a small-Q search in two launches: exact scores of the row sample, reduced on the fly to the MAXIMUM of
+// every 16-row tile (the k-th largest of those maxima is the score of at least k different rows, hence a lower bound of the k-th
+// best score over any bank that contains the sample -- and with a few hundred tiles per wanted row almost the sample's own k-th
+// best), then the one-wave selection over S / 16 values per query.  ws: Q * ceil(S / 16) floats.
+int skyemb_scores_stream_tilemax_launch(const float *tw, const float *qn, const float *bank, const float *xn, int Q, int64_t N, int D,
+                                        float eps, float *tile_max, hipStream_t st);
+extern "C" int skyemb_cosine_sample_floor(const float *tw, const float *qn, const float *sample, const float *sample_norms, int Q,
+                                          int64_t S, int D, int k, float eps, float *ws, float *floor_out, void *stream) {
+    SKY_CHECK_ARG(tw && qn && sample && sample_norms && ws && floor_out && Q > 0 && S > 0 && D > 0 && k >= 1,
+                  "skyemb_cosine_sample_floor: bad arguments");
+    const int64_t tiles = (S + 15) / 16;
+    SKY_CHECK_ARG(use_stream(Q, D, 1) && skyemb_scores_stream_applicable(Q, S, D) && tiles <= 2048 && k <= tiles,
+                  "skyemb_cosine_sample_floor: needs Q <= 16, D %% 64 == 0, D <= 1024 and k <= S / 16 <= 2048 (Q=%d D=%d S=%lld k=%d)", Q, D,
+                  (long long)S, k);
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = skyemb_scores_stream_tilemax_launch(tw, qn, sample, sample_norms, Q, S, D, eps, ws, st);
+    if (rc != 0) return rc;
+    hipLaunchKernelGGL(kth_floor_wave_kernel, dim3(Q), dim3(64), 0, st, ws, (int)tiles, k, floor_out);
+    SKY_LAUNCH_CHECK("skyemb_cosine_sample_floor");
+    return 0;
+}
+
 extern "C" int skyemb_kth_largest_floor(const float *x, int Q, int S, int k, float *out, void *stream) {
     SKY_CHECK_ARG(x && out && Q > 0 && S > 0 && k >= 1 && k <= S, "skyemb_kth_largest_floor: bad arguments (Q=%d S=%d k=%d)", Q, S, k);
-    hipLaunchKernelGGL(kth_floor_kernel, dim3(Q), dim3(1024), 0, (hipStream_t)stream, x, S, k, out);
+    if (S <= 2048) hipLaunchKernelGGL(kth_floor_wave_kernel, dim3(Q), dim3(64), 0, (hipStream_t)stream, x, S, k, out);
+    else if (S <= 32 * 1024) hipLaunchKernelGGL(kth_floor_bisect_kernel, dim3(Q), dim3(1024), 0, (hipStream_t)stream, x, S, k, out);
+    else hipLaunchKernelGGL(kth_floor_kernel, dim3(Q), dim3(1024), 0, (hipStream_t)stream, x, S, k, out);
     SKY_LAUNCH_CHECK("skyemb_kth_largest_floor");
     return 0;
 }

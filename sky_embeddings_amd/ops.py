@@ -279,6 +279,19 @@ def kth_largest_floor(x, k, out):
     check(lib().skyemb_kth_largest_floor(_p(x), Q, S, k, _p(out), _stream()), "skyemb_kth_largest_floor")
 
 
+def sample_floor_applicable(Q, S, D, k):
+    tiles = (S + 15) // 16
+    return Q <= 16 and D % 64 == 0 and D <= 1024 and k <= tiles <= 2048
+
+
+def cosine_sample_floor(tw, qn, sample, sample_norms, k, eps, ws, out):
+    """Pruning floor of a small-Q search from a row sample (tile maxima + one-wave selection): see include/skyemb.h."""
+    Q, D = tw.shape
+    S = sample.shape[0]
+    check(lib().skyemb_cosine_sample_floor(_p(tw), _p(qn), _p(sample), _p(sample_norms), Q, S, D, k, eps, _p(ws), _p(out), _stream()),
+          "skyemb_cosine_sample_floor")
+
+
 def topk_prefilter_applicable(Q, N, D, k):
     return bool(lib().skyemb_topk_prefilter_applicable(Q, N, D, k))
 

@@ -55,10 +55,13 @@ class TrainStep:
         self.ra_dec = torch.zeros(batch_size, 2, device=dev) if cfg.ra_dec else None
         self.loss = None
         self.external_noise = external_noise          # parity tests fill step.noise themselves (same noise on 1 and N ranks)
+        explicit_comm = grad_comm is not None
         if grad_comm is None:
             grad_comm = os.environ.get("SKYEMB_GRAD_COMM", "bf16")
         assert grad_comm in ("bf16", "f32"), grad_comm
-        self.grad_comm = grad_comm if world_size > 1 else "f32"
+        # (one process: no communication, so no mirror -- unless the caller asks for the N > 1 schedule explicitly, e.g.
+        # bench.py pricing the stage graphs + casts of the data-parallel step on one GPU)
+        self.grad_comm = grad_comm if (world_size > 1 or (staged and explicit_comm)) else "f32"
         self.g16 = None
         if self.grad_comm == "bf16":
             self.g16 = torch.zeros(engine.store.n, device=dev, dtype=torch.bfloat16)

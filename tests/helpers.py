@@ -42,3 +42,20 @@ def load_simmim_case(name):
         state[name_] = torch.from_numpy(z["state/" + name_].copy())
     ra_dec = torch.from_numpy(z["ra_dec"].copy()) if rd else None
     return z, cfg, state, torch.from_numpy(z["imgs"].copy()), torch.from_numpy(z["pixel_mask"].copy()), ra_dec
+
+
+def record_parity(name, values):
+    """Achieved errors of a parity test, merged into gpurun_out/parity_errors.json (scratch; `tests/parity_report.py` copies
+    the file into profiles/ after a GPU run) and printed: the bars in the tests are set at 2x these figures."""
+    import json
+    import os
+    root = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "gpurun_out", "parity_errors.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[name] = values
+        json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+    print(f"[parity] {name}: {values}")

@@ -85,5 +85,11 @@ def test_two_rank_training_step_matches_one_rank_on_the_concatenated_batch(tmp_p
     # Adam moves every element by ~lr per step; summation order (f32) or bf16 rounding of the gradients can change the
     # move of an element whose gradient is rounding noise, but not the bulk
     frac_close = float((err <= (0.05 if grad_comm == "f32" else 0.25) * LR * STEPS).float().mean())
+    from tests.helpers import record_parity
+    record_parity(f"ddp_two_ranks_vs_one_{grad_comm}",
+                  dict(loss_rel_max=float(np.max(np.abs(mean_losses - np.asarray(ref_losses)) / np.abs(ref_losses))),
+                       frac_within_band=frac_close, band_in_lr_steps=0.05 if grad_comm == "f32" else 0.25,
+                       err_max_in_lr_steps=float(err.max()) / (LR * STEPS), err_mean_in_lr_steps=float(err.mean()) / (LR * STEPS),
+                       comm_dtype=grad_comm, backend="nccl" if use_nccl else "gloo (both ranks on cuda:0)"))
     assert frac_close > (0.999 if grad_comm == "f32" else 0.98), frac_close
     assert float(err.max()) <= 2.5 * LR * STEPS and float(moved.max()) > 0.5 * LR

@@ -675,3 +675,21 @@ def test_augmentation_kernel_matches_oracle():
     # drop-in call on one sample: an augmented copy of the same shape
     one = aug(imgs[0])
     assert one.shape == imgs[0].shape and not torch.equal(torch.nan_to_num(one), imgs[0])
+
+
+@pytest.mark.parametrize("S,k", [(100, 100), (2048, 7), (25600, 100), (32768, 1), (40000, 100)])
+def test_kth_largest_floor_is_the_kth_value_minus_one_ulp(ops, S, k):
+    """Both selection kernels (register bisection for S <= 32 K, radix select above): out[q] = the k-th largest of row q, one
+    ulp lower; NaNs rank as -inf, duplicates and infinities are ordinary values."""
+    g = torch.Generator().manual_seed(S + k)
+    x = torch.randn(5, S, generator=g) * 0.04
+    x[1, :50] = x[1, 50:100]                      # duplicates around the top
+    x[2, 3] = float("nan")
+    x[2, 9] = float("inf")
+    x[3] = x[3].abs() * -1.0                      # all negative
+    x[4, : S // 2] = 0.125                        # one value repeated: the k-th may sit inside the run
+    out = torch.empty(5, device=DEV)
+    ops.kth_largest_floor(dev(x), k, out)
+    ref = torch.where(torch.isnan(x), torch.full_like(x, float("-inf")), x).sort(dim=1, descending=True).values[:, k - 1]
+    want = torch.nextafter(ref, torch.full_like(ref, float("-inf")))
+    assert torch.equal(out.cpu(), want), (out.cpu().view(torch.int32), want.view(torch.int32), ref.view(torch.int32))

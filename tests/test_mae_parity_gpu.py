@@ -13,7 +13,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import mae_oracle as mo
-from tests.helpers import load_case, rel_err
+from tests.helpers import record_parity, load_case, rel_err
 
 CASES = ["mae_tiny_A", "mae_tiny_B_nan", "mae_tiny_C_nonorm", "mae_tiny_D_l1", "mae_tiny_E_p8", "mae_tiny_I_radec"]
 
@@ -145,18 +145,24 @@ def test_full_size_config_a_against_oracle(B):
     imgs = torch.randn(B, 5, 64, 64, generator=g).clamp_(min=-3.0)
     noise = torch.rand(B, 16, generator=g)
     loss_o, pred_o, mask_o, _, _, grads_o = mo.loss_and_grads(st, imgs, cfg_o, 0.75, noise)
-    for dtype, ltol, ptol in ((torch.float32, 2e-5, 5e-5), (torch.bfloat16, 1e-2, 4e-2)):
+    # bars = 2x the errors measured on MI355X (profiles/r03_parity_errors.json); f32 is the north-star mode (1e-3)
+    for dtype, ltol, ptol, gtol in ((torch.float32, 2e-5, 5e-5, 3e-4), (torch.bfloat16, 1e-2, 4e-2, 1e-1)):
         eng = MAEEngine(config_for("base", patch_size=16, in_chans=5, img_size=64, embed_dim=768), compute_dtype=dtype, seed=0)
         eng.load_state_dict(st)
         loss, pred, mask = eng.forward_train(imgs.cuda(), 0.75, noise.cuda())
         eng.backward()
         assert torch.equal(mask.cpu(), mask_o)
-        assert abs(float(loss) - float(loss_o)) <= ltol * float(loss_o), (dtype, float(loss), float(loss_o))
-        assert rel_err(pred.cpu().numpy(), pred_o.numpy()) < ptol
-        for k in ("decoder_pred.weight", "blocks.0.attn.qkv.weight", "blocks.11.mlp.fc1.weight", "patch_embed.proj.weight",
-                  "cls_token", "mask_token", "norm.weight", "decoder_blocks.3.norm1.bias", "decoder_embed.weight"):
-            r = rel_err(eng.store.grad(k).cpu().numpy(), grads_o[k].numpy())
-            assert r < (3e-4 if dtype == torch.float32 else 1e-1), (dtype, k, r)
+        loss_rel = abs(float(loss) - float(loss_o)) / float(loss_o)
+        pred_rel = rel_err(pred.cpu().numpy(), pred_o.numpy())
+        grad_rel = {k: rel_err(eng.store.grad(k).cpu().numpy(), grads_o[k].numpy()) for k in eng.store.order}
+        worst = max(grad_rel, key=grad_rel.get)
+        record_parity(f"config_A_B{B}_{'f32' if dtype == torch.float32 else 'bf16'}",
+                      dict(loss_rel=loss_rel, pred_rel_l2=pred_rel, grad_rel_l2_max=grad_rel[worst], grad_worst_tensor=worst,
+                           grad_rel_l2_median=float(np.median(list(grad_rel.values())))))
+        assert loss_rel <= ltol, (dtype, float(loss), float(loss_o))
+        assert pred_rel < ptol
+        for k, r in grad_rel.items():
+            assert r < gtol, (dtype, k, r)
         del eng
         torch.cuda.empty_cache()
 

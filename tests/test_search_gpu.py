@@ -226,3 +226,32 @@ def test_degenerate_search_inputs():
     for k in (0, 51):
         with pytest.raises(ValueError):
             search.cosine_topk(torch.randn(3, 64, device="cuda"), bank, k)
+
+
+def test_sample_floor_is_a_valid_and_tight_lower_bound():
+    """skyemb_cosine_sample_floor (tile maxima of the sample's scores + one-wave selection) never exceeds the k-th best score of
+    the sample itself (so of any bank containing it), equals the k-th largest tile maximum minus one ulp, and sits within a
+    few ranks of the sample's own k-th best."""
+    from sky_embeddings_amd import ops
+    rng = np.random.default_rng(3)
+    S, D, k = 25600, 768, 100
+    x = rng.standard_normal((S, D), dtype=np.float32)
+    w = (rng.random(D, dtype=np.float32) + 0.5)
+    w /= w.sum()
+    for Q in (1, 16, 5):
+        q = rng.standard_normal((Q, D), dtype=np.float32)
+        sc = so.cosine_scores_np(q, x, w)                                  # oracle scores [Q, S]
+        xd, qd, wd = torch.from_numpy(x).cuda(), torch.from_numpy(q).cuda(), torch.from_numpy(w).cuda()
+        xn, qn, tw = torch.empty(S, device="cuda"), torch.empty(Q, device="cuda"), torch.empty(Q, D, device="cuda")
+        ops.weighted_norms(xd, wd, xn)
+        ops.weighted_norms(qd, wd, qn, tw)
+        floor, ws = torch.empty(Q, device="cuda"), torch.empty(Q * (S // 16), device="cuda")
+        ops.cosine_sample_floor(tw, qn, xd, xn, k, 1e-6, ws, floor)
+        got = floor.cpu().numpy()
+        tile_max = sc.reshape(Q, S // 16, 16).max(axis=2)
+        want = np.nextafter(np.sort(tile_max, axis=1)[:, ::-1][:, k - 1], np.float32(-np.inf))
+        assert np.array_equal(got, want)
+        kth_best = np.sort(sc, axis=1)[:, ::-1][:, k - 1]
+        assert (got < kth_best).all()
+        rank_of_floor = (sc > got[:, None]).sum(axis=1)                   # rows of the sample above the floor
+        assert (rank_of_floor >= k).all() and (rank_of_floor <= k + 12).all(), rank_of_floor

@@ -9,7 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from tests.helpers import load_simmim_case, rel_err
+from tests.helpers import record_parity, load_simmim_case, rel_err
 
 CASES = ["simmim_tiny_F_l1_nan", "simmim_tiny_G_mse", "simmim_tiny_H_radec", "simmim_tiny_J_attnpool"]   # J: attention-pooled
 
@@ -125,6 +125,10 @@ def _mim19_batch(cfg, B, seed, ratio=0.6):
     return x, m, count
 
 
+# bf16 bars of the mim_19 geometry test = 2x the errors measured on MI355X (profiles/r03_parity_errors.json)
+BF16_LOSS_BAR, BF16_PRED_BAR, BF16_GRAD_REL_BAR, BF16_GRAD_MAX_BAR = 1e-2, 3e-2, 8e-2, 6e-2
+
+
 def test_mim19_geometry_against_oracle():
     """BASELINE configs[4] geometry (SimMIM head on 5x128x128 cutouts with 16x16 patches: L = 64, up = patch_size) at a
     narrow width vs the CPU oracle: loss, prediction image, every gradient (f32 parity mode) and the bf16 mode."""
@@ -143,16 +147,25 @@ def test_mim19_geometry_against_oracle():
         eng.backward()
         torch.cuda.synchronize()
         assert pred.shape == (6, 5, 128, 128)
-        assert abs(float(loss) - float(loss_o)) <= (2e-5 if f32 else 1e-2) * abs(float(loss_o))
-        assert rel_err(pred.cpu().numpy(), pred_o.numpy()) < (2e-5 if f32 else 3e-2)
+        loss_rel = abs(float(loss) - float(loss_o)) / abs(float(loss_o))
+        pred_rel = rel_err(pred.cpu().numpy(), pred_o.numpy())
+        grel, gmax = {}, {}
         for k in eng.store.order:
             r = grads_o[k].numpy()
             gk = eng.store.grad(k).cpu().numpy().reshape(r.shape)
-            scale = max(float(np.abs(r).max()), 1e-6)
+            grel[k] = rel_err(gk, r)
+            gmax[k] = float(np.abs(gk - r).max()) / max(float(np.abs(r).max()), 1e-6)
+        wk = max(grel, key=grel.get)
+        record_parity(f"mim19_geometry_{'f32' if f32 else 'bf16'}",
+                      dict(loss_rel=loss_rel, pred_rel_l2=pred_rel, grad_rel_l2_max=grel[wk], grad_worst_tensor=wk,
+                           grad_max_abs_over_max_max=max(gmax.values())))
+        assert loss_rel <= (2e-5 if f32 else BF16_LOSS_BAR)
+        assert pred_rel < (2e-5 if f32 else BF16_PRED_BAR)
+        for k in eng.store.order:
             if f32:
-                assert float(np.abs(gk - r).max()) <= 2e-4 * scale, (k, float(np.abs(gk - r).max()), scale)
+                assert gmax[k] <= 2e-4, (k, gmax[k])
             else:
-                assert rel_err(gk, r) < 8e-2 or float(np.abs(gk - r).max()) < 6e-2 * scale, k
+                assert grel[k] < BF16_GRAD_REL_BAR or gmax[k] < BF16_GRAD_MAX_BAR, (k, grel[k], gmax[k])
 
 
 def test_mim19_full_size_step_properties():
