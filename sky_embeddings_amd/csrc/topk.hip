@@ -610,20 +610,29 @@ __device__ __forceinline__ float key_floor(unsigned int t) {
     return nextafterf(__uint_as_float(t ^ ((t >> 31) ? 0x80000000u : 0xFFFFFFFFu)), -INFINITY);
 }
 
-// S <= 2048 values per row (e.g. the per-tile maxima of a search's row sample): ONE wave per row, every key in registers, no
-// barriers.  ~4 us; the workgroup-wide kernels below need a barrier per bit.
-__global__ __launch_bounds__(64) void kth_floor_wave_kernel(const float *__restrict__ x, int S, int kth, float *__restrict__ out) {
-    const int lane = threadIdx.x;
+// S <= 2048 values per row (e.g. the per-tile maxima of a search's row sample): two keys per thread of a 1024-thread
+// workgroup, bisection on the key bits with one barrier per bit (two ballots per wave and sixteen LDS words per bit: ~4 us.
+// One wave holding all 2048 keys in 32 registers was tried first: 32 compare -> scalar-popcount pairs per bit made it 22 us).
+__global__ __launch_bounds__(1024) void kth_floor_wave_kernel(const float *__restrict__ x, int S, int kth, float *__restrict__ out) {
+    __shared__ int part[2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *row = x + (int64_t)blockIdx.x * S;
-    unsigned int key[32];
+    const int e0 = tid, e1 = tid + 1024;                       // (clamped, unconditional loads: see the kernel below)
+    const float v0 = row[e0 < S ? e0 : S - 1], v1 = row[e1 < S ? e1 : S - 1];
+    const unsigned int k0 = e0 < S ? score_key(v0) : 0u, k1 = e1 < S ? score_key(v1) : 0u;
+    unsigned int t = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned int cand = t | (1u << bit);
+        const int c = __popcll(__ballot(k0 >= cand)) + __popcll(__ballot(k1 >= cand));
+        const int buf = bit & 1;
+        if (lane == 0) part[buf][wave] = c;
+        __syncthreads();
+        int tot = 0;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        const int e = lane + 64 * i;                           // (clamped, unconditional loads: see the kernel below)
-        const float v = row[e < S ? e : S - 1];
-        key[i] = e < S ? score_key(v) : 0u;
+        for (int w = 0; w < 16; ++w) tot += part[buf][w];
+        if (tot >= kth) t = cand;
     }
-    const unsigned int t = wave_bisect<32>(key, 0u, 31, kth);
-    if (lane == 0) out[blockIdx.x] = key_floor(t);
+    if (tid == 0) out[blockIdx.x] = key_floor(t);
 }
 
 // 2048 < S <= 32 K: every thread of a 1024-thread workgroup keeps its (up to 32) keys in registers; a pivot from a sample
@@ -863,14 +872,14 @@ extern "C" int skyemb_cosine_sample_floor(const float *tw, const float *qn, cons
     hipStream_t st = (hipStream_t)stream;
     const int rc = skyemb_scores_stream_tilemax_launch(tw, qn, sample, sample_norms, Q, S, D, eps, ws, st);
     if (rc != 0) return rc;
-    hipLaunchKernelGGL(kth_floor_wave_kernel, dim3(Q), dim3(64), 0, st, ws, (int)tiles, k, floor_out);
+    hipLaunchKernelGGL(kth_floor_wave_kernel, dim3(Q), dim3(1024), 0, st, ws, (int)tiles, k, floor_out);
     SKY_LAUNCH_CHECK("skyemb_cosine_sample_floor");
     return 0;
 }
 
 extern "C" int skyemb_kth_largest_floor(const float *x, int Q, int S, int k, float *out, void *stream) {
     SKY_CHECK_ARG(x && out && Q > 0 && S > 0 && k >= 1 && k <= S, "skyemb_kth_largest_floor: bad arguments (Q=%d S=%d k=%d)", Q, S, k);
-    if (S <= 2048) hipLaunchKernelGGL(kth_floor_wave_kernel, dim3(Q), dim3(64), 0, (hipStream_t)stream, x, S, k, out);
+    if (S <= 2048) hipLaunchKernelGGL(kth_floor_wave_kernel, dim3(Q), dim3(1024), 0, (hipStream_t)stream, x, S, k, out);
     else if (S <= 32 * 1024) hipLaunchKernelGGL(kth_floor_bisect_kernel, dim3(Q), dim3(1024), 0, (hipStream_t)stream, x, S, k, out);
     else hipLaunchKernelGGL(kth_floor_kernel, dim3(Q), dim3(1024), 0, (hipStream_t)stream, x, S, k, out);
     SKY_LAUNCH_CHECK("skyemb_kth_largest_floor");
