@@ -418,7 +418,7 @@ __device__ __forceinline__ float unorderable(unsigned int o) {
 
 __global__ __launch_bounds__(1024) void topk_merge_sort_kernel(const float *__restrict__ in_s, const int64_t *__restrict__ in_i,
                                                                int nlists, int k, float *__restrict__ out_s,
-                                                               int64_t *__restrict__ out_i, int *__restrict__ fallback) {
+                                                               int64_t *__restrict__ out_i) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];   // [MERGE_CAP]
     __shared__ int wsum[16];
     __shared__ int total_s, bad_s;
@@ -428,12 +428,43 @@ __global__ __launch_bounds__(1024) void topk_merge_sort_kernel(const float *__re
     if (tid == 0) bad_s = 0;
     __syncthreads();
     // valid-prefix length of each list: entries up to the first negative index (what follows it is unspecified -- the
-    // bank-streaming kernel writes one terminator, not k - n padding slots); with a pruning floor a list holds a few rows
+    // bank-streaming kernel writes one terminator, not k - n padding slots).  With a pruning floor a list holds a few rows: the
+    // first HEAD entries of a thread's lists are requested together (one memory round trip instead of one per entry; k >= 1,
+    // clamped reads stay inside the list) and kept for the gather below
+    constexpr int HEAD = 4, LPT = 2;                          // lists per thread handled with the register heads (nlists <= 2048)
+    int64_t hix[LPT][HEAD];
+    float hsc[LPT][HEAD];
+    int hlen[LPT];
+    const bool heads = nlists <= LPT * 1024;
     int mycount = 0;
-    for (int l = tid; l < nlists; l += 1024) {
-        int e = 0;
-        while (e < k && pi[(int64_t)l * k + e] >= 0) ++e;
-        mycount += e;
+    if (heads) {
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            const int l = tid + j * 1024;
+            const int64_t base = (int64_t)(l < nlists ? l : 0) * k;
+#pragma unroll
+            for (int e = 0; e < HEAD; ++e) {
+                hix[j][e] = pi[base + (e < k ? e : k - 1)];
+                hsc[j][e] = ps[base + (e < k ? e : k - 1)];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            const int l = tid + j * 1024;
+            int e = 0;
+#pragma unroll
+            for (int h = 0; h < HEAD; ++h) e += (e == h && h < k && hix[j][h] >= 0) ? 1 : 0;
+            if (l < nlists && e == HEAD)
+                while (e < k && pi[(int64_t)l * k + e] >= 0) ++e;
+            hlen[j] = l < nlists ? e : 0;
+            mycount += hlen[j];
+        }
+    } else {
+        for (int l = tid; l < nlists; l += 1024) {
+            int e = 0;
+            while (e < k && pi[(int64_t)l * k + e] >= 0) ++e;
+            mycount += e;
+        }
     }
     // block exclusive scan of per-thread counts
     int incl = mycount;
@@ -452,28 +483,49 @@ __global__ __launch_bounds__(1024) void topk_merge_sort_kernel(const float *__re
     __syncthreads();
     const int T = total_s;
     if (T > MERGE_CAP) {
-        if (tid == 0) fallback[q] = 1;
+        // more entries than the LDS image takes: the first wave merges this query's lists by the tournament (heads in the
+        // image's space); it used to be a second launch behind every merge
+        if (tid < 64) tournament_merge(in_s, in_i, nlists, k, out_s, out_i, (char *)keys);
         return;
     }
     int off = wsum[tid >> 6] + incl - mycount;
-    for (int l = tid; l < nlists; l += 1024) {
-        for (int e = 0; e < k; ++e) {
-            const int64_t ix = pi[(int64_t)l * k + e];
-            if (ix < 0) break;
-            if (ix > 0xFFFFFFFFll) bad_s = 1;
-            keys[off++] = ((unsigned long long)orderable(ps[(int64_t)l * k + e]) << 32) | (unsigned int)(~(unsigned int)ix);
+    if (heads) {
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            const int l = tid + j * 1024;
+#pragma unroll
+            for (int e = 0; e < HEAD; ++e)
+                if (e < hlen[j]) {
+                    if (hix[j][e] > 0xFFFFFFFFll) bad_s = 1;
+                    keys[off++] = ((unsigned long long)orderable(hsc[j][e]) << 32) | (unsigned int)(~(unsigned int)hix[j][e]);
+                }
+            for (int e = HEAD; e < hlen[j]; ++e) {
+                const int64_t ix = pi[(int64_t)l * k + e];
+                if (ix > 0xFFFFFFFFll) bad_s = 1;
+                keys[off++] = ((unsigned long long)orderable(ps[(int64_t)l * k + e]) << 32) | (unsigned int)(~(unsigned int)ix);
+            }
+        }
+    } else {
+        for (int l = tid; l < nlists; l += 1024) {
+            for (int e = 0; e < k; ++e) {
+                const int64_t ix = pi[(int64_t)l * k + e];
+                if (ix < 0) break;
+                if (ix > 0xFFFFFFFFll) bad_s = 1;
+                keys[off++] = ((unsigned long long)orderable(ps[(int64_t)l * k + e]) << 32) | (unsigned int)(~(unsigned int)ix);
+            }
         }
     }
     __syncthreads();
     if (bad_s) {
-        if (tid == 0) fallback[q] = 1;
+        __syncthreads();                                       // (every wave has read bad_s; wave 0 now reuses the image)
+        if (tid < 64) tournament_merge(in_s, in_i, nlists, k, out_s, out_i, (char *)keys);
         return;
     }
     // Only the best k of the T gathered entries are wanted: select the k-th largest key first (keys are unique: 8 radix
     // passes of 8 bits over the 64-bit keys, histograms in LDS), keep the k keys >= it, and sort just those -- instead of a
     // bitonic sort of all T (thousands with a sample-derived floor: ~80 block-wide stages).
     int n = T;
-    if (T > k) {
+    if (T > k) {                                              // (a bitonic sort of all T <= 4096 entries, 78 block-wide stages, was measured: 73 vs 31 us)
         __shared__ int hist[258];
         unsigned long long prefix = 0ull, mask = 0ull;
         int kth = k;
@@ -532,17 +584,8 @@ __global__ __launch_bounds__(1024) void topk_merge_sort_kernel(const float *__re
             out_i[(int64_t)q * k + e] = -1;
         }
     }
-    if (tid == 0) fallback[q] = 0;
 }
 
-// tournament for the queries the sort kernel could not take (fallback[q] != 0)
-__global__ __launch_bounds__(64) void topk_merge_fallback_kernel(const float *__restrict__ in_s, const int64_t *__restrict__ in_i,
-                                                                 int nlists, int k, float *__restrict__ out_s,
-                                                                 int64_t *__restrict__ out_i, const int *__restrict__ fallback) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (fallback[blockIdx.x] == 0) return;
-    tournament_merge(in_s, in_i, nlists, k, out_s, out_i, smem);
-}
 
 
 // ------------------------------------------------------------------------------------------------
@@ -904,9 +947,8 @@ extern "C" int skyemb_topk_merge(const float *in_s, const int64_t *in_i, int Q, 
             attr_set = true;
         }
         hipLaunchKernelGGL(topk_merge_sort_kernel, dim3(Q), dim3(1024), (size_t)(MERGE_CAP + 512) * 8, (hipStream_t)stream, in_s, in_i,
-                           nlists, k, out_s, out_i, (int *)ws);
-        hipLaunchKernelGGL(topk_merge_fallback_kernel, dim3(Q), dim3(64), smem, (hipStream_t)stream, in_s, in_i, nlists, k,
-                           out_s, out_i, (const int *)ws);
+                           nlists, k, out_s, out_i);
+
         SKY_LAUNCH_CHECK("skyemb_topk_merge");
         return 0;
     }
