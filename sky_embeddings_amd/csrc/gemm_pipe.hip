@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
+#include <type_traits>
 
 namespace {
 
@@ -39,6 +40,18 @@ __device__ unsigned long long *g_gemm_stamp = nullptr;
 __device__ __forceinline__ void glds16(const void *src, char *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gvoid_t *)src, (lvoid_t *)lds_wave_base, 16, 0, 0);
 }
+
+// loads through an explicitly GLOBAL pointer: a struct member like `const float *bias` is a generic pointer to the compiler, which
+// then emits flat_load -- out of order with respect to global loads, so every wait behind one is a full `vmcnt(0) lgkmcnt(0)`
+typedef __attribute__((address_space(1))) const f32x4 gf32x4_t;
+typedef __attribute__((address_space(1))) const bf16x8 gbf16x8_t;
+typedef __attribute__((address_space(1))) const int gint_t;
+__device__ __forceinline__ float4 gload4(const float *p) {
+    const f32x4 v = *(gf32x4_t *)p;
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ bf16x8 gload8h(const bf16_t *p) { return *(gbf16x8_t *)p; }
+__device__ __forceinline__ int gloadi(const int *p) { return *(gint_t *)p; }
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -369,6 +382,59 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
     float *cs_out = S > 1 ? (float *)g.ws + (int64_t)S * g.M * g.N + (int64_t)split * g.M : g.colsum_a;
     constexpr int PITCH = BN * 4 + 16;                   // bytes per tile row in LDS (+16: conflict-free b128 writes)
     float *cs_lds = (float *)(smem + BM * PITCH);        // (two k-groups) the odd k-tiles' column sums, BM floats behind the image
+    // The fused inputs of this thread's pieces (8 consecutive columns of a row each) are requested HERE, all of them, before
+    // the tile goes through LDS: the row maps first (dst_row / tab_row), then bias, table rows, residual and the dGELU operand
+    // at clamped coordinates, with no use in between.  Loaded where they were used -- under `if (m < M)`, one input after the
+    // other -- the compiler waited for every load on the spot: two to five dependent memory round trips per piece (1.4-2.6 us
+    // of a 6-10 us workgroup, profiles/r03_gemm_timeline.json).
+    constexpr int PPR = BN / 8, PIECES = BM * PPR, NP = PIECES / (NW * 64);   // pieces per row / per tile / per thread
+    static_assert(PIECES % (NW * 64) == 0, "pieces do not divide over the threads");
+    // ... in chunks of at most two pieces per thread (the four pieces of a 128x128 tile at once cost 112 registers: past the
+    // 128 that let two such workgroups share a CU -- measured: mim_19 28.7 -> 32.5 ms)
+    constexpr int CH = NP < 2 ? NP : 2, NCH = NP / CH;
+    static_assert(NP % CH == 0, "pieces per thread must split into chunks");
+    const bool fused = S == 1;                           // split-K: raw partial tiles, splitk_reduce_kernel applies the epilogue
+    int orow[CH], trow[CH];
+    float4 e_bias[CH][2], e_tab[CH][2], e_res[CH][2];
+    bf16x8 e_aux[CH];
+    const bf16_t *aux = (const bf16_t *)g.aux;
+    // (two copies of the request block: without row maps -- every launch of a transformer block -- no load feeds an address,
+    // so nothing is waited for before the tile is staged; with them the residual / table rows wait for the maps only)
+    auto request_inputs = [&](int j0, auto with_maps) {
+        constexpr bool MAPS = decltype(with_maps)::value;
+#pragma unroll
+        for (int jj = 0; jj < CH; ++jj) {
+            const int p = tid + (j0 + jj) * NW * 64, m = m0 + p / PPR;
+            const int mc = m < g.M ? m : g.M - 1;
+            orow[jj] = (MAPS && g.dst_row) ? gloadi(g.dst_row + mc) : mc;
+            trow[jj] = (MAPS && g.tab_row) ? gloadi(g.tab_row + mc) : 0;
+        }
+#pragma unroll
+        for (int jj = 0; jj < CH; ++jj) {
+            const int p = tid + (j0 + jj) * NW * 64, m = m0 + p / PPR, n = n0 + (p % PPR) * 8;
+            const int mc = m < g.M ? m : g.M - 1, nc = n < g.N ? n : g.N - 8;
+            if (g.bias) {
+                e_bias[jj][0] = gload4(g.bias + nc);
+                e_bias[jj][1] = gload4(g.bias + nc + 4);
+            }
+            if (g.act == SKYEMB_ACT_DGELU) e_aux[jj] = gload8h(aux + (int64_t)mc * g.ldaux + nc);
+        }
+#pragma unroll
+        for (int jj = 0; jj < CH; ++jj) {
+            const int p = tid + (j0 + jj) * NW * 64, n = n0 + (p % PPR) * 8;
+            const int nc = n < g.N ? n : g.N - 8;
+            const int oc = orow[jj] < 0 ? 0 : orow[jj];
+            if (MAPS && g.table) {
+                e_tab[jj][0] = gload4(g.table + (int64_t)trow[jj] * g.ldt + nc);
+                e_tab[jj][1] = gload4(g.table + (int64_t)trow[jj] * g.ldt + nc + 4);
+            }
+            if (g.resid) {
+                e_res[jj][0] = gload4(g.resid + (int64_t)oc * g.ldr + nc);
+                e_res[jj][1] = gload4(g.resid + (int64_t)oc * g.ldr + nc + 4);
+            }
+        }
+    };
+    const bool maps = g.dst_row || g.tab_row;
     __builtin_amdgcn_s_barrier();                        // every wave is done with the fragments of the last stage
     if (WK == 2) {                                       // partial tile of the odd k-tiles first, the even ones are added to it
         if (wk == 1) {
@@ -406,52 +472,62 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
                 *(f32x4 *)(smem + r * PITCH + c * 4) = v * g.alpha;
             }
     }
+    // (requested once the accumulators have left the registers: hoisted above the staging, the inputs of a 128x128 tile's four
+    // pieces per thread pushed the kernel past 128 registers -- one workgroup per CU instead of two, mim_19 28.7 -> 32.5 ms)
+    if (fused) {
+        if (maps) request_inputs(0, std::true_type{});
+        else request_inputs(0, std::false_type{});
+    }
     __syncthreads();
     GSTAMP(st_staged);
-    constexpr int PPR = BN / 8, PIECES = BM * PPR;       // pieces (8 columns) per row / per tile
     bf16_t *out = (bf16_t *)g.out;
     bf16_t *out2 = (bf16_t *)g.out2;
-    const bf16_t *aux = (const bf16_t *)g.aux;
     float *slab = S > 1 ? (float *)g.ws + (int64_t)split * g.M * g.N : nullptr;
 #pragma unroll
-    for (int p = tid; p < PIECES; p += NW * 64) {
-        const int r = p / PPR, c = (p % PPR) * 8;
-        const int m = m0 + r, n = n0 + c;
-        if (m >= g.M || n >= g.N) continue;
-        const float4 lo = *(const float4 *)(smem + r * PITCH + c * 4), hi = *(const float4 *)(smem + r * PITCH + c * 4 + 16);
-        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    for (int ch = 0; ch < NCH; ++ch) {
+        if (ch > 0 && fused) {
+            if (maps) request_inputs(ch * CH, std::true_type{});
+            else request_inputs(ch * CH, std::false_type{});
+        }
+#pragma unroll
+        for (int jj = 0; jj < CH; ++jj) {
+            const int p = tid + (ch * CH + jj) * NW * 64;
+            const int r = p / PPR, c = (p % PPR) * 8;
+            const int m = m0 + r, n = n0 + c;
+            if (m >= g.M || n >= g.N) continue;
+            const float4 lo = *(const float4 *)(smem + r * PITCH + c * 4), hi = *(const float4 *)(smem + r * PITCH + c * 4 + 16);
+            float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #ifdef SKY_NOSTORE   // experiment build: everything but the global traffic of the epilogue
-        asm volatile("" ::"v"(v[0]), "v"(v[7]));
-        continue;
-#endif
-        if (S > 1) {   // split-K: raw partial tile to the workspace; splitk_reduce_kernel finishes (full epilogue there)
-            *(float4 *)(slab + (int64_t)m * g.N + n) = lo;
-            *(float4 *)(slab + (int64_t)m * g.N + n + 4) = hi;
+            asm volatile("" ::"v"(v[0]), "v"(v[7]));
             continue;
-        }
-        const int orow = g.dst_row ? g.dst_row[m] : m;
-        if (orow < 0) continue;
-        auto add8 = [&](const float *src) {
-            const float4 a = *(const float4 *)src, b = *(const float4 *)(src + 4);
-            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
-        };
-        if (g.bias) add8(g.bias + n);
-        if (g.table) add8(g.table + (int64_t)g.tab_row[m] * g.ldt + n);
-        if (g.resid) add8(g.resid + (int64_t)orow * g.ldr + n);
-        if (g.act == SKYEMB_ACT_GELU) {
-            if (out2) store8(out2 + (int64_t)orow * g.ldo2 + n, v);
+#endif
+            if (!fused) {   // split-K: raw partial tile to the workspace; splitk_reduce_kernel finishes (full epilogue there)
+                *(float4 *)(slab + (int64_t)m * g.N + n) = lo;
+                *(float4 *)(slab + (int64_t)m * g.N + n + 4) = hi;
+                continue;
+            }
+            const int orw = orow[jj];
+            if (orw < 0) continue;
+            auto add8 = [&](const float4 &a, const float4 &b) {
+                v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+            };
+            if (g.bias) add8(e_bias[jj][0], e_bias[jj][1]);
+            if (g.table) add8(e_tab[jj][0], e_tab[jj][1]);
+            if (g.resid) add8(e_res[jj][0], e_res[jj][1]);
+            if (g.act == SKYEMB_ACT_GELU) {
+                if (out2) store8(out2 + (int64_t)orw * g.ldo2 + n, v);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
-        } else if (g.act == SKYEMB_ACT_DGELU) {
-            const bf16x8 a = *(const bf16x8 *)(aux + (int64_t)m * g.ldaux + n);
+                for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+            } else if (g.act == SKYEMB_ACT_DGELU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= dgelu_f((float)a[e]);
+                for (int e = 0; e < 8; ++e) v[e] *= dgelu_f((float)e_aux[jj][e]);
+            }
+            if (g.out_f32) {
+                *(float4 *)(g.out_f32 + (int64_t)orw * g.ldo32 + n) = make_float4(v[0], v[1], v[2], v[3]);
+                *(float4 *)(g.out_f32 + (int64_t)orw * g.ldo32 + n + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+            if (out) store8(out + (int64_t)orw * g.ldo + n, v);
         }
-        if (g.out_f32) {
-            *(float4 *)(g.out_f32 + (int64_t)orow * g.ldo32 + n) = make_float4(v[0], v[1], v[2], v[3]);
-            *(float4 *)(g.out_f32 + (int64_t)orow * g.ldo32 + n + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        }
-        if (out) store8(out + (int64_t)orow * g.ldo + n, v);
     }
 #ifdef GEMM_STAMP
     {
@@ -491,12 +567,19 @@ constexpr int GROUP_HEADER_BYTES = 256, GROUP_MAX = 32;
 template <int BM, int BN, int NSTAGE, int WM, int WN, int CLASSES, int WK = 1>
 __global__ __launch_bounds__(WM * WN * WK * 64) void gemm_pipe_group_kernel(const char *__restrict__ blob) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // the tile prefix of every problem in one scalar request (the walk `while (blockIdx.x >= hdr[9 + p]) ++p` was one dependent
+    // scalar load per problem in front of every workgroup's first operand load); unused slots hold 0 and never match
     const int *hdr = (const int *)blob;
     const int n = hdr[0];
-    int p = 0;
-    while (p + 1 < n && (int)blockIdx.x >= hdr[8 + p + 1]) ++p;
+    int starts[GROUP_MAX + 1];
+#pragma unroll
+    for (int i = 0; i <= GROUP_MAX; ++i) starts[i] = hdr[8 + i];
+    int p = 0, first = 0;
+#pragma unroll
+    for (int i = 1; i < GROUP_MAX; ++i)
+        if (i < n && (int)blockIdx.x >= starts[i]) { p = i; first = starts[i]; }
     const skyemb_gemm_args g = ((const skyemb_gemm_args *)(blob + GROUP_HEADER_BYTES))[p];
-    const int tb = blockIdx.x - hdr[8 + p];
+    const int tb = blockIdx.x - first;
     const int ntiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     if (tb >= ntiles) return;                             // padding up to the next multiple of 8 (keeps tb & 7 == XCD)
     const bool a = g.a_layout == SKYEMB_KC, b = g.b_layout == SKYEMB_KC;   // workgroup-uniform

@@ -16,22 +16,26 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
     if (row >= M) return;
     const int nv = D >> 2;
     const float *xr = x + (int64_t)row * D;
-    float4 v[NV];
-    float s = 0.f;
+    // Every load of the row (and of gamma / beta) is issued up front, unconditionally, at a clamped column: a load under
+    // `if (c < nv)` makes the compiler branch around it and wait for it on the spot -- the kernel was six dependent memory round
+    // trips (three for the row, three for gamma / beta) for a 768-wide row; now one.
+    float4 v[NV], gm[NV], bt[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int c = lane + i * 64;
-        if (c < nv) {
-            v[i] = *(const float4 *)(xr + 4 * c);
-            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-        }
+        const int c = lane + i * 64, cc = c < nv ? c : nv - 1;
+        v[i] = *(const float4 *)(xr + 4 * cc);
+        gm[i] = *(const float4 *)(gamma + 4 * cc);
+        bt[i] = *(const float4 *)(beta + 4 * cc);
     }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + i * 64 < nv) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int c = lane + i * 64;
-        if (c < nv) {
+        if (lane + i * 64 < nv) {
             const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
             q += (a * a + b * b) + (cc * cc + d * d);
         }
@@ -45,7 +49,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
     for (int i = 0; i < NV; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
-            const float4 g = *(const float4 *)(gamma + 4 * c), b = *(const float4 *)(beta + 4 * c);
+            const float4 g = gm[i], b = bt[i];
             const float o0 = (v[i].x - mean) * rstd * g.x + b.x, o1 = (v[i].y - mean) * rstd * g.y + b.y;
             const float o2 = (v[i].z - mean) * rstd * g.z + b.z, o3 = (v[i].w - mean) * rstd * g.w + b.w;
             if (y) store4<T>(y + (int64_t)row * D + 4 * c, o0, o1, o2, o3);
@@ -70,21 +74,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD *__restrict__ dy, 
         dgam[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         dbet[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         const int c = lane + i * 64;
-        gam[i] = c < nv ? *(const float4 *)(gamma + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        gam[i] = *(const float4 *)(gamma + 4 * (c < nv ? c : nv - 1));      // (columns past the row are never used)
     }
+    const float *gsrc = g_in ? g_in : x;                      // (no incoming gradient: a harmless second read of x, selected away)
     for (int row = blockIdx.x * 4 + wave; row < M; row += nblk * 4) {
         const float mu = mean[row], rs = rstd[row];
         float4 xh[NV], dyv[NV], gi[NV];
         float s1 = 0.f, s2 = 0.f;
+        // the row of x, of dy and of the incoming residual gradient: all requested together, unconditionally, at clamped columns
+        // (loads under `if (c < nv)` were waited for one by one: 3 NV dependent memory round trips per row)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64, cc = c < nv ? c : nv - 1;
+            xh[i] = *(const float4 *)(x + (int64_t)row * D + 4 * cc);
+            dyv[i] = load4<TD>(dy + (int64_t)row * D + 4 * cc);
+            gi[i] = *(const float4 *)(gsrc + (int64_t)row * D + 4 * cc);
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = lane + i * 64;
             if (c < nv) {
-                const float4 xv = *(const float4 *)(x + (int64_t)row * D + 4 * c);
-                dyv[i] = load4<TD>(dy + (int64_t)row * D + 4 * c);
-                // the incoming residual gradient is requested with the row, not after the two reductions (one memory
-                // latency per row instead of two)
-                gi[i] = g_in ? *(const float4 *)(g_in + (int64_t)row * D + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 xv = xh[i];
+                if (!g_in) gi[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
                 const float a0 = dyv[i].x * gam[i].x, a1 = dyv[i].y * gam[i].y, a2 = dyv[i].z * gam[i].z,
                             a3 = dyv[i].w * gam[i].w;
