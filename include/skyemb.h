@@ -103,7 +103,7 @@ typedef struct skyemb_gemm_group_info {
     int32_t total_blocks; /* grid size of the launch                                                          */
     int32_t tile;         /* tile code the plan chose (BM * 1000 + BN): 64064, 128064 or 128128               */
     int32_t class_mask;   /* operand-layout classes present: 1 KC.KC, 2 KC.RC (dgrad), 4 RC.RC (wgrad)        */
-    int32_t reserved;
+    int32_t reserved;     /* 1: the blob carries a skyemb_adamw_desc (skyemb_gemm_group_plan_adamw)                         */
 } skyemb_gemm_group_info;
 int64_t skyemb_gemm_group_blob_bytes(int n);
 /* tile = 0: chosen from the total tile count.  The problems share ONE tile shape and may mix the data-gradient
@@ -112,6 +112,25 @@ int64_t skyemb_gemm_group_blob_bytes(int n);
 int skyemb_gemm_group_plan(const skyemb_gemm_args *args, int n, int tile, void *blob_host, int64_t blob_bytes,
                            skyemb_gemm_group_info *info);
 int skyemb_gemm_group_launch(const void *blob_dev, const skyemb_gemm_group_info *info, void *stream);
+/* The same grouped weight-gradient launch with the optimiser step fused into its epilogue (one process per model replica only:
+ * with N > 1 the gradients are summed over the ranks between backward and AdamW).  Every problem's out_f32 points into the flat
+ * gradient buffer `g_base`; p / m / v / p_lp are the flat parameter, moment and low-precision-shadow buffers with the SAME element
+ * offsets.  An output tile is then not stored as a gradient at all: the kernel reads p, m, v, applies torch.optim.AdamW's update
+ * to them (utils/mim_vit.py:126-129, utils/pretrain_fns.py:36-41; bit-identical to skyemb_adamw on the stored gradient) and writes
+ * p, m, v and the bf16 shadow -- 26 instead of 4 + 30 bytes per parameter through HBM, and no separate pass over those tensors.
+ * hyper: device fp32[4] {lr, 1 - beta1^t, 1 - beta2^t} of the step being taken (written before the launch: graph-safe).
+ * Elements of the flat buffers below n_decay are weight-decayed.  bias gradients (colsum_a) are still stored as gradients.
+ * RC.RC problems only; plan it with skyemb_gemm_group_plan_adamw, launch it with skyemb_gemm_group_launch. */
+typedef struct skyemb_adamw_desc {
+    float *g_base, *p, *m, *v;
+    void *p_lp;            /* bf16 shadow of p */
+    const float *hyper;
+    int64_t n_decay;
+    float beta1, beta2, eps, weight_decay, grad_scale;
+    int32_t enabled;       /* set by the plan */
+} skyemb_adamw_desc;
+int skyemb_gemm_group_plan_adamw(const skyemb_gemm_args *args, int n, int tile, const skyemb_adamw_desc *adamw, void *blob_host,
+                                 int64_t blob_bytes, skyemb_gemm_group_info *info);
 
 /* column sums: out[n] = sum_m X[m,n]; X is `dtype` (bias gradients) or fp32 partials
  * (LayerNorm dgamma/dbeta second stage).  Replaces autograd's bias-gradient reductions. */

@@ -45,6 +45,12 @@ class GemmArgs(ctypes.Structure):
     ]
 
 
+class AdamwDesc(ctypes.Structure):
+    """skyemb_adamw_desc (include/skyemb.h): the optimiser step fused into a grouped weight-gradient launch."""
+    _fields_ = [("g_base", c_vp), ("p", c_vp), ("m", c_vp), ("v", c_vp), ("p_lp", c_vp), ("hyper", c_vp), ("n_decay", c_i64),
+                ("beta1", c_f32), ("beta2", c_f32), ("eps", c_f32), ("weight_decay", c_f32), ("grad_scale", c_f32), ("enabled", c_i32)]
+
+
 class GemmGroupInfo(ctypes.Structure):
     _fields_ = [("total_blocks", c_i32), ("tile", c_i32), ("class_mask", c_i32), ("reserved", c_i32)]
 
@@ -57,6 +63,8 @@ PROTOTYPES = {
     "skyemb_gemm": (c_i32, [ctypes.POINTER(GemmArgs), c_vp]),
     "skyemb_gemm_group_blob_bytes": (c_i64, [c_i32]),
     "skyemb_gemm_group_plan": (c_i32, [ctypes.POINTER(GemmArgs), c_i32, c_i32, c_vp, c_i64, ctypes.POINTER(GemmGroupInfo)]),
+    "skyemb_gemm_group_plan_adamw": (c_i32, [ctypes.POINTER(GemmArgs), c_i32, c_i32, ctypes.POINTER(AdamwDesc), c_vp, c_i64,
+                                             ctypes.POINTER(GemmGroupInfo)]),
     "skyemb_gemm_group_launch": (c_i32, [c_vp, ctypes.POINTER(GemmGroupInfo), c_vp]),
     "skyemb_colsum": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "skyemb_random_mask_from_noise": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),

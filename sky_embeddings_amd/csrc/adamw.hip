@@ -4,6 +4,7 @@
 // per-element state is the position relative to n_decay.  HBM-bound: reads p,g,m,v, writes
 // p,m,v (+ the bf16/fp32 shadow copy the GEMMs read, + optional gradient zeroing).
 #include "common.h"
+#include "adamw_math.h"
 
 namespace {
 
@@ -15,9 +16,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float *__restrict__ p, GT *_
                                                     float wd, float grad_scale, int zero_grad) {
     // hyper (device) wins when given: kernel arguments are frozen inside a captured HIP graph
     const float lr = hyper ? hyper[0] : lr_arg, bc1 = hyper ? hyper[1] : bc1_arg, bc2 = hyper ? hyper[2] : bc2_arg;
-    const float step_size = lr / bc1;
-    const float bc2_sqrt = sqrtf(bc2);
-    const float decay = 1.0f - lr * wd;
+    const SkyAdamScalars sc = sky_adam_scalars(lr, bc1, bc2, beta1, beta2, eps, wd, grad_scale);
     // two float4 groups per thread and iteration keep 8 loads in flight per lane (non-temporal loads / stores were tried:
     // no gain at 4.8 TB/s)
     const int64_t stride = (int64_t)gridDim.x * 256;
@@ -40,17 +39,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float *__restrict__ p, GT *_
             if (i >= n4) break;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                // every rounding is pinned (explicit fmaf, no compiler contraction): the update of an element must not
-                // depend on which launch / unroll slot it lands in -- a step applied range by range (TrainStep's
-                // optimiser overlap) is bit-identical to one launch over the whole buffer
-#pragma clang fp contract(off)
-                const float gj = gv[u][j] * grad_scale;
-                float pj = pv[u][j];
-                if (4 * i + j < n_decay) pj *= decay;                                   // p.mul_(1 - lr*wd)
-                const float mj = fmaf(mv[u][j], beta1, gj * (1.0f - beta1));             // exp_avg.lerp_(grad, 1-beta1)
-                const float vj = fmaf(vv[u][j], beta2, (gj * gj) * (1.0f - beta2));      // exp_avg_sq.mul_().addcmul_()
-                const float denom = sqrtf(vj) / bc2_sqrt + eps;
-                pj = fmaf(-step_size, mj / denom, pj);                                  // p.addcdiv_(m, denom, -step_size)
+                // (adamw_math.h: every rounding pinned -- a step applied range by range, or inside the weight-gradient GEMM's
+                // epilogue, is bit-identical to one launch over the whole buffer)
+                float pj = pv[u][j], mj = mv[u][j], vj = vv[u][j];
+                sky_adamw_update(gv[u][j], pj, mj, vj, 4 * i + j < n_decay, sc);
                 pv[u][j] = pj; mv[u][j] = mj; vv[u][j] = vj;
             }
             *(f32x4 *)(p + 4 * i) = pv[u];

@@ -12,6 +12,7 @@
 // The MFMA is issued with operands swapped (D = B_frag x A_frag) so that every lane owns 4
 // consecutive output COLUMNS of one row: 16-byte fp32 / 8-byte bf16 stores, float4 bias loads.
 #include "common.h"
+#include "adamw_math.h"
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
@@ -217,9 +218,11 @@ __device__ __forceinline__ void wait_stages(int rem) {
 // outputs) a k-step is one wave's serial chain -- barrier, LDS-DMA issue, fragment reads, 8 MFMAs: 0.29 us whatever the ring
 // depth (K-sweeps with 3 / 4 / 6 / 8 stages all gave 0.29; three co-resident workgroups reach 0.14 per k-step and tile) --
 // and a second wave per SIMD running the same chain on the other half of the stage overlaps it.
-template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int WM, int WN, int WK = 1>
+// ADAM (grouped weight-gradient launches planned with skyemb_gemm_group_plan_adamw): the output tile is not stored as a gradient;
+// the epilogue applies the AdamW step to the parameters the tile belongs to (`ad`: the flat buffers; see include/skyemb.h).
+template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int WM, int WN, int WK = 1, bool ADAM = false>
 __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const int tb, const int ntiles, const int split,
-                                               const int S, char *smem) {
+                                               const int S, char *smem, const skyemb_adamw_desc *ad = nullptr) {
     constexpr int NWG = WM * WN, NW = NWG * WK;         // waves per k-group / per workgroup
     constexpr int SM = BM / WM, SN = BN / WN;           // rows / columns of the tile owned by one wave
     constexpr int TM = SM / 16, TN = SN / 16;
@@ -391,12 +394,14 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
     static_assert(PIECES % (NW * 64) == 0, "pieces do not divide over the threads");
     // ... in chunks of at most two pieces per thread (the four pieces of a 128x128 tile at once cost 112 registers: past the
     // 128 that let two such workgroups share a CU -- measured: mim_19 28.7 -> 32.5 ms)
-    constexpr int CH = NP < 2 ? NP : 2, NCH = NP / CH;
+    constexpr int CH = (ADAM || NP < 2) ? 1 : 2, NCH = NP / CH;   // (ADAM: p, m, v of a piece are 24 registers more)
     static_assert(NP % CH == 0, "pieces per thread must split into chunks");
     const bool fused = S == 1;                           // split-K: raw partial tiles, splitk_reduce_kernel applies the epilogue
     int orow[CH], trow[CH];
     float4 e_bias[CH][2], e_tab[CH][2], e_res[CH][2];
     bf16x8 e_aux[CH];
+    float4 e_p[CH][2], e_m[CH][2], e_v[CH][2];           // (ADAM) the parameters and moments the piece updates
+    const int64_t ad_off = ADAM ? (int64_t)(g.out_f32 - ad->g_base) : 0;   // element offset of this problem in the flat buffers
     const bf16_t *aux = (const bf16_t *)g.aux;
     // (two copies of the request block: without row maps -- every launch of a transformer block -- no load feeds an address,
     // so nothing is waited for before the tile is staged; with them the residual / table rows wait for the maps only)
@@ -431,6 +436,12 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
             if (g.resid) {
                 e_res[jj][0] = gload4(g.resid + (int64_t)oc * g.ldr + nc);
                 e_res[jj][1] = gload4(g.resid + (int64_t)oc * g.ldr + nc + 4);
+            }
+            if (ADAM) {
+                const int64_t o = ad_off + (int64_t)oc * g.ldo32 + nc;
+                e_p[jj][0] = gload4(ad->p + o); e_p[jj][1] = gload4(ad->p + o + 4);
+                e_m[jj][0] = gload4(ad->m + o); e_m[jj][1] = gload4(ad->m + o + 4);
+                e_v[jj][0] = gload4(ad->v + o); e_v[jj][1] = gload4(ad->v + o + 4);
             }
         }
     };
@@ -522,6 +533,25 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= dgelu_f((float)e_aux[jj][e]);
             }
+            if (ADAM) {
+                // v[] is the gradient of 8 consecutive parameters: the optimiser step, here (adamw_math.h)
+                const float lr = ad->hyper[0], bc1 = ad->hyper[1], bc2 = ad->hyper[2];
+                const SkyAdamScalars sc = sky_adam_scalars(lr, bc1, bc2, ad->beta1, ad->beta2, ad->eps, ad->weight_decay, ad->grad_scale);
+                const int64_t o = ad_off + (int64_t)orw * g.ldo32 + n;
+                float pp[8] = {e_p[jj][0].x, e_p[jj][0].y, e_p[jj][0].z, e_p[jj][0].w, e_p[jj][1].x, e_p[jj][1].y, e_p[jj][1].z, e_p[jj][1].w};
+                float mm[8] = {e_m[jj][0].x, e_m[jj][0].y, e_m[jj][0].z, e_m[jj][0].w, e_m[jj][1].x, e_m[jj][1].y, e_m[jj][1].z, e_m[jj][1].w};
+                float vv[8] = {e_v[jj][0].x, e_v[jj][0].y, e_v[jj][0].z, e_v[jj][0].w, e_v[jj][1].x, e_v[jj][1].y, e_v[jj][1].z, e_v[jj][1].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sky_adamw_update(v[e], pp[e], mm[e], vv[e], o + e < ad->n_decay, sc);
+                *(float4 *)(ad->p + o) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+                *(float4 *)(ad->p + o + 4) = make_float4(pp[4], pp[5], pp[6], pp[7]);
+                *(float4 *)(ad->m + o) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+                *(float4 *)(ad->m + o + 4) = make_float4(mm[4], mm[5], mm[6], mm[7]);
+                *(float4 *)(ad->v + o) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                *(float4 *)(ad->v + o + 4) = make_float4(vv[4], vv[5], vv[6], vv[7]);
+                store8((bf16_t *)ad->p_lp + o, pp);
+                continue;
+            }
             if (g.out_f32) {
                 *(float4 *)(g.out_f32 + (int64_t)orw * g.ldo32 + n) = make_float4(v[0], v[1], v[2], v[3]);
                 *(float4 *)(g.out_f32 + (int64_t)orw * g.ldo32 + n + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -564,7 +594,9 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm_pipe_kernel(const skye
 // 1 KC.KC, 2 KC.RC, 4 RC.RC, 8 RC.KC).
 // blob = [int32 n, total_blocks, 6 x pad, start[0..n] (multiples of 8), ...pad to 256 B][n x skyemb_gemm_args]
 constexpr int GROUP_HEADER_BYTES = 256, GROUP_MAX = 32;
-template <int BM, int BN, int NSTAGE, int WM, int WN, int CLASSES, int WK = 1>
+constexpr int GROUP_ADAMW_OFFSET = 176;                  // skyemb_adamw_desc (80 bytes) ends the 256-byte header
+static_assert(sizeof(skyemb_adamw_desc) == 80, "the blob header reserves 80 bytes for the fused-AdamW descriptor");
+template <int BM, int BN, int NSTAGE, int WM, int WN, int CLASSES, int WK = 1, bool ADAM = false>
 __global__ __launch_bounds__(WM * WN * WK * 64) void gemm_pipe_group_kernel(const char *__restrict__ blob) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // the tile prefix of every problem in one scalar request (the walk `while (blockIdx.x >= hdr[9 + p]) ++p` was one dependent
@@ -585,6 +617,11 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm_pipe_group_kernel(cons
     const bool a = g.a_layout == SKYEMB_KC, b = g.b_layout == SKYEMB_KC;   // workgroup-uniform
     if constexpr (CLASSES & 1) if (a && b) return gemm_pipe_body<BM, BN, true, true, NSTAGE, WM, WN, WK>(g, tb, ntiles, 0, 1, smem);
     if constexpr (CLASSES & 2) if (a && !b) return gemm_pipe_body<BM, BN, true, false, NSTAGE, WM, WN, WK>(g, tb, ntiles, 0, 1, smem);
+    if constexpr (ADAM) {
+        static_assert(CLASSES == 4, "the fused optimiser step exists for weight-gradient (RC.RC) groups only");
+        return gemm_pipe_body<BM, BN, false, false, NSTAGE, WM, WN, WK, true>(g, tb, ntiles, 0, 1, smem,
+                                                                            (const skyemb_adamw_desc *)(blob + GROUP_ADAMW_OFFSET));
+    }
     if constexpr (CLASSES & 4) if (!a && !b) return gemm_pipe_body<BM, BN, false, false, NSTAGE, WM, WN, WK>(g, tb, ntiles, 0, 1, smem);
     if constexpr (CLASSES & 8) if (!a && b) return gemm_pipe_body<BM, BN, false, true, NSTAGE, WM, WN, WK>(g, tb, ntiles, 0, 1, smem);
 }
@@ -918,11 +955,37 @@ extern "C" int skyemb_gemm_group_plan(const skyemb_gemm_args *args, int n, int t
     return 0;
 }
 
-template <int BM, int BN, int NSTAGE, int WM, int WN, int CLASSES, int WK = 1>
+extern "C" int skyemb_gemm_group_plan_adamw(const skyemb_gemm_args *args, int n, int tile, const skyemb_adamw_desc *adamw, void *blob_host,
+                                            int64_t blob_bytes, skyemb_gemm_group_info *info) {
+    SKY_CHECK_ARG(adamw && adamw->g_base && adamw->p && adamw->m && adamw->v && adamw->p_lp && adamw->hyper,
+                  "skyemb_gemm_group_plan_adamw: incomplete descriptor");
+    const int rc = skyemb_gemm_group_plan(args, n, tile, blob_host, blob_bytes, info);
+    if (rc != 0) return rc;
+    if (info->class_mask != 4 || !(info->tile == 64064 || info->tile == 128064 || info->tile == 128128)) {
+        skyemb_set_error("skyemb_gemm_group_plan_adamw: weight-gradient (RC.RC) problems on the 64x64 / 128x64 / 128x128 tiles only");
+        return -1;
+    }
+    for (int i = 0; i < n; ++i) {
+        // a whole number of 8-element pieces per output row, inside the flat buffers, no fused extras besides the bias gradient
+        const skyemb_gemm_args &g = args[i];
+        if (!g.out_f32 || g.out || g.out2 || g.bias || g.table || g.resid || g.dst_row || g.act != SKYEMB_ACT_NONE || g.alpha != 1.0f ||
+            g.out_f32 < adamw->g_base || ((g.out_f32 - adamw->g_base) % 8) != 0 || (g.ldo32 ? g.ldo32 : g.N) % 8 != 0) {
+            skyemb_set_error("skyemb_gemm_group_plan_adamw: problem %d is not a plain weight gradient into the flat buffer", i);
+            return -1;
+        }
+    }
+    skyemb_adamw_desc d = *adamw;
+    d.enabled = 1;
+    memcpy((char *)blob_host + GROUP_ADAMW_OFFSET, &d, sizeof d);
+    info->reserved = 1;
+    return 0;
+}
+
+template <int BM, int BN, int NSTAGE, int WM, int WN, int CLASSES, int WK = 1, bool ADAM = false>
 static int group_launch_n(const void *blob_dev, int total_blocks, hipStream_t st) {
     constexpr size_t ring = (size_t)NSTAGE * (BM + BN) * BK * 2 * WK, image = (size_t)BM * (BN * 4 + 16) + (WK > 1 ? BM * 4 : 0);
     constexpr size_t smem = ring > image ? ring : image;
-    auto kern = gemm_pipe_group_kernel<BM, BN, NSTAGE, WM, WN, CLASSES, WK>;
+    auto kern = gemm_pipe_group_kernel<BM, BN, NSTAGE, WM, WN, CLASSES, WK, ADAM>;
     static std::mutex attr_mutex;
     static bool attr_done[64] = {};
     int dev = 0;
@@ -958,6 +1021,15 @@ extern "C" int skyemb_gemm_group_launch(const void *blob_dev, const skyemb_gemm_
     SKY_CHECK_ARG(blob_dev && info && info->total_blocks > 0, "skyemb_gemm_group_launch: bad arguments");
     if (skyemb_skip_mask() & 1) return 0;
     hipStream_t st = (hipStream_t)stream;
+    if (info->reserved == 1) {                                 // optimiser step fused into the epilogue (plan_adamw: class 4 only)
+        switch (info->tile) {
+            case 64064: return group_launch_n<64, 64, 3, 2, 2, 4, 1, true>(blob_dev, info->total_blocks, st);
+            case 128064: return group_launch_n<128, 64, 3, 4, 2, 4, 1, true>(blob_dev, info->total_blocks, st);
+            case 128128: return group_launch_n<128, 128, 2, 4, 2, 4, 1, true>(blob_dev, info->total_blocks, st);
+        }
+        skyemb_set_error("skyemb_gemm_group_launch: tile %d not built with the fused optimiser step", info->tile);
+        return 1;
+    }
     switch (info->tile) {
         case 64064: return group_launch_classes<64, 64, 3, 2, 2>(blob_dev, info->total_blocks, info->class_mask, st);
         case 128064: return group_launch_classes<128, 64, 3, 4, 2>(blob_dev, info->total_blocks, info->class_mask, st);

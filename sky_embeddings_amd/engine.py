@@ -264,6 +264,8 @@ class MAEEngine:
                 for tag, blocks, M_, dim in (("blocks", w["enc"], Me, D), ("decoder_blocks", w["dec"], Md, Dd)):
                     for i, bufs in enumerate(blocks):
                         w["wgrad_groups"][f"{tag}.{i}"] = self._make_wgrad_group(f"{tag}.{i}", bufs, M_, dim, w)
+        if train and getattr(self, "_fused_adamw", None) is not None and w.get("wgrad_groups"):
+            self._build_adamw_groups(w)
         self._ws[key] = w
         return w
 
@@ -476,7 +478,7 @@ class MAEEngine:
         return [(g_lp, bufs["hact"], f"{prefix}.mlp.fc2", dim, hidden), (dh, bufs["ln2"], f"{prefix}.mlp.fc1", hidden, dim),
                 (g_lp2, bufs["att"], f"{prefix}.attn.proj", dim, dim), (dqkv, bufs["ln1"], f"{prefix}.attn.qkv", 3 * dim, dim)]
 
-    def _make_wgrad_group(self, prefix, bufs, M, dim, w):
+    def _make_wgrad_group(self, prefix, bufs, M, dim, w, adamw=None):
         st = self.store
         args = [ops.gemm_args(dy, x_in, M=n_out, N=k_in, K=M, a_layout=RC, b_layout=RC, lda=n_out, ldb=k_in,
                               out_f32=st.grad(f"{name}.weight"), colsum_a=st.grad(f"{name}.bias"))
@@ -484,8 +486,63 @@ class MAEEngine:
         # (experiments: SKYEMB_WGRAD_TILE_ENC / _DEC force the grouped launch's tile code for one stack)
         import os
         tile = int(os.environ.get("SKYEMB_WGRAD_TILE_DEC" if prefix.startswith("decoder") else "SKYEMB_WGRAD_TILE_ENC", "0"))
-        grp = ops.GemmGroup(args, self.device, tile=tile)
+        grp = ops.GemmGroup(args, self.device, tile=tile, adamw=adamw)
         return grp if grp.ok else None
+
+    # -- optimiser step fused into the weight-gradient launches (one process per replica: TrainStep(fused_adamw=True)) --
+    def enable_fused_adamw(self, optimizer, on=True):
+        """The grouped weight-gradient launch of every transformer block applies AdamW to its four weight matrices in its
+        epilogue instead of storing their gradients (include/skyemb.h, skyemb_gemm_group_plan_adamw).  Returns the slices of
+        the flat buffers those launches update -- the caller runs the ordinary AdamW on the rest (embeddings, biases,
+        LayerNorms, the single weight gradients): fused_adamw_ranges(workspace).  The gradient buffer is then NOT written for
+        the fused tensors."""
+        self._fused_adamw = None
+        if not on:
+            return
+        assert self.dtype == torch.bfloat16, "the fused optimiser step exists on the bf16 path (grouped weight gradients)"
+        from ._lib import AdamwDesc
+        st = self.store
+        b1, b2 = optimizer.defaults["betas"]
+        d = AdamwDesc()
+        d.g_base, d.p, d.m, d.v, d.p_lp = (t.data_ptr() for t in (st.g, st.p, st.m, st.v, st.p_lp))
+        d.hyper = optimizer.hyper_device.data_ptr()
+        d.n_decay = st.n_decay
+        d.beta1, d.beta2, d.eps = b1, b2, optimizer.defaults["eps"]
+        d.weight_decay, d.grad_scale = optimizer.param_groups[1]["weight_decay"], optimizer.grad_scale
+        self._fused_adamw = d
+        for w in self._ws.values():                           # workspaces built before the switch
+            if "wgrad_groups" in w:
+                self._build_adamw_groups(w)
+
+    def fused_adamw_ranges(self, w):
+        """Slices of the flat buffers the fused launches of workspace `w` update (merged, ascending)."""
+        return list(w.get("fused_ranges", []))
+
+    def _build_adamw_groups(self, w):
+        st = self.store
+        w["wgrad_groups_adamw"] = {}
+        spans = []
+        for prefix, plain in w["wgrad_groups"].items():
+            if plain is None:                                 # (token counts the grouped kernel does not take: single launches)
+                continue
+            tag, i = prefix.rsplit(".", 1)
+            bufs = (w["enc"] if tag == "blocks" else w["dec"])[int(i)]
+            M, dim = bufs["ln1"].shape
+            grp = self._make_wgrad_group(prefix, bufs, M, dim, w, adamw=self._fused_adamw)
+            if grp is None:
+                continue
+            w["wgrad_groups_adamw"][prefix] = grp
+            for name in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2"):
+                o = st.offsets[f"{prefix}.{name}.weight"]
+                spans.append((o, o + _pad8(int(np.prod(st.shapes[f"{prefix}.{name}.weight"])))))
+        spans.sort()
+        merged = []
+        for s_, e_ in spans:
+            if merged and merged[-1][1] == s_:
+                merged[-1] = (merged[-1][0], e_)
+            else:
+                merged.append((s_, e_))
+        w["fused_ranges"] = merged
 
     def _block_bwd(self, x_in, bufs, prefix, M, dim, heads, Bsz, N, g, g_lp, w):
         """g holds d(block output) on entry and d(block input) on exit (fp32); its compute-dtype copy is read from the
@@ -499,7 +556,11 @@ class MAEEngine:
         dqkv = self._scratch(w, "dqkv", s, 3 * M * dim).view(M, 3 * dim)
         dln = w["dln"][:M * dim].view(M, dim)
         datt = w["datt"][:M * dim].view(M, dim)
-        group = w["wgrad_groups"].get(prefix)
+        # (only inside a TrainStep that owns the optimiser step: `_fused_active` is raised around ITS launches, so that
+        # engine.backward() called by anybody else -- loss.backward() of the module API, tests -- stores plain gradients)
+        fused = (getattr(self, "_fused_active", False) and getattr(self, "_fused_adamw", None) is not None
+                 and prefix in w.get("wgrad_groups_adamw", {}))
+        group = (w["wgrad_groups_adamw"] if fused else w["wgrad_groups"]).get(prefix)
         single = group is None                      # weight gradients launch by launch (fp32 mode)
         g_mid = g_lp if single else self._scratch(w, "g_lp2", s, M * dim).view(M, dim)
         # MLP: x_out = xmid + fc2(gelu(fc1(ln2(xmid))))

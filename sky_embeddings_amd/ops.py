@@ -10,7 +10,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ACT_DGELU, ACT_GELU, ACT_NONE, BF16, F32, KC, RC, GemmArgs, GemmGroupInfo, check, lib
+from ._lib import ACT_DGELU, ACT_GELU, ACT_NONE, BF16, F32, KC, RC, AdamwDesc, GemmArgs, GemmGroupInfo, check, lib
 
 TORCH_DTYPE = {BF16: torch.bfloat16, F32: torch.float32}
 
@@ -68,13 +68,18 @@ class GemmGroup:
     structs -- the device blob holds the raw pointers, so the operand buffers must stay allocated -- and replayed with
     launch().  `ok` is False when a problem is outside the grouped subset (launch them singly)."""
 
-    def __init__(self, args, device, tile=0):
+    def __init__(self, args, device, tile=0, adamw=None):
+        """adamw: an _lib.AdamwDesc -- the optimiser step fused into the launch's epilogue (weight-gradient groups of a
+        single-process run: skyemb_gemm_group_plan_adamw)."""
         n = len(args)
         arr = (GemmArgs * n)(*args)
         nbytes = lib().skyemb_gemm_group_blob_bytes(n)
         host = torch.zeros(nbytes, dtype=torch.uint8)
         self.info = GemmGroupInfo()
-        rc = lib().skyemb_gemm_group_plan(arr, n, tile, host.data_ptr(), nbytes, ctypes.byref(self.info))
+        if adamw is not None:
+            rc = lib().skyemb_gemm_group_plan_adamw(arr, n, tile, ctypes.byref(adamw), host.data_ptr(), nbytes, ctypes.byref(self.info))
+        else:
+            rc = lib().skyemb_gemm_group_plan(arr, n, tile, host.data_ptr(), nbytes, ctypes.byref(self.info))
         self.ok = rc == 0
         if rc > 0:
             check(rc, "skyemb_gemm_group_plan")

@@ -138,6 +138,8 @@ class SimMIMEngine(MAEEngine):
             if self.dtype == torch.bfloat16:
                 for i, bufs in enumerate(w["enc"]):
                     w["wgrad_groups"][f"blocks.{i}"] = self._make_wgrad_group(f"blocks.{i}", bufs, M, D, w)
+        if train and getattr(self, "_fused_adamw", None) is not None and w.get("wgrad_groups"):
+            self._build_adamw_groups(w)
         self._ws[key] = w
         return w
 

@@ -33,7 +33,7 @@ class TrainStep:
                  use_graph: bool = True, process_group=None, world_size: int = 1, warmup_iters: int = 2,
                  staged: bool | None = None, n_encoder_groups: int | None = None, bucket_elems: int = 32 * 1024 * 1024,
                  wgrad_overlap: bool | None = None, optimizer_overlap: bool | None = None, grad_comm: str | None = None,
-                 external_noise: bool = False, max_mask_ratio: float | None = None):
+                 external_noise: bool = False, max_mask_ratio: float | None = None, fused_adamw: bool | None = None):
         self.engine, self.optimizer, self.scheduler = engine, optimizer, scheduler
         self.mask_ratio = mask_ratio
         self.world_size = world_size
@@ -108,6 +108,31 @@ class TrainStep:
             assert covered[0][0] == 0 and covered[-1][1] == engine.store.n and all(a[1] == b[0] for a, b in zip(covered, covered[1:])), \
                 "backward stages must partition the flat parameter buffer"
             self.opt_stream = torch.cuda.Stream(device=dev)
+        # One process per replica: the AdamW step of every transformer block's weights runs in the epilogue of that block's grouped
+        # weight-gradient launch (no gradient round trip through HBM, no separate pass over 99 % of the parameters); the ordinary
+        # kernel updates the rest after the graph.  Not with N > 1 (the all-reduce sits between backward and the update).
+        if fused_adamw is None:
+            fused_adamw = os.environ.get("SKYEMB_FUSED_ADAMW", "1") == "1"
+        self.fused_adamw = bool(fused_adamw and world_size == 1 and not self.staged and not self.optimizer_overlap
+                                and engine.dtype == torch.bfloat16 and hasattr(engine, "enable_fused_adamw"))
+        self._rest_ranges = None
+        snap = None
+        if self.fused_adamw:
+            optimizer.use_device_scalars(dev)
+            engine.enable_fused_adamw(optimizer)
+            # (the warm-up launches below would already step the fused tensors: restore them afterwards)
+            st = engine.store
+            snap = [t.clone() for t in (st.p, st.m, st.v, st.p_lp)]
+
+            def owning(fn):
+                def run():
+                    engine._fused_active = True          # these launches carry the optimiser step
+                    try:
+                        fn()
+                    finally:
+                        engine._fused_active = False
+                return run
+            self.stages = [(owning(fn), ranges) for fn, ranges in self.stages]
         self.graphs = None
         if use_graph:
             # warm up on a side stream (lazy hipFuncSetAttribute calls, workspace allocation), then capture
@@ -127,6 +152,17 @@ class TrainStep:
                     fn()
                 pool = g.pool()
                 self.graphs.append(g)
+        if snap is not None:
+            if not use_graph:                                  # (graph mode ran the warm-up above: the workspace exists)
+                self.stages[0][0]()
+            # what the fused launches of THIS batch shape update; the ordinary kernel takes the rest after the graph
+            ws = [w for k, w in engine._ws.items() if k[-1] is True and k[0] == batch_size]
+            fused = engine.fused_adamw_ranges(ws[-1]) if ws else []
+            bounds = [0] + [b for r in fused for b in r] + [engine.store.n]
+            self._rest_ranges = [(bounds[i], bounds[i + 1]) for i in range(0, len(bounds), 2) if bounds[i] < bounds[i + 1]]
+            torch.cuda.synchronize(dev)
+            for dst, src in zip((engine.store.p, engine.store.m, engine.store.v, engine.store.p_lp), snap):
+                dst.copy_(src)
 
     def _forward(self):
         if self.simmim:
@@ -157,6 +193,18 @@ class TrainStep:
     def __call__(self, imgs=None, mask=None, ra_dec=None):
         if imgs is not None:
             self.load_batch(imgs, mask, ra_dec)
+        if self.fused_adamw:
+            # step t's scalars to the device, forward + backward (+ the fused updates), the ordinary kernel on the rest
+            self.optimizer.begin_step()
+            self.optimizer.write_scalars(self.optimizer.step_count)
+            if self.graphs is not None:
+                self.graphs[0].replay()
+            else:
+                self.stages[0][0]()
+            for (s, e) in self._rest_ranges:
+                self.optimizer.apply_range(s, e)
+            self.scheduler.step()
+            return self.loss
         works = []
         g = self.engine.store.g if self.g16 is None else self.g16
         self.optimizer.grad_buffer = self.g16      # (eager steps outside TrainStep keep reading the fp32 buffer)

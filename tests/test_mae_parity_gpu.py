@@ -187,7 +187,7 @@ def test_staged_backward_equals_monolithic_and_graph_replay():
                                                 (True, True, False, False)):
         eng = MAEEngine(cfg, compute_dtype=torch.bfloat16, seed=1)
         opt = FusedAdamW(eng, lr=1e-3)
-        step = TrainStep(eng, opt, CosineLR(opt, 100), 8, use_graph=graph, staged=staged, n_encoder_groups=4,
+        step = TrainStep(eng, opt, CosineLR(opt, 100), 8, use_graph=graph, staged=staged, n_encoder_groups=4, fused_adamw=False,
                          wgrad_overlap=overlap, optimizer_overlap=opt_overlap)
         torch.manual_seed(123)            # same masking noise stream for every schedule
         for _ in range(3):
@@ -197,3 +197,71 @@ def test_staged_backward_equals_monolithic_and_graph_replay():
     for r in results[1:]:
         assert r[0] == results[0][0]
         assert torch.equal(r[1], results[0][1]) and torch.equal(r[2], results[0][2])
+
+
+def test_fused_adamw_step_at_the_benchmark_size():
+    """The same bit-equality at BASELINE configs[1] (ViT-B/16, B = 256): the 128x128 (encoder) and 128x64 (decoder) grouped
+    launches with the optimiser step in their epilogue against the separate AdamW launch, four steps, no host sync in between."""
+    from sky_embeddings_amd.engine import MAEEngine
+    from sky_embeddings_amd.model_config import config_for
+    from sky_embeddings_amd.optim import CosineLR, FusedAdamW
+    from sky_embeddings_amd.train_step import TrainStep
+    cfg = config_for("base", img_size=64, patch_size=16, in_chans=5, embed_dim=768, norm_pix_loss=True, loss_fn="mse")
+    imgs = torch.randn(256, 5, 64, 64, generator=torch.Generator().manual_seed(0)).clamp_(min=-3).cuda()
+    res = []
+    for fused in (False, True):
+        eng = MAEEngine(cfg, compute_dtype=torch.bfloat16, seed=0)
+        opt = FusedAdamW(eng, lr=1e-4, weight_decay=0.05)
+        step = TrainStep(eng, opt, CosineLR(opt, 1000), 256, fused_adamw=fused)
+        torch.manual_seed(5)
+        ls = [step(imgs).clone() for _ in range(4)]
+        torch.cuda.synchronize()
+        res.append(([float(l) for l in ls], eng.store.p.clone(), eng.store.m.clone(), eng.store.v.clone(), eng.store.p_lp.clone()))
+        if fused:
+            assert sum(e - s_ for s_, e in step._rest_ranges) < 0.06 * eng.store.n     # 94 % of the parameters step in the GEMM epilogues
+        del step, opt, eng
+        torch.cuda.empty_cache()
+    assert res[0][0] == res[1][0]
+    for k in range(1, 5):
+        assert torch.equal(res[0][k], res[1][k]), k
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_fused_adamw_step_equals_the_separate_optimiser_launch(graph):
+    """TrainStep(fused_adamw=True): the AdamW step of every transformer block's weight matrices runs in the epilogue of the
+    block's grouped weight-gradient launch.  Parameters, both moments and the bf16 shadow are bit-identical to the schedule
+    with the separate optimiser launch after ten steps; engine.backward() outside the step still stores plain gradients."""
+    from sky_embeddings_amd.engine import MAEEngine
+    from sky_embeddings_amd.model_config import config_for
+    from sky_embeddings_amd.optim import CosineLR, FusedAdamW
+    from sky_embeddings_amd.train_step import TrainStep
+    cfg = config_for("tiny", img_size=64, patch_size=16, in_chans=5, embed_dim=192)
+    g = torch.Generator().manual_seed(0)
+    imgs = torch.randn(64, 5, 64, 64, generator=g).cuda()       # 320 / 1088 token rows: multiples of 64, so the grouped launches exist
+    out = []
+    for fused in (False, True):
+        eng = MAEEngine(cfg, compute_dtype=torch.bfloat16, seed=1)
+        opt = FusedAdamW(eng, lr=1e-3, weight_decay=0.05)
+        step = TrainStep(eng, opt, CosineLR(opt, 100), 64, use_graph=graph, fused_adamw=fused)
+        assert step.fused_adamw == fused
+        torch.manual_seed(123)
+        # ten steps WITHOUT a host sync in between: the host runs ahead of the GPU, so step t's launches must still read step t's
+        # scalars (a single pinned staging slot handed them step t + 1's)
+        dev_losses = [step(imgs).clone() for _ in range(10)]
+        torch.cuda.synchronize()
+        losses = [float(l) for l in dev_losses]
+        st = eng.store
+        out.append((losses, st.p.clone(), st.m.clone(), st.v.clone(), st.p_lp.clone(), opt.step_count))
+        if fused:
+            # the fused tensors moved (their gradients were never stored), the optimiser counted three steps
+            assert opt.step_count == 10 and len(step._rest_ranges) >= 2
+            assert sum(e - s_ for s_, e in step._rest_ranges) < 0.2 * st.n          # the block weights are the bulk
+            # plain backward outside the step: gradients of a fused tensor are written again
+            st.g.fill_(float("nan"))
+            eng.forward_train(imgs, 0.75, torch.rand(64, 16, device="cuda"))
+            eng.backward()
+            assert bool(torch.isfinite(st.grad("blocks.0.attn.qkv.weight")).all())
+    a, b = out
+    assert a[0] == b[0] and a[5] == b[5]
+    for k in range(1, 5):
+        assert torch.equal(a[k], b[k]), k
