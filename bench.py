@@ -193,7 +193,7 @@ def bench_pretrain(args, rank, world, dev):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
     executed, algorithmic = eng.flops_per_image(0.75)
-    out = dict(ms_per_step=1e3 * dt / args.steps, images_per_sec=world * B * args.steps / dt, gpu_ms_per_step=gpu_ms,
+    out = dict(fused_adamw=step.fused_adamw, ms_per_step=1e3 * dt / args.steps, images_per_sec=world * B * args.steps / dt, gpu_ms_per_step=gpu_ms,
                loss=float(loss), flops_per_image_executed=executed, flops_per_image_reference=algorithmic, B=B)
     if rank == 0:
         # In-step time of the dominant kernel family: the same step with the MFMA GEMM launches left out (the C ABI's
@@ -252,6 +252,19 @@ def staged_schedule_price(eng, opt, sched, B, pool, dev, args):
     counters = (opt.step_count, sched.last_epoch)
     res = {}
     try:
+        # the monolithic step with the separate AdamW launch (what every rank of a data-parallel run executes per stage set)
+        s1 = TrainStep(eng, opt, sched, B, mask_ratio=0.75, use_graph=not args.no_graph, world_size=1, fused_adamw=False)
+        for i in range(5):
+            s1(pool[i % 2])
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(50):
+            s1(pool[i % 2])
+        e1.record()
+        e1.synchronize()
+        res["monolithic_separate_adamw"] = dict(ms_per_step=e0.elapsed_time(e1) / 50)
+        del s1
         for comm in ("bf16", "f32"):
             s2 = TrainStep(eng, opt, sched, B, mask_ratio=0.75, use_graph=not args.no_graph, world_size=1, staged=True,
                            n_encoder_groups=6, grad_comm=comm)
@@ -564,10 +577,13 @@ def main():
                                    f"bs={pre['B']}/GPU, AdamW+cosine, norm_pix mse",
                        "global_batch": pre["B"] * world, "parallelism": f"dp{world}",
                        "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
-                       "graph": not args.no_graph},
+                       "graph": not args.no_graph, "adamw_in_wgrad_epilogue": bool(pre.get("fused_adamw"))},
             "roofline": {"bound": "mfma", "achieved": gi["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": gi["tflops"] / peak,
                          "traffic": gemm_pmc_traffic(),
-                         "note": "dominant kernel family = the pipelined MFMA GEMM launches: algorithmic 2MNK FLOPs of every GEMM "
+                         "note": "(one process: the AdamW step of the transformer blocks' weights runs INSIDE the grouped weight-gradient "
+                                 "launches, so the family's in-step time includes that HBM traffic -- 26 B per parameter; "
+                                 "extra.staged.monolithic_separate_adamw is the step with the separate optimiser launch) "
+                                 "dominant kernel family = the pipelined MFMA GEMM launches: algorithmic 2MNK FLOPs of every GEMM "
                                  "launch of one step / their IN-STEP time = HIP-event time of the timed steps minus the same "
                                  "steps replayed with the GEMM launches left out (kernel.step_without_gemm_ms); agrees with the "
                                  "sum of the gemm_pipe_* rows of the rocprofv3 kernel_stats in profiles/.  step = whole-step rate "

@@ -79,7 +79,9 @@ def test_two_rank_training_step_matches_one_rank_on_the_concatenated_batch(tmp_p
     mean_losses = np.mean([r[0]["losses"], r[1]["losses"]], axis=0)
     # MAE mode masks the same number of patches per sample, so the mean of the rank losses is the global loss and the mean of
     # the rank gradients the global gradient
-    assert np.allclose(mean_losses, ref_losses, rtol=2e-4 if grad_comm == "f32" else 2e-3), (mean_losses, ref_losses)
+    # (bars = 2x the errors measured on MI355X, profiles/r03_parity_errors.json: losses 1.0e-5 / 4.5e-5 relative, 99.98 % of the
+    # parameters inside the band, largest deviation 1.36 lr-steps)
+    assert np.allclose(mean_losses, ref_losses, rtol=2e-5 if grad_comm == "f32" else 1e-4), (mean_losses, ref_losses)
     moved = (ref - p0).abs()
     err = (r[0]["p"] - ref).abs()
     # Adam moves every element by ~lr per step; summation order (f32) or bf16 rounding of the gradients can change the
@@ -91,5 +93,5 @@ def test_two_rank_training_step_matches_one_rank_on_the_concatenated_batch(tmp_p
                        frac_within_band=frac_close, band_in_lr_steps=0.05 if grad_comm == "f32" else 0.25,
                        err_max_in_lr_steps=float(err.max()) / (LR * STEPS), err_mean_in_lr_steps=float(err.mean()) / (LR * STEPS),
                        comm_dtype=grad_comm, backend="nccl" if use_nccl else "gloo (both ranks on cuda:0)"))
-    assert frac_close > (0.999 if grad_comm == "f32" else 0.98), frac_close
+    assert frac_close > 0.9995, frac_close
     assert float(err.max()) <= 2.5 * LR * STEPS and float(moved.max()) > 0.5 * LR

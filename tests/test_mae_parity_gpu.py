@@ -146,7 +146,9 @@ def test_full_size_config_a_against_oracle(B):
     noise = torch.rand(B, 16, generator=g)
     loss_o, pred_o, mask_o, _, _, grads_o = mo.loss_and_grads(st, imgs, cfg_o, 0.75, noise)
     # bars = 2x the errors measured on MI355X (profiles/r03_parity_errors.json); f32 is the north-star mode (1e-3)
-    for dtype, ltol, ptol, gtol in ((torch.float32, 2e-5, 5e-5, 3e-4), (torch.bfloat16, 1e-2, 4e-2, 1e-1)):
+    # measured (B = 256 / 8): f32 loss 0 / 0, pred 1.2e-6, worst gradient 2.0e-6 (patch_embed.proj.weight); bf16 loss 9.5e-5 / 1.4e-4,
+    # pred 6.0e-3, worst gradient 1.07e-2
+    for dtype, ltol, ptol, gtol in ((torch.float32, 1e-6, 2.5e-6, 4e-6), (torch.bfloat16, 3e-4, 1.2e-2, 2.2e-2)):
         eng = MAEEngine(config_for("base", patch_size=16, in_chans=5, img_size=64, embed_dim=768), compute_dtype=dtype, seed=0)
         eng.load_state_dict(st)
         loss, pred, mask = eng.forward_train(imgs.cuda(), 0.75, noise.cuda())

@@ -127,7 +127,9 @@ def _mim19_batch(cfg, B, seed, ratio=0.6):
 
 
 # bf16 bars of the mim_19 geometry test = 2x the errors measured on MI355X (profiles/r03_parity_errors.json)
-BF16_LOSS_BAR, BF16_PRED_BAR, BF16_GRAD_REL_BAR, BF16_GRAD_MAX_BAR = 1e-2, 3e-2, 8e-2, 6e-2
+# (measured: loss 4.0e-6, prediction image 3.9e-3 rel-L2, worst gradient 4.8e-2 rel-L2 / 4.7e-2 of its maximum -- patch_embed.proj.weight
+# at this narrow width; the loss bar is the f32 mode's, twice the measured bf16 figure would be below it)
+BF16_LOSS_BAR, BF16_PRED_BAR, BF16_GRAD_REL_BAR, BF16_GRAD_MAX_BAR = 2e-5, 8e-3, 8e-2, 6e-2
 
 
 def test_mim19_geometry_against_oracle():
