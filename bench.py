@@ -476,6 +476,33 @@ def pmc_traffic(args):
     return prof["kernels"]["cosine_topk_stream_kernel<8>"]["traffic_bytes_per_launch"]
 
 
+def parity_of_timed_mode(args, mo, cfg_o, st):
+    """Checker leg (outside every timed region): the mode the headline times -- bf16 MFMA GEMMs -- and the fp32 parity mode on a
+    B = 32 slice of the benchmark's synthetic batch against the CPU oracle with the same weights, noise and inputs."""
+    from sky_embeddings_amd.engine import MAEEngine
+    from sky_embeddings_amd.model_config import config_for
+    import numpy as np
+    B = 32
+    g = torch.Generator().manual_seed(1234)
+    imgs = torch.randn(B, 5, 64, 64, generator=g).clamp_(min=-3.0)
+    noise = torch.rand(B, 16, generator=g)
+    loss_o, pred_o, mask_o, _, _, grads_o = mo.loss_and_grads(st, imgs, cfg_o, 0.75, noise)
+    out = {"sample": "config A, B = 32 slice of the synthetic batch, seed-0 reference init, against oracle/mae_oracle.py (fp32, CPU)"}
+    for name, dtype in (("bf16", torch.bfloat16), ("f32", torch.float32)):
+        eng = MAEEngine(config_for("base", patch_size=16, in_chans=5, img_size=64, embed_dim=768), compute_dtype=dtype, seed=0)
+        eng.load_state_dict(st)
+        loss, pred, mask = eng.forward_train(imgs.cuda(), 0.75, noise.cuda())
+        eng.backward()
+        torch.cuda.synchronize()
+        rel = lambda a, b: float(np.linalg.norm(a.double().numpy() - b.double().numpy()) / (np.linalg.norm(b.double().numpy()) + 1e-30))
+        gr = max(rel(eng.store.grad(k).cpu().reshape(grads_o[k].shape), grads_o[k]) for k in eng.store.order)
+        out[name] = dict(loss_rel=abs(float(loss) - float(loss_o)) / float(loss_o), pred_rel_l2=rel(pred.cpu(), pred_o),
+                         grad_rel_l2_max=gr, mask_equal=bool(torch.equal(mask.cpu(), mask_o)))
+        del eng
+        torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baselines(args, search_inputs):
     """The CPU restatement (oracle/) timed on this box's host cores, rank 0 at N = 1 only, on bounded samples of the SAME
     workloads (BASELINE.md section 3): pretraining = config A at B = 256, one warm-up + three timed optimiser steps;
@@ -485,6 +512,7 @@ def cpu_baselines(args, search_inputs):
     threads = torch.get_num_threads()
     cfg = mo.config_for("base", patch_size=16, in_chans=5, img_size=64, embed_dim=768)
     st = mo.init_state(cfg, seed=0)
+    parity = parity_of_timed_mode(args, mo, cfg, st)           # (before the oracle's optimiser steps move `st`)
     tr = mo.Trainer(cfg, st, init_lr=1e-4, weight_decay=0.05, total_iters=1_000_000, final_lr_factor=1e7)
     B = args.batch
     g = torch.Generator().manual_seed(1234)
@@ -497,6 +525,7 @@ def cpu_baselines(args, search_inputs):
     pre = dict(value=B / dt, unit="images/sec", cores=threads, kind="port",
                sample=f"config A at B={B}: 1 warm-up + 3 timed optimiser steps (fwd+bwd+AdamW), torch fp32 CPU restatement "
                       f"(oracle/mae_oracle.py), {dt:.2f} s per step")
+    pre["parity"] = parity
     sea = None
     if search_inputs is not None:
         queries, w, bank = search_inputs
@@ -619,6 +648,7 @@ def main():
             }
         if world == 1 and not args.skip_cpu:
             cpre, csea = cpu_baselines(args, search_inputs)
+            line["parity"] = cpre.pop("parity")
             line["cpu_baseline"] = cpre
             if search is not None and csea is not None:
                 line["search"]["cpu_baseline"] = csea
