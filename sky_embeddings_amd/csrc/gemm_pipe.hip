@@ -870,6 +870,12 @@ int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
             if (St < 1) St = 1;
             gt.tile = 64064;
             gt.split_k = St;
+            // short k-loops: the tail as ONE launch of the two-k-group tile (at most one workgroup per CU, no slabs, no reduce
+            // launch -- mim_19 spent 145 reduce launches per step on its row tails)
+            if (wk2_on && (g.K / BK) % 2 == 0 && g.K <= 2048 && t64 <= 256) {
+                gt.tile = 9064064;
+                gt.split_k = 1;
+            }
             const int rc = dispatch_code(tile, gm, st);
             if (rc != 0) return rc;
             return skyemb_gemm_pipe_try(gt, st);
