@@ -247,6 +247,10 @@ int skyemb_simmim_pixel_loss(const float *imgs, const float *pred_tok, const flo
                              int dtype, float *pred_img, float *ws, int B, int C, int H, int W, int p, int extra,
                              float pixel_mean, float pixel_std, int norm_pix, int loss_l1, int pooled, void *stream);
 
+/* dst[0..3] = {a, b, c, d} by a kernel launch (the values travel as kernel arguments): how the scalars of optimiser step t --
+ * lr, 1 - beta1^t, 1 - beta2^t -- reach the device buffer `hyper` of skyemb_adamw / skyemb_adamw_desc in front of a replayed HIP
+ * graph (torch.optim.AdamW keeps them on the host: utils/pretrain_fns.py:36-41). */
+int skyemb_set_scalars(float *dst, float a, float b, float c, float d, void *stream);
 /* ----------------------------------------------------------- optimiser ----
  * torch.optim.AdamW single-tensor update order (utils/mim_vit.py:126-129,
  * utils/pretrain_fns.py:36-41) over one flat fp32 parameter buffer:

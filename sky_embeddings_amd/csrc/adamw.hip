@@ -54,7 +54,21 @@ __global__ __launch_bounds__(256) void adamw_kernel(float *__restrict__ p, GT *_
     }
 }
 
+__global__ void set_scalars_kernel(float *dst, float a, float b, float c, float d) {
+    if (threadIdx.x == 0) { dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d; }
+}
+
 }  // namespace
+
+// four floats into device memory by a kernel launch (values travel as kernel arguments): the step scalars of a graph-replayed
+// optimiser step.  (A 16-byte host-to-device copy in front of every step put the copy engine's hand-over to the compute queue
+// -- tens of microseconds -- on the step's critical path.)
+extern "C" int skyemb_set_scalars(float *dst, float a, float b, float c, float d, void *stream) {
+    SKY_CHECK_ARG(dst != nullptr, "skyemb_set_scalars: null destination");
+    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dst, a, b, c, d);
+    SKY_LAUNCH_CHECK("skyemb_set_scalars");
+    return 0;
+}
 
 extern "C" int skyemb_adamw(float *p, void *g, float *m, float *v, void *p_lp, int dtype, int64_t n, int64_t n_decay,
                             const float *hyper, float lr, float bc1, float bc2, float beta1, float beta2, float eps,

@@ -254,6 +254,10 @@ def adamw(p, g, m, v, p_lp, n, n_decay, hyper, beta1, beta2, eps, wd, grad_scale
                              beta2, eps, wd, grad_scale, int(zero_grad), dtype_code(g.dtype), _stream()), "skyemb_adamw")
 
 
+def set_scalars(dst, a, b=0.0, c=0.0, d=0.0):
+    check(lib().skyemb_set_scalars(_p(dst), a, b, c, d, _stream()), "skyemb_set_scalars")
+
+
 def cast(src, dst, n):
     check(lib().skyemb_cast(_p(src), _p(dst), dtype_code(dst.dtype), n, _stream()), "skyemb_cast")
 

@@ -54,27 +54,14 @@ class FusedAdamW:
         graph; the optimiser step fused into the weight-gradient launches reads them from there)."""
         if self.hyper_device is None:
             self.hyper_device = torch.zeros(4, device=device, dtype=torch.float32)
-            # a ring of pinned slots: the host runs steps ahead of the GPU, so the slot an asynchronous copy reads must not be
-            # rewritten before that copy has run (one shared slot handed step t's launches the scalars of step t + 1)
-            self._hyper_host = torch.zeros(32, 4, dtype=torch.float32).pin_memory()
-            self._hyper_done = [None] * 32
-            self._hyper_slot = 0
         self.write_scalars(max(self.step_count, 1))
         return self.hyper_device
 
     def write_scalars(self, t):
-        """Device scalars of optimiser step t (async copy on the current stream, ordered before the launches that follow)."""
+        """Device scalars of optimiser step t: a one-thread kernel launch on the current stream whose ARGUMENTS carry the values
+        (ordered before the launches that follow; nothing on the host is read later, so the host may run steps ahead)."""
         lr, bc1, bc2 = self.step_scalars(t)
-        k = self._hyper_slot
-        self._hyper_slot = (k + 1) % len(self._hyper_done)
-        if self._hyper_done[k] is not None:
-            self._hyper_done[k].synchronize()                  # (32 steps behind: practically never waits)
-        row = self._hyper_host[k]
-        row[0], row[1], row[2] = lr, bc1, bc2
-        self.hyper_device.copy_(row, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self._hyper_done[k] = ev
+        ops.set_scalars(self.hyper_device, lr, bc1, bc2)
 
     def begin_step(self):
         """Open optimiser step t; follow with apply_range() calls that together cover [0, n) exactly once (a backward

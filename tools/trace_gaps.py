@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Per-launch durations AND inter-kernel gaps of the replayed step from a rocprofv3 kernel_trace.csv.
-usage: trace_gaps.py <kernel_trace.csv> [launches_per_step]  -- takes the last 20 steps (each step ends with adamw_kernel)."""
+usage: trace_gaps.py <kernel_trace.csv> [rows]  -- takes the last 20 steps (each step starts with its mask_kernel launch)."""
 import csv, sys, re, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-ends = [i for i, r in enumerate(rows) if "adamw_kernel" in r["Kernel_Name"]]
-first, last = ends[-21] + 1, ends[-1] + 1          # 20 whole steps
+starts = [i for i, r in enumerate(rows) if "mask_kernel" in r["Kernel_Name"] and "simmim" not in r["Kernel_Name"]]
+first, last = starts[-21], starts[-1]              # 20 whole steps (the noise draw in front of mask_kernel goes with the previous step)
 steps = 20
 sel = rows[first:last]
 span = (int(sel[-1]["End_Timestamp"]) - int(sel[0]["Start_Timestamp"])) / steps / 1e3
