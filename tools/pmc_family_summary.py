@@ -4,7 +4,12 @@ matrix-core utilisation (SQ_VALU_MFMA_BUSY_CYCLES against the SIMD-cycles the la
 usage: pmc_family_summary.py <out.json> <pass.csv> [<pass.csv> ...]      (every CSV = one pass; counters may repeat)"""
 import csv, json, re, sys, collections
 out, paths = sys.argv[1], sys.argv[2:]
-STEPS, SIMDS, XCDS = 3, 1024, 8
+SIMDS, XCDS = 1024, 8
+# executions of the step in the profiled run = launches of a once-per-step kernel (pmc_step.py: three steps + the warm-up
+# execution TrainStep makes when the optimiser step is fused into the weight-gradient launches)
+_first = list(csv.DictReader(open(paths[0])))
+_c0 = _first[0]["Counter_Name"]
+STEPS = sum(1 for r in _first if r["Counter_Name"] == _c0 and "loss_finalize" in r["Kernel_Name"])
 def family(k):
     if "gemm_pipe_group" in k: return "gemm_group (weight gradients)"
     if "gemm_pipe_kernel" in k:
