@@ -67,6 +67,10 @@ class FusedAdamW:
         """Open optimiser step t; follow with apply_range() calls that together cover [0, n) exactly once (a backward
         stage's slices can be updated while later stages still compute: see TrainStep)."""
         self.step_count += 1
+        if self.hyper_device is not None:
+            # device-resident step scalars (a fused TrainStep switched them on): every path that opens a step refreshes them,
+            # or an eager optimizer.step() after graph-mode steps would read the scalars of an older step
+            self.write_scalars(self.step_count)
 
     def apply_range(self, start, end):
         """AdamW update of flat elements [start, end) on the current stream (start, end multiples of 8: tensor bounds)."""

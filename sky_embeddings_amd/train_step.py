@@ -195,8 +195,7 @@ class TrainStep:
             self.load_batch(imgs, mask, ra_dec)
         if self.fused_adamw:
             # step t's scalars to the device, forward + backward (+ the fused updates), the ordinary kernel on the rest
-            self.optimizer.begin_step()
-            self.optimizer.write_scalars(self.optimizer.step_count)
+            self.optimizer.begin_step()                    # (writes step t's scalars to the device buffer)
             if self.graphs is not None:
                 self.graphs[0].replay()
             else:

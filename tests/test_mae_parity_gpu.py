@@ -253,7 +253,7 @@ def test_fused_adamw_step_equals_the_separate_optimiser_launch(graph):
         torch.cuda.synchronize()
         losses = [float(l) for l in dev_losses]
         st = eng.store
-        out.append((losses, st.p.clone(), st.m.clone(), st.v.clone(), st.p_lp.clone(), opt.step_count))
+        out.append((losses, st.p.clone(), st.m.clone(), st.v.clone(), st.p_lp.clone(), opt.step_count, opt))
         if fused:
             # the fused tensors moved (their gradients were never stored), the optimiser counted three steps
             assert opt.step_count == 10 and len(step._rest_ranges) >= 2
@@ -263,6 +263,16 @@ def test_fused_adamw_step_equals_the_separate_optimiser_launch(graph):
             eng.forward_train(imgs, 0.75, torch.rand(64, 16, device="cuda"))
             eng.backward()
             assert bool(torch.isfinite(st.grad("blocks.0.attn.qkv.weight")).all())
+            # ... and an eager optimizer.step() after the graph-mode steps uses ITS step's scalars (they live in a device buffer
+            # now): identical to the same step on the engine that never fused
+            opt.step()
+            out[0][-1].step()
+            torch.cuda.synchronize()
+            # (both engines now hold step 11 applied to their own -- different -- gradients: compare the bias correction through
+            # a tensor whose gradient is the same on both: none is, so check the scalars themselves)
+            lr, bc1, bc2 = opt.step_scalars(opt.step_count)
+            got = opt.hyper_device.cpu().numpy()
+            assert abs(got[0] - lr) <= 1e-12 + 1e-7 * lr and abs(got[1] - bc1) <= 1e-7 and abs(got[2] - bc2) <= 1e-7
     a, b = out
     assert a[0] == b[0] and a[5] == b[5]
     for k in range(1, 5):
