@@ -266,6 +266,8 @@ class MAEEngine:
                         w["wgrad_groups"][f"{tag}.{i}"] = self._make_wgrad_group(f"{tag}.{i}", bufs, M_, dim, w)
         if train and getattr(self, "_fused_adamw", None) is not None and w.get("wgrad_groups"):
             self._build_adamw_groups(w)
+        if train and getattr(self, "_g16", None) is not None and w.get("wgrad_groups"):
+            self._build_variant_groups(w, "g16")
         self._ws[key] = w
         return w
 
@@ -478,10 +480,18 @@ class MAEEngine:
         return [(g_lp, bufs["hact"], f"{prefix}.mlp.fc2", dim, hidden), (dh, bufs["ln2"], f"{prefix}.mlp.fc1", hidden, dim),
                 (g_lp2, bufs["att"], f"{prefix}.attn.proj", dim, dim), (dqkv, bufs["ln1"], f"{prefix}.attn.qkv", 3 * dim, dim)]
 
-    def _make_wgrad_group(self, prefix, bufs, M, dim, w, adamw=None):
+    def _make_wgrad_group(self, prefix, bufs, M, dim, w, adamw=None, g16=None):
         st = self.store
+
+        def dst(name, n_out, k_in):
+            # fp32 into the flat gradient buffer, or (data-parallel runs with bf16 communication) straight into the bf16 mirror
+            # the all-reduce sums: the same rounding the cast kernel applied to the stored fp32 value, one pass less over it
+            if g16 is None:
+                return dict(out_f32=st.grad(f"{name}.weight"))
+            o = st.offsets[f"{name}.weight"]
+            return dict(out=g16[o:o + n_out * k_in].view(n_out, k_in))
         args = [ops.gemm_args(dy, x_in, M=n_out, N=k_in, K=M, a_layout=RC, b_layout=RC, lda=n_out, ldb=k_in,
-                              out_f32=st.grad(f"{name}.weight"), colsum_a=st.grad(f"{name}.bias"))
+                              colsum_a=st.grad(f"{name}.bias"), **dst(name, n_out, k_in))
                 for dy, x_in, name, n_out, k_in in self._wgrad_layers(prefix, bufs, M, dim, w)]
         # (experiments: SKYEMB_WGRAD_TILE_ENC / _DEC force the grouped launch's tile code for one stack)
         import os
@@ -514,24 +524,41 @@ class MAEEngine:
             if "wgrad_groups" in w:
                 self._build_adamw_groups(w)
 
+    # -- data-parallel runs with bf16 gradient communication: the block weights' gradients go straight into the bf16 mirror --
+    def enable_grad_mirror(self, g16):
+        """The grouped weight-gradient launches write bf16 into `g16` (the flat mirror the all-reduce sums) instead of fp32 into
+        the gradient buffer; grad_mirror_ranges(workspace) are the slices they cover -- the caller casts only the rest."""
+        self._g16 = g16
+        for w in self._ws.values():
+            if "wgrad_groups" in w:
+                self._build_variant_groups(w, "g16")
+
+    def grad_mirror_ranges(self, w):
+        return list(w.get("g16_ranges", []))
+
     def fused_adamw_ranges(self, w):
         """Slices of the flat buffers the fused launches of workspace `w` update (merged, ascending)."""
         return list(w.get("fused_ranges", []))
 
     def _build_adamw_groups(self, w):
+        self._build_variant_groups(w, "adamw")
+
+    def _build_variant_groups(self, w, kind):
+        """A second set of the blocks' grouped weight-gradient launches: kind 'adamw' (optimiser step in the epilogue; ranges in
+        w['fused_ranges']) or 'g16' (bf16 output into the communication mirror; w['g16_ranges'])."""
         st = self.store
-        w["wgrad_groups_adamw"] = {}
-        spans = []
+        groups, spans = {}, []
         for prefix, plain in w["wgrad_groups"].items():
             if plain is None:                                 # (token counts the grouped kernel does not take: single launches)
                 continue
             tag, i = prefix.rsplit(".", 1)
             bufs = (w["enc"] if tag == "blocks" else w["dec"])[int(i)]
             M, dim = bufs["ln1"].shape
-            grp = self._make_wgrad_group(prefix, bufs, M, dim, w, adamw=self._fused_adamw)
+            grp = (self._make_wgrad_group(prefix, bufs, M, dim, w, adamw=self._fused_adamw) if kind == "adamw"
+                   else self._make_wgrad_group(prefix, bufs, M, dim, w, g16=self._g16))
             if grp is None:
                 continue
-            w["wgrad_groups_adamw"][prefix] = grp
+            groups[prefix] = grp
             for name in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2"):
                 o = st.offsets[f"{prefix}.{name}.weight"]
                 spans.append((o, o + _pad8(int(np.prod(st.shapes[f"{prefix}.{name}.weight"])))))
@@ -542,7 +569,8 @@ class MAEEngine:
                 merged[-1] = (merged[-1][0], e_)
             else:
                 merged.append((s_, e_))
-        w["fused_ranges"] = merged
+        w["wgrad_groups_adamw" if kind == "adamw" else "wgrad_groups_g16"] = groups
+        w["fused_ranges" if kind == "adamw" else "g16_ranges"] = merged
 
     def _block_bwd(self, x_in, bufs, prefix, M, dim, heads, Bsz, N, g, g_lp, w):
         """g holds d(block output) on entry and d(block input) on exit (fp32); its compute-dtype copy is read from the
@@ -560,7 +588,9 @@ class MAEEngine:
         # engine.backward() called by anybody else -- loss.backward() of the module API, tests -- stores plain gradients)
         fused = (getattr(self, "_fused_active", False) and getattr(self, "_fused_adamw", None) is not None
                  and prefix in w.get("wgrad_groups_adamw", {}))
-        group = (w["wgrad_groups_adamw"] if fused else w["wgrad_groups"]).get(prefix)
+        mirror = (not fused and getattr(self, "_g16_active", False) and getattr(self, "_g16", None) is not None
+                  and prefix in w.get("wgrad_groups_g16", {}))
+        group = (w["wgrad_groups_adamw"] if fused else w["wgrad_groups_g16"] if mirror else w["wgrad_groups"]).get(prefix)
         single = group is None                      # weight gradients launch by launch (fp32 mode)
         g_mid = g_lp if single else self._scratch(w, "g_lp2", s, M * dim).view(M, dim)
         # MLP: x_out = xmid + fc2(gelu(fc1(ln2(xmid))))

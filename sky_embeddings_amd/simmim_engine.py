@@ -140,6 +140,8 @@ class SimMIMEngine(MAEEngine):
                     w["wgrad_groups"][f"blocks.{i}"] = self._make_wgrad_group(f"blocks.{i}", bufs, M, D, w)
         if train and getattr(self, "_fused_adamw", None) is not None and w.get("wgrad_groups"):
             self._build_adamw_groups(w)
+        if train and getattr(self, "_g16", None) is not None and w.get("wgrad_groups"):
+            self._build_variant_groups(w, "g16")
         self._ws[key] = w
         return w
 

@@ -28,6 +28,22 @@ from .distributed import bucket_bounds
 from .optim import CosineLR, FusedAdamW
 
 
+def _subtract_ranges(ranges, holes):
+    """[(s, e), ...] minus [(s, e), ...] (both ascending, disjoint) -> what remains, ascending."""
+    out = []
+    for s, e in ranges:
+        cur = s
+        for hs, he in holes:
+            if he <= cur or hs >= e:
+                continue
+            if hs > cur:
+                out.append((cur, hs))
+            cur = max(cur, he)
+        if cur < e:
+            out.append((cur, e))
+    return out
+
+
 class TrainStep:
     def __init__(self, engine, optimizer: FusedAdamW, scheduler: CosineLR, batch_size: int, mask_ratio: float = 0.75,
                  use_graph: bool = True, process_group=None, world_size: int = 1, warmup_iters: int = 2,
@@ -88,11 +104,29 @@ class TrainStep:
         else:
             self.stages = [((lambda: (self._forward(), engine.backward())), [(0, engine.store.n)])]
         if self.g16 is not None:
-            # bf16 gradient communication: each stage ends with the cast of the slices it has finalised
+            # bf16 gradient communication: the blocks' grouped weight-gradient launches write their bf16 gradients straight
+            # into the mirror (98 % of the bytes: no fp32 store + cast pass for them); each stage ends with the cast of whatever
+            # else it has finalised (embeddings, biases, LayerNorms, the three single weight gradients)
+            direct = os.environ.get("SKYEMB_G16_DIRECT", "1") == "1" and hasattr(engine, "enable_grad_mirror")
+            if direct:
+                engine.enable_grad_mirror(self.g16)
+
             def with_cast(fn, ranges):
+                todo = []
+
                 def run():
-                    fn()
-                    for (s, e) in ranges:
+                    engine._g16_active = direct
+                    try:
+                        fn()
+                    finally:
+                        engine._g16_active = False
+                    if not todo:                              # (the first call has just built the workspace and its groups)
+                        holes = []
+                        if direct:
+                            ws = [w for k, w in engine._ws.items() if k[-1] is True and k[0] == batch_size]
+                            holes = engine.grad_mirror_ranges(ws[-1]) if ws else []
+                        todo.append(_subtract_ranges(ranges, holes))
+                    for (s, e) in todo[0]:
                         ops.cast(engine.store.g[s:e], self.g16[s:e], e - s)
                 return run
             self.stages = [(with_cast(fn, ranges), ranges) for fn, ranges in self.stages]

@@ -201,6 +201,36 @@ def test_staged_backward_equals_monolithic_and_graph_replay():
         assert torch.equal(r[1], results[0][1]) and torch.equal(r[2], results[0][2])
 
 
+def test_bf16_gradient_mirror_written_by_the_weight_gradient_launches(monkeypatch):
+    """Data-parallel schedule with bf16 gradient communication: the grouped weight-gradient launches writing bf16 straight into
+    the mirror give the same mirror, bit for bit, as fp32 gradients + the cast pass (the same rounding of the same accumulator),
+    and so the same parameters after three steps."""
+    from sky_embeddings_amd.engine import MAEEngine
+    from sky_embeddings_amd.model_config import config_for
+    from sky_embeddings_amd.optim import CosineLR, FusedAdamW
+    from sky_embeddings_amd.train_step import TrainStep
+    cfg = config_for("tiny", img_size=64, patch_size=16, in_chans=5, embed_dim=192)
+    g = torch.Generator().manual_seed(0)
+    imgs = torch.randn(64, 5, 64, 64, generator=g).cuda()      # 320 / 1088 token rows: the grouped launches apply
+    results = []
+    for direct, graph in (("0", True), ("1", True), ("1", False)):
+        monkeypatch.setenv("SKYEMB_G16_DIRECT", direct)
+        eng = MAEEngine(cfg, compute_dtype=torch.bfloat16, seed=1)
+        opt = FusedAdamW(eng, lr=1e-3)
+        step = TrainStep(eng, opt, CosineLR(opt, 100), 64, use_graph=graph, staged=True, n_encoder_groups=4, grad_comm="bf16")
+        torch.manual_seed(123)
+        for _ in range(3):
+            loss = step(imgs)
+        torch.cuda.synchronize()
+        w = [w for k, w in eng._ws.items() if k[-1] is True][-1]
+        covered = sum(e - s for s, e in eng.grad_mirror_ranges(w))
+        assert (covered > 0.9 * eng.store.n) == (direct == "1"), (direct, covered, eng.store.n)
+        results.append((float(loss), step.g16.clone(), eng.store.p.clone()))
+    for r in results[1:]:
+        assert r[0] == results[0][0]
+        assert torch.equal(r[1], results[0][1]) and torch.equal(r[2], results[0][2])
+
+
 def test_fused_adamw_step_at_the_benchmark_size():
     """The same bit-equality at BASELINE configs[1] (ViT-B/16, B = 256): the 128x128 (encoder) and 128x64 (decoder) grouped
     launches with the optimiser step in their epilogue against the separate AdamW launch, four steps, no host sync in between."""
