@@ -126,7 +126,7 @@ int main(int argc, char **argv) {
 #undef X
     }
     const int ROT = 6;
-    size_t max_a = (size_t)Md * 2048, max_b = (size_t)3072 * 4352, max_o = (size_t)Md * 2048;
+    size_t max_a = (size_t)Md * 3072, max_b = (size_t)3072 * 4352, max_o = (size_t)Md * 2048;
     for (const Shape &s : shapes) {
         max_a = std::max(max_a, (size_t)s.M * s.K);
         max_b = std::max(max_b, (size_t)s.N * s.K);
@@ -180,7 +180,7 @@ int main(int argc, char **argv) {
                 continue;
             Shape s = s0;
             s.epi = 1;
-            if (code / 1000000 >= 9 && !s.a_kc) continue;      // two-k-group tiles: k-contiguous A only
+            if ((code / 1000000 >= 9 || code % 1000000 == 256256) && !s.a_kc) continue;      // two-k-group tiles, 256x256: k-contiguous A only
             skyemb_gemm_args g = make_args(s, 0, code, 1);
             g.resid = nullptr; g.bias = nullptr;
             CK(hipMemset(o32, 0xff, (size_t)s.M * s.N * 4));
@@ -355,6 +355,30 @@ int main(int argc, char **argv) {
         }
         return 0;
     }
+    if (getenv("LAB_WSWEEP")) {
+        // weight-gradient launches (both operands row-contiguous, contraction over token rows): time vs the token count
+        for (int code : codes) {
+            if (code / 1000000 >= 9) continue;
+            int bm, bn;
+            tile_dims(code, bm, bn);
+            for (auto mn : {std::pair<int, int>{2048, 512}, {512, 2048}, {1536, 512}, {3072, 768}, {768, 3072}, {2304, 768}}) {
+                const int64_t tiles = ceil_div64(mn.first, bm) * ceil_div64(mn.second, bn);
+                printf("wsweep code %7d M %d N %d (%4ld tiles):", code, mn.first, mn.second, (long)tiles);
+                float t1 = 0, t2 = 0;
+                for (int K : {256, 1088, 2176, 4352}) {
+                    Shape s{"w", mn.first, mn.second, K, 0, 0, 1, 4};
+                    if ((size_t)mn.first * K > max_a || (size_t)mn.second * K > max_b || (size_t)mn.first * mn.second > max_o) continue;
+                    const float t = time_us(s, code, 1);
+                    printf("  K%d:%.1f", K, t);
+                    if (K == 2176) t1 = t;
+                    if (K == 4352) t2 = t;
+                }
+                const double per_step = (t2 - t1) / 34.0;
+                printf("  | %.2f us/k-step, %.0f TF/s at K = 4352\n", per_step, 2.0 * mn.first * mn.second * 4352 / t2 / 1e6);
+            }
+        }
+        return 0;
+    }
     if (getenv("LAB_KSWEEP")) {
         // time vs K at fixed M, N: the intercept is the launch + prologue + epilogue cost, the slope the k-loop
         const int epi = atoi(getenv("LAB_KSWEEP"));
@@ -362,7 +386,9 @@ int main(int argc, char **argv) {
         for (int code : codes) {
             int bm, bn;
             tile_dims(code, bm, bn);
-            for (auto mn : {std::pair<int, int>{1280, 3072}, {1280, 768}, {4352, 2048}, {4352, 512}}) {
+            std::vector<std::pair<int, int>> mns = {{1280, 3072}, {1280, 768}, {4352, 2048}, {4352, 512}};
+            if (vitl) mns = {{8320, 4096}, {8320, 3072}, {8320, 1024}, {8192, 4096}, {8192, 1024}};
+            for (auto mn : mns) {
                 const int64_t tiles = ceil_div64(mn.first, bm) * ceil_div64(mn.second, bn);
                 printf("ksweep code %7d epi %d M %d N %d (%4ld tiles):", code, epi, mn.first, mn.second, (long)tiles);
                 float t768 = 0, t1536 = 0;
