@@ -398,6 +398,12 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
         unsigned int msk[MI / 2];
 #pragma unroll
         for (int w2 = 0; w2 < MI / 2; ++w2) msk[w2] = 0;
+#ifdef PF_NOTEST   // experiment build: the accumulators are consumed, no pair is tested (what the 128 tests per lane and item cost)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+#else
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -412,6 +418,7 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
                 // (keeps the scheduler from fetching all 4 MI parameter rows up front: 128 more live registers than there are)
                 if (MI > 4 && r == 3) __builtin_amdgcn_sched_barrier(0);
             }
+#endif
         unsigned int any = 0;
 #pragma unroll
         for (int w2 = 0; w2 < MI / 2; ++w2) any |= msk[w2];
