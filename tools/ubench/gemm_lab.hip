@@ -166,7 +166,7 @@ int main(int argc, char **argv) {
             case 1: g.bias = bias; g.resid = resid; g.ldr = s.N; g.out_f32 = o32; g.ldo32 = s.N; break;
             case 2: g.bias = bias; g.act = SKYEMB_ACT_GELU; g.out = o16; g.ldo = s.N; g.out2 = o16b; g.ldo2 = s.N; break;
             case 3: g.act = SKYEMB_ACT_DGELU; g.aux = aux; g.ldaux = s.N; g.out = o16; g.ldo = s.N; break;
-            default: g.out_f32 = o32; g.ldo32 = s.N; g.colsum_a = colsum; break;
+            default: g.out_f32 = o32; g.ldo32 = s.N; g.colsum_a = getenv("LAB_NOCOLSUM") ? nullptr : colsum; break;
         }
         return g;
     };
