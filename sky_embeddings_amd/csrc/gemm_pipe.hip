@@ -181,8 +181,13 @@ __device__ __forceinline__ bf16x8 frag_rc_asm(const char *sbase, int rbase, int 
     const int kb = kk * 32 + 8 * (lane >> 4);
     const int ch = (rbase >> 3) + (p >> 1);
     bf16x4 lo, hi;
+#ifdef SKY_RC_AS_B64      // experiment build (wrong products): plain 8-byte reads at the same addresses -- same k-step time
+    asm volatile("ds_read_b64 %0, %1" : "=v"(lo) : "v"(lds_addr(sbase + rc_off<R>(kb + q, ch) + 8 * (p & 1))) : "memory");
+    asm volatile("ds_read_b64 %0, %1" : "=v"(hi) : "v"(lds_addr(sbase + rc_off<R>(kb + 4 + q, ch) + 8 * (p & 1))) : "memory");
+#else
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(lds_addr(sbase + rc_off<R>(kb + q, ch) + 8 * (p & 1))) : "memory");
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(lds_addr(sbase + rc_off<R>(kb + 4 + q, ch) + 8 * (p & 1))) : "memory");
+#endif
     bf16x8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
@@ -360,11 +365,13 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
                 for (int i = 0; i < TM; ++i) lds_use(fa[kk][i]);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) lds_use(fb[kk][j]);
+#ifndef SKY_NOMFMA     // experiment build: load pipeline + fragment reads, no matrix instruction
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);  // D[n][m]
+#endif
                 if (!A_KC && do_colsum) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
