@@ -171,6 +171,33 @@ def test_mim19_geometry_against_oracle():
                 assert grel[k] < BF16_GRAD_REL_BAR or gmax[k] < BF16_GRAD_MAX_BAR, (k, grel[k], gmax[k])
 
 
+def test_simmim_bf16_gradient_mirror_written_by_the_weight_gradient_launches(monkeypatch):
+    """SimMIM mode of the data-parallel schedule with bf16 gradient communication (mim_19 geometry at a narrow width, 64 x 65 token
+    rows so that the grouped launches apply): bf16 gradients written straight into the mirror == fp32 gradients + cast, bit for bit."""
+    from sky_embeddings_amd.model_config import config_for
+    from sky_embeddings_amd.optim import CosineLR, FusedAdamW
+    from sky_embeddings_amd.simmim_engine import SimMIMEngine
+    from sky_embeddings_amd.train_step import TrainStep
+    cfg = config_for("simmim", img_size=128, patch_size=16, in_chans=5, embed_dim=128, depth=2, num_heads=4, norm_pix_loss=True, loss_fn="L1")
+    B = 64
+    x, m, _ = _mim19_batch(cfg, B, seed=3)
+    results = []
+    for direct in ("0", "1"):
+        monkeypatch.setenv("SKYEMB_G16_DIRECT", direct)
+        eng = SimMIMEngine(cfg, device="cuda", compute_dtype=torch.bfloat16, seed=0)
+        opt = FusedAdamW(eng, lr=1e-3)
+        step = TrainStep(eng, opt, CosineLR(opt, 100), B, use_graph=True, staged=True, n_encoder_groups=2, grad_comm="bf16")
+        for _ in range(3):
+            loss = step(x.cuda(), m.cuda())
+        torch.cuda.synchronize()
+        w = [w for k, w in eng._ws.items() if k[-1] is True][-1]
+        covered = sum(e - s for s, e in eng.grad_mirror_ranges(w))
+        assert (covered > 0.5 * eng.store.n) == (direct == "1"), (direct, covered, eng.store.n)
+        results.append((float(loss), step.g16.clone(), eng.store.p.clone()))
+    assert results[0][0] == results[1][0]
+    assert torch.equal(results[0][1], results[1][1]) and torch.equal(results[0][2], results[1][2])
+
+
 def test_mim19_full_size_step_properties():
     """configs/mim_19.ini at full size (SimMIM ViT-Large/16, 5x128x128, B = 128, bf16): the ini builds the model the
     BASELINE names, the loss is finite and close to the untrained level, every gradient is finite, the HIP-graph step
