@@ -573,7 +573,7 @@ def spawn_ranks(args):
     import socket
     import subprocess
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and os.environ.get("SKYEMB_BENCH_REHEARSAL", "0") != "1":
         print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible on this node", file=sys.stderr)
         return 3
     with socket.socket() as sk:
@@ -594,10 +594,18 @@ def main():
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
+    # SKYEMB_BENCH_REHEARSAL=1: every rank on cuda:0 over gloo -- walks the N > 1 code path of this file on a one-GPU box (the
+    # numbers mean nothing: the ranks share the card and the collectives go through the host; the line says so)
+    rehearsal = world > 1 and os.environ.get("SKYEMB_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     pre, eng = bench_pretrain(args, rank, world, dev)
@@ -634,7 +642,9 @@ def main():
             "config": {"workload": "mim_32.ini-as-BASELINE configs[1]: MAE ViT-Base/16, 5x64x64, mask_ratio=0.75, "
                                    f"bs={pre['B']}/GPU, AdamW+cosine, norm_pix mse",
                        "global_batch": pre["B"] * world, "parallelism": f"dp{world}",
-                       "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
+                       "rccl_ranks": 0 if rehearsal else torch.distributed.get_world_size() if world > 1 else 1,
+                       **({"rehearsal": "SKYEMB_BENCH_REHEARSAL=1: all ranks on cuda:0 over gloo; a walk through the N > 1 code path, "
+                                        "NOT a measurement"} if rehearsal else {}),
                        "graph": not args.no_graph, "adamw_in_wgrad_epilogue": bool(pre.get("fused_adamw"))},
             "roofline": {"bound": "mfma", "achieved": gi["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": gi["tflops"] / peak,
                          "traffic": gemm_pmc_traffic(),
