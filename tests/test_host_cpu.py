@@ -415,6 +415,38 @@ def test_tile_file_discovery_and_overlap_grid(tmp_path):
     assert generate_overlap_coords((8, 8), 4, 0.0) == [(0, 0), (0, 4), (4, 0), (4, 4)]
 
 
+def test_fits_lite_header_grammar_against_a_third_party_file():
+    """The header-card grammar and the HDU walk (the parts of fits_lite every image read rests on) against a FITS file this repo
+    did not write: numpy ships `recarray_from_file.fits` (STScI STSDAS TABLES, 2001: an empty primary HDU + one BINTABLE) in its
+    test data.  Skipped where that file is absent."""
+    import numpy
+    from sky_embeddings_amd import fits_lite
+    path = os.path.join(os.path.dirname(numpy.__file__), "_core", "tests", "data", "recarray_from_file.fits")
+    if not os.path.exists(path):
+        pytest.skip("numpy's test data is not installed")
+    buf = open(path, "rb").read()
+    assert len(buf) == 3 * fits_lite.BLOCK
+    h0, pos = fits_lite._read_header(buf, 0)
+    assert pos == fits_lite.BLOCK
+    assert h0["SIMPLE"] is True and h0["BITPIX"] == 16 and h0["NAXIS"] == 0 and h0["EXTEND"] is True and h0["NEXTEND"] == 1
+    assert h0["ORIGIN"] == "STScI-STSDAS/TABLES" and h0["FILENAME"] == "tb.fits"      # quoted strings, trailing blanks dropped
+    assert "COMMENT" not in h0 and "HISTORY" not in h0
+    assert fits_lite._data_bytes(h0) == 0                                             # NAXIS = 0: the extension follows at once
+    h1, pos1 = fits_lite._read_header(buf, pos)
+    assert pos1 == 2 * fits_lite.BLOCK
+    assert h1["XTENSION"] == "BINTABLE" and (h1["BITPIX"], h1["NAXIS"], h1["NAXIS1"], h1["NAXIS2"]) == (8, 2, 17, 3)
+    assert (h1["PCOUNT"], h1["GCOUNT"], h1["TFIELDS"]) == (0, 1, 3)
+    assert [h1[f"TFORM{i}"] for i in (1, 2, 3)] == ["1D", "1J", "5A"] and [h1[f"TTYPE{i}"] for i in (1, 2, 3)] == ["a", "b", "c"]
+    assert h1["TNULL2"] == -2147483647 and h1["TDISP1"] == "G25.16"
+    n = fits_lite._data_bytes(h1)
+    assert n == 17 * 3 and pos1 + -(-n // fits_lite.BLOCK) * fits_lite.BLOCK == len(buf)   # data padded to one block: end of file
+    # the table rows decode with the formats the header names (big-endian 1D, 1J, 5A): what numpy's own test reads from this file
+    rows = np.frombuffer(buf, dtype=np.dtype([("a", ">f8"), ("b", ">i4"), ("c", "S5")]), count=3, offset=pos1)
+    assert np.all(np.isfinite(rows["a"])) and rows["c"].dtype.itemsize == 5
+    with pytest.raises(NotImplementedError):                                           # a table is not an image HDU
+        fits_lite.read_image_hdu(path, hdu=1)
+
+
 def test_fits_lite_reads_lossless_tile_compressed_images(tmp_path):
     """ZIMAGE binary tables with the lossless gzip codecs (FITS 4.0 section 10; what fpack -g / the LSST stack's GZIP_SHUFFLE
     write) decode to the same pixels and keep the image header; lossy / other codecs are refused by name."""
