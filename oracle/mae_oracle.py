@@ -336,7 +336,8 @@ def block(x, st, prefix, num_heads, eps):
     """timm ``Block`` as the reference instantiates it (mim_vit.py:231-233):
     pre-LN, qkv bias, softmax(q k^T * hd^-0.5) v, exact-erf GELU MLP, no
     dropout / drop-path / LayerScale / qk-norm (SURVEY §8c stand-in contract).
-    THIRD-PARTY ARITHMETIC, parity unpinned (timm, no pinned version)."""
+    THIRD-PARTY ARITHMETIC, parity unpinned (timm, no pinned version); checked against an independent implementation of the
+    same layer (transformers' ViTLayer) in tests/test_oracle_golden.py."""
     B, N, D = x.shape
     hd = D // num_heads
     h = layer_norm(x, st[f"{prefix}.norm1.weight"], st[f"{prefix}.norm1.bias"], eps)

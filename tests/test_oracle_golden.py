@@ -214,3 +214,59 @@ def test_mask_generator_oracle_matches_reference_counts():
         assert bool((ref_count == ref_count[:, :1]).all())                                     # same count in every channel
         differs = (masks[:, 0] != masks[:, 1]).flatten(1).any(dim=1)
         assert bool(differs[ref_count[:, 0] > 0].float().mean() > 0.8)                         # channels masked independently
+
+
+def test_block_arithmetic_against_an_independent_implementation():
+    """The transformer block the oracle restates (timm's `Block`, which is not installed: SURVEY 8c stand-in contract) against an
+    INDEPENDENT published implementation of the same pre-norm ViT layer that is installed: Hugging Face `transformers`
+    `ViTLayer` (separate q / k / v projections, eager attention, exact-erf GELU, LayerNorm eps from the config).  Same weights,
+    same input: outputs AND input / weight gradients agree to fp32 rounding.  Pins the block's arithmetic (LayerNorm placement,
+    head split of the fused qkv, score scaling, softmax axis, residuals, GELU flavour) to third-party code; the timm wiring
+    around it (cls token, pos-embed, final norm) stays pinned by the reference-generated goldens only."""
+    tr = pytest.importorskip("transformers")
+    from transformers import ViTConfig
+    from transformers.models.vit.modeling_vit import ViTLayer
+    D, H, hidden, eps = 96, 6, 384, 1e-6
+    cfg = ViTConfig(hidden_size=D, num_attention_heads=H, intermediate_size=hidden, hidden_act="gelu", layer_norm_eps=eps,
+                    qkv_bias=True, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    cfg._attn_implementation = "eager"
+    layer = ViTLayer(cfg).eval()
+    g = torch.Generator().manual_seed(11)
+    st = {}
+    for name, shape in (("norm1.weight", (D,)), ("norm1.bias", (D,)), ("attn.qkv.weight", (3 * D, D)), ("attn.qkv.bias", (3 * D,)),
+                        ("attn.proj.weight", (D, D)), ("attn.proj.bias", (D,)), ("norm2.weight", (D,)), ("norm2.bias", (D,)),
+                        ("mlp.fc1.weight", (hidden, D)), ("mlp.fc1.bias", (hidden,)), ("mlp.fc2.weight", (D, hidden)),
+                        ("mlp.fc2.bias", (D,))):
+        t = torch.randn(*shape, generator=g) * (0.2 if name.endswith("weight") and len(shape) == 2 else 0.5)
+        if name in ("norm1.weight", "norm2.weight"):
+            t = 1.0 + 0.3 * t
+        st[f"b.{name}"] = t.requires_grad_(True)
+    names = dict(layer.named_parameters())
+    if "attention.q_proj.weight" in names:                      # transformers >= 5
+        qkv = ("attention.q_proj", "attention.k_proj", "attention.v_proj")
+        proj, fc1, fc2 = "attention.o_proj", "mlp.fc1", "mlp.fc2"
+    else:                                                       # transformers 4.x module names
+        qkv = ("attention.attention.query", "attention.attention.key", "attention.attention.value")
+        proj, fc1, fc2 = "attention.output.dense", "intermediate.dense", "output.dense"
+    with torch.no_grad():
+        for i, mod in enumerate(qkv):                           # the fused qkv rows are [q | k | v], each [heads x head_dim]
+            names[f"{mod}.weight"].copy_(st["b.attn.qkv.weight"][i * D:(i + 1) * D])
+            names[f"{mod}.bias"].copy_(st["b.attn.qkv.bias"][i * D:(i + 1) * D])
+        for mod, key in ((proj, "attn.proj"), (fc1, "mlp.fc1"), (fc2, "mlp.fc2"), ("layernorm_before", "norm1"), ("layernorm_after", "norm2")):
+            names[f"{mod}.weight"].copy_(st[f"b.{key}.weight"])
+            names[f"{mod}.bias"].copy_(st[f"b.{key}.bias"])
+    x = torch.randn(3, 17, D, generator=g)
+    dy = torch.randn(3, 17, D, generator=g)
+    xo = x.clone().requires_grad_(True)
+    yo = mo.block(xo, st, "b", H, eps)
+    yo.backward(dy)
+    xh = x.clone().requires_grad_(True)
+    yh = layer(xh)
+    yh = yh[0] if isinstance(yh, tuple) else yh
+    yh.backward(dy)
+    assert rel_err(yo.detach().numpy(), yh.detach().numpy()) < 2e-6
+    assert rel_err(xo.grad.numpy(), xh.grad.numpy()) < 5e-6
+    assert rel_err(st["b.mlp.fc2.weight"].grad.numpy(), names[f"{fc2}.weight"].grad.numpy()) < 5e-6
+    assert rel_err(st["b.norm1.weight"].grad.numpy(), names["layernorm_before.weight"].grad.numpy()) < 5e-6
+    gq = torch.cat([names[f"{m}.weight"].grad for m in qkv])
+    assert rel_err(st["b.attn.qkv.weight"].grad.numpy(), gq.numpy()) < 5e-6
