@@ -75,7 +75,10 @@ class Dataset:
 
     def _cache_valid(self, path, meta, stamp, nbytes):
         try:
-            return os.path.getsize(path) == nbytes and json.load(open(meta)) == stamp
+            if os.path.getsize(path) != nbytes:
+                return False
+            with open(meta) as fh:
+                return json.load(fh) == stamp
         except (OSError, ValueError):
             return False
 
@@ -95,7 +98,13 @@ class Dataset:
         if self._cache_valid(path, meta, stamp, nbytes):
             return np.memmap(path, dtype=self.dtype, mode="r", shape=self.shape)
         with open(path + ".lock", "w") as lock:
-            fcntl.flock(lock, fcntl.LOCK_EX)                    # released when the file is closed (also if the builder dies)
+            locked = True
+            try:
+                fcntl.flock(lock, fcntl.LOCK_EX)                # released when the file is closed (also if the builder dies)
+            except OSError:
+                # some NFS / Lustre mounts have no flock: build unlocked.  Still safe -- every builder writes its own
+                # <pid>.tmp and renames it into place atomically; concurrent builders only duplicate the work.
+                locked = False
             try:
                 if not self._cache_valid(path, meta, stamp, nbytes):      # somebody else may have built it while we waited
                     addr, off = self.chunk_table()
@@ -121,7 +130,8 @@ class Dataset:
                         if os.path.exists(tmp):
                             os.unlink(tmp)
             finally:
-                fcntl.flock(lock, fcntl.LOCK_UN)
+                if locked:
+                    fcntl.flock(lock, fcntl.LOCK_UN)
         return np.memmap(path, dtype=self.dtype, mode="r", shape=self.shape)
 
     def _read_chunked(self, idx):

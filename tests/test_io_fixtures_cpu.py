@@ -1,0 +1,112 @@
+"""CPU: ``hdf5_lite`` and ``fits_lite`` against files WRITTEN BY h5py 3.3.0 / astropy 4.3.1 and against what those libraries
+read back from them (tests/golden/io/, made by tests/golden/make_io_fixtures.py under /opt/conda's interpreter).
+
+This is what pins the product's file readers to the libraries the reference uses (``utils/dataloaders.py:281-328`` h5py,
+``:418-432`` astropy ``fits.open`` + ``WCS.all_pix2world``); before round 4 they were checked against their own writers only.
+"""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from sky_embeddings_amd import fits_lite, hdf5_lite
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+IO = os.path.join(ROOT, "tests", "golden", "io")
+CONDA_PY = "/opt/conda/bin/python3.9"
+
+
+def same(a, b):
+    """bit-equal including NaN payload positions"""
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def check_h5(folder, exp, tmp_path):
+    # (i) fixed-shape datasets written by h5py: contiguous layout (data_processing/utils.py:346-361)
+    with hdf5_lite.File(os.path.join(folder, "h5py_contiguous.h5")) as f:
+        assert sorted(f.keys()) == ["cutouts", "dec", "ra", "zspec", "zspec_err"]
+        for k in f.keys():
+            assert same(f[k][:], exp["contig/" + k]), k
+        assert same(f["cutouts"][1], exp["contig/cutouts"][1])
+    # (ii) maxshape=(None, ...) datasets, grown by two appends: h5py's automatic chunks behind a v1 B-tree
+    with hdf5_lite.File(os.path.join(folder, "h5py_resizable.h5")) as f:
+        assert sorted(f.keys()) == ["class", "cutouts", "dec", "ra"]
+        d = f["cutouts"]
+        full = exp["resizable/cutouts"]
+        assert d.shape == full.shape and d.dtype == np.float32
+        assert tuple(d.chunks) == tuple(int(v) for v in exp["resizable/chunks"])
+        # the chunk shape h5py picked is the one our own writer predicts for this shape (feeder tests rely on that)
+        assert hdf5_lite.h5py_guess_chunk((0,) + full.shape[1:], 4) == tuple(d.chunks)
+        for i in (0, 1, full.shape[0] // 2, full.shape[0] - 1):
+            assert same(d[i], full[i]), i
+        assert same(d[:], full)
+        assert same(f["class"][:], exp["resizable/class"]) and f["class"].dtype == np.int64
+        assert same(f["ra"][:], exp["resizable/ra"]) and same(f["dec"][:], exp["resizable/dec"])
+
+
+def check_fits(folder, exp):
+    hdu = fits_lite.read_image_hdu(os.path.join(folder, "astropy_f4.fits"), hdu=1)
+    assert hdu.bitpix == -32 and hdu.raw.dtype == np.dtype(">f4")
+    want = exp["fits_f4/data"]
+    assert same(hdu.array(), want.astype(np.float32))           # astropy hands out big-endian floats; values identical
+    wcs = fits_lite.TanSipWCS(hdu.header)
+    assert wcs.sip and len(wcs.a) == 5 and len(wcs.b) == 5
+    x, y = exp["fits_f4/pix_x"], exp["fits_f4/pix_y"]
+    for origin in (0, 1):
+        ra, dec = wcs.all_pix2world(x, y, origin)
+        # 1e-11 deg = 3.6e-8 arcsec; wcslib iterates nothing here (pix -> world is closed form), so only rounding differs
+        assert np.abs(ra - exp[f"fits_f4/ra_o{origin}"]).max() < 1e-11
+        assert np.abs(dec - exp[f"fits_f4/dec_o{origin}"]).max() < 1e-11
+    hdu = fits_lite.read_image_hdu(os.path.join(folder, "astropy_i2_scaled.fits"), hdu=1)
+    assert hdu.bitpix == 16 and hdu.bscale == 0.25 and hdu.bzero == 100.0
+    want = exp["fits_i2/data"]                                  # astropy: float32 = raw * BSCALE + BZERO for 16-bit integers
+    got = hdu.array()
+    assert np.array_equal(got.astype(want.dtype), want)
+    wcs = fits_lite.TanSipWCS(hdu.header)
+    assert not wcs.sip
+    ra, dec = wcs.all_pix2world(exp["fits_i2/pix_x"], exp["fits_i2/pix_y"], 0)
+    dra = (ra - exp["fits_i2/ra_o0"] + 180.0) % 360.0 - 180.0  # the field straddles RA = 0
+    assert np.abs(dra).max() < 1e-11 and np.abs(dec - exp["fits_i2/dec_o0"]).max() < 1e-11
+    assert ra.min() >= 0.0 and ra.max() < 360.0 and (ra < 1).any() and (ra > 359).any()
+
+
+def test_committed_h5py_files_read_bit_exactly(tmp_path):
+    exp = np.load(os.path.join(IO, "io_expected.npz"))
+    assert "h5py 3.3.0" in list(exp["versions"])
+    check_h5(IO, exp, tmp_path)
+
+
+def test_committed_astropy_files_and_world_coordinates():
+    exp = np.load(os.path.join(IO, "io_expected.npz"))
+    assert "astropy 4.3.1" in list(exp["versions"])
+    check_fits(IO, exp)
+
+
+def test_feeder_source_on_an_h5py_chunked_file(tmp_path):
+    """The feeder's one-off un-chunking (``Dataset._array`` -> contiguous side file) on a file h5py wrote."""
+    exp = np.load(os.path.join(IO, "io_expected.npz"))
+    p = str(tmp_path / "r.h5")
+    shutil.copy(os.path.join(IO, "h5py_resizable.h5"), p)
+    with hdf5_lite.File(p) as f:
+        a = f["cutouts"]._array()
+        assert same(np.asarray(a), exp["resizable/cutouts"])
+
+
+@pytest.mark.skipif(not os.path.exists(CONDA_PY), reason="no /opt/conda interpreter with h5py / astropy in this image")
+def test_live_files_in_the_reference_geometry(tmp_path):
+    """Same checks on files made NOW by the image's own h5py / astropy in the reference's real geometry
+    ([n, 5, 64, 64] cutouts -> chunks (128, 1, 8, 16); too large to commit)."""
+    out = str(tmp_path / "io")
+    env = {"PATH": "/opt/conda/bin:/usr/bin:/bin"}
+    r = subprocess.run([CONDA_PY, os.path.join(ROOT, "tests", "golden", "make_io_fixtures.py"), "--out", out, "--full"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    if r.returncode != 0 and "ModuleNotFoundError" in r.stderr:
+        pytest.skip("conda interpreter lacks h5py / astropy: " + r.stderr.strip().splitlines()[-1])
+    assert r.returncode == 0, r.stderr[-2000:]
+    exp = np.load(os.path.join(out, "io_expected.npz"))
+    assert tuple(int(v) for v in exp["resizable/chunks"]) == (128, 1, 8, 16)
+    check_h5(out, exp, tmp_path)
+    check_fits(out, exp)
