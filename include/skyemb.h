@@ -334,6 +334,10 @@ int skyemb_kth_largest_floor(const float *x, int Q, int S, int k, float *out, vo
  * every score, utils/similarity.py:18-35.) */
 int skyemb_cosine_sample_floor(const float *tw, const float *qn, const float *sample, const float *sample_norms, int Q, int64_t S,
                                int D, int k, float eps, float *ws, float *floor_out, void *stream);
+/* 1 when skyemb_cosine_sample_floor accepts (Q, S, D, k) in THIS process -- the shape limits above and the streaming kernels not
+ * switched off (SKYEMB_TOPK_STREAM=0) -- else 0: the caller then uses skyemb_cosine_scores + skyemb_kth_largest_floor.  Base
+ * addresses of tw and sample must additionally be 16-byte aligned (checked by the call itself). */
+int skyemb_cosine_sample_floor_applicable(int Q, int64_t S, int D, int k);
 int skyemb_topk_merge(const float *in_s, const int64_t *in_i, int Q, int nlists, int k, float *out_s,
                       int64_t *out_i, void *ws, void *stream);
 

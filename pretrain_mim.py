@@ -41,7 +41,7 @@ def main(args):
     rank, world, local = sdist.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("pretrain_mim.py needs a GPU: the hot path is HIP-only (no CPU fallback)")
-    device = torch.device('cuda', local)
+    device = torch.device('cuda', sdist.local_device_index(local))
     torch.cuda.set_device(device)
     if rank == 0:
         print(f'Using Torch version: {torch.__version__}')
@@ -223,6 +223,10 @@ def main(args):
             # an epoch without a single batch (fewer cutouts per rank than one batch): the loop would never end
             raise RuntimeError('the training data yields no batch of %i samples per rank (world size %i)'
                                % (common['batch_size'], world))
+    if os.environ.get('SKYEMB_SAVE_RANK_PARAMS'):
+        # test hook: every rank's flat fp32 master weights, to check that the replicas stayed identical
+        torch.cuda.synchronize(device)
+        torch.save(model.module.engine.store.p.cpu(), os.path.join(os.environ['SKYEMB_SAVE_RANK_PARAMS'], f'rank{rank}.pt'))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

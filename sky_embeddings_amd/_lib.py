@@ -111,6 +111,7 @@ PROTOTYPES = {
                                    c_vp, c_vp]),
     "skyemb_kth_largest_floor": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "skyemb_cosine_sample_floor": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp]),
+    "skyemb_cosine_sample_floor_applicable": (c_i32, [c_i32, c_i64, c_i32, c_i32]),
     "skyemb_topk_merge": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "skyemb_topk_prefilter_applicable": (c_i32, [c_i32, c_i64, c_i32, c_i32]),
     "skyemb_topk_prefilter_ws_bytes": (c_i64, [c_i32, c_i32, c_i32]),

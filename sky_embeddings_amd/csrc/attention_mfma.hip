@@ -12,6 +12,7 @@
 //             dQ^T = K^T . dS^T (sum over j),   dK^T = Q^T . dS,   dV^T = dO^T . P  (sum over i)
 // qkv layout is the reference's [B, N, 3, H, hd] (timm Attention: qkv(x).reshape(B,N,3,H,hd)); softmax statistics,
 // probabilities and dS are fp32, rounded to bf16 only as MFMA operands.
+#include <mutex>
 #include "common.h"
 #include <stdlib.h>
 
@@ -557,15 +558,20 @@ int launch_strip(bool bwd, const bf16_t *x, const bf16_t *dout, bf16_t *out, int
     const dim3 grid(B * H), block(64 * NT);
     const int smem = (bwd ? 4 : 2) * (((N + 3) & ~3) + 4) * (HD + 8) * 2;
     if (smem > 65536) {
-        static bool attr_set = false;                     // (one per instantiation; only the backward kernel gets this large)
-        if (!attr_set) {
+        // one flag per instantiation AND device: the dynamic-LDS limit is an attribute of the function per device
+        static std::mutex attr_mutex;
+        static bool attr_done[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lock(attr_mutex);
+        if (!attr_done[dev & 63]) {
             hipError_t e = hipFuncSetAttribute((const void *)mha_bwd_strip_kernel<HD, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                4 * (32 * NT + 4) * (HD + 8) * 2);     // the longest sequence of this instance
             if (e != hipSuccess) {
                 skyemb_set_error("skyemb_mha: hipFuncSetAttribute: %s", hipGetErrorString(e));
                 return 2;
             }
-            attr_set = true;
+            attr_done[dev & 63] = true;
         }
     }
     if (!bwd) hipLaunchKernelGGL((mha_fwd_strip_kernel<HD, NT>), grid, block, smem, st, x, out, B, N, H);

@@ -12,6 +12,7 @@
 //
 // Block = 256 threads = 4 waves (2x2), tile BM x BN in {128x128, 64x64}, BK = 64 (bf16) / 16 (f32),
 // register-staged global->LDS double buffer (one barrier per k-tile).
+#include <mutex>
 #include "common.h"
 #include <stdlib.h>
 
@@ -264,15 +265,22 @@ template <typename T, int BM, int BN, bool A_KC, bool B_KC>
 int launch(const skyemb_gemm_args &g, hipStream_t st) {
     constexpr size_t smem =
         2 * (size_t)(TileShape<T, A_KC, BM>::ELEMS + TileShape<T, B_KC, BN>::ELEMS) * sizeof(T);
-    static bool attr_set = false;
     auto kern = gemm_kernel<T, BM, BN, A_KC, B_KC>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) {
-            skyemb_set_error("skyemb_gemm: hipFuncSetAttribute(%zu B LDS): %s", smem, hipGetErrorString(e));
-            return 2;
+    // the dynamic-LDS limit is an attribute of the function PER DEVICE
+    static std::mutex attr_mutex;
+    static bool attr_done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lock(attr_mutex);
+        if (!attr_done[dev & 63]) {
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) {
+                skyemb_set_error("skyemb_gemm: hipFuncSetAttribute(%zu B LDS): %s", smem, hipGetErrorString(e));
+                return 2;
+            }
+            attr_done[dev & 63] = true;
         }
-        attr_set = true;
     }
     const int64_t tiles = ceil_div64(g.M, BM) * ceil_div64(g.N, BN);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), smem, st, g);

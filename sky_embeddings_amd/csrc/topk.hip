@@ -904,14 +904,23 @@ extern "C" int skyemb_cosine_scores(const float *tw, const float *qn, const floa
 // best), then the one-wave selection over S / 16 values per query.  ws: Q * ceil(S / 16) floats.
 int skyemb_scores_stream_tilemax_launch(const float *tw, const float *qn, const float *bank, const float *xn, int Q, int64_t N, int D,
                                         float eps, float *tile_max, hipStream_t st);
+extern "C" int skyemb_cosine_sample_floor_applicable(int Q, int64_t S, int D, int k) {
+    if (Q <= 0 || S <= 0 || D <= 0 || k < 1) return 0;
+    const int64_t tiles = (S + 15) / 16;
+    return (use_stream(Q, D, 1) && skyemb_scores_stream_applicable(Q, S, D) && tiles <= 2048 && k <= tiles) ? 1 : 0;
+}
+
 extern "C" int skyemb_cosine_sample_floor(const float *tw, const float *qn, const float *sample, const float *sample_norms, int Q,
                                           int64_t S, int D, int k, float eps, float *ws, float *floor_out, void *stream) {
     SKY_CHECK_ARG(tw && qn && sample && sample_norms && ws && floor_out && Q > 0 && S > 0 && D > 0 && k >= 1,
                   "skyemb_cosine_sample_floor: bad arguments");
     const int64_t tiles = (S + 15) / 16;
-    SKY_CHECK_ARG(use_stream(Q, D, 1) && skyemb_scores_stream_applicable(Q, S, D) && tiles <= 2048 && k <= tiles,
-                  "skyemb_cosine_sample_floor: needs Q <= 16, D %% 64 == 0, D <= 1024 and k <= S / 16 <= 2048 (Q=%d D=%d S=%lld k=%d)", Q, D,
-                  (long long)S, k);
+    SKY_CHECK_ARG(skyemb_cosine_sample_floor_applicable(Q, S, D, k),
+                  "skyemb_cosine_sample_floor: needs Q <= 16, D %% 64 == 0, D <= 1024, k <= S / 16 <= 2048 and the streaming kernels "
+                  "enabled (SKYEMB_TOPK_STREAM) (Q=%d D=%d S=%lld k=%d)", Q, D, (long long)S, k);
+    // the streaming scorer reads 16 bytes per lane: rows must start on 16-byte boundaries (D % 64 == 0 keeps the pitch aligned)
+    SKY_CHECK_ARG(((uintptr_t)sample & 15) == 0 && ((uintptr_t)tw & 15) == 0,
+                  "skyemb_cosine_sample_floor: sample and tw must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const int rc = skyemb_scores_stream_tilemax_launch(tw, qn, sample, sample_norms, Q, S, D, eps, ws, st);
     if (rc != 0) return rc;

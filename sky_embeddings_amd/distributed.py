@@ -14,8 +14,19 @@ import torch
 import torch.distributed as dist
 
 
+def local_device_index(local_rank: int) -> int:
+    """The GPU of this rank: its LOCAL_RANK, wrapped onto the devices that exist -- two gloo ranks rehearsing the N > 1 path
+    on a one-GPU box both get cuda:0 (an RCCL world needs one device per rank; ``init_from_env`` refuses it otherwise)."""
+    n = torch.cuda.device_count()
+    return local_rank % n if n > 0 else 0
+
+
 def init_from_env(backend: str | None = None):
-    """-> (rank, world, local_rank).  No-op single process when WORLD_SIZE is unset / 1."""
+    """-> (rank, world, local_rank).  No-op single process when WORLD_SIZE is unset / 1.
+
+    Backend: the argument, else ``SKYEMB_DIST_BACKEND`` (``nccl`` | ``gloo``), else RCCL ("nccl") when a GPU is visible and
+    gloo otherwise.  gloo with CUDA tensors is the rehearsal mode (collectives staged through the host): same schedule, same
+    bucketing, any number of ranks per GPU."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -23,8 +34,13 @@ def init_from_env(backend: str | None = None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("SKYEMB_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend not in ("nccl", "gloo"):
+            raise ValueError(f"SKYEMB_DIST_BACKEND / backend must be 'nccl' or 'gloo', not {backend!r}")
         if backend == "nccl":
+            if local >= torch.cuda.device_count():
+                raise RuntimeError(f"RCCL needs one GPU per rank: LOCAL_RANK {local} but {torch.cuda.device_count()} device(s) visible "
+                                   f"(SKYEMB_DIST_BACKEND=gloo rehearses several ranks on one GPU)")
             torch.cuda.set_device(local)
             dist.init_process_group(backend, device_id=torch.device("cuda", local))
         else:

@@ -288,9 +288,10 @@ def kth_largest_floor(x, k, out):
     check(lib().skyemb_kth_largest_floor(_p(x), Q, S, k, _p(out), _stream()), "skyemb_kth_largest_floor")
 
 
-def sample_floor_applicable(Q, S, D, k):
-    tiles = (S + 15) // 16
-    return Q <= 16 and D % 64 == 0 and D <= 1024 and k <= tiles <= 2048
+def sample_floor_applicable(Q, S, D, k, *tensors):
+    """The library's own predicate (shape limits AND the SKYEMB_TOPK_STREAM switch) plus the 16-byte alignment the streaming
+    scorer needs of the tensors it reads rows from."""
+    return bool(lib().skyemb_cosine_sample_floor_applicable(Q, S, D, k)) and all(t.data_ptr() % 16 == 0 for t in tensors)
 
 
 def cosine_sample_floor(tw, qn, sample, sample_norms, k, eps, ws, out):

@@ -89,7 +89,7 @@ def pruning_floor(tw, qn, pb: "PreparedBank", k: int, eps: float, sample_rows: i
     if N < 8 * sample_rows:
         return None
     sb, sn = pb.sample(sample_rows)
-    if ops.sample_floor_applicable(tw.shape[0], sb.shape[0], tw.shape[1], k):
+    if ops.sample_floor_applicable(tw.shape[0], sb.shape[0], tw.shape[1], k, tw, sb):
         # Q <= 16: tile maxima of the sample scores + a one-wave selection (two short launches, no [Q, sample] matrix)
         floor = torch.empty(tw.shape[0], device=tw.device)
         ws = torch.empty(tw.shape[0] * ((sb.shape[0] + 15) // 16), device=tw.device)

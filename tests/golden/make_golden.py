@@ -29,7 +29,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 REF = "/root/reference"
-OUT = os.path.dirname(os.path.abspath(__file__))
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("SKYEMB_GOLDEN_OUT") or HERE      # the reproducibility test regenerates into a temporary directory
 
 
 # --------------------------------------------------------------------------
@@ -474,7 +475,7 @@ def maskgen_cases():
 def main():
     pgwd = install_standins()
     # this repo ships a drop-in ``utils`` package of the same name: keep it off the path so that the REFERENCE is imported
-    repo = os.path.dirname(os.path.dirname(OUT))
+    repo = os.path.dirname(os.path.dirname(HERE))
     sys.path[:] = [p for p in sys.path if os.path.abspath(p or os.getcwd()) != repo]
     sys.path.insert(0, REF)
     sys.path.insert(0, os.path.join(REF, "utils"))

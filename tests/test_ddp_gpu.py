@@ -95,3 +95,117 @@ def test_two_rank_training_step_matches_one_rank_on_the_concatenated_batch(tmp_p
                        comm_dtype=grad_comm, backend="nccl" if use_nccl else "gloo (both ranks on cuda:0)"))
     assert frac_close > 0.9995, frac_close
     assert float(err.max()) <= 2.5 * LR * STEPS and float(moved.max()) > 0.5 * LR
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# sharded-bank search in two processes: per-shard HIP top-k -> all-gather -> HIP merge (BASELINE configs[3]'s split)
+# ----------------------------------------------------------------------------------------------------------------
+def _search_case(Q):
+    """Bank with exact duplicates planted ACROSS the shard boundary (ties -> lower global index) and inside one shard."""
+    from oracle import similarity_oracle as so
+    N, D, k = 30000 if Q <= 16 else 12000, 128, 12
+    rng = np.random.default_rng(1000 + Q)
+    q = rng.standard_normal((Q, D), dtype=np.float32)
+    x = rng.standard_normal((N, D), dtype=np.float32)
+    w = rng.random(D, dtype=np.float32) + 0.1
+    best = np.argsort(-so.cosine_scores_np(q[:1], x, w)[0])[:3]
+    lo_half = [b for b in best if b < N // 2]
+    hi_half = [b for b in best if b >= N // 2]
+    # a copy of a top row of query 0 in the OTHER shard: the two ranks return the same score, the merge must order them by index
+    if lo_half:
+        x[N - 5] = x[lo_half[0]]
+    if hi_half:
+        x[3] = x[hi_half[0]]
+    x[N // 2 - 1] = x[N // 2 + 7] = x[best[0]]               # and one either side of the seam
+    return q, x, w, k
+
+
+def _search_rank_main(rank, port, out_dir, Q, use_nccl):
+    import torch.distributed as dist
+    from sky_embeddings_amd import search
+    from sky_embeddings_amd.distributed import shard_rows
+    dev = torch.device("cuda", rank if use_nccl else 0)
+    torch.cuda.set_device(dev)
+    if use_nccl:
+        dist.init_process_group("nccl", rank=rank, world_size=WORLD, init_method=f"tcp://127.0.0.1:{port}", device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=WORLD, init_method=f"tcp://127.0.0.1:{port}")
+    q, x, w, k = _search_case(Q)
+    lo, hi = shard_rows(x.shape[0], rank, WORLD)
+    pb = search.PreparedBank(torch.from_numpy(x[lo:hi]).to(dev), torch.from_numpy(w).to(dev), idx_offset=lo)
+    stats = {}
+    s, i = search.cosine_topk(torch.from_numpy(q).to(dev), pb, k, world_size=WORLD, stats=stats)
+    torch.cuda.synchronize(dev)
+    torch.save({"s": s.cpu(), "i": i.cpu(), "path": stats["path"]}, os.path.join(out_dir, f"search{Q}_rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("Q", [5, 40])           # the bank-streaming kernel (Q <= 16) and the two-stage many-query path
+def test_two_rank_sharded_search_equals_single_bank_and_oracle(tmp_path, Q):
+    import torch.multiprocessing as mp
+    from oracle import similarity_oracle as so
+    from sky_embeddings_amd import search
+    use_nccl = torch.cuda.device_count() >= WORLD
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_search_rank_main, args=(port, str(tmp_path), Q, use_nccl), nprocs=WORLD, join=True)
+    r = [torch.load(tmp_path / f"search{Q}_rank{k}.pt") for k in range(WORLD)]
+    assert torch.equal(r[0]["i"], r[1]["i"]) and torch.equal(r[0]["s"], r[1]["s"])     # every rank holds the merged answer
+    assert r[0]["path"] == ("exact" if Q <= 16 else "prefiltered")
+    q, x, w, k = _search_case(Q)
+    ref_s, ref_i = so.cosine_topk_np(q, x, k, w)
+    assert np.array_equal(r[0]["i"].numpy(), ref_i) and np.array_equal(r[0]["s"].numpy(), ref_s)
+    # the planted cross-shard duplicates really are in query 0's answer, lower index first
+    sc = r[0]["s"][0].numpy()
+    ties = np.nonzero(sc[1:] == sc[:-1])[0]
+    assert len(ties) >= 2 and all(ref_i[0][t] < ref_i[0][t + 1] for t in ties)
+    whole_s, whole_i = search.cosine_topk(torch.from_numpy(q).cuda(), torch.from_numpy(x).cuda(), k, weights=torch.from_numpy(w).cuda())
+    assert torch.equal(whole_i.cpu(), r[0]["i"]) and torch.equal(whole_s.cpu(), r[0]["s"])
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the pretraining entry point itself under the launcher, two ranks
+# ----------------------------------------------------------------------------------------------------------------
+def test_pretrain_entry_point_under_the_launcher_two_ranks(tmp_path):
+    """``python -m torch.distributed.run --nproc-per-node 2 pretrain_mim.py <ini>``: rank 0 writes the checkpoint, both ranks end
+    with bit-equal master weights.  One GPU: both ranks on cuda:0 over gloo (SKYEMB_DIST_BACKEND); two or more: RCCL."""
+    import configparser
+    import subprocess
+    import sys
+    from sky_embeddings_amd import hdf5_lite
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dd = tmp_path / "data"
+    dd.mkdir()
+    hdf5_lite.make_synthetic_cutouts(str(dd / "synthetic_cutouts_GRIZY_64_train.h5"), n=96, seed=1234)
+    hdf5_lite.make_synthetic_cutouts(str(dd / "synthetic_cutouts_GRIZY_64_val.h5"), n=16, seed=4321)
+    work = tmp_path / "work"
+    (work / "configs").mkdir(parents=True)
+    cfg = configparser.ConfigParser()
+    cfg.read(os.path.join(ROOT, "configs", "mim_1.ini"))
+    cfg["TRAINING"]["total_batch_iters"] = "8"
+    cfg["TRAINING"]["batch_size"] = "8"
+    with open(work / "configs" / "mim_t.ini", "w") as fh:
+        cfg.write(fh)
+    for name in ("pretrain_mim.py", "utils", "sky_embeddings_amd"):
+        os.symlink(os.path.join(ROOT, name), work / name)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=str(work), SKYEMB_SAVE_RANK_PARAMS=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if torch.cuda.device_count() < WORLD:
+        env["SKYEMB_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(WORLD),
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          str(work / "pretrain_mim.py"), "mim_t", "-v", "4", "-ct", "0.001", "-dd", str(dd)],
+                         cwd=str(work), env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "2 process(es)" in out.stdout and out.stdout.count("Training complete.") == WORLD
+    ck = torch.load(str(work / "models" / "mim_t.pth.tar"), map_location="cpu", weights_only=False)
+    assert ck["batch_iters"] >= 8 and np.isfinite(ck["losses"]["train_loss"]).all()
+    p0, p1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert torch.equal(p0, p1)
+    # and training happened: the optimiser state in the checkpoint carries the step count of the run
+    steps = {float(v["step"]) for v in ck["optimizer"]["state"].values()}
+    assert len(steps) == 1 and steps.pop() >= 8

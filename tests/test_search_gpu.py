@@ -255,3 +255,45 @@ def test_sample_floor_is_a_valid_and_tight_lower_bound():
         assert (got < kth_best).all()
         rank_of_floor = (sc > got[:, None]).sum(axis=1)                   # rows of the sample above the floor
         assert (rank_of_floor >= k).all() and (rank_of_floor <= k + 12).all(), rank_of_floor
+
+
+def test_small_q_search_with_the_streaming_kernels_switched_off(tmp_path):
+    """SKYEMB_TOPK_STREAM=0 (route everything to the simpler kernels) must still give a pruned, bit-exact search:
+    the sample floor then comes from ``skyemb_cosine_scores`` + ``skyemb_kth_largest_floor`` (the library's own predicate
+    ``skyemb_cosine_sample_floor_applicable`` says so), not from a call that rejects its arguments.  The switch is read once per
+    process, hence the child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import numpy as np, torch
+from oracle import similarity_oracle as so
+from sky_embeddings_amd import ops, search
+Q, N, D, k = 3, 21000, 128, 10
+assert not ops.sample_floor_applicable(Q, 256 * k, D, k)
+rng = np.random.default_rng(5)
+q = rng.standard_normal((Q, D), dtype=np.float32); x = rng.standard_normal((N, D), dtype=np.float32)
+w = rng.random(D, dtype=np.float32) + 0.1
+pb = search.PreparedBank(torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda())
+tw, qn = search.prepare_queries(torch.from_numpy(q).cuda(), pb.weights)
+assert search.pruning_floor(tw, qn, pb, k, 1e-6) is not None
+s, i = search.cosine_topk(torch.from_numpy(q).cuda(), pb, k)
+rs, ri = so.cosine_topk_np(q, x, k, w)
+assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(s.cpu().numpy(), rs)
+print("stream-off search ok")
+'''
+    env = dict(os.environ, SKYEMB_TOPK_STREAM="0", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "stream-off search ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+def test_sample_floor_predicate_follows_the_shape_limits():
+    from sky_embeddings_amd import ops
+    assert ops.sample_floor_applicable(16, 25600, 768, 100)
+    assert not ops.sample_floor_applicable(17, 25600, 768, 100)        # more than 16 queries
+    assert not ops.sample_floor_applicable(4, 25600, 96, 100)          # D % 64
+    assert not ops.sample_floor_applicable(4, 25600, 768, 2000)        # k above the number of 16-row tiles
+    assert not ops.sample_floor_applicable(4, 16 * 4096, 768, 100)     # more than 2048 tiles
+    t = torch.empty(64 * 768 + 1, device="cuda")[1:].view(64, 768)     # rows 4 bytes off a 16-byte boundary
+    assert not ops.sample_floor_applicable(4, 25600, 768, 100, t)
