@@ -94,14 +94,22 @@ __device__ __forceinline__ void store8(bf16_t *p, const float (&v)[8]) {
 
 // ---- stage issue -----------------------------------------------------------------------------
 // KC operand: R rows x 64 k.  One wave-instruction = 8 rows x 128 B.
+// Instructions of one operand tile per wave: R / 8 of them over NW waves, rounded up.  When they do not divide (144-row tiles,
+// six-wave workgroups) the waves past the end repeat the LAST instruction -- the same bytes to the same LDS address -- so that
+// every wave issues the same number and the counted vmcnt waits stay uniform.
+template <int R, int NW>
+constexpr int issue_per_wave() { return (R / 8 + NW - 1) / NW; }
 template <int R, int NW>
 __device__ __forceinline__ void issue_kc(const bf16_t *__restrict__ X, int64_t ld, int r0, int rows, int k0, char *sbase,
                                          int wave, int lane) {
-    constexpr int PER_WAVE = R / 8 / NW;
+    constexpr int PER_WAVE = issue_per_wave<R, NW>();
+    constexpr bool EXACT = (R / 8) % NW == 0;
     const int rr = lane >> 3, cs = (lane & 7) ^ rr;   // source chunk for LDS chunk lane&7 of row rr (rows8 % 8 == 0)
 #pragma unroll
     for (int j = 0; j < PER_WAVE; ++j) {
-        const int rows8 = (wave * PER_WAVE + j) * 8;
+        int idx = wave * PER_WAVE + j;
+        if (!EXACT) idx = idx < R / 8 ? idx : R / 8 - 1;
+        const int rows8 = idx * 8;
         int gr = r0 + rows8 + rr;
         gr = gr < rows ? gr : rows - 1;            // rows past the edge feed outputs that are never stored
         glds16(X + (int64_t)gr * ld + k0 + cs * 8, sbase + rows8 * 128);
@@ -121,11 +129,15 @@ __device__ __forceinline__ void issue_rc(const bf16_t *__restrict__ X, int64_t l
                                          int wave, int lane) {
     constexpr int CH = R / 8;                 // 16-byte chunks per k-row
     constexpr int KROWS = 64 / CH;            // k-rows per wave-instruction (4 for R=128, 8 for R=64)
-    constexpr int PER_WAVE = 64 / KROWS / NW; // instructions per wave
+    constexpr int PER_WAVE = issue_per_wave<R, NW>(); // instructions per wave (64 / KROWS = R / 8 in all)
+    constexpr bool EXACT = (R / 8) % NW == 0;
+    static_assert(R == 64 || R == 128 || R == 256, "row-contiguous operand tiles: 64, 128 or 256 rows");
     const int kr = lane / CH, ch = lane % CH;
 #pragma unroll
     for (int j = 0; j < PER_WAVE; ++j) {
-        const int kbase = (wave * PER_WAVE + j) * KROWS;
+        int idx = wave * PER_WAVE + j;
+        if (!EXACT) idx = idx < R / 8 ? idx : R / 8 - 1;
+        const int kbase = idx * KROWS;
         const int k = kbase + kr;
         const int sch = ch ^ rc_swz<R>(k);                          // source chunk for LDS chunk `ch`
         int gr = r0 + sch * 8;
@@ -225,16 +237,21 @@ __device__ __forceinline__ void wait_stages(int rem) {
 // and a second wave per SIMD running the same chain on the other half of the stage overlaps it.
 // ADAM (grouped weight-gradient launches planned with skyemb_gemm_group_plan_adamw): the output tile is not stored as a gradient;
 // the epilogue applies the AdamW step to the parameters the tile belongs to (`ad`: the flat buffers; see include/skyemb.h).
-template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int WM, int WN, int WK = 1, bool ADAM = false>
+// BMS = row STRIDE of the tiles (default BM).  BMS < BM: consecutive tiles overlap by BM - BMS rows, which the later tile computes
+// and the earlier one does not store -- a 144-row image (nine 16-row MFMA fragments) stepping by 136 rows cuts the decoder's
+// 4352 = 32 x 136 token rows into exactly 32 row blocks: [4352 x 512] outputs are then 256 tiles of 136 x 64, one per CU, where
+// 64-row tiles gave 544 (three on 32 CUs, two on the rest: the launch ran at the pace of the CUs with three).
+template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int WM, int WN, int WK = 1, bool ADAM = false, int BMS = BM>
 __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const int tb, const int ntiles, const int split,
                                                const int S, char *smem, const skyemb_adamw_desc *ad = nullptr) {
     constexpr int NWG = WM * WN, NW = NWG * WK;         // waves per k-group / per workgroup
     constexpr int SM = BM / WM, SN = BN / WN;           // rows / columns of the tile owned by one wave
     constexpr int TM = SM / 16, TN = SN / 16;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, SUB = A_BYTES + B_BYTES, STAGE = SUB * WK;
-    constexpr int NI = (BM + BN) / 8 * WK / NW;         // LDS-DMA instructions per wave per stage
-    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && SM % 16 == 0 && SN % 16 == 0, "tile / wave grid mismatch");
+    constexpr int NI = (issue_per_wave<BM, NW>() + issue_per_wave<BN, NW>()) * WK;   // LDS-DMA instructions per wave per stage
+    static_assert(BM % 8 == 0 && BN % 8 == 0 && SM % 16 == 0 && SN % 16 == 0 && SM * WM == BM && SN * WN == BN, "tile / wave grid mismatch");
     static_assert(WK == 1 || WK == 2, "one or two k-groups");
+    static_assert(BMS <= BM && BMS % 8 == 0 && (BMS == BM || A_KC), "overlapping row blocks: k-contiguous A only");
 
     GSTAMP(st_entry);
 #ifdef GEMM_STAMP
@@ -259,7 +276,7 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
     // operand be the one every L2 fetches whole (PMC, round 2: 12.1 GB of L2-side fetches + writes per step against 4.7 GB
     // of single-copy bytes, mostly the weight matrices fetched by all eight L2s).
 #ifndef SKY_TILE_ROWMAJOR
-    const unsigned int tiles_m = ((unsigned int)g.M + BM - 1) / BM;
+    const unsigned int tiles_m = ((unsigned int)g.M + BMS - 1) / BMS;
     const bool colmajor = g.N > g.M;
     const unsigned int div = colmajor ? tiles_m : tiles_n, quo = wg / div, rem = wg - quo * div;     // one division
     const int tile_m = (int)(colmajor ? rem : quo), tile_n = (int)(colmajor ? quo : rem);
@@ -267,7 +284,7 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
     const unsigned int quo = wg / tiles_n;
     const int tile_m = (int)quo, tile_n = (int)(wg - quo * tiles_n);
 #endif
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int m0 = tile_m * BMS, n0 = tile_n * BN;
     const bf16_t *A = (const bf16_t *)g.A;
     const bf16_t *B = (const bf16_t *)g.B;
     const int KT_all = g.K / (BK * WK);                 // ring stages (WK k-tiles each; the host checks divisibility)
@@ -288,9 +305,9 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
         for (int j = 0; j < WK; ++j) {                   // every wave takes its share of every k-tile of the stage
             char *sa = smem + buf * STAGE + j * SUB, *sb = sa + A_BYTES;
             const int k0 = ((kt_begin + kt) * WK + j) * BK;
-            if (A_KC) issue_kc<BM, NW>(A, g.lda, m0, g.M, k0, sa, wave, lane);
+            if constexpr (A_KC) issue_kc<BM, NW>(A, g.lda, m0, g.M, k0, sa, wave, lane);
             else issue_rc<BM, NW>(A, g.lda, m0, g.M, k0, sa, wave, lane);
-            if (B_KC) issue_kc<BN, NW>(B, g.ldb, n0, g.N, k0, sb, wave, lane);
+            if constexpr (B_KC) issue_kc<BN, NW>(B, g.ldb, n0, g.N, k0, sb, wave, lane);
             else issue_rc<BN, NW>(B, g.ldb, n0, g.N, k0, sb, wave, lane);
         }
     };
@@ -397,11 +414,11 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
     // at clamped coordinates, with no use in between.  Loaded where they were used -- under `if (m < M)`, one input after the
     // other -- the compiler waited for every load on the spot: two to five dependent memory round trips per piece (1.4-2.6 us
     // of a 6-10 us workgroup, profiles/r03_gemm_timeline.json).
-    constexpr int PPR = BN / 8, PIECES = BM * PPR, NP = PIECES / (NW * 64);   // pieces per row / per tile / per thread
-    static_assert(PIECES % (NW * 64) == 0, "pieces do not divide over the threads");
+    constexpr int PPR = BN / 8, PIECES = BM * PPR, NP = (PIECES + NW * 64 - 1) / (NW * 64);   // pieces per row / per tile / per thread
+    constexpr bool PIECES_EXACT = PIECES % (NW * 64) == 0;   // (else the last round of pieces is short: clamped requests, skipped stores)
     // ... in chunks of at most two pieces per thread (the four pieces of a 128x128 tile at once cost 112 registers: past the
     // 128 that let two such workgroups share a CU -- measured: mim_19 28.7 -> 32.5 ms)
-    constexpr int CH = (ADAM || NP < 2) ? 1 : 2, NCH = NP / CH;   // (ADAM: p, m, v of a piece are 24 registers more)
+    constexpr int CH = (ADAM || NP < 2 || NP % 2) ? 1 : 2, NCH = NP / CH;   // (ADAM: p, m, v of a piece are 24 registers more)
     static_assert(NP % CH == 0, "pieces per thread must split into chunks");
     const bool fused = S == 1;                           // split-K: raw partial tiles, splitk_reduce_kernel applies the epilogue
     int orow[CH], trow[CH];
@@ -416,14 +433,18 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
         constexpr bool MAPS = decltype(with_maps)::value;
 #pragma unroll
         for (int jj = 0; jj < CH; ++jj) {
-            const int p = tid + (j0 + jj) * NW * 64, m = m0 + p / PPR;
+            int p = tid + (j0 + jj) * NW * 64;
+            if (!PIECES_EXACT) p = p < PIECES ? p : PIECES - 1;
+            const int m = m0 + p / PPR;
             const int mc = m < g.M ? m : g.M - 1;
             orow[jj] = (MAPS && g.dst_row) ? gloadi(g.dst_row + mc) : mc;
             trow[jj] = (MAPS && g.tab_row) ? gloadi(g.tab_row + mc) : 0;
         }
 #pragma unroll
         for (int jj = 0; jj < CH; ++jj) {
-            const int p = tid + (j0 + jj) * NW * 64, m = m0 + p / PPR, n = n0 + (p % PPR) * 8;
+            int p = tid + (j0 + jj) * NW * 64;
+            if (!PIECES_EXACT) p = p < PIECES ? p : PIECES - 1;
+            const int m = m0 + p / PPR, n = n0 + (p % PPR) * 8;
             const int mc = m < g.M ? m : g.M - 1, nc = n < g.N ? n : g.N - 8;
             if (g.bias) {
                 e_bias[jj][0] = gload4(g.bias + nc);
@@ -433,7 +454,9 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
         }
 #pragma unroll
         for (int jj = 0; jj < CH; ++jj) {
-            const int p = tid + (j0 + jj) * NW * 64, n = n0 + (p % PPR) * 8;
+            int p = tid + (j0 + jj) * NW * 64;
+            if (!PIECES_EXACT) p = p < PIECES ? p : PIECES - 1;
+            const int n = n0 + (p % PPR) * 8;
             const int nc = n < g.N ? n : g.N - 8;
             const int oc = orow[jj] < 0 ? 0 : orow[jj];
             if (MAPS && g.table) {
@@ -510,9 +533,10 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
 #pragma unroll
         for (int jj = 0; jj < CH; ++jj) {
             const int p = tid + (ch * CH + jj) * NW * 64;
+            if (!PIECES_EXACT && p >= PIECES) continue;
             const int r = p / PPR, c = (p % PPR) * 8;
             const int m = m0 + r, n = n0 + c;
-            if (m >= g.M || n >= g.N) continue;
+            if (m >= g.M || n >= g.N || (BMS < BM && r >= BMS)) continue;
             const float4 lo = *(const float4 *)(smem + r * PITCH + c * 4), hi = *(const float4 *)(smem + r * PITCH + c * 4 + 16);
             float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #ifdef SKY_NOSTORE   // experiment build: everything but the global traffic of the epilogue
@@ -582,6 +606,10 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
 #endif
 }
 
+// row stride of a tile shape: the 144-row image steps by 136 rows (gemm_pipe_body, BMS)
+constexpr int tile_stride_m(int bm) { return bm == 144 ? 136 : bm; }
+constexpr bool pow2_rows(int r) { return r == 64 || r == 128 || r == 256; }
+
 template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int WM, int WN, int WK = 1>
 __global__ __launch_bounds__(WM * WN * WK * 64) void gemm_pipe_kernel(const skyemb_gemm_args g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -591,7 +619,8 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm_pipe_kernel(const skye
         ntiles = gridDim.x / (unsigned int)S;
         split = blockIdx.x / ntiles;
     }
-    gemm_pipe_body<BM, BN, A_KC, B_KC, NSTAGE, WM, WN, WK>(g, (int)(blockIdx.x - split * ntiles), (int)ntiles, (int)split, S, smem);
+    gemm_pipe_body<BM, BN, A_KC, B_KC, NSTAGE, WM, WN, WK, false, tile_stride_m(BM)>(g, (int)(blockIdx.x - split * ntiles), (int)ntiles,
+                                                                                      (int)split, S, smem);
 }
 
 // Grouped launch: several independent problems in ONE grid (the four weight-gradient GEMMs of a transformer block,
@@ -705,7 +734,7 @@ int launch_n(const skyemb_gemm_args &g, hipStream_t st) {
             attr_done[dev & 63] = true;
         }
     }
-    const int64_t tiles = ceil_div64(g.M, BM) * ceil_div64(g.N, BN);
+    const int64_t tiles = ceil_div64(g.M, tile_stride_m(BM)) * ceil_div64(g.N, BN);
     const int S = g.split_k > 1 ? g.split_k : 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * S)), dim3(WM * WN * WK * 64), smem, st, g);
     if (S > 1) {
@@ -726,10 +755,19 @@ int dispatch(const skyemb_gemm_args &g, hipStream_t st) {
             return 1;
         }
     }
+    // row-contiguous operand tiles exist with 64 / 128 / 256 rows (one LDS-DMA instruction = a whole number of k-rows)
     if (a && b) return launch_n<BM, BN, true, true, NSTAGE, WM, WN, WK>(g, st);
-    if (a && !b) return launch_n<BM, BN, true, false, NSTAGE, WM, WN, WK>(g, st);
-    if (!a && !b) return launch_n<BM, BN, false, false, NSTAGE, WM, WN, WK>(g, st);
-    return launch_n<BM, BN, false, true, NSTAGE, WM, WN, WK>(g, st);
+    if constexpr (pow2_rows(BN)) {
+        if (a && !b) return launch_n<BM, BN, true, false, NSTAGE, WM, WN, WK>(g, st);
+    }
+    if constexpr (pow2_rows(BM) && pow2_rows(BN)) {
+        if (!a && !b) return launch_n<BM, BN, false, false, NSTAGE, WM, WN, WK>(g, st);
+    }
+    if constexpr (pow2_rows(BM)) {
+        if (!a && b) return launch_n<BM, BN, false, true, NSTAGE, WM, WN, WK>(g, st);
+    }
+    skyemb_set_error("skyemb_gemm(pipe): the %d x %d tile is not built for this operand layout", BM, BN);
+    return 1;
 }
 
 // Launch shapes.  code = variant * 1,000,000 + BM * 1000 + BN; X(variant, BM, BN, NSTAGE, WM, WN, WK).
@@ -747,7 +785,8 @@ int dispatch(const skyemb_gemm_args &g, hipStream_t st) {
     X(6, 128, 64, 2, 4, 2, 1)        \
     X(6, 64, 64, 2, 2, 2, 1)         \
     X(9, 64, 64, 3, 2, 2, 2)         \
-    X(9, 128, 128, 2, 4, 2, 2)
+    X(9, 128, 128, 2, 4, 2, 2)       \
+    X(9, 144, 64, 3, 3, 2, 2)
 #ifdef SKY_GEMM_LAB   // experiment builds (tools/ubench/gemm_lab.hip): every shape under study
 #define SKY_GEMM_VARIANTS(X) SKY_GEMM_PRODUCT_VARIANTS(X) SKY_GEMM_LAB_VARIANTS(X)
 #else
@@ -762,8 +801,8 @@ int dispatch_code(int code, const skyemb_gemm_args &g, hipStream_t st) {
     skyemb_set_error("skyemb_gemm(pipe): unknown tile code %d", code);
     return 1;
 }
-void tile_dims(int code, int &bm, int &bn) {
-    bm = (code % 1000000) / 1000;
+void tile_dims(int code, int &bm, int &bn) {   // bm = the row STRIDE of the tiles (136 for the 144-row image)
+    bm = tile_stride_m((code % 1000000) / 1000);
     bn = code % 1000;
 }
 int canonical_tile(int tile) {   // legacy codes of the round-1 ABI

@@ -24,7 +24,12 @@
     X(1, 128, 256, 2, 2, 4, 1)   \
     X(10, 64, 64, 2, 2, 2, 2)    \
     X(11, 64, 64, 4, 2, 2, 2)    \
-    X(9, 128, 128, 2, 4, 2, 2)
+    X(9, 128, 128, 2, 4, 2, 2)   \
+    X(9, 144, 64, 3, 3, 2, 2)    \
+    X(10, 144, 64, 2, 3, 2, 2)   \
+    X(9, 144, 128, 2, 3, 2, 2)   \
+    X(1, 144, 64, 2, 3, 2, 1)    \
+    X(2, 144, 64, 4, 3, 2, 1)
 #include "../../sky_embeddings_amd/csrc/gemm_pipe.hip"
 
 #include <stdarg.h>
@@ -181,6 +186,8 @@ int main(int argc, char **argv) {
             Shape s = s0;
             s.epi = 1;
             if ((code / 1000000 >= 9 || code % 1000000 == 256256) && !s.a_kc) continue;      // two-k-group tiles, 256x256: k-contiguous A only
+            if ((code % 1000000) / 1000 == 144 && !s.a_kc) continue;                           // 144-row image (136-row stride): k-contiguous A only
+            if (code % 1000 == 192 && !s.b_kc) continue;                                       // 192 columns: k-contiguous B only
             skyemb_gemm_args g = make_args(s, 0, code, 1);
             g.resid = nullptr; g.bias = nullptr;
             CK(hipMemset(o32, 0xff, (size_t)s.M * s.N * 4));
@@ -407,7 +414,9 @@ int main(int argc, char **argv) {
         return 0;
     }
     double tot_base = 0, tot_best = 0;
+    const char *only = getenv("LAB_ONLY");              // e.g. LAB_ONLY=dec. : the decoder's shapes only
     for (const Shape &s : shapes) {
+        if (only && !strstr(s.name, only)) continue;
         struct R { int code, split; float us; };
         std::vector<R> res;
         const float base = time_us(s, 0, 0);    // current product choice (tuned table / heuristic)
