@@ -68,7 +68,9 @@ __host__ __device__ inline double eps_a_of(int D, bool lo) {
 
 // ---- preparation --------------------------------------------------------------------------------------------------
 // one wave per row: scale exponent, fp16 image, ||x'||_2 (rounded up), scaled weighted norm.
-// rowp[i] = {xn * 2^-e, ||x'||_2 (1 + D 2^-22), 2^-e, xn}; rows N .. rows_padded-1 (whole tiles of BT rows) hold a sentinel
+// rowp[i] = {xn * 2^-e, ||x'||_2 (1 + D 2^-22), 2^-e, 0}; rows N .. rows_padded-1 (whole tiles of BT rows) hold a sentinel.
+// The four components are the row's B operand of the candidate test's v_mfma_f32_16x16x4_f32 (prefilter_kernel, item epilogue):
+// the last one multiplies the queries' 0 and must stay finite.
 __global__ __launch_bounds__(256) void bank16_kernel(const float *__restrict__ bank, const float *__restrict__ xn, int64_t N, int D,
                                                       half_t *__restrict__ bank16, float4 *__restrict__ rowp, int64_t rows_padded) {
     const int lane = threadIdx.x & 63;
@@ -99,7 +101,8 @@ __global__ __launch_bounds__(256) void bank16_kernel(const float *__restrict__ b
         // overflow (largest |x| below ~2^-113: the fp16 image would be inf / NaN and the row silently lost): fp16 zeros
         // + ||x'|| = inf make every query keep it as a candidate (U = inf), so the exact stage decides
         for (int d = lane * 4; d < D; d += 256) *(uint2 *)(o + d) = make_uint2(0u, 0u);
-        if (lane == 0) rowp[row] = make_float4(xn[row], INFINITY, 1.0f, xn[row]);
+        // (the weighted-norm slot is 0, not the row's -- possibly infinite -- norm: the test's fma chain must not meet inf - inf)
+        if (lane == 0) rowp[row] = make_float4(0.f, INFINITY, 1.0f, 0.f);
         return;
     }
     const float s = ldexpf(1.0f, -e);
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256) void bank16_kernel(const float *__restrict__ b
     if (lane == 0) {
         const float nx = sqrtf(ss) * (1.0f + (float)D * 0x1p-22f);
         const float xnv = xn[row];
-        rowp[row] = make_float4(xnv * s, nx, s, xnv);
+        rowp[row] = make_float4(xnv * s, nx, s, 0.f);
     }
 }
 
@@ -211,8 +214,19 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// qpar[q] = {a, b, c, _}: the pair (q, i) is a candidate iff  dot^ + c * nx'_i >= a * xn'_i + b * se_i
-//   a = tau * qn'   b = tau * eps * 2^-f   (both lowered by 2^-20 relative: covers the roundings of this test)   c = eps_a ||q'||
+// The pair (q, i) is a candidate iff  dot^ + c * nx'_i >= a * xn'_i + b * se_i  with
+//   a = tau * qn'   b = tau * eps * 2^-f   c = eps_a ||q'||     (a, b lowered and c raised by 2^-19 relative, see below).
+// Round 4: the test is ONE matrix instruction per 16 x 16 block of pairs.  qpar[q] = {-a, c, -b, 0} is the query's row of an
+// A operand, rowp[i] = {xn', nx', se, 0} the row's column of a B operand, and
+//   t = v_mfma_f32_16x16x4_f32(qpar rows, rowp columns, C = dot^ block)  =  dot^ - a xn' + c nx' - b se   (fp32 fma chain)
+// lands in scratch registers (the accumulators keep dot^ for the candidate lists); the pair passes iff t >= 0 (NaN fails), one
+// compare + one add-with-carry per pair into the lane's bit mask.  Before, every pair cost two fmas, a multiply, a compare and
+// the mask update on the vector ALU: 128 pairs per lane and item = 31 % of the pass.
+// Roundings: the chain rounds four times, each by <= 2^-24 of a partial sum bounded by S = |dot^| + |a xn'| + |c nx'| + |b se|, and
+// a, b carry one or two roundings of their own.  The slack 2^-19 (|a xn'| + |b se| + |c nx'|) =: 2^-19 T1 built into the constants
+// covers them: if |dot^| <= 2 T1 the chain's error is <= 2^-22 * 3.01 T1 < 2^-19 T1; if |dot^| > 2 T1 the exact value has the
+// sign of dot^ and magnitude > |dot^| / 2, far above the error.  So every pair that satisfies the inequality in exact arithmetic
+// (the condition the proof of the file header needs) passes.
 // Work items: bank tile t of [t0, t1) x query tile; bank tiles are dealt to the XCDs (t - t0) % 8 == blockIdx.x % 8, and an
 // XCD walks its items group-of-GQ-query-tiles outermost, then bank tile, then query tile: the GQ query tiles stay in its
 // L2 while its bank tiles stream through once per group.  The LDS ring never drains between items.
@@ -386,15 +400,16 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
     };
     auto item_epilogue = [&](int qt, int t) {
         // ---- epilogue of the item: per 16x16 block a lane holds queries 4*(lane>>4)+r (r = 0..3) x bank row (lane & 15).
-        // All 16 MI tests of the lane are branch-free (bit masks: test (i, r, j) is bit (r*4 + j) of half-word i); only lanes
-        // that found something enter the append path.
+        // All 16 MI tests of the lane are branch-free (bit masks: test (i, r, j) is bit (r*4 + j) of a half-word of msk[i / 2]); only
+        // lanes that found something enter the append path.
         // (the lane coordinates go through an empty asm: everything addressed from them is then computed HERE, once per item,
         // instead of being hoisted out of the k-loop into registers that the accumulators and fragments need)
         const int ln = lane_now();
         const int l16 = ln & 15, l4 = ln >> 4;
-        float4 rp[4];
+        // B operand of the test: component (lane >> 4) of the constants of bank row (lane & 15) of each 16-row block
+        float tb[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rp[j] = srow[wn * 64 + j * 16 + l16];
+        for (int j = 0; j < 4; ++j) tb[j] = ((const float *)srow)[(wn * 64 + j * 16 + l16) * 4 + l4];
         unsigned int msk[MI / 2];
 #pragma unroll
         for (int w2 = 0; w2 < MI / 2; ++w2) msk[w2] = 0;
@@ -404,20 +419,40 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
+        // Two blocks in flight: the four matrix instructions of block i + 1 are issued before the sixteen compare / add-with-carry
+        // pairs of block i, so the matrix pipe and the vector ALU work side by side (left to itself the compiler issued all 32
+        // instructions first and spilled their 128 result registers).
+        f32x4 tst[2][4];
+        auto test_block = [&](int i) {
+            // A operand: component (lane >> 4) of the parameters of query (lane & 15) of the block
+            const float ta = ((const float *)spar)[(wm * (QT / 2) + i * 16 + l16) * 4 + l4];
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+            for (int j = 0; j < 4; ++j) tst[i & 1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta, tb[j], acc[i][j], 0, 0, 0);
+        };
+        test_block(0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float4 p = spar[wm * (QT / 2) + i * 16 + 4 * l4 + r];
+        for (int i = 0; i < MI; ++i) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 1 < MI) test_block(i + 1);
+            else asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");     // the last block's results: 8-pass matrix instruction -> vector ALU read
+            __builtin_amdgcn_sched_barrier(0);
+            // bit (r * 4 + j) of a half-word: shifted in from the top, so r and j run downwards
+            unsigned int m = msk[i >> 1];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float rhs = fmaf(p.x, rp[j].x, p.y * rp[j].z);
-                    const float lhs = fmaf(p.z, rp[j].y, acc[i][j][r]);
-                    msk[i >> 1] |= lhs >= rhs ? (1u << ((i & 1) * 16 + r * 4 + j)) : 0u;
-                }
-                // (keeps the scheduler from fetching all 4 MI parameter rows up front: 128 more live registers than there are)
-                if (MI > 4 && r == 3) __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int r = 3; r >= 0; --r)
+                // m = 2 m + (t >= 0) for j = 3, 2, 1, 0: compare into vcc, add-with-carry (NaN compares false).  Written out: the
+                // compiler built the mask from v_cndmask / v_or / v_lshl_or, 2.5 instructions per pair, with every result of the 32
+                // matrix instructions live at once (spills).  The matrix instructions that produced these registers were issued a
+                // whole block (four 8-pass instructions) earlier.
+                asm volatile("v_cmp_le_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                             "v_cmp_le_f32 vcc, 0, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                             "v_cmp_le_f32 vcc, 0, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                             "v_cmp_le_f32 vcc, 0, %4\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                             : "+v"(m)
+                             : "v"(tst[i & 1][3][r]), "v"(tst[i & 1][2][r]), "v"(tst[i & 1][1][r]), "v"(tst[i & 1][0][r])
+                             : "vcc");
+            msk[i >> 1] = m;
+        }
 #endif
         unsigned int any = 0;
 #pragma unroll
@@ -428,8 +463,9 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
 #pragma unroll
         for (int w2 = 0; w2 < MI / 2; ++w2) msk[w2] = 0;
 #endif
-        auto passed = [&](int i, int r, int j) -> bool { return (msk[i >> 1] >> ((i & 1) * 16 + r * 4 + j)) & 1u; };
-        auto passed4 = [&](int i, int r) -> bool { return (msk[i >> 1] >> ((i & 1) * 16 + r * 4)) & 15u; };
+        // (the bits were shifted in: the even block of a pair sits in the HIGH half-word)
+        auto passed = [&](int i, int r, int j) -> bool { return (msk[i >> 1] >> (((i & 1) ^ 1) * 16 + r * 4 + j)) & 1u; };
+        auto passed4 = [&](int i, int r) -> bool { return (msk[i >> 1] >> (((i & 1) ^ 1) * 16 + r * 4)) & 15u; };
         if (TAKE_ALL) {
             // first slice: every (query, row) pair of the slice is a candidate, slot = row within the slice (no counters);
             // pairs that fail even the open test (NaN) are stored as -inf and dropped by the select step
@@ -627,6 +663,9 @@ __global__ __launch_bounds__(256) void bucket_kernel(const uint4 *__restrict__ w
     }
 }
 
+// the query's row of the candidate test's A operand (see prefilter_kernel): {-a, c (raised), -b, 0}
+__device__ __forceinline__ float4 test_row(float a, float b, float c) { return make_float4(-a, c * (1.0f + 0x1p-19f), -b, 0.f); }
+
 // ---- between phases: new threshold, compaction; last phase: pick the candidates to re-score ---------------------------------
 __device__ __forceinline__ unsigned int orderable(float f) {
     const unsigned int u = __float_as_uint(f);
@@ -661,7 +700,7 @@ __device__ unsigned int radix_kth_largest(const unsigned int *keys, int n, int k
 // final == 1: sel_i[q][0..nsel) <- the (up to) RESCORE_MAX candidates with the largest U; bound[q] = largest U NOT selected
 //             (-inf when every candidate is selected).
 __global__ __launch_bounds__(256) void select_kernel(int Q, int k, int cap, float eps, const float4 *__restrict__ qbase,
-                                                     const float4 *__restrict__ rowp, int *__restrict__ cnt,
+                                                     const float4 *__restrict__ rowp, const float *__restrict__ xn, int *__restrict__ cnt,
                                                      int *__restrict__ cand_i, float *__restrict__ cand_d,
                                                      float4 *__restrict__ qpar, float *__restrict__ tau_q, int *__restrict__ overflow,
                                                      int final, int *__restrict__ sel_i, int *__restrict__ nsel,
@@ -680,8 +719,8 @@ __global__ __launch_bounds__(256) void select_kernel(int Q, int k, int cap, floa
     float *cd = cand_d + (int64_t)q * cap;
     const float inv_sf = 1.0f / qb.z;                         // 2^f (exact)
     for (int e = tid; e < n; e += 256) {
-        const float4 rp = rowp[ci[e]];                        // {xn', ||x'||, 2^-e, xn}
-        const float den = fmaf(qb.w, rp.w, eps);
+        const float4 rp = rowp[ci[e]];                        // {xn', ||x'||, 2^-e, 0}
+        const float den = fmaf(qb.w, xn[ci[e]], eps);
         const float sc = inv_sf * (1.0f / rp.z);              // 2^(e+f), exact
         const float err = qb.y * rp.y;
         const float hi = (cd[e] + err) * sc, lo = (cd[e] - err) * sc;
@@ -727,10 +766,10 @@ __global__ __launch_bounds__(256) void select_kernel(int Q, int k, int cap, floa
             // test parameters of the next phase (see prefilter_kernel); tau = -inf -> everything passes
             const float t = tau > -3.0e38f ? tau : -3.0e38f;
             float a = t * qb.x, b = t * eps * qb.z;
-            a -= fabsf(a) * 0x1p-20f;
-            b -= fabsf(b) * 0x1p-20f;
+            a -= fabsf(a) * 0x1p-19f;
+            b -= fabsf(b) * 0x1p-19f;
             if (!(a > -3.0e38f)) a = -3.0e38f;
-            qpar[q] = make_float4(a, b, qb.y, 0.f);
+            qpar[q] = test_row(a, b, qb.y);
         }
         return;
     }
@@ -857,7 +896,7 @@ __global__ void init_state_kernel(int Q, int Q_padded, const float *__restrict__
                                   int *__restrict__ overflow, int first_rows) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= Q) {
-        if (q < Q_padded) qpar[q] = make_float4(NAN, 0.f, 0.f, 0.f);   // padding of the last query tile: no pair passes
+        if (q < Q_padded) qpar[q] = make_float4(NAN, NAN, NAN, NAN);   // padding of the last query tile: t = NaN, no pair passes
         return;
     }
     const float tau = thr0 ? thr0[q] : -INFINITY;
@@ -869,10 +908,10 @@ __global__ void init_state_kernel(int Q, int Q_padded, const float *__restrict__
     overflow[q] = qb.z >= 0x1p126f ? 1 : 0;
     const float t = tau > -3.0e38f ? tau : -3.0e38f;
     float a = t * qb.x, b = t * eps * qb.z;
-    a -= fabsf(a) * 0x1p-20f;
-    b -= fabsf(b) * 0x1p-20f;
+    a -= fabsf(a) * 0x1p-19f;
+    b -= fabsf(b) * 0x1p-19f;
     if (!(a > -3.0e38f)) a = -3.0e38f;
-    qpar[q] = make_float4(a, b, qb.y, 0.f);
+    qpar[q] = test_row(a, b, qb.y);
 }
 
 struct Workspace {
@@ -1047,7 +1086,7 @@ extern "C" int skyemb_cosine_topk_prefiltered(const float *tw, const float *qn, 
         }
 #endif
         const int final = t1 == T;
-        hipLaunchKernelGGL(select_kernel, dim3((unsigned)Q), dim3(256), smem_sel, st, Q, k, cap, eps, w.qbase, (const float4 *)rowp,
+        hipLaunchKernelGGL(select_kernel, dim3((unsigned)Q), dim3(256), smem_sel, st, Q, k, cap, eps, w.qbase, (const float4 *)rowp, xn,
                            w.cnt, w.cand_i, w.cand_d, w.qpar, w.tau, w.overflow, final, w.sel_i, w.nsel, w.bound);
         t0 = t1;
     }
