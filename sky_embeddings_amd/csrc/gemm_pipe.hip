@@ -314,7 +314,13 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
 
     // bias gradient = column sums of the RC A tile, taken by the waves of the first tile column with one extra MFMA
     // per A fragment against a fragment of ones (exact products, fp32 accumulation in k order)
-    const bool do_colsum = !A_KC && g.colsum_a != nullptr && tile_n == 0 && wn == 0;
+    // ... or, with colsum_parts, by EVERY tile column for the k-tiles kt % tiles_n == its index: partial sums the caller adds up.
+    // The first column alone made its tiles the stragglers of every weight-gradient launch (0.52 -> 0.44 us per k-step without
+    // the sums on the 64x64 tile, 0.66 -> 0.60 on 128x128: tools/ubench/gemm_lab, LAB_NOCOLSUM).
+    const bool cs_parts = !A_KC && S == 1 && g.colsum_parts != nullptr;
+    const bool do_colsum = !A_KC && wn == 0 && (cs_parts || (g.colsum_a != nullptr && tile_n == 0));
+    int cs_next = cs_parts ? tile_n : 0;                 // the next stage whose column sums this tile takes (every stage without parts)
+    const int cs_step = cs_parts ? (int)tiles_n : 1;
     f32x4 cacc[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) cacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -389,10 +395,11 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);  // D[n][m]
 #endif
-                if (!A_KC && do_colsum) {
+                if (!A_KC && do_colsum && kt == cs_next) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
                         cacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[kk][i], cacc[i], 0, 0, 0);
+                    if (kk == 1) cs_next += cs_step;
                 }
             }
         }
@@ -406,7 +413,8 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
     // through LDS (the ring is free now) and written in pieces of 8 consecutive columns per lane, consecutive lanes on
     // consecutive pieces of a row: every wave-instruction writes whole 128-byte lines.  The fused inputs (bias, table
     // rows, residual, dGELU operand) are read in the same lane order.
-    float *cs_out = S > 1 ? (float *)g.ws + (int64_t)S * g.M * g.N + (int64_t)split * g.M : g.colsum_a;
+    float *cs_out = cs_parts ? g.colsum_parts + (int64_t)tile_n * g.M
+                             : S > 1 ? (float *)g.ws + (int64_t)S * g.M * g.N + (int64_t)split * g.M : g.colsum_a;
     constexpr int PITCH = BN * 4 + 16;                   // bytes per tile row in LDS (+16: conflict-free b128 writes)
     float *cs_lds = (float *)(smem + BM * PITCH);        // (two k-groups) the odd k-tiles' column sums, BM floats behind the image
     // The fused inputs of this thread's pieces (8 consecutive columns of a row each) are requested HERE, all of them, before
@@ -982,6 +990,10 @@ extern "C" int skyemb_gemm_group_plan(const skyemb_gemm_args *args, int n, int t
                         aligned16(g.bias) && aligned16(g.table) && (g.out || g.out_f32);
         if (!ok) {
             skyemb_set_error("skyemb_gemm_group_plan: problem %d is outside the pipelined bf16 subset", i);
+            return -1;
+        }
+        if (g.colsum_parts && g.a_layout != SKYEMB_RC) {
+            skyemb_set_error("skyemb_gemm_group_plan: problem %d: colsum_parts needs an RC A operand", i);
             return -1;
         }
         g.split_k = 1;

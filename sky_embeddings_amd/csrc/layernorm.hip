@@ -171,14 +171,18 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float *__rest
     }
 }
 
-// every LayerNorm of a backward stage in one launch: blockIdx.z = item
-__global__ __launch_bounds__(1024) void ln_bwd_reduce_batch_kernel(const skyemb_ln_reduce_item *__restrict__ items) {
+// every column reduce of a backward stage in one launch.  blocks[b] = {item, x | y << 16}: workgroup b takes columns [32 x, +32) of
+// half y (0 dgamma, 1 dbeta) of items[item] -- a flat list, so that items of different widths (LayerNorm: dim; bias-gradient
+// partial sums: up to 4 dim) share a launch without empty workgroups.
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_batch_kernel(const skyemb_ln_reduce_item *__restrict__ items,
+                                                                   const int2 *__restrict__ blocks) {
     __shared__ float red[32][33];
-    const skyemb_ln_reduce_item it = items[blockIdx.z];
+    const int2 blk = blocks[blockIdx.x];
+    const skyemb_ln_reduce_item it = items[blk.x];
+    const int bx = blk.y & 0xffff, by = blk.y >> 16;
     const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int d = blockIdx.x * 32 + col;
-    if (blockIdx.x * 32 >= it.D) return;
-    const float *src = it.part + (int64_t)blockIdx.y * it.nblk * it.D;
+    const int d = bx * 32 + col;
+    const float *src = it.part + (int64_t)by * it.nblk * it.D;
     float acc = 0.f;
     if (d < it.D) {
 #pragma unroll 8
@@ -190,15 +194,15 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_batch_kernel(const skyemb_
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < 32; ++r) t += red[r][col];
-        (blockIdx.y == 0 ? it.dgamma : it.dbeta)[d] = t;
+        (by == 0 ? it.dgamma : it.dbeta)[d] = t;
     }
 }
 
 }  // namespace
 
-extern "C" int skyemb_layernorm_bwd_reduce_batch(const skyemb_ln_reduce_item *items, int n_items, int max_D, void *stream) {
-    SKY_CHECK_ARG(items && n_items > 0 && n_items <= 65535 && max_D > 0, "skyemb_layernorm_bwd_reduce_batch: bad arguments");
-    hipLaunchKernelGGL(ln_bwd_reduce_batch_kernel, dim3((max_D + 31) / 32, 2, n_items), dim3(1024), 0, (hipStream_t)stream, items);
+extern "C" int skyemb_layernorm_bwd_reduce_batch(const skyemb_ln_reduce_item *items, const int32_t *blocks, int n_blocks, void *stream) {
+    SKY_CHECK_ARG(items && blocks && n_blocks > 0, "skyemb_layernorm_bwd_reduce_batch: bad arguments");
+    hipLaunchKernelGGL(ln_bwd_reduce_batch_kernel, dim3((unsigned)n_blocks), dim3(1024), 0, (hipStream_t)stream, items, (const int2 *)blocks);
     SKY_LAUNCH_CHECK("skyemb_layernorm_bwd_reduce_batch");
     return 0;
 }

@@ -233,43 +233,64 @@ class MAEEngine:
             w["datt"] = torch.empty(Mx * Dx, **lp)
             w["dh"] = torch.empty(Hx, **lp)
             w["dqkv"] = torch.empty(3 * Mx * Dx, **lp)
+            # the four weight-gradient GEMMs of a block as ONE grouped launch (ops.GemmGroup): together they fill the
+            # chip, so none needs split-K slabs or a reduce launch.  bf16 path only; pointers are fixed from here on.
+            w["splitk_ws"] = self._splitk_ws
+            w["wgrad_groups"], w["bias_parts"] = {}, {}
+            if self.dtype == torch.bfloat16:
+                for tag, blocks, M_, dim in (("blocks", w["enc"], Me, D), ("decoder_blocks", w["dec"], Md, Dd)):
+                    for i, bufs in enumerate(blocks):
+                        w["wgrad_groups"][f"{tag}.{i}"] = self._make_wgrad_group(f"{tag}.{i}", bufs, M_, dim, w)
             # LayerNorm dgamma/dbeta: every LN keeps its own partial sums; ONE batched launch per backward stage
-            # finishes them (42 reduce launches -> 3-6).  Table order = the order backward visits the LNs.
-            order = [("decoder_norm", Md, Dd)]
+            # finishes them (42 reduce launches -> 3-6).  Table order = the order backward visits the LNs.  The same launch adds
+            # up the bias gradients of the grouped weight-gradient launches, which leave them as partial sums per tile column
+            # (skyemb_gemm_args.colsum_parts): four single-vector items per block, between its norm2 and norm1.
+            order = [("ln", "decoder_norm", Md, Dd)]
             for i in reversed(range(cfg.decoder_depth)):
-                order += [(f"decoder_blocks.{i}.norm2", Md, Dd), (f"decoder_blocks.{i}.norm1", Md, Dd)]
-            order.append(("norm", Me, D))
+                order.append(("block", f"decoder_blocks.{i}", w["dec"][i], Md, Dd))
+            order.append(("ln", "norm", Me, D))
             for i in reversed(range(cfg.depth)):
-                order += [(f"blocks.{i}.norm2", Me, D), (f"blocks.{i}.norm1", Me, D)]
-            entries = []
-            w["ln_index"], w["ln_parts"] = {}, []
-            for k, (name, M_, D_) in enumerate(order):
-                nb = ops.layernorm_bwd_blocks(M_)
-                part = torch.empty(2, nb, D_, **f32)
-                w["ln_index"][name] = k
-                w["ln_parts"].append(part)
-                entries.append((part, self.store.grad(f"{name}.weight"), self.store.grad(f"{name}.bias"), nb, D_))
-            w["ln_items"] = ops.ln_reduce_items(entries, dev)
-            w["ln_max_D"] = Dx
+                order.append(("block", f"blocks.{i}", w["enc"][i], Me, D))
+            self._build_reduce_table(w, order)
             w["dE"] = torch.empty(Me, Dd, **lp)
             w["dT"] = torch.empty(B * keep, D, **lp)
             w["drows"] = torch.empty(B * keep, pv, **f32)
             w["pmv_part"] = torch.empty(B, pv, **f32)
             w["rs_part"] = torch.empty(256, max(D, Dd), **f32)
-            w["splitk_ws"] = self._splitk_ws
-            # the four weight-gradient GEMMs of a block as ONE grouped launch (ops.GemmGroup): together they fill the
-            # chip, so none needs split-K slabs or a reduce launch.  bf16 path only; pointers are fixed from here on.
-            w["wgrad_groups"] = {}
-            if self.dtype == torch.bfloat16:
-                for tag, blocks, M_, dim in (("blocks", w["enc"], Me, D), ("decoder_blocks", w["dec"], Md, Dd)):
-                    for i, bufs in enumerate(blocks):
-                        w["wgrad_groups"][f"{tag}.{i}"] = self._make_wgrad_group(f"{tag}.{i}", bufs, M_, dim, w)
         if train and getattr(self, "_fused_adamw", None) is not None and w.get("wgrad_groups"):
             self._build_adamw_groups(w)
         if train and getattr(self, "_g16", None) is not None and w.get("wgrad_groups"):
             self._build_variant_groups(w, "g16")
         self._ws[key] = w
         return w
+
+    def _build_reduce_table(self, w, order):
+        """Device table of the batched column reduces of backward (ops.layernorm_bwd_reduce_batch), in the order backward visits
+        its entries: ("ln", name, M, D) = one LayerNorm's dgamma / dbeta partial sums; ("block", prefix, bufs, M, dim) = a
+        transformer block: norm2, the four bias gradients of its grouped weight-gradient launch (when that launch leaves them
+        as partial sums per tile column: w["bias_parts"]), norm1."""
+        f32 = dict(device=self.device, dtype=torch.float32)
+        entries = []
+        w["ln_index"], w["ln_parts"] = {}, {}
+
+        def ln(name, M_, D_):
+            nb = ops.layernorm_bwd_blocks(M_)
+            part = torch.empty(2, nb, D_, **f32)
+            w["ln_index"][name] = len(entries)
+            w["ln_parts"][name] = part
+            entries.append((part, self.store.grad(f"{name}.weight"), self.store.grad(f"{name}.bias"), nb, D_))
+        for item in order:
+            if item[0] == "ln":
+                ln(*item[1:])
+                continue
+            _, prefix, bufs, M_, dim = item
+            ln(f"{prefix}.norm2", M_, dim)
+            if prefix in w["bias_parts"]:
+                w["ln_index"][prefix + ".bias"] = len(entries)
+                for (dy, x_in, lname, n_out, k_in), part in zip(self._wgrad_layers(prefix, bufs, M_, dim, w), w["bias_parts"][prefix][1]):
+                    entries.append((part, self.store.grad(f"{lname}.bias"), None, part.shape[0], n_out))
+            ln(f"{prefix}.norm1", M_, dim)
+        w["ln_items"] = ops.ln_reduce_items(entries, self.device)
 
     # ------------------------------------------------------------------ forward pieces
     def _embed(self, imgs, noise, keep, w, ra_dec=None):
@@ -442,13 +463,13 @@ class MAEEngine:
     def _end_stage(self, w, last=False):
         """End of a backward stage: finish the dgamma/dbeta of the LayerNorms it visited (one launch), join the
         weight-gradient stream."""
-        if self._ln_count:
-            ops.layernorm_bwd_reduce_batch(w["ln_items"], self._ln_first, self._ln_count, w["ln_max_D"])
-        self._ln_first, self._ln_count = (0, 0) if last else (self._ln_first + self._ln_count, 0)
-        if self._side is not None:
+        if self._side is not None:                            # (the grouped launches' bias partial sums are reduced below)
             torch.cuda.current_stream().wait_stream(self._side)
             self._pending.clear()
             self._group_done = None
+        if self._ln_count:
+            ops.layernorm_bwd_reduce_batch(w["ln_items"], self._ln_first, self._ln_count)
+        self._ln_first, self._ln_count = (0, 0) if last else (self._ln_first + self._ln_count, 0)
 
     def _ln_bwd(self, dy, x, prefix, mean, rstd, g_in, g, g_lp, M, dim, w):
         st = self.store
@@ -456,7 +477,7 @@ class MAEEngine:
         assert k == self._ln_first + self._ln_count, "LayerNorm backward visited out of table order"
         self._ln_count += 1
         self._before_write(g_lp)
-        ops.layernorm_bwd(dy, x, st.param(f"{prefix}.weight"), mean, rstd, g_in, g, g_lp, w["ln_parts"][k], None, None,
+        ops.layernorm_bwd(dy, x, st.param(f"{prefix}.weight"), mean, rstd, g_in, g, g_lp, w["ln_parts"][prefix], None, None,
                           M, dim, self.code)
 
     def _bwd_set(self, prefix):
@@ -490,13 +511,42 @@ class MAEEngine:
                 return dict(out_f32=st.grad(f"{name}.weight"))
             o = st.offsets[f"{name}.weight"]
             return dict(out=g16[o:o + n_out * k_in].view(n_out, k_in))
-        args = [ops.gemm_args(dy, x_in, M=n_out, N=k_in, K=M, a_layout=RC, b_layout=RC, lda=n_out, ldb=k_in,
-                              colsum_a=st.grad(f"{name}.bias"), **dst(name, n_out, k_in))
-                for dy, x_in, name, n_out, k_in in self._wgrad_layers(prefix, bufs, M, dim, w)]
-        # (experiments: SKYEMB_WGRAD_TILE_ENC / _DEC force the grouped launch's tile code for one stack)
+        layers = self._wgrad_layers(prefix, bufs, M, dim, w)
         import os
-        tile = int(os.environ.get("SKYEMB_WGRAD_TILE_DEC" if prefix.startswith("decoder") else "SKYEMB_WGRAD_TILE_ENC", "0"))
-        grp = ops.GemmGroup(args, self.device, tile=tile, adamw=adamw)
+
+        def build(tile, parts):
+            args = [ops.gemm_args(dy, x_in, M=n_out, N=k_in, K=M, a_layout=RC, b_layout=RC, lda=n_out, ldb=k_in,
+                                  colsum_a=None if parts else st.grad(f"{name}.bias"), colsum_parts=parts[j] if parts else None,
+                                  **dst(name, n_out, k_in))
+                    for j, (dy, x_in, name, n_out, k_in) in enumerate(layers)]
+            return ops.GemmGroup(args, self.device, tile=tile, adamw=adamw)
+        if prefix not in w["bias_parts"] and adamw is None and g16 is None:
+            # the plain group is planned first: its tile shape fixes how many tile columns share a bias gradient's partial sums
+            # (experiments: SKYEMB_WGRAD_TILE_ENC / _DEC force the grouped launch's tile code for one stack; SKYEMB_BIAS_PARTS=0
+            # keeps the column sums on the first tile column, as before round 4)
+            tile = int(os.environ.get("SKYEMB_WGRAD_TILE_DEC" if prefix.startswith("decoder") else "SKYEMB_WGRAD_TILE_ENC", "0"))
+            probe = build(tile, None)
+            if not probe.ok:
+                return None
+            # measured at config A (round 4): the 128x128 groups of the encoder gain 2.3 us per launch, the 128x64 groups of the
+            # decoder nothing, and every group adds four items to its stage's batched reduce -- "auto" uses the partial sums on
+            # the 128x128 tile only
+            # Measured at config A (round 4, interleaved A/B of the whole step): OFF wins by 0.004-0.02 ms.  The 128x128 groups of
+            # the encoder do gain 2.3 us per launch (755 -> 727 us per step), the 128x64 groups of the decoder nothing, and the
+            # four extra items per block in the stage's batched reduce cost what was gained.  Kept behind the switch ("1": every
+            # group, "auto": 128x128 tiles only) for shapes where the first tile column is a larger share of the launch.
+            mode = os.environ.get("SKYEMB_BIAS_PARTS", "0")
+            if mode == "0" or (mode == "auto" and probe.info.tile % 1000000 != 128128):
+                return probe
+            bn = probe.info.tile % 1000
+            w["bias_parts"][prefix] = (probe.info.tile, [torch.empty((k_in + bn - 1) // bn, n_out, device=self.device, dtype=torch.float32)
+                                                       for _, _, _, n_out, k_in in layers])
+        if prefix in w["bias_parts"]:
+            tile, parts = w["bias_parts"][prefix]
+            grp = build(tile, parts)
+        else:
+            tile = int(os.environ.get("SKYEMB_WGRAD_TILE_DEC" if prefix.startswith("decoder") else "SKYEMB_WGRAD_TILE_ENC", "0"))
+            grp = build(tile, None)
         return grp if grp.ok else None
 
     # -- optimiser step fused into the weight-gradient launches (one process per replica: TrainStep(fused_adamw=True)) --
@@ -607,6 +657,10 @@ class MAEEngine:
         self._linear_bwd(dqkv, bufs["ln1"], f"{prefix}.attn.qkv.weight", f"{prefix}.attn.qkv.bias", M, 3 * dim, dim, w,
                          dx_out=dln, wgrad=single)
         prev_done = self._group_done
+        if group is not None and prefix in w["bias_parts"]:
+            # the launch leaves the four bias gradients as partial sums: their items of the stage's batched reduce come next
+            assert w["ln_index"][prefix + ".bias"] == self._ln_first + self._ln_count, "bias-gradient items out of table order"
+            self._ln_count += 4
         if group is not None:
             # all four dW / db of the block in ONE launch.  With the side stream it runs under the next block's dgrad
             # chain (a bandwidth-bound launch next to a chain of latency-bound ones); its four dy live in this block's
@@ -624,6 +678,11 @@ class MAEEngine:
         if prev_done is not None:
             torch.cuda.current_stream().wait_event(prev_done)   # the previous block's launch still reads g_lp_next
         self._ln_bwd(dln, x_in, f"{prefix}.norm1", bufs["mean1"], bufs["rstd1"], g, g, g_lp_next, M, dim, w)
+
+    def _last_key(self):
+        """Workspace key of the last forward_train() call."""
+        assert self._last is not None, "no forward_train() yet"
+        return (self._last[1], self._last[2], True)
 
     def _bwd_ctx(self):
         assert self._last is not None, "backward() without forward_train()"

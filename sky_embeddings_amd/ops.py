@@ -36,7 +36,7 @@ def _p(t):
 
 def gemm_args(A, B, *, M, N, K, a_layout=KC, b_layout=KC, lda=None, ldb=None, alpha=1.0, bias=None, table=None,
               tab_row=None, ldt=0, dst_row=None, resid=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, out_f32=None, ldo32=0,
-              out=None, ldo=0, out2=None, ldo2=0, tile=0, colsum_a=None, ws=None, split_k=0):
+              out=None, ldo=0, out2=None, ldo2=0, tile=0, colsum_a=None, ws=None, split_k=0, colsum_parts=None):
     """skyemb_gemm_args for C[M,N] = alpha * A[M,K] B[N,K]^T with fused epilogue (see include/skyemb.h)."""
     g = GemmArgs()
     g.A, g.B = _p(A), _p(B)
@@ -52,6 +52,7 @@ def gemm_args(A, B, *, M, N, K, a_layout=KC, b_layout=KC, lda=None, ldb=None, al
     g.out_f32, g.ldo32, g.out, g.ldo, g.out2, g.ldo2 = _p(out_f32), ldo32 or N, _p(out), ldo or N, _p(out2), ldo2 or N
     g.tile = tile
     g.colsum_a = _p(colsum_a)
+    g.colsum_parts = _p(colsum_parts)
     g.ws, g.ws_bytes, g.split_k = _p(ws), (ws.numel() * ws.element_size() if ws is not None else 0), split_k
     return g
 
@@ -203,13 +204,24 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, g_in, g_out, g_lp, part, dgamma, dbe
 
 
 def ln_reduce_items(entries, device):
-    """Device table of skyemb_ln_reduce_item (32 bytes each) from [(part, dgamma, dbeta, nblk, D), ...]."""
-    rows = [[part.data_ptr(), dg.data_ptr(), db.data_ptr(), nblk + (D << 32)] for part, dg, db, nblk, D in entries]
-    return torch.tensor(rows, dtype=torch.int64).to(device)
+    """Device tables of a batched column reduce from [(part, dgamma, dbeta, nblk, D), ...]; dbeta None = a single vector
+    (part [nblk, D] -> dgamma: the bias-gradient partial sums of a grouped weight-gradient launch).
+    -> (items: skyemb_ln_reduce_item x n (32 bytes each), blocks: int32 pairs {item, x | y << 16} per workgroup,
+        first_block: [n + 1] host prefix of the items' workgroups)."""
+    rows = [[part.data_ptr(), dg.data_ptr(), db.data_ptr() if db is not None else 0, nblk + (D << 32)] for part, dg, db, nblk, D in entries]
+    blocks, first = [], [0]
+    for k, (part, dg, db, nblk, D) in enumerate(entries):
+        for y in range(2 if db is not None else 1):
+            blocks += [[k, x | (y << 16)] for x in range((D + 31) // 32)]
+        first.append(len(blocks))
+    return (torch.tensor(rows, dtype=torch.int64).to(device), torch.tensor(blocks, dtype=torch.int32).to(device), first)
 
 
-def layernorm_bwd_reduce_batch(items, first, count, max_D):
-    check(lib().skyemb_layernorm_bwd_reduce_batch(items.data_ptr() + 32 * first, count, max_D, _stream()),
+def layernorm_bwd_reduce_batch(table, first, count):
+    """Items [first, first + count) of a table made by ln_reduce_items, one launch."""
+    items, blocks, first_block = table
+    b0, b1 = first_block[first], first_block[first + count]
+    check(lib().skyemb_layernorm_bwd_reduce_batch(items.data_ptr(), blocks.data_ptr() + 8 * b0, b1 - b0, _stream()),
           "skyemb_layernorm_bwd_reduce_batch")
 
 

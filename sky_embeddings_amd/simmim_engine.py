@@ -121,23 +121,14 @@ class SimMIMEngine(MAEEngine):
             w["pmv_part"] = torch.empty(B, pv, **f32)
             w["rs_part"] = torch.empty(256, D, **f32)
             w["splitk_ws"] = self._splitk_ws
-            order = [("norm", R, D)] + ([("attn_pool.norm", B, D)] if pool else [])
-            for i in reversed(range(cfg.depth)):
-                order += [(f"blocks.{i}.norm2", M, D), (f"blocks.{i}.norm1", M, D)]
-            entries = []
-            w["ln_index"], w["ln_parts"] = {}, []
-            for k, (name, M_, D_) in enumerate(order):
-                nb = ops.layernorm_bwd_blocks(M_)
-                part = torch.empty(2, nb, D_, **f32)
-                w["ln_index"][name] = k
-                w["ln_parts"].append(part)
-                entries.append((part, self.store.grad(f"{name}.weight"), self.store.grad(f"{name}.bias"), nb, D_))
-            w["ln_items"] = ops.ln_reduce_items(entries, dev)
-            w["ln_max_D"] = D
-            w["wgrad_groups"] = {}
+            w["wgrad_groups"], w["bias_parts"] = {}, {}
             if self.dtype == torch.bfloat16:
                 for i, bufs in enumerate(w["enc"]):
                     w["wgrad_groups"][f"blocks.{i}"] = self._make_wgrad_group(f"blocks.{i}", bufs, M, D, w)
+            order = [("ln", "norm", R, D)] + ([("ln", "attn_pool.norm", B, D)] if pool else [])
+            for i in reversed(range(cfg.depth)):
+                order.append(("block", f"blocks.{i}", w["enc"][i], M, D))
+            self._build_reduce_table(w, order)
         if train and getattr(self, "_fused_adamw", None) is not None and w.get("wgrad_groups"):
             self._build_adamw_groups(w)
         if train and getattr(self, "_g16", None) is not None and w.get("wgrad_groups"):

@@ -123,8 +123,7 @@ class TrainStep:
                     if not todo:                              # (the first call has just built the workspace and its groups)
                         holes = []
                         if direct:
-                            ws = [w for k, w in engine._ws.items() if k[-1] is True and k[0] == batch_size]
-                            holes = engine.grad_mirror_ranges(ws[-1]) if ws else []
+                            holes = engine.grad_mirror_ranges(engine._ws[engine._last_key()])   # the workspace this step ran on
                         todo.append(_subtract_ranges(ranges, holes))
                     for (s, e) in todo[0]:
                         ops.cast(engine.store.g[s:e], self.g16[s:e], e - s)
@@ -158,6 +157,10 @@ class TrainStep:
             st = engine.store
             snap = [t.clone() for t in (st.p, st.m, st.v, st.p_lp)]
 
+            # what the fused launches were built with: changing these afterwards (load_state_dict, a new grad_scale) would leave
+            # the block weights stepping with the old constants while apply_range() uses the new ones
+            self._fused_consts = self._optimizer_consts()
+
             def owning(fn):
                 def run():
                     engine._fused_active = True          # these launches carry the optimiser step
@@ -165,6 +168,11 @@ class TrainStep:
                         fn()
                     finally:
                         engine._fused_active = False
+                    # ... and the ordinary kernel updates the rest (embeddings, biases, LayerNorms, the single weight gradients)
+                    # right behind them, inside the same graph: as separate launches after the replay they started 8.6 us late
+                    # (the host's launch latency on the critical path of every step)
+                    for (s_, e_) in self._rest():
+                        optimizer.apply_range(s_, e_)
                 return run
             self.stages = [(owning(fn), ranges) for fn, ranges in self.stages]
         self.graphs = None
@@ -189,14 +197,25 @@ class TrainStep:
         if snap is not None:
             if not use_graph:                                  # (graph mode ran the warm-up above: the workspace exists)
                 self.stages[0][0]()
-            # what the fused launches of THIS batch shape update; the ordinary kernel takes the rest after the graph
-            ws = [w for k, w in engine._ws.items() if k[-1] is True and k[0] == batch_size]
-            fused = engine.fused_adamw_ranges(ws[-1]) if ws else []
-            bounds = [0] + [b for r in fused for b in r] + [engine.store.n]
-            self._rest_ranges = [(bounds[i], bounds[i + 1]) for i in range(0, len(bounds), 2) if bounds[i] < bounds[i + 1]]
             torch.cuda.synchronize(dev)
             for dst, src in zip((engine.store.p, engine.store.m, engine.store.v, engine.store.p_lp), snap):
                 dst.copy_(src)
+
+    def _optimizer_consts(self):
+        o = self.optimizer
+        return (tuple(o.defaults["betas"]), o.defaults["eps"], o.param_groups[1]["weight_decay"], o.grad_scale)
+
+    def _rest(self):
+        """Slices of the flat buffers the fused launches of THIS step's workspace do not update (the ordinary kernel takes them)."""
+        if self._rest_ranges is None:
+            eng = self.engine
+            w = eng._ws[eng._last_key()]                       # the workspace forward_train has just run on
+            fused = eng.fused_adamw_ranges(w)
+            bounds = [0] + [b for r in fused for b in r] + [eng.store.n]
+            self._rest_ranges = [(bounds[i], bounds[i + 1]) for i in range(0, len(bounds), 2) if bounds[i] < bounds[i + 1]]
+            self._rest_key = eng._last_key()
+        assert self._rest_key == self.engine._last_key(), "TrainStep: the batch shape changed under a fused optimiser step"
+        return self._rest_ranges
 
     def _forward(self):
         if self.simmim:
@@ -229,13 +248,14 @@ class TrainStep:
             self.load_batch(imgs, mask, ra_dec)
         if self.fused_adamw:
             # step t's scalars to the device, forward + backward (+ the fused updates), the ordinary kernel on the rest
+            if self._optimizer_consts() != self._fused_consts:
+                raise RuntimeError("TrainStep: betas / eps / weight_decay / grad_scale of the optimiser changed after the fused "
+                                   "weight-gradient launches were built (load the checkpoint BEFORE constructing TrainStep, or rebuild it)")
             self.optimizer.begin_step()                    # (writes step t's scalars to the device buffer)
             if self.graphs is not None:
-                self.graphs[0].replay()
+                self.graphs[0].replay()                    # forward + backward + every AdamW launch
             else:
                 self.stages[0][0]()
-            for (s, e) in self._rest_ranges:
-                self.optimizer.apply_range(s, e)
             self.scheduler.step()
             return self.loss
         works = []

@@ -280,13 +280,53 @@ def test_layernorm_bwd_batched_reduce(ops):
             outs.append((part, dgam, dbet, nblk, D))
         direct.append(outs[0])
         entries.append(outs[1])
+    # a single-vector item of another width (the bias-gradient partial sums of a grouped weight-gradient launch): [nblk, D] -> [D]
+    parts = dev(torch.randn(6, 3072, generator=g))
+    vec = torch.full((3072,), float("nan"), device=DEV)
+    entries.append((parts, vec, None, 6, 3072))
     items = ops.ln_reduce_items(entries, DEV)
-    ops.layernorm_bwd_reduce_batch(items, 1, 2, 768)      # a sub-range first, then everything
+    ops.layernorm_bwd_reduce_batch(items, 1, 2)      # a sub-range first, then everything
     assert torch.equal(entries[1][1], direct[1][1]) and torch.equal(entries[2][2], direct[2][2])
-    assert bool(torch.isnan(entries[0][1]).all())
-    ops.layernorm_bwd_reduce_batch(items, 0, 3, 768)
-    for e, d in zip(entries, direct):
+    assert bool(torch.isnan(entries[0][1]).all()) and bool(torch.isnan(vec).all())
+    ops.layernorm_bwd_reduce_batch(items, 0, 4)
+    for e, d in zip(entries[:3], direct):
         assert torch.equal(e[1], d[1]) and torch.equal(e[2], d[2])
+    ref = parts[0].clone()
+    for r in range(1, 6):
+        ref += parts[r]                                # the kernel's order for nblk <= 32: one row per row group, summed 0, 1, 2, ...
+    assert torch.equal(vec, ref)
+
+
+def test_grouped_wgrad_bias_partial_sums(ops):
+    """skyemb_gemm_args.colsum_parts: the column sums of dy spread over the tile columns of a grouped weight-gradient launch,
+    added up afterwards == colsum_a of the same launch (same products; fp32 sums in another order) == torch."""
+    g = torch.Generator().manual_seed(11)
+    T, n_out, k_in = 1280, 768, 512                      # tokens, dW [n_out, k_in]
+    dy = dev(torch.randn(T, n_out, generator=g), torch.bfloat16)
+    x = dev(torch.randn(T, k_in, generator=g), torch.bfloat16)
+    from sky_embeddings_amd._lib import RC
+    outs = {}
+    for mode in ("first_column", "parts"):
+        dW = torch.empty(n_out, k_in, device=DEV)
+        db = torch.full((n_out,), float("nan"), device=DEV)
+        probe = ops.GemmGroup([ops.gemm_args(dy, x, M=n_out, N=k_in, K=T, a_layout=RC, b_layout=RC, lda=n_out, ldb=k_in, out_f32=dW, colsum_a=db)], DEV)
+        assert probe.ok
+        if mode == "first_column":
+            probe.launch()
+        else:
+            bn = probe.info.tile % 1000
+            parts = torch.full(((k_in + bn - 1) // bn, n_out), float("nan"), device=DEV)
+            grp = ops.GemmGroup([ops.gemm_args(dy, x, M=n_out, N=k_in, K=T, a_layout=RC, b_layout=RC, lda=n_out, ldb=k_in, out_f32=dW,
+                                               colsum_parts=parts)], DEV, tile=probe.info.tile)
+            assert grp.ok
+            grp.launch()
+            assert not bool(torch.isnan(parts).any())
+            table = ops.ln_reduce_items([(parts, db, None, parts.shape[0], n_out)], DEV)
+            ops.layernorm_bwd_reduce_batch(table, 0, 1)
+        outs[mode] = (dW, db)
+    assert torch.equal(outs["parts"][0], outs["first_column"][0])
+    ref = dy.float().sum(0)
+    assert relerr(outs["first_column"][1], ref) < 1e-5 and relerr(outs["parts"][1], ref) < 1e-5
 
 
 # ------------------------------------------------------------------------------------ attention
