@@ -126,18 +126,66 @@ def install_standins():
                 decay.append(p)
         return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
 
+    class VisionTransformer(nn.Module):
+        """timm.models.vision_transformer.VisionTransformer restated for what utils/vit.py uses (its subclass calls
+        super().__init__(**kwargs) with img_size, patch_size, in_chans, num_classes, global_pool, embed_dim, depth, num_heads,
+        mlp_ratio, qkv_bias, drop_rate, norm_layer and then reads patch_embed / cls_token / blocks / norm / fc_norm / head /
+        forward_head / no_weight_decay): class token, final norm unless the pooled features get their own (global_pool =
+        'avg' -> fc_norm), pooling = attention pool | mean of the patch tokens | class token, dropout, linear head."""
+        def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, global_pool="token", embed_dim=768, depth=12,
+                     num_heads=12, mlp_ratio=4.0, qkv_bias=True, drop_rate=0.0, norm_layer=None, **unused):
+            super().__init__()
+            assert global_pool in ("", "avg", "token", "map")
+            norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-6)
+            use_fc_norm = global_pool == "avg"
+            self.num_classes, self.global_pool, self.num_prefix_tokens = num_classes, global_pool, 1
+            self.num_features = self.embed_dim = embed_dim
+            self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
+            self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+            self.pos_embed = nn.Parameter(torch.randn(1, self.patch_embed.num_patches + 1, embed_dim) * 0.02)
+            self.pos_drop = nn.Dropout(drop_rate)
+            self.blocks = nn.Sequential(*[Block(embed_dim, num_heads, mlp_ratio, qkv_bias, norm_layer) for _ in range(depth)])
+            self.norm = norm_layer(embed_dim) if not use_fc_norm else nn.Identity()
+            self.attn_pool = AttentionPoolLatent(embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, norm_layer=norm_layer) if global_pool == "map" else None
+            self.fc_norm = norm_layer(embed_dim) if use_fc_norm else nn.Identity()
+            self.head_drop = nn.Dropout(drop_rate)
+            self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+            nn.init.normal_(self.cls_token, std=1e-6)
+            for m in self.modules():
+                if isinstance(m, nn.Linear):
+                    nn.init.trunc_normal_(m.weight, std=0.02)
+                    if m.bias is not None:
+                        nn.init.zeros_(m.bias)
+
+        def no_weight_decay(self):
+            return {"pos_embed", "cls_token", "dist_token"}
+
+        def forward_head(self, x, pre_logits=False):
+            if self.attn_pool is not None:
+                x = self.attn_pool(x)
+            elif self.global_pool == "avg":
+                x = x[:, self.num_prefix_tokens:].mean(dim=1)
+            elif self.global_pool:
+                x = x[:, 0]
+            x = self.fc_norm(x)
+            x = self.head_drop(x)
+            return x if pre_logits else self.head(x)
+
     timm = types.ModuleType("timm")
     optim = types.ModuleType("timm.optim")
     of = types.ModuleType("timm.optim.optim_factory")
     of.param_groups_weight_decay = param_groups_weight_decay
     models = types.ModuleType("timm.models")
     vt = types.ModuleType("timm.models.vision_transformer")
-    vt.PatchEmbed, vt.Block = PatchEmbed, Block
+    vt.PatchEmbed, vt.Block, vt.VisionTransformer = PatchEmbed, Block, VisionTransformer
     layers = types.ModuleType("timm.layers")
     layers.AttentionPoolLatent = AttentionPoolLatent
+    mlayers = types.ModuleType("timm.models.layers")                       # utils/vit.py:9
+    mlayers.trunc_normal_ = nn.init.trunc_normal_
+    models.layers = mlayers
     timm.optim, optim.optim_factory, timm.models, models.vision_transformer, timm.layers = optim, of, models, vt, layers
     for n, m in [("timm", timm), ("timm.optim", optim), ("timm.optim.optim_factory", of), ("timm.models", models),
-                 ("timm.models.vision_transformer", vt), ("timm.layers", layers)]:
+                 ("timm.models.vision_transformer", vt), ("timm.layers", layers), ("timm.models.layers", mlayers)]:
         sys.modules[n] = m
     sys.modules["h5py"] = types.ModuleType("h5py")  # inert: never called on this path
     return param_groups_weight_decay
@@ -472,6 +520,102 @@ def maskgen_cases():
     print("wrote maskgen")
 
 
+def predictor_cases():
+    """Downstream predictor (utils/vit.py:258-393 VisionTransformer, :134-172 optimisers, utils/predictor_training_fns.py:3-61
+    run_iter, utils/pos_embed.py:122-144 interpolate_pos_embed via utils/vit.py:198-256 load_model) through the timm stand-in:
+    forward logits and THREE optimiser steps for
+      lp_token_ce   linear probe (norm + head trained), class-token pooling, cross-entropy
+      ft_avg_mse    fine-tuning with layer-wise lr decay (param_groups_lrd as utils/vit.py:141-143 calls it), mean pooling +
+                    fc_norm, MSE on normalised labels, NaN pixels in the input
+      fs_token_mse  "fully supervised" branch: timm's weight-decay split, one lr
+    plus the checkpoint surgery of load_model on an MAE checkpoint of another image size (bicubic pos_embed interpolation)."""
+    import importlib
+    vit = importlib.import_module("utils.vit")
+    ptf = importlib.import_module("utils.predictor_training_fns")
+    lrd = importlib.import_module("lr_decay")
+    assert vit.__file__.startswith(REF) and ptf.__file__.startswith(REF)
+    out = {}
+    img, patch, C, D, depth, heads = 32, 8, 5, 32, 2, 2
+    for case, method, pool, loss_fn, ncls in (("lp_token_ce", "lp", "token", "crossentropy", 3), ("ft_avg_mse", "ft", "avg", "mse", 2),
+                                              ("fs_token_mse", "fs", "token", "mse", 1)):
+        torch.manual_seed({"lp_token_ce": 21, "ft_avg_mse": 22, "fs_token_mse": 23}[case])
+        label_means, label_stds = ([0.5, -1.0][:ncls], [2.0, 0.5][:ncls]) if loss_fn == "mse" else ([0.0], [1.0])
+        model = vit.VisionTransformer(label_means, label_stds, 0.1, 1.7, False, ra_dec=False, depth=depth, num_heads=heads, mlp_ratio=4,
+                                      qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), img_size=img, in_chans=C, embed_dim=D,
+                                      patch_size=patch, num_classes=ncls, global_pool=pool, drop_rate=0.0)
+        with torch.no_grad():                                   # a "pre-trained" state: nothing at its init value
+            for n, prm in model.named_parameters():
+                if prm.ndim == 1 and "norm" in n and n.endswith("weight"):
+                    prm.copy_(1.0 + 0.1 * torch.randn_like(prm))
+                elif n == "pos_embed":
+                    prm.copy_(torch.randn_like(prm) * 0.05)
+                else:
+                    prm.copy_(torch.randn_like(prm) * (0.3 if prm.ndim == 1 else 0.08))
+        model = nn.DataParallel(model)
+        init_lr, weight_decay, layer_decay, total, final_lr_factor = 2e-3, 0.03, 0.7, 50, 100.0
+        if method == "ft":                                      # utils/vit.py:138-143 (positional call: weight_decay lands in init_lr)
+            groups, _ = lrd.param_groups_lrd(model.module, weight_decay, no_weight_decay_list=model.module.no_weight_decay(),
+                                             layer_decay=layer_decay)
+            opt = torch.optim.AdamW(groups)
+        elif method == "lp":                                    # utils/vit.py:145-160
+            comps = [model.module.norm, model.module.fc_norm, model.module.head]
+            opt = torch.optim.AdamW([{"params": m.parameters()} for m in comps], lr=init_lr, weight_decay=weight_decay)
+            for prm in model.module.parameters():
+                prm.requires_grad = False
+            for m in comps:
+                for prm in m.parameters():
+                    prm.requires_grad = True
+        else:                                                   # utils/vit.py:162-171 (the split sees the DataParallel wrapper's names)
+            import timm.optim.optim_factory as of
+            opt = torch.optim.AdamW(of.param_groups_weight_decay(model, weight_decay), lr=init_lr)
+        sched = torch.optim.lr_scheduler.LinearLR(opt, start_factor=1.0, end_factor=1 / final_lr_factor, total_iters=total)
+        out[f"{case}/hyper"] = np.array([init_lr, weight_decay, layer_decay, total, final_lr_factor])
+        out[f"{case}/cfg"] = np.array([img, patch, C, D, depth, heads, ncls])
+        out[f"{case}/label_means"], out[f"{case}/label_stds"] = np.array(label_means, np.float32), np.array(label_stds, np.float32)
+        for k, v in sd_np(model.module.state_dict()).items():
+            out[f"{case}/state/{k}"] = v
+        B = 4
+        g = torch.Generator().manual_seed(5)
+        xs = torch.randn(3, B, C, img, img, generator=g)
+        if case == "ft_avg_mse":
+            xs[:, 1, 2, 4:9, 3:7] = float("nan")
+        labels = torch.randint(0, ncls, (3, B, 1), generator=g) if loss_fn == "crossentropy" else torch.randn(3, B, ncls, generator=g)
+        out[f"{case}/x"], out[f"{case}/labels"] = xs.numpy(), labels.numpy()
+        model.eval()
+        with torch.no_grad():
+            out[f"{case}/logits0"] = model(xs[0]).numpy()
+        from collections import defaultdict
+        cp = defaultdict(list)
+        for it in range(3):
+            model, opt, sched, cp = ptf.run_iter(model, xs[it], None, None, labels[it], opt, sched, cp, loss_fn=loss_fn, mode="train")
+            if it != 1:                                          # (states after the first and the third step)
+                for k, v in sd_np(model.module.state_dict()).items():
+                    out[f"{case}/step{it}/{k}"] = v
+        out[f"{case}/train_loss"] = np.array(cp["train_loss"])
+        out[f"{case}/train_metric"] = np.array(cp["train_acc" if loss_fn == "crossentropy" else "train_mae"])
+        out[f"{case}/lr_after"] = np.array([gp["lr"] for gp in opt.param_groups])
+        print("wrote predictor", case, "losses", cp["train_loss"])
+    # checkpoint surgery: an MAE checkpoint made at 32x32 (16 patches) loaded into a 48x48 model (36 patches)
+    torch.manual_seed(31)
+    src = {"pos_embed": torch.randn(1, 17, D), "cls_token": torch.randn(1, 1, D), "head.weight": torch.randn(7, D), "head.bias": torch.randn(7)}
+    big = vit.VisionTransformer([0.0], [1.0], 0.0, 1.0, False, ra_dec=False, depth=1, num_heads=heads, mlp_ratio=4, qkv_bias=True,
+                                norm_layer=partial(nn.LayerNorm, eps=1e-6), img_size=48, in_chans=C, embed_dim=D, patch_size=patch,
+                                num_classes=2, global_pool="token", drop_rate=0.0)
+    ck = {k: v.clone() for k, v in src.items()}
+    pe = importlib.import_module("pos_embed")
+    pe.interpolate_pos_embed(big, ck)
+    out["surgery/pos_embed_in"], out["surgery/pos_embed_out"] = src["pos_embed"].numpy(), ck["pos_embed"].numpy()
+    ck2 = {k: v.clone() for k, v in src.items()}
+    ck2["pos_embed"] = torch.randn(1, 37, D)
+    small = vit.VisionTransformer([0.0], [1.0], 0.0, 1.0, False, ra_dec=False, depth=1, num_heads=heads, mlp_ratio=4, qkv_bias=True,
+                                  norm_layer=partial(nn.LayerNorm, eps=1e-6), img_size=32, in_chans=C, embed_dim=D, patch_size=patch,
+                                  num_classes=2, global_pool="token", drop_rate=0.0)
+    out["surgery/crop_in"] = ck2["pos_embed"].numpy().copy()
+    pe.crop_pos_embed(small, ck2)
+    out["surgery/crop_out"] = ck2["pos_embed"].numpy()
+    np.savez_compressed(os.path.join(OUT, "predictor.npz"), **out)
+
+
 def main():
     pgwd = install_standins()
     # this repo ships a drop-in ``utils`` package of the same name: keep it off the path so that the REFERENCE is imported
@@ -496,6 +640,8 @@ def main():
         # I: MAE mode WITH the RA/Dec token (two extra tokens through encoder and decoder), three optimiser steps
         mae_case(mim_vit, pgwd, "mae_tiny_I_radec", img=64, patch=16, D=32, heads=2, Dd=32, dheads=2, norm_pix=True, loss_fn="mse",
                  nan=True, ra_dec=True, seed=12, steps=3)
+    if "predictor" in only or not only:
+        predictor_cases()
     if "attnpool" in only or not only:
         # J: SimMIM behind timm's AttentionPoolLatent (mim_vit.py:246-250, 426-427): one pooled token per image, head up-samples
         # it to the whole image; NaNs, RA/Dec token, three optimiser steps.  (32 x 32 cutouts keep the D x img^2 C head small.)

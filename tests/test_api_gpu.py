@@ -279,8 +279,9 @@ def test_downstream_vit_forward_features_matches_reference_goldens(case):
     img_like, _, _ = vit.forward_features(imgs.cuda(), ra_dec=ra_dec, reshape_out=True)
     assert img_like.shape == (imgs.shape[0], cfg.embed_dim, grid, grid)
     assert torch.equal(img_like, tok[:, E:].permute(0, 2, 1).reshape(imgs.shape[0], cfg.embed_dim, grid, grid))
-    with pytest.raises(NotImplementedError):
-        vit.train(True)
+    assert vit.train(True).training and not vit.eval().training            # training is built (tests/test_predictor_gpu.py) ...
+    with pytest.raises(NotImplementedError):                               # ... except through the attention pool
+        VisionTransformer(c, "cuda", torch.float32, num_classes=2, global_pool="map").train(True)
 
 
 def test_linear_probe_hook_on_hip_embeddings(tmp_path):

@@ -525,3 +525,40 @@ def test_hdf5_lite_unchunk_cache_is_built_once_by_concurrent_openers(tmp_path):
     left = sorted(os.listdir(cache))
     assert not [p for p in left if p.endswith(".tmp")], left
     assert [p for p in left if p.endswith(".contig")] and [p for p in left if p.endswith(".contig.json")]
+
+
+def test_predictor_schedule_and_layer_decay_groups_match_torch_and_the_reference_recipe():
+    """Host logic of the downstream predictor's optimiser (utils/vit.py:134-186): LinearLR in closed form == torch's, and the
+    layer-wise lr-decay grouping of utils/lr_decay.py on a model's tensor names."""
+    from sky_embeddings_amd.utils.lr_decay import get_layer_id_for_vit, param_groups_lrd
+    from sky_embeddings_amd.utils.vit import LinearLR
+
+    class Opt:
+        def __init__(self, lrs):
+            self.param_groups = [{"lr": v, "initial_lr": v} for v in lrs]
+    mine = Opt([1e-3, 2.5e-4])
+    sched = LinearLR(mine, start_factor=1.0, end_factor=0.01, total_iters=7)
+    prm = [torch.nn.Parameter(torch.zeros(1)), torch.nn.Parameter(torch.zeros(1))]
+    ref_opt = torch.optim.AdamW([{"params": [prm[0]], "lr": 1e-3}, {"params": [prm[1]], "lr": 2.5e-4}])
+    ref = torch.optim.lr_scheduler.LinearLR(ref_opt, start_factor=1.0, end_factor=0.01, total_iters=7)
+    for _ in range(10):                                  # past total_iters: the factor stays at end_factor
+        assert np.allclose(sched.get_last_lr(), ref.get_last_lr(), rtol=1e-12)
+        ref_opt.step()
+        ref.step()
+        sched.step()
+
+    class Model:
+        num_blocks = 3
+
+        def trainable_tensors(self):
+            return [("cls_token", 3), ("patch_mask_values", 3), ("patch_embed.proj.weight", 4), ("patch_embed.proj.bias", 1),
+                    ("blocks.0.attn.qkv.weight", 2), ("blocks.0.norm1.weight", 1), ("blocks.2.mlp.fc2.weight", 2),
+                    ("norm.weight", 1), ("head.weight", 2), ("head.bias", 1)]
+    groups, lrs = param_groups_lrd(Model(), 0.1, weight_decay=0.05, no_weight_decay_list={"pos_embed", "cls_token"}, layer_decay=0.5)
+    by_name = {n: (g["lr"], g["weight_decay"]) for g in groups for n in g["params"]}
+    assert get_layer_id_for_vit("blocks.2.mlp.fc2.weight", 4) == 3 and get_layer_id_for_vit("head.bias", 4) == 4
+    assert by_name["cls_token"] == (0.1 * 0.5 ** 4, 0.0)                 # layer 0, listed as not decayed although 3-D
+    assert by_name["patch_embed.proj.weight"] == (0.1 * 0.5 ** 4, 0.05) and by_name["patch_embed.proj.bias"] == (0.1 * 0.5 ** 4, 0.0)
+    assert by_name["blocks.0.attn.qkv.weight"] == (0.1 * 0.5 ** 3, 0.05) and by_name["blocks.2.mlp.fc2.weight"] == (0.1 * 0.5, 0.05)
+    assert by_name["patch_mask_values"] == (0.1, 0.05) and by_name["norm.weight"] == (0.1, 0.0) and by_name["head.weight"] == (0.1, 0.05)
+    assert lrs == [g["lr"] for g in groups] and len(groups) == len({(round(l, 12), w) for l, w in by_name.values()})
