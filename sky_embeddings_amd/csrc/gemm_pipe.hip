@@ -817,6 +817,8 @@ int canonical_tile(int tile) {   // legacy codes of the round-1 ABI
     return tile == 64 ? 64064 : tile == 128 ? 128128 : tile == 12864 ? 128064 : tile;
 }
 
+#include "gemm_pipe256.h"
+
 struct TunedGemm {
     int M, N, K, a_kc, b_kc, tile, split;
 };
@@ -862,6 +864,18 @@ int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
     // ViT-L token counts, long k-loops or the widest outputs: 256x128 with 16 waves, one workgroup per CU (fc2 forward
     // [8320 x 1024 x 4096]: 91 -> 84 us, fc1 forward [8320 x 4096 x 1024]: 128 -> 120 us; the [8320 x 3072 x 1024] launch is
     // better off with two 128x128 workgroups per CU overlapping each other's prologue and epilogue: 73 vs 80 us)
+    // Two or more rounds of 256 x 256 tiles, one per CU (gemm_pipe256.h: half the L2 -> LDS bytes per FLOP of the 128 x 128 tile,
+    // matrix pipe and load pipe side by side on every SIMD).  Taken when the tile count is within a sixth of whole rounds of 256 --
+    // a few tiles over are cut off as a row tail below, a few under leave CUs idle for one round -- and the epilogue is one the
+    // kernel has (no row maps, column sums or split-K).
+    static const bool t256_on = []() { const char *e = getenv("SKYEMB_GEMM_256"); return !(e && e[0] == '0'); }();
+    if (tile == 0 && t256_on && g_in.split_k <= 1 && gemm256_applicable(g)) {
+        const int64_t R = ceil_div64(g.M, 256), C = ceil_div64(g.N, 256), T = R * C;
+        const int64_t over = T % 256;                     // tiles beyond whole rounds
+        const bool tail_ok = over > 0 && over <= C && (R - 1) * C % 256 == 0 &&              // the last row block alone is the excess
+                             (g.ws || ((g.K / BK) % 2 == 0 && g.K <= 2048 && ceil_div64(g.M - (R - 1) * 256, 64) * ceil_div64(g.N, 64) <= 256));
+        if (T >= 512 && g.N % 256 == 0 && (over == 0 || over >= 214 || tail_ok)) tile = 256256;
+    }
     if (tile == 0 && g.a_layout == SKYEMB_KC && ((t128 >= 512 && g.K >= 2048) || (t128 >= 2048 && g.N >= 4096))) tile = 2256128;
     if (tile == 0 && (t128 >= 1024 || (t128 >= 512 && g.K >= 1024))) tile = 128128;   // >= 2 rounds of 2 workgroups per CU
     if (tile == 0 && (t12864 >= 2048 || (t12864 >= 1024 && g.K >= 1024))) tile = 128064;
@@ -897,15 +911,24 @@ int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
     // rest of the chip idles.  The row blocks that fill whole rounds go as one launch; the remaining rows as a second,
     // finely split launch (64x64 tiles, split-K) that is over in a fraction of a round.
     static const bool tail_on = []() { const char *e = getenv("SKYEMB_GEMM_TAIL"); return !(e && e[0] == '0'); }();
-    if (tail_on && (tile == 128128 || tile == 2256128) && S == 1 && g.a_layout == SKYEMB_KC && g.ws && !g.dst_row && !g.tab_row &&
-        !g.colsum_a) {
-        const int64_t bm_t = tile == 128128 ? 128 : 256, slots = tile == 128128 ? 512 : 256;   // 256x128: one workgroup per CU
-        const int64_t R = ceil_div64(g.M, bm_t), C = ceil_div64(g.N, 128);
+    if (tile == 256256 && (g_in.split_k > 1 || !gemm256_applicable(g))) {
+        skyemb_set_error("skyemb_gemm(256x256): the problem is outside this tile's subset (k-contiguous A, plain epilogue, K >= 128, no split-K)");
+        return 1;
+    }
+    if (tile == 256256) S = g.split_k = 1;
+    // (without a split-K workspace the tail must fit the one-launch two-k-group form)
+    const bool tail_wk2 = wk2_on && (g.K / BK) % 2 == 0 && g.K <= 2048;
+    if (tail_on && (tile == 128128 || tile == 2256128 || tile == 256256) && S == 1 && g.a_layout == SKYEMB_KC && (g.ws || tail_wk2) && !g.dst_row &&
+        !g.tab_row && !g.colsum_a) {
+        const int64_t bm_t = tile == 128128 ? 128 : 256, slots = tile == 128128 ? 512 : 256;   // 256x128, 256x256: one workgroup per CU
+        const int64_t R = ceil_div64(g.M, bm_t), C = ceil_div64(g.N, tile == 256256 ? 256 : 128);
         const int64_t full = (R * C / slots) * slots;                 // tiles in whole rounds
         const int64_t Rm = full / C;                                  // row blocks of the main launch
         const int64_t tail_tiles = (R - Rm) * C;
         // (measured on the ViT-L shapes: 118 -> 92 us at one round + 8 tiles; nothing gained at three or four rounds)
-        if (Rm >= 1 && Rm < R && tail_tiles <= 64 && full - Rm * C < C && (full <= 2 * slots || tile == 2256128)) {
+        const int64_t t64_tail = ceil_div64(g.M - Rm * bm_t, 64) * ceil_div64(g.N, 64);
+        if (Rm >= 1 && Rm < R && tail_tiles <= 64 && full - Rm * C < C && (full <= 2 * slots || tile == 2256128 || tile == 256256) &&
+            (g.ws || t64_tail <= 256)) {
             const int64_t r0 = Rm * bm_t;
             skyemb_gemm_args gm = g, gt = g;
             gm.M = (int)r0;
@@ -921,7 +944,7 @@ int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
             if (St > 8) St = 8;
             if (St > g.K / BK / 4) St = g.K / BK / 4;
             while (St > 1 && (int64_t)St * ((int64_t)gt.M * gt.N + gt.M) * 4 > g.ws_bytes) --St;
-            if (St < 1) St = 1;
+            if (St < 1 || !g.ws) St = 1;
             gt.tile = 64064;
             gt.split_k = St;
             // short k-loops: the tail as ONE launch of the two-k-group tile (at most one workgroup per CU, no slabs, no reduce
@@ -930,11 +953,12 @@ int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
                 gt.tile = 9064064;
                 gt.split_k = 1;
             }
-            const int rc = dispatch_code(tile, gm, st);
+            const int rc = tile == 256256 ? gemm256_launch(gm, st) : dispatch_code(tile, gm, st);
             if (rc != 0) return rc;
             return skyemb_gemm_pipe_try(gt, st);
         }
     }
+    if (tile == 256256) return gemm256_launch(g, st);
     return dispatch_code(tile, g, st);
 }
 

@@ -635,6 +635,90 @@ def test_gemm_row_tail_launch_at_vit_l_token_counts(ops, b_layout, monkeypatch):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("b_l", [0, 1])
+@pytest.mark.parametrize("shape", [(1000, 512, 256), (520, 768, 128), (256, 256, 1024)])
+def test_gemm_256x256_eight_wave_tile(ops, b_l, shape):
+    """csrc/gemm_pipe256.h (tile code 256256): persistent workgroups, ten-slot half-tile ring, two wave groups half a phase apart.
+    Ragged row / column edges, the shortest k-loop it takes (two k-tiles: prologue = whole problem) and a longer one, k-contiguous
+    and row-contiguous B, every epilogue it carries (bias, fp32 residual, GELU with pre-activation, dGELU, alpha, fp32 + bf16
+    outputs) -- against fp64."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + 3 * N + K + b_l)
+    A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.2
+    bias, resid = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    T = torch.bfloat16
+    Ar, Br = A.to(T).double(), B.to(T).double()
+    Ad, Bd = dev(A, T), dev(B.T.contiguous() if b_l else B, T)
+    kw = dict(M=M, N=N, K=K, a_layout=0, b_layout=b_l, tile=256256)
+    prod = Ar @ Br.T
+    scale = float((Ar.abs() @ Br.abs().T).max())
+    out = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(Ad, Bd, out_f32=out, **kw)
+    assert float((out.cpu().double() - prod).abs().max()) <= 2e-6 * scale
+    out2 = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(Ad, Bd, out_f32=out2, **kw)
+    assert torch.equal(out, out2)                                      # run-to-run deterministic
+    out32, outlp = torch.zeros(M, N, device=DEV), torch.zeros(M, N, device=DEV, dtype=T)
+    ops.gemm(Ad, Bd, alpha=0.5, bias=dev(bias), resid=dev(resid), ldr=N, out_f32=out32, out=outlp, **kw)
+    ref = prod * 0.5 + bias.double() + resid.double()
+    assert float((out32.cpu().double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    assert float((outlp.float().cpu().double() - ref).abs().max()) <= 1e-2 * max(1.0, float(ref.abs().max()))
+    act, pre = torch.zeros(M, N, device=DEV, dtype=T), torch.zeros(M, N, device=DEV, dtype=T)
+    ops.gemm(Ad, Bd, bias=dev(bias), act=ops.ACT_GELU, out=act, out2=pre, **kw)
+    v = (prod + bias.double()).float()
+    assert float((pre.float().cpu() - v).abs().max()) <= 1e-2 * float(v.abs().max())
+    assert float((act.float().cpu() - torch.nn.functional.gelu(v)).abs().max()) <= 1e-2 * float(v.abs().max())
+    aux = torch.randn(M, N, generator=g)
+    auxr = aux.to(T).float().requires_grad_(True)
+    torch.nn.functional.gelu(auxr).sum().backward()
+    dg = torch.zeros(M, N, device=DEV, dtype=T)
+    ops.gemm(Ad, Bd, aux=dev(aux, T), ldaux=N, act=ops.ACT_DGELU, out=dg, **kw)
+    refd = prod.float() * auxr.grad
+    assert float((dg.float().cpu() - refd).abs().max()) <= 1e-2 * float(refd.abs().max())
+    # outside its subset (row-contiguous A, a single k-tile) the explicit tile is refused, not silently served by another kernel
+    with pytest.raises(Exception):
+        ops.gemm(dev(A.T.contiguous(), T), Bd, M=M, N=N, K=K, a_layout=1, b_layout=b_l, out_f32=out, tile=256256)
+    with pytest.raises(Exception):
+        ops.gemm(Ad[:, :64].contiguous(), dev(B[:, :64].contiguous(), T), M=M, N=N, K=64, out_f32=out, tile=256256)
+
+
+@pytest.mark.parametrize("b_layout", [0, 1])
+def test_gemm_256x256_chosen_at_vit_l_size_with_its_row_tail(ops, b_layout):
+    """[8320 x 4096 x 1024] (mim_19's fc1 forward / fc2 data gradient) with the tile choice left open: 33 x 16 = 528 tiles of
+    256 x 256 = two rounds of 256 + one row block of 16, which the dispatcher cuts off as a second launch (no workspace given:
+    the one-launch two-k-group tail).  GELU with both outputs / dGELU, against the 128 x 128 ring kernel on the same inputs
+    (different summation order: compared with a bf16-sized tolerance) and spot rows against fp64."""
+    M, N, K = 8320, 4096, 1024
+    g = torch.Generator(device=DEV).manual_seed(11 + b_layout)
+    A = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    W = (torch.randn(N, K, device=DEV, generator=g) * 0.05).bfloat16()
+    Bd = W if b_layout == 0 else W.T.contiguous()
+    bias = torch.randn(N, device=DEV, generator=g)
+    aux = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+    outs = []
+    for tile in (0, 128128):
+        o1, o2 = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16), torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        if b_layout == 0:
+            ops.gemm(A, Bd, M=M, N=N, K=K, bias=bias, act=ops.ACT_GELU, out=o1, out2=o2, tile=tile)
+        else:
+            ops.gemm(A, Bd, M=M, N=N, K=K, a_layout=ops.KC, b_layout=ops.RC, lda=K, ldb=N, act=ops.ACT_DGELU, aux=aux, ldaux=N, out=o1, tile=tile)
+        outs.append((o1.float(), o2.float()))
+    torch.cuda.synchronize()
+    for a, b in zip(outs[0], outs[1]):
+        assert float((a - b).abs().max()) <= 2e-2 * max(float(b.abs().max()), 1e-6)
+    rows = [0, 255, 256, 4111, 8191, 8192, 8319]                       # both sides of the main / tail seam and of tile seams
+    ref = A[rows].double() @ W.double().T
+    if b_layout == 0:
+        v = (ref + bias.double()).float()
+        assert float((outs[0][1][rows] - v).abs().max()) <= 1e-2 * float(v.abs().max())
+        assert float((outs[0][0][rows] - torch.nn.functional.gelu(v)).abs().max()) <= 1e-2 * float(v.abs().max())
+    else:
+        x = aux[rows].double()
+        dgelu = 0.5 * (1.0 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5
+        want = (ref * dgelu).float()
+        assert float((outs[0][0][rows] - want).abs().max()) <= 1e-2 * float(want.abs().max())
+
+
 def test_simmim_mask_counts_match_reference_mask_generator():
     """The device MaskGenerator against masks the reference's own class drew (tests/golden/maskgen.npz, made by
     tests/golden/make_golden.py maskgen): fed the reference's ratio draw, the kernel masks exactly as many patches per

@@ -229,6 +229,36 @@ int main(int argc, char **argv) {
     };
 
 #ifdef GEMM_STAMP
+    if (getenv("LAB_STAMP256")) {
+        // the 256 x 256 kernel's phases: cycles per phase and wave in its four parts (READ part, first barrier, MFMA part, second
+        // barrier), waves 0-3 = the early group, 4-7 the late one; workgroups 0-7
+        unsigned long long *d_st;
+        CK(hipMalloc(&d_st, 64 * 8 * 8));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamp), &d_st, sizeof(d_st)));
+        for (int bkc = 1; bkc >= 0; --bkc) {
+            Shape s{"stamp256", 8192, 4096, 1024, 1, bkc, 1, 0};
+            CK(hipMemset(d_st, 0, 64 * 8 * 8));
+            for (int it = 0; it < 4; ++it) {
+                skyemb_gemm_args g = make_args(s, it % ROT, 256256, 1);
+                if (skyemb_gemm_pipe_try(g, 0) != 0) { fprintf(stderr, "refused: %s\n", g_err); return 1; }
+            }
+            CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> h(64 * 8);
+            CK(hipMemcpy(h.data(), d_st, 64 * 8 * 8, hipMemcpyDeviceToHost));
+            for (int w = 0; w < 8; ++w) {
+                double a[4] = {0, 0, 0, 0}, n = 0;
+                for (int b = 0; b < 8; ++b) {
+                    for (int i = 0; i < 4; ++i) a[i] += (double)h[(b * 8 + w) * 8 + i];
+                    n += (double)h[(b * 8 + w) * 8 + 4];
+                }
+                double pro = 0, epi = 0, nt = 0;
+                for (int b = 0; b < 8; ++b) { pro += (double)h[(b * 8 + w) * 8 + 5]; epi += (double)h[(b * 8 + w) * 8 + 6]; nt += (double)h[(b * 8 + w) * 8 + 7]; }
+                printf("B %s wave %d: per phase  read %.0f  barrier1 %.0f  mfma %.0f  barrier2 %.0f  = %.0f cycles | per tile: prologue %.0f  k-loop %.0f  epilogue %.0f cycles\n", bkc ? "kc" : "rc", w,
+                       a[0] / n, a[1] / n, a[2] / n, a[3] / n, (a[0] + a[1] + a[2] + a[3]) / n, pro / nt, (a[0] + a[1] + a[2] + a[3]) / nt, epi / nt);
+            }
+        }
+        return 0;
+    }
     if (getenv("LAB_STAMP")) {
         // timeline of the launches that dominate the step (product tile choice: code 0 = tuned table / heuristic), cold
         // operands (rotation over six sets, as in the step)
