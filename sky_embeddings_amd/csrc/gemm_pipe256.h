@@ -5,31 +5,33 @@
 // Why another loop structure.  The ring kernels above keep one barrier per k-tile and let co-resident workgroups (or a second
 // wave group over k) cover each other's waits; per byte brought into LDS a 128 x 128 tile does 64 MFMA-columns of work, a
 // 256 x 256 tile 128: the ViT-L launches sat at 650-800 TFLOP/s on the L2 -> LDS fill rate.  Here a wave owns 128 x 64 of the
-// tile (32 accumulator fragments = 128 registers), the k-tile (64 wide) is consumed in FOUR PHASES of 16 MFMAs (one quadrant of
+// tile (32 accumulator fragments = 128 registers), the k-tile (64 wide) is consumed in TWO PHASES of 32 MFMAs (one 64-row half of
 // the wave's block each), and the two waves that share a SIMD run half a phase apart: while one multiplies, the other reads
 // the fragments of its next phase and issues the next LDS-DMA pieces -- matrix pipe beside LDS / memory pipe on every SIMD,
 // all the time (MI355X_MICROARCH.md, "Two waves per SIMD").
 //
 // LDS: a ring of ten 16 KiB HALF-TILES (128 rows x 64 k of A or of B) = all 160 KiB.  Half-tile h = 4 t + e of k-tile t, e in
 // {0: B rows 0-127, 1: B rows 128-255, 2: A rows 0-127, 3: A rows 128-255}, lives in slot h mod 10.  Every wave issues two of
-// a half-tile's sixteen 1 KiB pieces.  Phase p = 4 t + q requests half-tile p + 7 in its READ part: seven half-tiles (1.75 k-tiles) run ahead.
+// a half-tile's sixteen 1 KiB pieces.  Phase p = 2 t + q requests half-tiles 2 p + 6 and 2 p + 7 in its READ part: six to seven
+// half-tiles (1.5+ k-tiles) run ahead.
 //
 // Synchronisation (slots = the intervals between consecutive workgroup barriers; wave group G0 = waves 0-3 runs the READ part
-// of phase p in slot 2p and its MFMA part in slot 2p + 1, G1 = waves 4-7 one slot later):
-//   RAW  phase 4t + 3 ends its READ part with a counted wait that leaves the three youngest half-tiles in flight (4t + 8 .. 10,
-//        requested in phases 4t + 1 .. 4t + 3) and thereby retires every piece of k-tile t + 1 this wave issued; G0 has waited by
-//        slot 8t + 6, G1 by 8t + 7; the first read of k-tile t + 1 is G0's in slot 8t + 8 -- a barrier interval after the LAST wait.
-//   WAR  slot of half-tile h is re-filled by half-tile h + 10, requested in the READ part of phase h + 3, i.e. no earlier than
-//        slot 2h + 6 (G0).  The last reads of k-tile t: B halves (h = 4t, 4t + 1) in phase 4t + 1, G1's issued in slot 8t + 3
-//        and complete (lgkmcnt, at the head of its MFMA part) in slot 8t + 4 -> re-fills from slots 8t + 6, 8t + 8; A rows 0-127
-//        (4t + 2) by G0 in phase 4t + 2, complete in slot 8t + 5 -> re-fill from 8t + 10; A rows 128-255 (4t + 3) by G1, complete
-//        in slot 8t + 6 -> re-fill from 8t + 12.  Every re-fill is two or more barriers behind the completion of the reads.
+// of phase p in slot 2p and its MFMA part in slot 2p + 1, G1 = waves 4-7 one slot later; a wave reads its B fragments and the
+// first half of its A rows in phase 2t, the second half in phase 2t + 1):
+//   RAW  phase 2t + 1 ends its READ part with a counted wait that leaves the two youngest half-tiles in flight (4t + 8, 4t + 9,
+//        requested in that phase) and thereby retires every piece of k-tile t + 1 this wave issued; G0 has waited by slot
+//        4t + 2, G1 by 4t + 3; the first read of k-tile t + 1 is G0's in slot 4t + 4 -- a barrier interval after the LAST wait.
+//   WAR  slot of half-tile h = 4t + e is re-filled by half-tile h + 10, requested in phase (h + 4) / 2 (rounded down), by G0 in
+//        slot 4t + 4 (e = 0, 1) or 4t + 6 (e = 2, 3).  The last reads of k-tile t: B halves in phase 2t, G1's issued in slot
+//        4t + 1 and complete (lgkmcnt, at the head of its MFMA part) in slot 4t + 2; A rows 0-127 by G0 in phase 2t + 1, complete
+//        in slot 4t + 3; A rows 128-255 by G1, complete in slot 4t + 4.  Every re-fill is behind a barrier that follows the
+//        completion of the reads it overwrites (two or more barriers, one for A rows 128-255).
 // Fragments are read by ds_read_b128 from the XOR-swizzled k-contiguous images (conflict-free, see issue_kc / frag_kc); a
 // row-contiguous B (data gradients) uses the transposing reads of the ring kernels on two [64 k][128 n] images.
 // Epilogue: the fp32 tile goes through LDS in two halves of 128 rows (133 KB each) and leaves in 16 / 32-byte row pieces with
 // bias, fp32 residual, GELU (+ pre-activation) or dGELU fused, like the ring kernels'.
 
-constexpr int G256_HT = 16384, G256_RING = 10, G256_AHEAD = 7;
+constexpr int G256_HT = 16384, G256_RING = 10, G256_AHEAD = 6;
 
 // LDS-DMA of 16 bytes per lane from a WORKGROUP-UNIFORM base (scalar registers) + one 32-bit per-lane offset, destination = the
 // wave's 1 KiB piece at `lds_wave_base` (M0).  Written out: through the builtin every piece's 64-bit per-lane address lived in
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const skyemb_gemm_args g) 
         ++iss;
         iss_slot = next(iss_slot, 1);
     }
-    wait_vmcnt<2 * (G256_AHEAD - 4)>();                   // (K >= 128: half-tiles 0-7 all exist; 4-7 stay in flight)
+    wait_vmcnt<2 * (G256_AHEAD - 4)>();                   // (K >= 128: half-tiles 0-5 all exist; 4 and 5 stay in flight)
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();            // the second wave group runs half a phase behind
 #ifdef GEMM_STAMP
@@ -170,10 +172,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const skyemb_gemm_args g) 
                 else fb[sub][jj][kk] = frag_rc_asm<128>(sb, b_rows + sub * 32 + jj * 16, kk, lane);
             }
     };
-    // 16 MFMAs of one quadrant.  (The phase's two LDS-DMA pieces were tried BETWEEN these: an LDS-DMA costs ~100 cycles of the
-    // wave's issue wherever it stands -- stamped: MFMA part 307 cycles without, 515 with them -- and the partner's READ part is
-    // the shorter one, so they stay there: READ + 2 pieces = 400 beside MFMA = 307.)
-    auto mfma_quadrant = [&](int ih, int jh) {
+    // 32 MFMAs: one 64-row half of the wave's block against all four of its column fragments, both k halves of the k-tile.
+    // (LDS-DMA pieces were tried BETWEEN the MFMAs: an LDS-DMA costs ~100 cycles of the wave's issue wherever it stands --
+    // stamped: a 16-MFMA part 307 cycles without, 515 with two of them -- so they stay in the READ part, beside the partner's
+    // MFMAs.  And FOUR phases of 16 MFMAs per k-tile were measured first: READ + 2 pieces = 435 cycles beside MFMA = 306, two
+    // barriers of ~75 each per phase, 1025 cycles per phase = 4100 per k-tile; two phases balance 16 / 8 reads + 4 pieces
+    // against 32 MFMAs and halve the barriers.)
+    auto mfma_half = [&](int ih) {
 #ifndef G256_NOPRIO
         __builtin_amdgcn_s_setprio(1);
 #endif
@@ -182,36 +187,41 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const skyemb_gemm_args g) 
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-                    acc[ih * 4 + ii][jh * 2 + jj] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[jh][jj][kk], fa[ii][kk], acc[ih * 4 + ii][jh * 2 + jj], 0, 0, 0);  // D[n][m]
+                for (int j = 0; j < 4; ++j)
+                    acc[ih * 4 + ii][j] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j >> 1][j & 1][kk], fa[ii][kk], acc[ih * 4 + ii][j], 0, 0, 0);  // D[n][m]
 #ifndef G256_NOPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
     };
-    // one phase: READ part (fragments of this phase, one half-tile requested, the counted wait in the last phase of a k-tile),
+    // one phase: READ part (fragments of this phase, two half-tiles requested, the counted wait in the last phase of a k-tile),
     // barrier, MFMA part, barrier
     auto phase = [&](auto Q, int t) {
         constexpr int q = decltype(Q)::value;
         if constexpr (q == 0) {
             read_b(0);
-            __builtin_amdgcn_sched_barrier(0);            // (the four B fragments first: the first MFMAs need them)
-            read_a(0);
-        } else if constexpr (q == 1) {
             read_b(1);
-        } else if constexpr (q == 2) {
+            __builtin_amdgcn_sched_barrier(0);            // (the B fragments first)
+            read_a(0);
+        } else {
             read_a(1);
         }
 #ifndef G256_NODMA
-        if (iss < H) {                                    // half-tile p + 7: kind (q + 3) & 3
-            issue_piece((q + 3) & 3, (iss >> 2) * BK, iss_slot, 0);
-            issue_piece((q + 3) & 3, (iss >> 2) * BK, iss_slot, 1);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                     // half-tiles 2 p + 6, 2 p + 7: kinds 2, 3 (A) in the first phase of a k-tile, 0, 1 (B) in the second
+            if (iss < H) {
+                issue_piece((2 * q + 2 + u) & 3, (iss >> 2) * BK, iss_slot, 0);
+                issue_piece((2 * q + 2 + u) & 3, (iss >> 2) * BK, iss_slot, 1);
+            }
+            ++iss;
+            iss_slot = next(iss_slot, 1);
         }
+#else
+        iss += 2;
+        iss_slot = next(iss_slot, 2);
 #endif
-        ++iss;
-        iss_slot = next(iss_slot, 1);
-        if constexpr (q == 3) {
-            if (t + 2 < KT) wait_vmcnt<6>();              // k-tile t + 1 has landed; the three half-tiles behind it stay in flight
+        if constexpr (q == 1) {
+            if (t + 2 < KT) wait_vmcnt<4>();              // k-tile t + 1 has landed; the two half-tiles behind it stay in flight
             else if (t + 1 < KT) wait_vmcnt<0>();
         }
         G256_STAMP(0);
@@ -221,18 +231,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const skyemb_gemm_args g) 
         G256_STAMP(1);
         if constexpr (!B_KC) {                            // asm fragment reads: counted by hand (see frag_rc_asm), waited for HERE
             lds_wait<0>();
-            if constexpr (q == 0 || q == 2)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) lds_use(fa[ii][kk]);
+            if constexpr (q == 0)
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                    for (int ii = 0; ii < 4; ++ii) lds_use(fa[ii][kk]);
-            if constexpr (q == 0 || q == 1)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) lds_use(fb[q][jj][kk]);
+                    for (int j = 0; j < 4; ++j) lds_use(fb[j >> 1][j & 1][kk]);
         }
-        mfma_quadrant(q >= 2 ? 1 : 0, (q == 1 || q == 2) ? 1 : 0);
+        mfma_half(q);
         G256_STAMP(2);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -242,8 +251,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const skyemb_gemm_args g) 
     for (int t = 0; t < KT; ++t) {
         phase(std::integral_constant<int, 0>{}, t);
         phase(std::integral_constant<int, 1>{}, t);
-        phase(std::integral_constant<int, 2>{}, t);
-        phase(std::integral_constant<int, 3>{}, t);
         rs = next(rs, 4);
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();            // (the first group is a barrier ahead: both have now left the last MFMA part)
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const skyemb_gemm_args g) 
         if (g_gemm_stamp && lane_fresh() == 0 && blockIdx.x < 8) {
             unsigned long long *o = g_gemm_stamp + (size_t)(blockIdx.x * 8 + wave) * 8;
             for (int i = 0; i < 4; ++i) atomicAdd(o + i, (unsigned long long)seg[i]);
-            atomicAdd(o + 4, (unsigned long long)(4 * KT));
+            atomicAdd(o + 4, (unsigned long long)(2 * KT));
             atomicAdd(o + 5, (unsigned long long)(t_loop0 - t_tile0));      // prologue: tile start -> first phase
             atomicAdd(o + 6, (unsigned long long)(t_end - t_loop_end));     // epilogue incl. store acknowledgement
             atomicAdd(o + 7, 1ull);
