@@ -349,6 +349,49 @@ def test_pretrain_entry_point_trains_from_survey_tiles(tmp_path):
     assert ck["batch_iters"] >= 10 and np.isfinite(ck["losses"]["train_loss"]).all()
 
 
+def test_sky_sim_search_entry_point_streams_survey_tiles(tmp_path):
+    """python sky_sim_search.py <ini> (sky_sim_search.py:123-173): targets from an HDF5 file, the test set = OVERLAPPING cutouts
+    of every FITS tile under --test_dirs (use_overlap, overlap 0.4, nested batches), best n_save kept.  One target is a window
+    cut out of one of the tiles: it must come back as the best match, at its sky position."""
+    from sky_embeddings_amd import fits_lite, hdf5_lite
+    from tests.test_feeder_gpu import _make_tiles
+    dd = tmp_path / "data"
+    tiles = dd / "pdr3_dud"
+    tiles.mkdir(parents=True)
+    _make_tiles(str(tiles), n_patches=2, missing=())
+    # targets: windows of tile 0 at grid positions of the overlapping sampler (step = int(64 * 0.6) = 38) + a synthetic cutout
+    bands = ("G", "R", "I", "Z", "Y")
+    first = sorted(f for f in os.listdir(tiles) if "-G-" in f)[0]
+    imgs = [fits_lite.read_image_hdu(str(tiles / first.replace("-G-", f"-{b}-")), hdu=1).array() for b in bands]
+    win = np.stack([im[38:38 + 64, 76:76 + 64] for im in imgs]).astype(np.float32)
+    win = np.where(win < -3.0, -3.0, win)
+    rng = np.random.default_rng(3)
+    # (two targets: the window and a faintly perturbed copy -- the inverse-variance weights of determine_target_features need a
+    # non-degenerate target set; their mean is the window's embedding to ~1e-3)
+    cut = np.stack([win, win + 0.02 * rng.standard_normal((5, 64, 64)).astype(np.float32)])
+    hdf5_lite.write_datasets(str(dd / "targets.h5"), {"cutouts": cut, "ra": np.zeros(2, np.float32), "dec": np.zeros(2, np.float32)})
+    work = tmp_path / "work"
+    (work / "configs").mkdir(parents=True)
+    cfg = _tiny_ini(tmp_path)
+    cfg["TRAINING"]["compute_dtype"] = "f32"
+    cfg["DATA"].update(bands="['G','R','I','Z','Y']", min_bands="5", cutouts_per_tile="48", use_calexp="True")
+    with open(work / "configs" / "mim_t.ini", "w") as fh:
+        cfg.write(fh)
+    for name in ("sky_sim_search.py", "utils", "sky_embeddings_amd"):
+        os.symlink(os.path.join(ROOT, name), work / name)
+    out = subprocess.run([sys.executable, str(work / "sky_sim_search.py"), "mim_t", "-tgt_fn", "targets.h5", "-tst_dirs", str(tiles), "-tgt_i", "[0,1]",
+                          "-aug", "False", "-bs", "16", "-ns", "12", "-dd", str(dd)],
+                         cwd=str(work), env=dict(os.environ, PYTHONPATH=str(work)), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    z = np.load(str(work / "results" / "mim_t_targets_simsearch_results.npz"))
+    assert set(z.files) == {"test_ra_decs", "test_scores", "target_images", "target_features", "test_images", "test_features"}
+    assert z["test_images"].shape == (12, 5, 64, 64) and z["test_ra_decs"].shape == (12, 2) and z["test_scores"].shape == (12,)
+    assert bool((z["test_scores"][:-1] >= z["test_scores"][1:]).all())
+    # the window the target was cut from is the best match (a randomly initialised encoder still maps equal pixels to equal embeddings)
+    assert np.array_equal(np.nan_to_num(z["test_images"][0]), np.nan_to_num(win)) and z["test_scores"][0] > 0.99
+    assert z["test_scores"][1] < z["test_scores"][0] - 0.005           # ... clear of every other window (noise tiles through a random encoder: ~0.985)
+
+
 def test_compute_similarity_central_patches_matches_reference_goldens():
     """n_central_patches (utils/similarity.py:238-240): the reference's own compute_similarity with the select_centre import it
     lacks supplied by the generator (tests/golden/make_golden.py central_cases)."""
