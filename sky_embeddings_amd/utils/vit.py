@@ -7,8 +7,10 @@ torch on the same device, joined to the engine by an autograd node whose backwar
 Training methods of utils/vit.py:134-172: ``ft`` (fine-tuning with layer-wise lr decay), ``lp`` (linear probe: final norm,
 ``fc_norm`` and head only; the encoder backward is not run at all), anything else "fully supervised" (timm's weight-decay split,
 one lr); schedule = the LinearLR the reference ends up with (its OneCycleLR is overwritten, utils/vit.py:174-186).
-Pooling: ``token`` (class token), ``avg`` (mean of the patch tokens + ``fc_norm``; timm then has no final norm), ``''``.
-``global_pool = map`` (attention pool) is served for inference features only: training it raises by name.
+Pooling: ``token`` (class token), ``avg`` (mean of the patch tokens + ``fc_norm``; timm then has no final norm), ``map`` (timm's
+``AttentionPoolLatent`` with two heads, as every shipped predictor config asks for: one learned query over the encoder's tokens,
+projection, LayerNorm + MLP residual -- evaluated in torch like the rest of the head, ~1.5 % of the encoder's FLOPs; its gradient
+with respect to ALL tokens enters the engine's backward), ``''``.
 """
 from __future__ import annotations
 
@@ -70,6 +72,19 @@ class VisionTransformer:
         self.head = OrderedDict()
         if global_pool == 'avg':
             self.head["fc_norm.weight"], self.head["fc_norm.bias"] = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+        if global_pool == 'map':
+            # timm AttentionPoolLatent(embed_dim, num_heads=2, mlp_ratio, norm_layer) (utils/vit.py:303-309): trunc-normal latent, Linear init
+            hid = int(D * cfg.mlp_ratio)
+
+            def lin(o, i):
+                return (torch.randn(o, i, generator=gen) * 0.02).clamp_(-0.04, 0.04).to(dev), torch.zeros(o, device=dev)
+            self.pool_heads = 2
+            self.head["attn_pool.latent"] = (torch.randn(1, 1, D, generator=gen) * D ** -0.5).clamp_(-2 * D ** -0.5, 2 * D ** -0.5).to(dev)
+            for name, (o, i) in (("q", (D, D)), ("kv", (2 * D, D)), ("proj", (D, D))):
+                self.head[f"attn_pool.{name}.weight"], self.head[f"attn_pool.{name}.bias"] = lin(o, i)
+            self.head["attn_pool.norm.weight"], self.head["attn_pool.norm.bias"] = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+            self.head["attn_pool.mlp.fc1.weight"], self.head["attn_pool.mlp.fc1.bias"] = lin(hid, D)
+            self.head["attn_pool.mlp.fc2.weight"], self.head["attn_pool.mlp.fc2.bias"] = lin(D, hid)
         if self.num_classes > 0:
             self.head["head.weight"] = (torch.randn(self.num_classes, D, generator=gen) * 0.02).clamp_(-0.04, 0.04).to(dev)
             self.head["head.bias"] = torch.zeros(self.num_classes, device=dev)
@@ -85,8 +100,6 @@ class VisionTransformer:
         return self.train(False)
 
     def train(self, mode=True):
-        if mode and self.global_pool == 'map':
-            raise NotImplementedError("training through the attention pool (global_pool = map) is not built: use token or avg pooling")
         if mode and self.drop_rate != 0.0:
             raise NotImplementedError("dropout in the downstream predictor (ARCHITECTURE.dropout != 0) is not built")
         self.training = bool(mode)
@@ -175,11 +188,27 @@ class VisionTransformer:
         if self.global_pool == 'token':
             return tokens[:, 0]
         if self.global_pool == 'map':
-            raise NotImplementedError("global_pool = map: the attention-pool head of the downstream predictor is not built")
+            return self._attn_pool(tokens)
         return tokens
 
+    def _attn_pool(self, x):
+        """timm.layers.AttentionPoolLatent.forward (latent_len 1, pool 'token', no q / k norm, no positional table)."""
+        F, P = torch.nn.functional, self.head
+        B, N, C = x.shape
+        H = self.pool_heads
+        hd = C // H
+        q = F.linear(P["attn_pool.latent"].expand(B, -1, -1), P["attn_pool.q.weight"], P["attn_pool.q.bias"]).reshape(B, 1, H, hd).transpose(1, 2)
+        kv = F.linear(x, P["attn_pool.kv.weight"], P["attn_pool.kv.bias"]).reshape(B, N, 2, H, hd).permute(2, 0, 3, 1, 4)
+        k, v = kv.unbind(0)
+        attn = ((q * hd ** -0.5) @ k.transpose(-2, -1)).softmax(dim=-1)
+        y = F.linear((attn @ v).transpose(1, 2).reshape(B, 1, C), P["attn_pool.proj.weight"], P["attn_pool.proj.bias"])
+        z = F.layer_norm(y, (C,), P["attn_pool.norm.weight"], P["attn_pool.norm.bias"], 1e-6)
+        z = F.linear(F.gelu(F.linear(z, P["attn_pool.mlp.fc1.weight"], P["attn_pool.mlp.fc1.bias"])), P["attn_pool.mlp.fc2.weight"], P["attn_pool.mlp.fc2.bias"])
+        return (y + z)[:, 0]
+
     def _encode_train(self, x, ra_dec):
-        """Encoder forward with activations kept; -> what the head pools from: [B, D] (token / avg)."""
+        """Encoder forward with activations kept; -> what the head starts from: [B, D] (token / avg: already pooled) or every
+        token [B, N, D] (map: the attention pool is part of the torch head)."""
         eng, cfg = self.engine, self.cfg
         B, L = x.shape[0], cfg.num_patches
         w = eng._workspace(B, L, True)
@@ -188,6 +217,8 @@ class VisionTransformer:
         Ne, D = cfg.num_extra_tokens + L, cfg.embed_dim
         if self.global_pool == 'avg':
             return w["xs"][cfg.depth].view(B, Ne, D)[:, 1:].mean(dim=1)
+        if self.global_pool == 'map':
+            return w["latent32"].view(B, Ne, D).clone()
         return w["latent32"].view(B, Ne, D)[:, 0].clone()
 
     def _encode_backward(self, dfeat):
@@ -209,8 +240,11 @@ class VisionTransformer:
             eng.backward_embed()
             return
         dlat = w["dln"][:Me * D].view(B, Ne, D)
-        dlat.zero_()
-        dlat[:, 0] = dfeat
+        if self.global_pool == 'map':
+            dlat.copy_(dfeat)                          # d loss / d every token
+        else:
+            dlat.zero_()
+            dlat[:, 0] = dfeat
         if self.frozen_encoder:
             # linear probe: the final norm's own gradients, nothing below it (utils/vit.py:145-160)
             tmp = w["g"][:Me * D].view(Me, D)
@@ -226,6 +260,8 @@ class VisionTransformer:
         return self._head(self._pool(x), pre_logits)
 
     def _head(self, f, pre_logits=False):
+        if f.dim() == 3:                                # (training path with global_pool = map: f holds every token)
+            f = self._attn_pool(f)
         if self.global_pool == 'avg':
             f = torch.nn.functional.layer_norm(f, (f.shape[-1],), self.head["fc_norm.weight"], self.head["fc_norm.bias"], 1e-6)
         if pre_logits or self.num_classes <= 0:

@@ -528,6 +528,8 @@ def predictor_cases():
       ft_avg_mse    fine-tuning with layer-wise lr decay (param_groups_lrd as utils/vit.py:141-143 calls it), mean pooling +
                     fc_norm, MSE on normalised labels, NaN pixels in the input
       fs_token_mse  "fully supervised" branch: timm's weight-decay split, one lr
+      lp_map_ce     attentive probe (the shipped cls_ap_*.ini): the two-head AttentionPoolLatent + norm + head trained, encoder frozen
+      ft_map_mse    fine-tuning through the attention pool (z_ft_2.ini)
     plus the checkpoint surgery of load_model on an MAE checkpoint of another image size (bicubic pos_embed interpolation)."""
     import importlib
     vit = importlib.import_module("utils.vit")
@@ -537,8 +539,9 @@ def predictor_cases():
     out = {}
     img, patch, C, D, depth, heads = 32, 8, 5, 32, 2, 2
     for case, method, pool, loss_fn, ncls in (("lp_token_ce", "lp", "token", "crossentropy", 3), ("ft_avg_mse", "ft", "avg", "mse", 2),
-                                              ("fs_token_mse", "fs", "token", "mse", 1)):
-        torch.manual_seed({"lp_token_ce": 21, "ft_avg_mse": 22, "fs_token_mse": 23}[case])
+                                              ("fs_token_mse", "fs", "token", "mse", 1), ("lp_map_ce", "lp", "map", "crossentropy", 3),
+                                              ("ft_map_mse", "ft", "map", "mse", 1)):
+        torch.manual_seed({"lp_token_ce": 21, "ft_avg_mse": 22, "fs_token_mse": 23, "lp_map_ce": 24, "ft_map_mse": 25}[case])
         label_means, label_stds = ([0.5, -1.0][:ncls], [2.0, 0.5][:ncls]) if loss_fn == "mse" else ([0.0], [1.0])
         model = vit.VisionTransformer(label_means, label_stds, 0.1, 1.7, False, ra_dec=False, depth=depth, num_heads=heads, mlp_ratio=4,
                                       qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), img_size=img, in_chans=C, embed_dim=D,
@@ -559,6 +562,8 @@ def predictor_cases():
             opt = torch.optim.AdamW(groups)
         elif method == "lp":                                    # utils/vit.py:145-160
             comps = [model.module.norm, model.module.fc_norm, model.module.head]
+            if pool == "map":                                   # utils/vit.py:148-149: the attentive probe of the shipped cls_ap_* configs
+                comps.append(model.module.attn_pool)
             opt = torch.optim.AdamW([{"params": m.parameters()} for m in comps], lr=init_lr, weight_decay=weight_decay)
             for prm in model.module.parameters():
                 prm.requires_grad = False

@@ -12,7 +12,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CASES = {"lp_token_ce": ("lp", "token", "crossentropy"), "ft_avg_mse": ("ft", "avg", "mse"), "fs_token_mse": ("fs", "token", "mse")}
+CASES = {"lp_token_ce": ("lp", "token", "crossentropy"), "ft_avg_mse": ("ft", "avg", "mse"), "fs_token_mse": ("fs", "token", "mse"),
+         "lp_map_ce": ("lp", "map", "crossentropy"), "ft_map_mse": ("ft", "map", "mse")}
 
 
 def build(z, case, dtype):
@@ -59,8 +60,10 @@ def test_predictor_training_steps_match_reference(case):
         lrs = sorted({round(g["initial_lr"], 12) for g in opt.param_groups})
         assert lrs == sorted({round(wd * layer_decay ** (m.num_blocks + 1 - i), 12) for i in range(m.num_blocks + 2)})
         assert {g["weight_decay"] for g in opt.param_groups} == {0.0, 0.05}
+    pool_names = {k for k in m.head if k.startswith("attn_pool.")}
+    assert (len(pool_names) == 13) == (pool == "map")
     if method == "lp":
-        assert m.frozen_encoder and m.trainable == {"norm.weight", "norm.bias", "head.weight", "head.bias"}
+        assert m.frozen_encoder and m.trainable == {"norm.weight", "norm.bias", "head.weight", "head.bias"} | pool_names
     x, labels = torch.from_numpy(z[f"{case}/x"]), torch.from_numpy(z[f"{case}/labels"])
     before = {k: v.detach().clone() for k, v in m.state_dict().items()}
     cp = defaultdict(list)
@@ -76,13 +79,14 @@ def test_predictor_training_steps_match_reference(case):
                 # fraction of lr (tests/test_mae_parity_gpu.py)
                 tol = 5e-6 * max(float(np.abs(ref).max()), 1e-3) + 3e-2 * lr_k
                 diff = np.abs(v.detach().cpu().numpy().reshape(ref.shape) - ref)
-                if k.endswith("attn.qkv.bias"):
+                if k.endswith("attn.qkv.bias") or k == "attn_pool.kv.bias":
                     # the KEY bias has an identically zero gradient (softmax is invariant to a shift of every score of a row): what
                     # either implementation computes for it is rounding noise, which Adam's normalisation turns into steps of the
                     # order of lr with an arbitrary sign -- bounded here, not compared
-                    D = ref.shape[0] // 3
-                    assert float(diff[D:2 * D].max()) <= 1.5 * (it + 1) * lr_k, (it, k)
-                    diff = np.concatenate([diff[:D], diff[2 * D:]])
+                    D = ref.shape[0] // (3 if k.endswith("qkv.bias") else 2)
+                    lo = D if k.endswith("qkv.bias") else 0            # [q | k | v] and [k | v]
+                    assert float(diff[lo:lo + D].max()) <= 1.5 * (it + 1) * lr_k, (it, k)
+                    diff = np.concatenate([diff[:lo], diff[lo + D:]])
                 assert float(diff.max()) <= tol, (it, k, float(diff.max()), tol)
     metric = cp["train_acc" if loss_fn == "crossentropy" else "train_mae"]
     assert np.allclose(metric, z[f"{case}/train_metric"], rtol=1e-4, atol=1e-6)
@@ -90,7 +94,7 @@ def test_predictor_training_steps_match_reference(case):
     after = m.state_dict()
     moved = {k for k in after if not torch.equal(after[k], before[k])}
     if method == "lp":
-        assert moved == {"norm.weight", "norm.bias", "head.weight", "head.bias"}          # the encoder stayed frozen
+        assert moved == {"norm.weight", "norm.bias", "head.weight", "head.bias"} | pool_names     # the encoder stayed frozen
     else:
         assert "pos_embed" not in moved and {"cls_token", "patch_mask_values", "patch_embed.proj.weight", "blocks.0.attn.qkv.weight",
                                               "blocks.1.mlp.fc2.bias", "head.weight"} <= moved
