@@ -64,3 +64,26 @@ def select_centre(latent, n_patches):
     side = int(latent.shape[1] ** 0.5)
     ij = central_indices(np.empty((side, side)), n_patches)
     return latent[:, ij[:, 0] * side + ij[:, 1]]
+
+
+def calculate_n_samples_per_class(class_counts, num_train, balanced=False):
+    """utils/misc.py:34-46: how many samples of each class a training subset of ``num_train`` takes -- the same number of every
+    class (balanced: limited by the rarest class), or each class's share of the whole set (rounded down)."""
+    if balanced:
+        n = min(num_train // len(class_counts), min(class_counts.values()))
+        return {c: n for c in class_counts}
+    total = sum(class_counts.values())
+    return {c: int((cnt / total) * num_train) for c, cnt in class_counts.items()}
+
+
+def select_training_indices(data_file_path, num_train, balanced=False):
+    """utils/misc.py:48-66: indices of the FIRST n samples of every class of the file's ``class`` column."""
+    from ..hdf5_lite import File
+    with File(data_file_path, 'r') as f:
+        classes = np.asarray(f['class'])
+    values, counts = np.unique(classes, return_counts=True)
+    per_class = calculate_n_samples_per_class(dict(zip(values.tolist(), counts.tolist())), num_train, balanced)
+    out = []
+    for c, n in per_class.items():
+        out.extend(np.where(classes == c)[0][:n].tolist())
+    return out

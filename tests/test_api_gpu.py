@@ -392,6 +392,55 @@ def test_sky_sim_search_entry_point_streams_survey_tiles(tmp_path):
     assert z["test_scores"][1] < z["test_scores"][0] - 0.005           # ... clear of every other window (noise tiles through a random encoder: ~0.985)
 
 
+@pytest.mark.parametrize("method,loss_fn", [("lp", "crossentropy"), ("ft", "mse")])
+def test_train_predictor_entry_point(tmp_path, method, loss_fn):
+    """python train_predictor.py <ini> (train_predictor.py:13-270): a predictor on a pre-trained MAE checkpoint -- attentive probe
+    with cross-entropy on the class labels (the shipped cls_ap_*.ini), fine-tuning with MSE on a normalised redshift (z_ft_2.ini) --
+    validation, best-model and periodic checkpoints in the reference's format, resume from the best checkpoint."""
+    from sky_embeddings_amd import hdf5_lite
+    from sky_embeddings_amd.utils.mim_vit import build_model as build_mae
+    dd = tmp_path / "data"
+    dd.mkdir()
+    hdf5_lite.make_synthetic_cutouts(str(dd / "train.h5"), n=64, seed=11, with_labels=True)
+    hdf5_lite.make_synthetic_cutouts(str(dd / "val.h5"), n=16, seed=12, with_labels=True)
+    work = tmp_path / "work"
+    (work / "configs").mkdir(parents=True)
+    (work / "models").mkdir()
+    mae_cfg = _tiny_ini(tmp_path)
+    with open(work / "configs" / "mim_t.ini", "w") as fh:
+        mae_cfg.write(fh)
+    mae, _, _ = build_mae(mae_cfg, str(tmp_path / "none.pth.tar"), torch.device("cuda"))
+    torch.save({"batch_iters": 5, "losses": {}, "model": {k: v.cpu() for k, v in mae.module.state_dict().items()}}, str(work / "models" / "mim_t.pth.tar"))
+    cfg = configparser.ConfigParser()
+    cfg["DATA"] = {"train_data_file": "train.h5", "val_data_file": "val.h5", "label_means": "[1.0]", "label_stds": "[0.6]"}
+    cfg["DATA"].update({"label_keys": "['class']", "num_classes": "3"} if loss_fn == "crossentropy" else {"label_keys": "['zspec']"})
+    cfg["TRAINING"] = {"train_method": method, "pretained_mae": "mim_t", "num_train": "40", "batch_size": "8", "total_batch_iters": "6", "layer_decay": "0.7",
+                       "weight_decay": "0.05", "init_lr": "0.001", "final_lr_factor": "10", "augment": "False", "brightness": "0.8", "noise": "0.1",
+                       "nan_channels": "5", "use_label_errs": "False", "loss_fn": loss_fn}
+    cfg["ARCHITECTURE"] = {"img_size": "64", "global_pool": "map", "dropout": "0.0"}
+    with open(work / "configs" / "pred_t.ini", "w") as fh:
+        cfg.write(fh)
+    for name in ("train_predictor.py", "utils", "sky_embeddings_amd"):
+        os.symlink(os.path.join(ROOT, name), work / name)
+    cmd = [sys.executable, str(work / "train_predictor.py"), "pred_t", "-v", "3", "-ct", "0.0005", "-dd", str(dd)]
+    env = dict(os.environ, PYTHONPATH=str(work))
+    out = subprocess.run(cmd, cwd=str(work), env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "Training complete." in out.stdout and "Loading pre-trained MAE model weights..." in out.stdout and "Validation Dataset" in out.stdout
+    assert ("linear probing" if method == "lp" else "fine-tuning") in out.stdout and ("Accuracy" if loss_fn == "crossentropy" else "MAE") in out.stdout
+    for fn in ("pred_t.pth.tar", "pred_t_best.pth.tar"):
+        ck = torch.load(str(work / "models" / fn), map_location="cpu", weights_only=False)
+        assert set(ck) == {"batch_iters", "losses", "optimizer", "lr_scheduler", "model"}
+        assert "attn_pool.latent" in ck["model"] and "head.weight" in ck["model"] and "decoder_embed.weight" not in ck["model"]
+        assert np.isfinite(ck["losses"]["val_loss"]).all() and len(ck["losses"]["batch_iters"]) >= 1
+    enc_key = "blocks.0.attn.qkv.weight"
+    trained = torch.load(str(work / "models" / "pred_t.pth.tar"), map_location="cpu", weights_only=False)["model"]
+    same = torch.equal(trained[enc_key], mae.module.state_dict()[enc_key].cpu())
+    assert same == (method == "lp")                                       # the probe leaves the encoder alone, fine-tuning moves it
+    out2 = subprocess.run(cmd, cwd=str(work), env=env, capture_output=True, text=True, timeout=600)       # resume: from the best checkpoint
+    assert out2.returncode == 0 and "Loading saved model weights..." in out2.stdout, out2.stdout[-1500:] + out2.stderr[-1500:]
+
+
 def test_compute_similarity_central_patches_matches_reference_goldens():
     """n_central_patches (utils/similarity.py:238-240): the reference's own compute_similarity with the select_centre import it
     lacks supplied by the generator (tests/golden/make_golden.py central_cases)."""

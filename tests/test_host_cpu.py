@@ -88,7 +88,7 @@ def test_product_refuses_cpu_and_never_imports_oracle():
             if fn.endswith(".py"):
                 src = open(os.path.join(base, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
-    for fn in ("pretrain_mim.py", "similarity_search.py", "sky_sim_search.py"):
+    for fn in ("pretrain_mim.py", "similarity_search.py", "sky_sim_search.py", "train_predictor.py"):
         assert not re.search(r"^\s*(from|import)\s+oracle", open(os.path.join(ROOT, fn)).read(), flags=re.M)
 
 
