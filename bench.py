@@ -485,17 +485,16 @@ def bench_search(args, rank, world, dev):
 
 
 def pmc_traffic(args):
-    """HBM bytes per launch of the Q=16 streaming kernel from the committed PMC passes (FETCH_SIZE doubled per the gfx950
-    correction, + WRITE_SIZE); counters cannot be read from inside the timed process, so this is the profiles/ figure for
-    the same workload, or None when the workload differs."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r03_topk_stream_pmc.json")) as f:
-            prof = json.load(f)
-    except OSError:
-        return None
+    """HBM-side bytes per Q = 16 bank-pass launch from the newest committed PMC summary (profiles/rNN_topk_stream_pmc.json), or None."""
     if args.bank_rows != 1_000_000 or args.topk != 100 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
-        return None
-    return prof["kernels"]["cosine_topk_stream_kernel<8>"]["traffic_bytes_per_launch"]
+        return None                                        # (counters cannot be read from inside the timed process: the profiles/ figure of the same workload)
+    for name in ("r04_topk_stream_pmc.json", "r03_topk_stream_pmc.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f)["kernels"]["cosine_topk_stream_kernel<8>"]["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def parity_of_timed_mode(args, mo, cfg_o, st):
