@@ -249,7 +249,7 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
     constexpr int STAGE = stage_bytes(LO), NI = pieces(LO), A_BYTES = QT * BK * 2, B_OFF = Q_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef PF_STAMP
-    unsigned int seg[5] = {0, 0, 0, 0, 0};
+    unsigned int seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev;
     auto stamp = [&](int which) {
         unsigned long long t;
@@ -400,8 +400,7 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
     };
     auto item_epilogue = [&](int qt, int t) {
         // ---- epilogue of the item: per 16x16 block a lane holds queries 4*(lane>>4)+r (r = 0..3) x bank row (lane & 15).
-        // All 16 MI tests of the lane are branch-free (bit masks: test (i, r, j) is bit (r*4 + j) of a half-word of msk[i / 2]); only
-        // lanes that found something enter the append path.
+        // All 16 MI tests of the lane are branch-free (bit masks mr[r]); only waves that found something enter the append path.
         // (the lane coordinates go through an empty asm: everything addressed from them is then computed HERE, once per item,
         // instead of being hoisted out of the k-loop into registers that the accumulators and fragments need)
         const int ln = lane_now();
@@ -410,62 +409,70 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
         float tb[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) tb[j] = ((const float *)srow)[(wn * 64 + j * 16 + l16) * 4 + l4];
-        unsigned int msk[MI / 2];
-#pragma unroll
-        for (int w2 = 0; w2 < MI / 2; ++w2) msk[w2] = 0;
+        // mr[r]: the lane's tests of query 4 * (lane >> 4) + r, one bit per (block i, row fragment j): bit (MI - 1 - i) * 4 + j
+        unsigned int mr[4] = {0u, 0u, 0u, 0u};
 #ifdef PF_NOTEST   // experiment build: the accumulators are consumed, no pair is tested (what the 128 tests per lane and item cost)
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
-        // Two blocks in flight: the four matrix instructions of block i + 1 are issued before the sixteen compare / add-with-carry
-        // pairs of block i, so the matrix pipe and the vector ALU work side by side (left to itself the compiler issued all 32
-        // instructions first and spilled their 128 result registers).
-        f32x4 tst[2][4];
-        auto test_block = [&](int i) {
-            // A operand: component (lane >> 4) of the parameters of query (lane & 15) of the block
-            const float ta = ((const float *)spar)[(wm * (QT / 2) + i * 16 + l16) * 4 + l4];
+        // A operands: component (lane >> 4) of the parameters of query (lane & 15) of each block
+        float ta[MI];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) tst[i & 1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta, tb[j], acc[i][j], 0, 0, 0);
-        };
-        test_block(0);
+        for (int i = 0; i < MI; ++i) ta[i] = ((const float *)spar)[(wm * (QT / 2) + i * 16 + l16) * 4 + l4];
+        // Software pipeline, written out: one group = the matrix instruction of fragment j of block i + 1, then the eight vector
+        // instructions that fold fragment j of block i into the four masks (mr[r] = 2 mr[r] + (t >= 0): compare into a scalar
+        // pair, add-with-carry; NaN compares false).  An 8-pass matrix instruction occupies its pipe for the 32 cycles the eight
+        // vector instructions take to issue, so both run all the time; the four masks are four independent chains (one mask
+        // register for all sixteen pairs of a block was a chain of 32 dependent instructions: 375 cycles per block, stamped).
+        // The compiler does not see the matrix instruction inside the asm: the distance from it to the first read of its result
+        // (three more groups = 27 instructions) is kept by construction.
+        f32x4 tst[2][4];
+#pragma unroll
+        for (int j = 3; j >= 0; --j) tst[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[0], tb[j], acc[0][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (i + 1 < MI) test_block(i + 1);
-            else asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");     // the last block's results: 8-pass matrix instruction -> vector ALU read
-            __builtin_amdgcn_sched_barrier(0);
-            // bit (r * 4 + j) of a half-word: shifted in from the top, so r and j run downwards
-            unsigned int m = msk[i >> 1];
 #pragma unroll
-            for (int r = 3; r >= 0; --r)
-                // m = 2 m + (t >= 0) for j = 3, 2, 1, 0: compare into vcc, add-with-carry (NaN compares false).  Written out: the
-                // compiler built the mask from v_cndmask / v_or / v_lshl_or, 2.5 instructions per pair, with every result of the 32
-                // matrix instructions live at once (spills).  The matrix instructions that produced these registers were issued a
-                // whole block (four 8-pass instructions) earlier.
-                asm volatile("v_cmp_le_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
-                             "v_cmp_le_f32 vcc, 0, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
-                             "v_cmp_le_f32 vcc, 0, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
-                             "v_cmp_le_f32 vcc, 0, %4\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-                             : "+v"(m)
-                             : "v"(tst[i & 1][3][r]), "v"(tst[i & 1][2][r]), "v"(tst[i & 1][1][r]), "v"(tst[i & 1][0][r])
-                             : "vcc");
-            msk[i >> 1] = m;
+            for (int j = 3; j >= 0; --j) {
+                unsigned long long c0, c1, c2, c3;
+                if (i + 1 < MI)
+                    asm volatile("v_mfma_f32_16x16x4_f32 %0, %9, %10, %11\n\t"
+                                 "v_cmp_le_f32_e64 %5, 0, %12\n\tv_cmp_le_f32_e64 %6, 0, %13\n\t"
+                                 "v_cmp_le_f32_e64 %7, 0, %14\n\tv_cmp_le_f32_e64 %8, 0, %15\n\t"
+                                 "v_addc_co_u32_e64 %1, %5, %1, %1, %5\n\tv_addc_co_u32_e64 %2, %6, %2, %2, %6\n\t"
+                                 "v_addc_co_u32_e64 %3, %7, %3, %3, %7\n\tv_addc_co_u32_e64 %4, %8, %4, %4, %8"
+                                 : "=&v"(tst[(i + 1) & 1][j]), "+v"(mr[0]), "+v"(mr[1]), "+v"(mr[2]), "+v"(mr[3]), "=&s"(c0), "=&s"(c1),
+                                   "=&s"(c2), "=&s"(c3)
+                                 : "v"(ta[(i + 1) % MI]), "v"(tb[j]), "v"(acc[(i + 1) % MI][j]), "v"(tst[i & 1][j][0]), "v"(tst[i & 1][j][1]),
+                                   "v"(tst[i & 1][j][2]), "v"(tst[i & 1][j][3]));
+                else
+                    asm volatile("v_cmp_le_f32_e64 %4, 0, %8\n\tv_cmp_le_f32_e64 %5, 0, %9\n\t"
+                                 "v_cmp_le_f32_e64 %6, 0, %10\n\tv_cmp_le_f32_e64 %7, 0, %11\n\t"
+                                 "v_addc_co_u32_e64 %0, %4, %0, %0, %4\n\tv_addc_co_u32_e64 %1, %5, %1, %1, %5\n\t"
+                                 "v_addc_co_u32_e64 %2, %6, %2, %2, %6\n\tv_addc_co_u32_e64 %3, %7, %3, %3, %7"
+                                 : "+v"(mr[0]), "+v"(mr[1]), "+v"(mr[2]), "+v"(mr[3]), "=&s"(c0), "=&s"(c1), "=&s"(c2), "=&s"(c3)
+                                 : "v"(tst[i & 1][j][0]), "v"(tst[i & 1][j][1]), "v"(tst[i & 1][j][2]), "v"(tst[i & 1][j][3]));
+            }
         }
 #endif
-        unsigned int any = 0;
-#pragma unroll
-        for (int w2 = 0; w2 < MI / 2; ++w2) any |= msk[w2];
+        STAMP(5);
 #if defined(PF_NOMFMA) || defined(PF_NOREAD) || defined(PF_NODMA) || defined(PF_NOAPPEND)
-        asm volatile("" ::"v"(any));                 // experiment builds: the tests are computed, nothing is appended
-        any = 0;
 #pragma unroll
-        for (int w2 = 0; w2 < MI / 2; ++w2) msk[w2] = 0;
+        for (int r = 0; r < 4; ++r) {                // experiment builds: the tests are computed, nothing is appended
+            asm volatile("" ::"v"(mr[r]));
+            mr[r] = 0;
+        }
 #endif
-        // (the bits were shifted in: the even block of a pair sits in the HIGH half-word)
-        auto passed = [&](int i, int r, int j) -> bool { return (msk[i >> 1] >> (((i & 1) ^ 1) * 16 + r * 4 + j)) & 1u; };
-        auto passed4 = [&](int i, int r) -> bool { return (msk[i >> 1] >> (((i & 1) ^ 1) * 16 + r * 4)) & 15u; };
+        auto passed = [&](int i, int r, int j) -> bool { return (mr[r] >> ((MI - 1 - i) * 4 + j)) & 1u; };
+        // Appends are rare (a few per wave and item): the walk over the lane's 128 bits is pruned by WAVE-UNIFORM branches (a
+        // ballot per block, then per query row of a flagged block); per-lane branches only below those.  (Thirty-two per-lane
+        // branches per item, taken or not, cost 2.7 k cycles per item and wave group, stamped.)
+        const unsigned int anyr = mr[0] | mr[1] | mr[2] | mr[3];
+        auto block_flagged = [&](int i) -> bool { return __builtin_amdgcn_ballot_w64(((anyr >> ((MI - 1 - i) * 4)) & 15u) != 0u) != 0ull; };
+        auto row_flagged = [&](int i, int r) -> bool { return __builtin_amdgcn_ballot_w64(((mr[r] >> ((MI - 1 - i) * 4)) & 15u) != 0u) != 0ull; };
         if (TAKE_ALL) {
             // first slice: every (query, row) pair of the slice is a candidate, slot = row within the slice (no counters);
             // pairs that fail even the open test (NaN) are stored as -inf and dropped by the select step
@@ -485,12 +492,12 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
                     }
                 }
         } else if (!STAGED) {
-            if (any) {
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i)
+                if (block_flagged(i)) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (passed4(i, r)) {
+                        if (row_flagged(i, r)) {
                             const int q = qt * QT + wm * (QT / 2) + i * 16 + 4 * l4 + r;
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
@@ -502,8 +509,8 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
                                     }
                                 }
                         }
-            }
-        } else if (any) {
+                }
+        } else {
             // Candidates go to a list in LDS (slot from an LDS counter: no global atomic, no wait on the vector-memory
             // counter that the LDS-DMA ring lives on -- a returning global atomic per candidate cost ~750 cycles per k-step).
             // The workgroup flushes the list to its OWN region of wg_list with plain stores (flush_item); bucket_kernel sorts
@@ -511,19 +518,22 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
             const int kbase = ((wm * (QT / 2) + 4 * l4) << 8) | (wn * 64 + l16);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
+                if (block_flagged(i)) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (passed4(i, r)) {
+                    for (int r = 0; r < 4; ++r)
+                        if (row_flagged(i, r)) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (passed(i, r, j)) {
-                                const int key = kbase + (((i * 16 + r) << 8) | (j * 16));      // q_local << 8 | row_local
-                                const int slot = atomicAdd(stg_n, 1);
-                                if (slot < SCAP) stg[slot] = make_uint2((unsigned int)key, __float_as_uint(acc[i][j][r]));
-                                else overflow[qt * QT + (key >> 8)] = 1;     // more than the staging list holds: the query is re-run exactly
-                            }
-                    }
+                            for (int j = 0; j < 4; ++j)
+                                if (passed(i, r, j)) {
+                                    const int key = kbase + (((i * 16 + r) << 8) | (j * 16));      // q_local << 8 | row_local
+                                    const int slot = atomicAdd(stg_n, 1);
+                                    if (slot < SCAP) stg[slot] = make_uint2((unsigned int)key, __float_as_uint(acc[i][j][r]));
+                                    else overflow[qt * QT + (key >> 8)] = 1;     // more than the staging list holds: the query is re-run exactly
+                                }
+                        }
+                }
         }
+        STAMP(6);
     };
     // the staged candidates of item (qt, t) -> this workgroup's region of wg_list (16 bytes each: query, row, dot^)
     int wpos = 0;
@@ -551,8 +561,10 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
     auto multiply_stage = [&](bool issue, int ibuf, int half) {
         multiply(issue, ibuf, half);
         if (++kt_c == KT) {
+            STAMP(4);
             item_epilogue(qt_cur, t_cur);
             zero_acc();
+            STAMP(7);
             kt_c = 0;
             qt_done = qt_cur;         // (flushed after the next P1, when both groups have finished the item)
             t_done = t_cur;
@@ -640,8 +652,9 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
     }
 #ifdef PF_STAMP
     if (lane == 0)
-        for (int i = 0; i < 5; ++i) atomicAdd(dbg + (late ? 8 : 0) + i, (unsigned long long)seg[i]);
+        for (int i = 0; i < 8; ++i) atomicAdd(dbg + (late ? 8 : 0) + i, (unsigned long long)seg[i]);
     if (lane == 0 && wave == 0) atomicAdd(dbg + 16, (unsigned long long)steps);
+    if (lane == 0 && wave == 0) atomicAdd(dbg + 17, (unsigned long long)my_items);
 #endif
 }
 
@@ -1083,6 +1096,9 @@ extern "C" int skyemb_cosine_topk_prefiltered(const float *tw, const float *qn, 
             }
             fprintf(stderr, "[stamp] phase %d steps/wg %.0f | early: wait %.0f P0 %.0f read+issue %.0f P1 %.0f mult %.0f | late: wait %.0f P0 %.0f read+issue %.0f P1 %.0f mult %.0f (cycles of s_memtime per k-step)\n",
                     p, (double)h[16] / 256.0, h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[8] / n, h[9] / n, h[10] / n, h[11] / n, h[12] / n);
+            const double ni = (double)h[17] * 4.0;    // items summed over workgroups x 4 waves per group
+            fprintf(stderr, "[stamp] phase %d items/wg %.0f | item epilogue, cycles per item: early tests %.0f appends %.0f zero %.0f | late tests %.0f appends %.0f zero %.0f\n",
+                    p, (double)h[17] / 256.0, h[5] / ni, h[6] / ni, h[7] / ni, h[13] / ni, h[14] / ni, h[15] / ni);
         }
 #endif
         const int final = t1 == T;
