@@ -911,8 +911,8 @@ int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
     // rest of the chip idles.  The row blocks that fill whole rounds go as one launch; the remaining rows as a second,
     // finely split launch (64x64 tiles, split-K) that is over in a fraction of a round.
     static const bool tail_on = []() { const char *e = getenv("SKYEMB_GEMM_TAIL"); return !(e && e[0] == '0'); }();
-    if (tile == 256256 && (g_in.split_k > 1 || !gemm256_applicable(g))) {
-        skyemb_set_error("skyemb_gemm(256x256): the problem is outside this tile's subset (k-contiguous A, plain epilogue, K >= 128, no split-K)");
+    if (tile == 256256 && (g_in.split_k > 1 || !(gemm256_applicable(g) || (gemm256_wgrad_applicable(g) && !g.colsum_parts)))) {
+        skyemb_set_error("skyemb_gemm(256x256): the problem is outside this tile's subset (k-contiguous A, or a weight gradient of whole tiles; plain epilogue, K >= 128, no split-K)");
         return 1;
     }
     if (tile == 256256) S = g.split_k = 1;
@@ -991,10 +991,28 @@ extern "C" int skyemb_gemm_group_plan(const skyemb_gemm_args *args, int n, int t
             for (int i = 0; i < n; ++i) even = even && (args[i].K / BK) % 2 == 0 && args[i].K >= 4 * BK;
             if (even) tile = 9128128;
         }
+        // ViT-L weight gradients as ONE round of 256x256 tiles (mim_19: 192 tiles over 8320 token rows: 1.85 us per k-tile and
+        // workgroup against 4 x 0.82 on the 128x128 tile)
+        static const bool g256 = []() { const char *e = getenv("SKYEMB_GROUP_256"); return !(e && e[0] == '0'); }();
+        if (g256) {
+            int64_t t256 = 0;
+            bool ok = true;
+            for (int i = 0; i < n; ++i) {
+                ok = ok && gemm256_wgrad_applicable(args[i]) && args[i].K >= 2048 && !args[i].bias && !args[i].resid &&
+                     args[i].act == SKYEMB_ACT_NONE && !args[i].out2;
+                t256 += (args[i].M / 256) * (args[i].N / 256);
+            }
+            if (ok && t256 >= 160 && t256 <= 256) tile = 256256;
+        }
         static const int env_tile = []() { const char *e = getenv("SKYEMB_GROUP_TILE"); return e ? atoi(e) : 0; }();   // experiments
         if (env_tile) tile = canonical_tile(env_tile);
     }
-    SKY_CHECK_ARG(tile == 64064 || tile == 128064 || tile == 128128 || tile == 9128128, "skyemb_gemm_group_plan: tile %d is not built for grouped launches", tile);
+    SKY_CHECK_ARG(tile == 64064 || tile == 128064 || tile == 128128 || tile == 9128128 || tile == 256256,
+                  "skyemb_gemm_group_plan: tile %d is not built for grouped launches", tile);
+    if (tile == 256256)
+        for (int i = 0; i < n; ++i)
+            SKY_CHECK_ARG(gemm256_wgrad_applicable(args[i]) && !args[i].bias && !args[i].resid && args[i].act == SKYEMB_ACT_NONE && !args[i].out2,
+                          "skyemb_gemm_group_plan: the 256x256 tile takes weight gradients of whole tiles only (problem %d)", i);
     if (tile == 9128128)
         for (int i = 0; i < n; ++i)
             SKY_CHECK_ARG((args[i].K / BK) % 2 == 0, "skyemb_gemm_group_plan: the two-k-group tile needs K %% 128 == 0 (problem %d)", i);
@@ -1049,8 +1067,8 @@ extern "C" int skyemb_gemm_group_plan_adamw(const skyemb_gemm_args *args, int n,
                   "skyemb_gemm_group_plan_adamw: incomplete descriptor");
     const int rc = skyemb_gemm_group_plan(args, n, tile, blob_host, blob_bytes, info);
     if (rc != 0) return rc;
-    if (info->class_mask != 4 || !(info->tile == 64064 || info->tile == 128064 || info->tile == 128128)) {
-        skyemb_set_error("skyemb_gemm_group_plan_adamw: weight-gradient (RC.RC) problems on the 64x64 / 128x64 / 128x128 tiles only");
+    if (info->class_mask != 4 || !(info->tile == 64064 || info->tile == 128064 || info->tile == 128128 || info->tile == 256256)) {
+        skyemb_set_error("skyemb_gemm_group_plan_adamw: weight-gradient (RC.RC) problems on the 64x64 / 128x64 / 128x128 / 256x256 tiles only");
         return -1;
     }
     for (int i = 0; i < n; ++i) {
@@ -1114,6 +1132,7 @@ extern "C" int skyemb_gemm_group_launch(const void *blob_dev, const skyemb_gemm_
             case 64064: return group_launch_n<64, 64, 3, 2, 2, 4, 1, true>(blob_dev, info->total_blocks, st);
             case 128064: return group_launch_n<128, 64, 3, 4, 2, 4, 1, true>(blob_dev, info->total_blocks, st);
             case 128128: return group_launch_n<128, 128, 2, 4, 2, 4, 1, true>(blob_dev, info->total_blocks, st);
+            case 256256: return gemm256_group_launch<true>(blob_dev, info->total_blocks, st);
         }
         skyemb_set_error("skyemb_gemm_group_launch: tile %d not built with the fused optimiser step", info->tile);
         return 1;
@@ -1123,6 +1142,7 @@ extern "C" int skyemb_gemm_group_launch(const void *blob_dev, const skyemb_gemm_
         case 128064: return group_launch_classes<128, 64, 3, 4, 2>(blob_dev, info->total_blocks, info->class_mask, st);
         case 128128: return group_launch_classes<128, 128, 2, 4, 2>(blob_dev, info->total_blocks, info->class_mask, st);
         case 9128128: return group_launch_classes<128, 128, 2, 4, 2, 2>(blob_dev, info->total_blocks, info->class_mask, st);
+        case 256256: return gemm256_group_launch<false>(blob_dev, info->total_blocks, st);
     }
     skyemb_set_error("skyemb_gemm_group_launch: tile %d not built", info->tile);
     return 1;

@@ -53,22 +53,21 @@ __device__ __forceinline__ int lane_fresh() {
     return l;
 }
 
-template <bool B_KC>
-__global__ __launch_bounds__(512) void gemm256_kernel(const skyemb_gemm_args g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// One 256 x 256 tile.  A_KC = false: the weight-gradient layout (both operands row-contiguous, contraction over token rows;
+// M, N multiples of 256).  ADAM: the tile is the gradient of a block of parameters in the flat buffers of `ad` and the epilogue is
+// their AdamW step (as in gemm_pipe_body); colsum_a / colsum_parts (row-contiguous A): the bias gradient, as there.
+template <bool A_KC, bool B_KC, bool ADAM>
+__device__ __forceinline__ void gemm256_tile(const skyemb_gemm_args &g, const unsigned int tile, const unsigned int ntiles, char *smem,
+                                             const skyemb_adamw_desc *ad = nullptr) {
+    static_assert(A_KC || !B_KC, "a row-contiguous A comes with a row-contiguous B (weight gradients)");
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const unsigned int tiles_n = ((unsigned int)g.N + 255u) / 256u, tiles_m = ((unsigned int)g.M + 255u) / 256u;
-    const unsigned int ntiles = tiles_m * tiles_n;
     const bf16_t *A = (const bf16_t *)g.A;
     const bf16_t *B = (const bf16_t *)g.B;
     const int KT = g.K / BK, H = 4 * KT;
     const bool colmajor = g.N > g.M;
-    // Persistent workgroups (one per CU): tile = blockIdx.x, + gridDim.x, ...  The epilogue's global stores are not waited for:
-    // they drain under the next tile's prologue and k-loop (every CU storing its 128-256 KB at the same moment was a
-    // synchronized HBM burst of 8-16 us at the end of each round of tiles).
-#pragma unroll 1
-  for (unsigned int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  {
     unsigned int wg;
     {   // XCD-aware bijective tile order (gemm_pipe_body): consecutive tiles of an XCD share operand panels in its L2
         const unsigned int nwg = ntiles, xcd = tile & 7u, local = tile >> 3;
@@ -93,7 +92,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const skyemb_gemm_args g) 
     // of row r at chunk c ^ (r & 7): the XOR is on the source address) or k-rows [8 wave, +8) of a row-contiguous one (4 k-rows
     // x 256 B per piece, chunk XOR rc_swz<128>).  Rows past the edge: the 8-row group is moved up to the last whole group (its
     // outputs are never stored), so the base stays uniform.
-    const unsigned int a_off = (unsigned int)((lane >> 3) * (int)g.lda * 2 + (((lane & 7) ^ (lane >> 3)) << 4));
+    const unsigned int a_off = A_KC ? (unsigned int)((lane >> 3) * (int)g.lda * 2 + (((lane & 7) ^ (lane >> 3)) << 4))
+                                    : (unsigned int)((lane >> 4) * (int)g.lda * 2 + (((lane & 15) ^ rc_swz<128>(wave * 8 + (lane >> 4))) << 4));
     const unsigned int b_off = B_KC ? (unsigned int)((lane >> 3) * (int)g.ldb * 2 + (((lane & 7) ^ (lane >> 3)) << 4))
                                     : (unsigned int)((lane >> 4) * (int)g.ldb * 2 + (((lane & 15) ^ rc_swz<128>(wave * 8 + (lane >> 4))) << 4));
     auto issue_piece = [&](int e, int k0, int slot, int j) {
@@ -101,9 +101,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const skyemb_gemm_args g) 
             const int idx = wave * 2 + j;
             char *dst = smem + slot * G256_HT + idx * 1024;
             if (e >= 2) {
-                int row = m0 + (e - 2) * 128 + idx * 8;
-                row = row + 8 <= g.M ? row : g.M - 8;
-                glds16_sbase(A + (int64_t)row * g.lda + k0, a_off, dst);
+                if constexpr (A_KC) {
+                    int row = m0 + (e - 2) * 128 + idx * 8;
+                    row = row + 8 <= g.M ? row : g.M - 8;
+                    glds16_sbase(A + (int64_t)row * g.lda + k0, a_off, dst);
+                } else {
+                    glds16_sbase(A + (int64_t)(k0 + idx * 4) * g.lda + m0 + (e - 2) * 128, a_off, dst);
+                }
             } else if constexpr (B_KC) {
                 int row = n0 + e * 128 + idx * 8;
                 row = row + 8 <= g.N ? row : g.N - 8;
@@ -159,7 +163,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const skyemb_gemm_args g) 
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii)
-                if constexpr (B_KC) fa[ii][kk] = frag_kc(sa, sub * 64 + ii * 16, kk, lane);
+                if constexpr (!A_KC) fa[ii][kk] = frag_rc_asm<128>(sa, sub * 64 + ii * 16, kk, lane);
+                else if constexpr (B_KC) fa[ii][kk] = frag_kc(sa, sub * 64 + ii * 16, kk, lane);
                 else fa[ii][kk] = frag_kc_asm(sa, sub * 64 + ii * 16, kk, lane);
     };
     auto read_b = [&](int sub) {
@@ -194,6 +199,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const skyemb_gemm_args g) 
         __builtin_amdgcn_s_setprio(0);
 #endif
     };
+    // Bias gradient (row-contiguous A only) = column sums of the A tile over k: waves of the first tile column (or, with
+    // colsum_parts, of every tile column for the k-tiles t % tiles_n == its index).  ONE accumulator collects the wave's eight
+    // 16-row blocks: block b's fragment is multiplied by an operand that is 1 in row b and 0 elsewhere, so D[b][m] += sum_k A[m][k]
+    // (4 + 4 registers; a ones-operand per block, as in the ring kernels, would be eight accumulators = 32 registers this kernel
+    // does not have).
+    const int tile_n = n0 >> 8;
+    const bool cs_parts = !A_KC && g.colsum_parts != nullptr;
+    const bool do_colsum = !A_KC && (wc == 0) && (cs_parts || (g.colsum_a != nullptr && tile_n == 0));
+    int cs_next = cs_parts ? tile_n : 0;
+    const int cs_step = cs_parts ? (int)tiles_n : 1;
+    f32x4 cacc = (f32x4){0.f, 0.f, 0.f, 0.f};
     // one phase: READ part (fragments of this phase, two half-tiles requested, the counted wait in the last phase of a k-tile),
     // barrier, MFMA part, barrier
     auto phase = [&](auto Q, int t) {
@@ -242,6 +258,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const skyemb_gemm_args g) 
                     for (int j = 0; j < 4; ++j) lds_use(fb[j >> 1][j & 1][kk]);
         }
         mfma_half(q);
+        if constexpr (!A_KC) {
+            if (do_colsum && t == cs_next) {
+                const int row = lane_fresh() & 15;
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    bf16x8 sel;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sel[e] = row == q * 4 + ii ? (bf16_t)1.0f : (bf16_t)0.0f;
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) cacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel, fa[ii][kk], cacc, 0, 0, 0);
+                }
+                if constexpr (q == 1) cs_next += cs_step;
+            }
+        }
         G256_STAMP(2);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -261,6 +291,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const skyemb_gemm_args g) 
     // ---- epilogue: two halves of 128 rows through LDS (the ring is free), rows leave in pieces of 8 columns per lane
     constexpr int PITCH = 256 * 4 + 16;
     const int lane_e = lane_fresh(), tid = wave * 64 + lane_e;
+    if constexpr (!A_KC) {
+        if (do_colsum && lane_e < 32) {                   // D[b][m]: lane (m = lane & 15, rows 4 (lane >> 4) + r) -> blocks 0-3 / 4-7
+            float *cs_out = cs_parts ? g.colsum_parts + (int64_t)tile_n * g.M : g.colsum_a;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cs_out[m0 + wr * 128 + (4 * (lane_e >> 4) + r) * 16 + (lane_e & 15)] = cacc[r];
+        }
+    }
+    const int64_t ad_off = ADAM ? (int64_t)(g.out_f32 - ad->g_base) : 0;
     bf16_t *out = (bf16_t *)g.out;
     bf16_t *out2 = (bf16_t *)g.out2;
     const bf16_t *aux = (const bf16_t *)g.aux;
@@ -280,10 +318,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const skyemb_gemm_args g) 
         for (int jj = 0; jj < 8; jj += 2) {               // 128 rows x 32 pieces over 512 threads: 8 each, two at a time
             float4 e_bias[2][2], e_res[2][2];
             bf16x8 e_aux[2];
+            float4 e_p[2][2], e_m[2][2], e_v[2][2];       // (ADAM) the parameters and moments the piece updates
 #pragma unroll
             for (int u = 0; u < 2; ++u) {                 // every fused input of the two pieces requested up front, clamped
                 const int p = tid + (jj + u) * 512, m = m0 + half * 128 + (p >> 5), n = n0 + (p & 31) * 8;
                 const int mc = m < g.M ? m : g.M - 1, nc = n < g.N ? n : g.N - 8;
+                if constexpr (ADAM) {
+                    const int64_t o = ad_off + (int64_t)mc * g.ldo32 + nc;
+                    e_p[u][0] = gload4(ad->p + o); e_p[u][1] = gload4(ad->p + o + 4);
+                    e_m[u][0] = gload4(ad->m + o); e_m[u][1] = gload4(ad->m + o + 4);
+                    e_v[u][0] = gload4(ad->v + o); e_v[u][1] = gload4(ad->v + o + 4);
+                    continue;
+                }
                 if (g.bias) { e_bias[u][0] = gload4(g.bias + nc); e_bias[u][1] = gload4(g.bias + nc + 4); }
                 if (g.resid) { e_res[u][0] = gload4(g.resid + (int64_t)mc * g.ldr + nc); e_res[u][1] = gload4(g.resid + (int64_t)mc * g.ldr + nc + 4); }
                 if (g.act == SKYEMB_ACT_DGELU) e_aux[u] = gload8h(aux + (int64_t)mc * g.ldaux + nc);
@@ -295,6 +341,25 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const skyemb_gemm_args g) 
                 if (m >= g.M || n >= g.N) continue;
                 const float4 lo = *(const float4 *)(smem + r * PITCH + c * 4), hi = *(const float4 *)(smem + r * PITCH + c * 4 + 16);
                 float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                if constexpr (ADAM) {
+                    // v[] is the gradient of 8 consecutive parameters: the optimiser step, here (adamw_math.h; as in gemm_pipe_body)
+                    const float lr = ad->hyper[0], bc1 = ad->hyper[1], bc2 = ad->hyper[2];
+                    const SkyAdamScalars sc = sky_adam_scalars(lr, bc1, bc2, ad->beta1, ad->beta2, ad->eps, ad->weight_decay, ad->grad_scale);
+                    const int64_t o = ad_off + (int64_t)m * g.ldo32 + n;
+                    float pp[8] = {e_p[u][0].x, e_p[u][0].y, e_p[u][0].z, e_p[u][0].w, e_p[u][1].x, e_p[u][1].y, e_p[u][1].z, e_p[u][1].w};
+                    float mm[8] = {e_m[u][0].x, e_m[u][0].y, e_m[u][0].z, e_m[u][0].w, e_m[u][1].x, e_m[u][1].y, e_m[u][1].z, e_m[u][1].w};
+                    float vv[8] = {e_v[u][0].x, e_v[u][0].y, e_v[u][0].z, e_v[u][0].w, e_v[u][1].x, e_v[u][1].y, e_v[u][1].z, e_v[u][1].w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sky_adamw_update(v[e], pp[e], mm[e], vv[e], o + e < ad->n_decay, sc);
+                    *(float4 *)(ad->p + o) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+                    *(float4 *)(ad->p + o + 4) = make_float4(pp[4], pp[5], pp[6], pp[7]);
+                    *(float4 *)(ad->m + o) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+                    *(float4 *)(ad->m + o + 4) = make_float4(mm[4], mm[5], mm[6], mm[7]);
+                    *(float4 *)(ad->v + o) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                    *(float4 *)(ad->v + o + 4) = make_float4(vv[4], vv[5], vv[6], vv[7]);
+                    store8((bf16_t *)ad->p_lp + o, pp);
+                    continue;
+                }
                 auto add8 = [&](const float4 &a, const float4 &b) {
                     v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
                 };
@@ -332,6 +397,74 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const skyemb_gemm_args g) 
     }
 #endif
   }
+}
+
+// Persistent workgroups (one per CU): tile = blockIdx.x, + gridDim.x, ...  The epilogue's global stores are not waited for: they
+// drain under the next tile's prologue and k-loop.
+template <bool B_KC>
+__global__ __launch_bounds__(512) void gemm256_kernel(const skyemb_gemm_args g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned int ntiles = (((unsigned int)g.N + 255u) / 256u) * (((unsigned int)g.M + 255u) / 256u);
+#pragma unroll 1
+    for (unsigned int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) gemm256_tile<true, B_KC, false>(g, tile, ntiles, smem);
+}
+
+// a single weight gradient: one tile per workgroup
+__global__ __launch_bounds__(512) void gemm256_wgrad_kernel(const skyemb_gemm_args g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm256_tile<false, false, false>(g, blockIdx.x, gridDim.x, smem);
+}
+
+// Grouped weight gradients (the blob of gemm_pipe_group_kernel below: header with the tile prefix of every problem, then the
+// problems; ADAM: the fused-AdamW descriptor in the header): one tile per workgroup.
+template <bool ADAM>
+__global__ __launch_bounds__(512) void gemm256_group_kernel(const char *__restrict__ blob) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int *hdr = (const int *)blob;
+    const int n = hdr[0];
+    int starts[GROUP_MAX + 1];
+#pragma unroll
+    for (int i = 0; i <= GROUP_MAX; ++i) starts[i] = hdr[8 + i];
+    int p = 0, first = 0;
+#pragma unroll
+    for (int i = 1; i < GROUP_MAX; ++i)
+        if (i < n && (int)blockIdx.x >= starts[i]) { p = i; first = starts[i]; }
+    const skyemb_gemm_args g = ((const skyemb_gemm_args *)(blob + GROUP_HEADER_BYTES))[p];
+    const unsigned int tb = blockIdx.x - first;
+    const unsigned int ntiles = ((unsigned int)g.M / 256u) * ((unsigned int)g.N / 256u);
+    if (tb >= ntiles) return;                             // padding up to the next multiple of 8 (keeps tb & 7 == XCD)
+    gemm256_tile<false, false, ADAM>(g, tb, ntiles, smem, ADAM ? (const skyemb_adamw_desc *)(blob + GROUP_ADAMW_OFFSET) : nullptr);
+}
+
+// the weight-gradient variant: both operands row-contiguous, whole tiles, K a multiple of 64 with at least two k-tiles
+bool gemm256_wgrad_applicable(const skyemb_gemm_args &g) {
+    return g.a_layout == SKYEMB_RC && g.b_layout == SKYEMB_RC && !g.dst_row && !g.tab_row && !g.table && g.split_k <= 1 &&
+           g.K % BK == 0 && g.K >= 2 * BK && g.M % 256 == 0 && g.N % 256 == 0 && g.M >= 256 && g.N >= 256 &&
+           g.lda * 2 * 4 < (1ll << 31) && g.ldb * 2 * 4 < (1ll << 31);
+}
+
+template <bool ADAM>
+int gemm256_group_launch(const void *blob_dev, int total_blocks, hipStream_t st) {
+    constexpr int smem = G256_RING * G256_HT;
+    auto kern = gemm256_group_kernel<ADAM>;
+    static std::mutex attr_mutex;
+    static bool attr_done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lock(attr_mutex);
+        if (!attr_done[dev & 63]) {
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e != hipSuccess) {
+                skyemb_set_error("skyemb_gemm_group_launch(256x256): hipFuncSetAttribute(%d B LDS): %s", smem, hipGetErrorString(e));
+                return 2;
+            }
+            attr_done[dev & 63] = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)total_blocks), dim3(512), smem, st, (const char *)blob_dev);
+    SKY_LAUNCH_CHECK("skyemb_gemm_group_launch(256x256)");
+    return 0;
 }
 
 // what the 256 x 256 kernel takes: k-contiguous A, no row maps / column sums / split-K, K a multiple of 64 with at least two k-tiles
@@ -372,7 +505,30 @@ int gemm256_launch_n(const skyemb_gemm_args &g, hipStream_t st) {
     return 0;
 }
 
+int gemm256_wgrad_launch(const skyemb_gemm_args &g, hipStream_t st) {
+    constexpr int smem = G256_RING * G256_HT;
+    static std::mutex attr_mutex;
+    static bool attr_done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lock(attr_mutex);
+        if (!attr_done[dev & 63]) {
+            hipError_t e = hipFuncSetAttribute((const void *)gemm256_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e != hipSuccess) {
+                skyemb_set_error("skyemb_gemm(256x256, weight gradient): hipFuncSetAttribute(%d B LDS): %s", smem, hipGetErrorString(e));
+                return 2;
+            }
+            attr_done[dev & 63] = true;
+        }
+    }
+    hipLaunchKernelGGL(gemm256_wgrad_kernel, dim3((unsigned)((g.M / 256) * (g.N / 256))), dim3(512), smem, st, g);
+    SKY_LAUNCH_CHECK("skyemb_gemm(256x256, weight gradient)");
+    return 0;
+}
+
 int gemm256_launch(const skyemb_gemm_args &g, hipStream_t st) {
+    if (gemm256_wgrad_applicable(g) && !g.colsum_parts) return gemm256_wgrad_launch(g, st);
     if (!gemm256_applicable(g)) {
         skyemb_set_error("skyemb_gemm(256x256): the problem is outside this tile's subset (k-contiguous A, plain epilogue, K >= 128)");
         return 1;

@@ -329,6 +329,79 @@ def test_grouped_wgrad_bias_partial_sums(ops):
     assert relerr(outs["first_column"][1], ref) < 1e-5 and relerr(outs["parts"][1], ref) < 1e-5
 
 
+def test_grouped_wgrad_256_tile(ops):
+    """The 256 x 256 weight-gradient tile (both operands row-contiguous; csrc/gemm_pipe256.h) in a grouped launch: gradients and
+    bias gradients (first tile column / partial sums) against torch and against the 128 x 128 tile; with the optimiser step in its
+    epilogue against the separate AdamW launch on the same gradient."""
+    from sky_embeddings_amd._lib import RC, AdamwDesc
+    g = torch.Generator().manual_seed(23)
+    T = 704                                              # token rows: 11 k-tiles
+    shapes = [(512, 256), (256, 768)]                    # dW [n_out, k_in]
+    dys = [dev(torch.randn(T, o, generator=g), torch.bfloat16) for o, _ in shapes]
+    xs = [dev(torch.randn(T, i, generator=g), torch.bfloat16) for _, i in shapes]
+    sizes = [o * i for o, i in shapes]
+    offs = [0, sizes[0]]
+    n = sum(sizes)
+
+    def problems(flat, dbs=None, parts=None):
+        out = []
+        for j, (o, i) in enumerate(shapes):
+            kw = {}
+            if dbs is not None:
+                kw["colsum_a"] = dbs[j]
+            if parts is not None:
+                kw["colsum_parts"] = parts[j]
+            out.append(ops.gemm_args(dys[j], xs[j], M=o, N=i, K=T, a_layout=RC, b_layout=RC, lda=o, ldb=i,
+                                     out_f32=flat[offs[j]:offs[j] + sizes[j]].view(o, i), **kw))
+        return out
+
+    res = {}
+    for tile in (128128, 256256):
+        flat = torch.full((n,), float("nan"), device=DEV)
+        dbs = [torch.full((o,), float("nan"), device=DEV) for o, _ in shapes]
+        grp = ops.GemmGroup(problems(flat, dbs), DEV, tile=tile)
+        assert grp.ok and grp.info.tile == tile
+        grp.launch()
+        res[tile] = (flat, dbs)
+    for j, (o, i) in enumerate(shapes):
+        ref = dys[j].float().t() @ xs[j].float()
+        got = res[256256][0][offs[j]:offs[j] + sizes[j]].view(o, i)
+        assert relerr(got, ref) < 2e-6
+        assert relerr(got, res[128128][0][offs[j]:offs[j] + sizes[j]].view(o, i)) < 2e-6
+        assert relerr(res[256256][1][j], dys[j].float().sum(0)) < 1e-5
+    # bias gradients as partial sums over the tile columns
+    flat2 = torch.full((n,), float("nan"), device=DEV)
+    parts = [torch.full((i // 256, o), float("nan"), device=DEV) for o, i in shapes]
+    grp = ops.GemmGroup(problems(flat2, parts=parts), DEV, tile=256256)
+    assert grp.ok
+    grp.launch()
+    assert torch.equal(flat2, res[256256][0])
+    for j in range(2):
+        assert not bool(torch.isnan(parts[j]).any())
+        assert relerr(parts[j].sum(0), dys[j].float().sum(0)) < 1e-5
+    # optimiser step in the epilogue
+    step, lr, wd, n_decay = 3, 1e-3, 0.05, sizes[0] + 1000
+    p0, m0, v0 = torch.randn(n, generator=g), torch.randn(n, generator=g) * 0.01, torch.rand(n, generator=g) * 0.01
+    hyper = dev(torch.tensor([lr, 1 - 0.9 ** step, 1 - 0.95 ** step, 0.0]))
+    # ... reference: the gradient of the plain launch through the separate AdamW launch
+    pr, mr, vr, gr = dev(p0.clone()), dev(m0.clone()), dev(v0.clone()), res[256256][0].clone()
+    plr = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    ops.adamw(pr, gr, mr, vr, plr, n, n_decay, hyper, 0.9, 0.95, 1e-8, wd, grad_scale=0.5)
+    pd, md, vd, gd = dev(p0.clone()), dev(m0.clone()), dev(v0.clone()), torch.zeros(n, device=DEV)
+    pl = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    d = AdamwDesc()
+    d.g_base, d.p, d.m, d.v, d.p_lp, d.hyper = (t.data_ptr() for t in (gd, pd, md, vd, pl, hyper))
+    d.n_decay, d.beta1, d.beta2, d.eps, d.weight_decay, d.grad_scale = n_decay, 0.9, 0.95, 1e-8, wd, 0.5
+    dbs = [torch.full((o,), float("nan"), device=DEV) for o, _ in shapes]
+    grp = ops.GemmGroup(problems(gd, dbs), DEV, tile=256256, adamw=d)
+    assert grp.ok and grp.info.tile == 256256
+    grp.launch()
+    assert torch.equal(pd, pr) and torch.equal(md, mr) and torch.equal(vd, vr) and torch.equal(pl, plr)
+    assert bool((gd == 0).all())                          # the gradient buffer is not written
+    for j in range(2):
+        assert torch.equal(dbs[j], res[256256][1][j])
+
+
 # ------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cfg", [(3, 5, 12, 64), (2, 17, 16, 32), (2, 66, 2, 64), (4, 5, 4, 16), (1, 65, 3, 8),
@@ -675,9 +748,15 @@ def test_gemm_256x256_eight_wave_tile(ops, b_l, shape):
     ops.gemm(Ad, Bd, aux=dev(aux, T), ldaux=N, act=ops.ACT_DGELU, out=dg, **kw)
     refd = prod.float() * auxr.grad
     assert float((dg.float().cpu() - refd).abs().max()) <= 1e-2 * float(refd.abs().max())
-    # outside its subset (row-contiguous A, a single k-tile) the explicit tile is refused, not silently served by another kernel
-    with pytest.raises(Exception):
+    # outside its subset (a row-contiguous A that is not a weight gradient of whole tiles, a single k-tile) the explicit tile is
+    # refused, not silently served by another kernel
+    if b_l == 1 and M % 256 == 0 and N % 256 == 0:
+        out.fill_(float("nan"))
         ops.gemm(dev(A.T.contiguous(), T), Bd, M=M, N=N, K=K, a_layout=1, b_layout=b_l, out_f32=out, tile=256256)
+        assert float((out.cpu().double() - prod).abs().max()) <= 2e-6 * scale
+    else:
+        with pytest.raises(Exception):
+            ops.gemm(dev(A.T.contiguous(), T), Bd, M=M, N=N, K=K, a_layout=1, b_layout=b_l, out_f32=out, tile=256256)
     with pytest.raises(Exception):
         ops.gemm(Ad[:, :64].contiguous(), dev(B[:, :64].contiguous(), T), M=M, N=N, K=64, out_f32=out, tile=256256)
 

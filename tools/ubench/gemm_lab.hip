@@ -132,6 +132,7 @@ int main(int argc, char **argv) {
     }
     const int ROT = 6;
     size_t max_a = (size_t)Md * 3072, max_b = (size_t)3072 * 4352, max_o = (size_t)Md * 2048;
+    if (vitl && getenv("LAB_WSWEEP")) { max_a = max_b = (size_t)4096 * 8320; max_o = (size_t)4096 * 1024; }
     for (const Shape &s : shapes) {
         max_a = std::max(max_a, (size_t)s.M * s.K);
         max_b = std::max(max_b, (size_t)s.N * s.K);
@@ -185,7 +186,8 @@ int main(int argc, char **argv) {
                 continue;
             Shape s = s0;
             s.epi = 1;
-            if ((code / 1000000 >= 9 || code % 1000000 == 256256) && !s.a_kc) continue;      // two-k-group tiles, 256x256: k-contiguous A only
+            if (code / 1000000 >= 9 && !s.a_kc) continue;                                       // two-k-group tiles: k-contiguous A only
+            if (code % 1000000 == 256256 && !s.a_kc && (s.b_kc || s.M % 256 || s.N % 256)) continue;   // 256x256: k-contiguous A, or a weight gradient of whole tiles
             if ((code % 1000000) / 1000 == 144 && !s.a_kc) continue;                           // 144-row image (136-row stride): k-contiguous A only
             if (code % 1000 == 192 && !s.b_kc) continue;                                       // 192 columns: k-contiguous B only
             skyemb_gemm_args g = make_args(s, 0, code, 1);
@@ -398,11 +400,21 @@ int main(int argc, char **argv) {
             if (code / 1000000 >= 9) continue;
             int bm, bn;
             tile_dims(code, bm, bn);
-            for (auto mn : {std::pair<int, int>{2048, 512}, {512, 2048}, {1536, 512}, {3072, 768}, {768, 3072}, {2304, 768}}) {
+            std::vector<std::pair<int, int>> wmn = {{2048, 512}, {512, 2048}, {1536, 512}, {3072, 768}, {768, 3072}, {2304, 768}};
+            std::vector<int> wk = {256, 1088, 2176, 4352};
+            if (vitl) {       // mim_19: the four weight gradients of a ViT-L block over 8320 token rows
+                wmn = {{3072, 1024}, {1024, 1024}, {4096, 1024}, {1024, 4096}};
+                wk = {1024, 2176, 4352, 8320};
+            }
+            for (auto mn : wmn) {
+                if (code % 1000000 == 256256 && (mn.first % 256 || mn.second % 256)) continue;
                 const int64_t tiles = ceil_div64(mn.first, bm) * ceil_div64(mn.second, bn);
                 printf("wsweep code %7d M %d N %d (%4ld tiles):", code, mn.first, mn.second, (long)tiles);
                 float t1 = 0, t2 = 0;
-                for (int K : {256, 1088, 2176, 4352}) {
+                for (int K : wk) {
+                    if (vitl && K == 4352) { Shape s{"w", mn.first, mn.second, K, 0, 0, 1, 4}; t1 = time_us(s, code, 1); printf("  K%d:%.1f", K, t1); continue; }
+                    if (vitl && K == 8320) { Shape s{"w", mn.first, mn.second, K, 0, 0, 1, 4}; t2 = time_us(s, code, 1); printf("  K%d:%.1f", K, t2);
+                        printf("  | %.2f us/k-step, %.0f TF/s at K = 8320\n", (t2 - t1) / 62.0, 2.0 * mn.first * mn.second * 8320 / t2 / 1e6); continue; }
                     Shape s{"w", mn.first, mn.second, K, 0, 0, 1, 4};
                     if ((size_t)mn.first * K > max_a || (size_t)mn.second * K > max_b || (size_t)mn.first * mn.second > max_o) continue;
                     const float t = time_us(s, code, 1);
@@ -410,6 +422,7 @@ int main(int argc, char **argv) {
                     if (K == 2176) t1 = t;
                     if (K == 4352) t2 = t;
                 }
+                if (vitl) continue;
                 const double per_step = (t2 - t1) / 34.0;
                 printf("  | %.2f us/k-step, %.0f TF/s at K = 4352\n", per_step, 2.0 * mn.first * mn.second * 4352 / t2 / 1e6);
             }
