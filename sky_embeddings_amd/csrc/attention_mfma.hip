@@ -312,6 +312,31 @@ __device__ __forceinline__ void stage_rows(bf16_t *tile, const bf16_t *base, int
         *(bf16x8 *)(tile + row * (HD + 8) + 8 * c) = row < N ? *(const bf16x8 *)(base + (int64_t)row * row_stride + 8 * c) : zero8();
     }
 }
+// NTILES operands of one head at once: every 16-byte piece of every tile is REQUESTED before the first one is written to LDS.
+// (stage_rows tile after tile, a loop of load -> write per piece, was 13 dependent global round trips per thread in the backward
+// kernel: most of a workgroup's 20 us at mim_19's 65 tokens, whose matrix work is ~3 k cycles per wave.)
+template <int HD, int NT, int NTILES>
+__device__ __forceinline__ void stage_tiles(bf16_t *const (&tiles)[NTILES], const bf16_t *const (&bases)[NTILES],
+                                            const int64_t (&strides)[NTILES], int N, int rows, int tid) {
+    constexpr int PR = HD / 8, THREADS = 64 * NT;
+    constexpr int MAXP = ((32 * NT + 4) * PR + THREADS - 1) / THREADS;       // pieces per thread and tile at the longest sequence
+    bf16x8 v[NTILES][MAXP];
+#pragma unroll
+    for (int t = 0; t < NTILES; ++t)
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int p = tid + i * THREADS, row = p / PR, c = p - row * PR;
+            const int rc = row < N ? row : N - 1;                                // clamped: the request is unconditional
+            v[t][i] = *(const bf16x8 *)(bases[t] + (int64_t)rc * strides[t] + 8 * c);
+        }
+#pragma unroll
+    for (int t = 0; t < NTILES; ++t)
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int p = tid + i * THREADS, row = p / PR, c = p - row * PR;
+            if (p < rows * PR) *(bf16x8 *)(tiles[t] + row * (HD + 8) + 8 * c) = row < N ? v[t][i] : zero8();
+        }
+}
 // The LDS tiles hold round_up(N, 4) + 4 rows: the data rows, zero-filled up to the 4-row group, and one all-zero group
 // (rows zrow..zrow+3) that every read past the sequence is redirected to -- 72 rows instead of 96 for the 65-token
 // sequences: with the register budget capped for three waves per SIMD (below) three backward workgroups share a CU.
@@ -357,11 +382,15 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(NT <= 3
     const int my = 32 * strip + r;                        // this lane's query token
     const float scale = rsqrtf((float)HD);
 
-    stage_rows<HD>(kt, kb, rs, N, ROWS, threadIdx.x, 64 * NT);
-    stage_rows<HD>(vt, vb, rs, N, ROWS, threadIdx.x, 64 * NT);
     bf16x8 qf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) qf[s] = row_frag_at(qb, rs, my, g, s, N);
+    {
+        bf16_t *const tiles[2] = {kt, vt};
+        const bf16_t *const bases[2] = {kb, vb};
+        const int64_t strides[2] = {rs, rs};
+        stage_tiles<HD, NT, 2>(tiles, bases, strides, N, ROWS, threadIdx.x);
+    }
     __syncthreads();
     f32x16 st[NT];
     float mx = -INFINITY;
@@ -426,10 +455,12 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(NT <= 3
     const float scale = rsqrtf((float)HD);
     bf16_t *dq = dqkv + ((int64_t)b * N + my) * rs + h * HD, *dk = dq + D, *dv = dq + 2 * D;
 
-    stage_rows<HD>(qt, qb, rs, N, ROWS, threadIdx.x, 64 * NT);
-    stage_rows<HD>(kt, kb, rs, N, ROWS, threadIdx.x, 64 * NT);
-    stage_rows<HD>(vt, vb, rs, N, ROWS, threadIdx.x, 64 * NT);
-    stage_rows<HD>(dot, ob, D, N, ROWS, threadIdx.x, 64 * NT);
+    {
+        bf16_t *const tiles[4] = {qt, kt, vt, dot};
+        const bf16_t *const bases[4] = {qb, kb, vb, ob};
+        const int64_t strides[4] = {rs, rs, rs, (int64_t)D};
+        stage_tiles<HD, NT, 4>(tiles, bases, strides, N, ROWS, threadIdx.x);
+    }
     __syncthreads();
 
     // ---- phase A: my query strip against every key tile: statistics, dS^T, dQ

@@ -1,6 +1,6 @@
 """utils/eval_fns.py mirror: ``mae_latent`` (encode a dataset into the embeddings that are searched, optionally with the
 target augmentations), ``mae_predict`` (reconstructions), and the bank builder of SURVEY.md §8f rank 1.
-``ft_predict`` (downstream predictor) is out of scope."""
+``ft_predict``: the predictions of a trained downstream predictor."""
 from __future__ import annotations
 
 import numpy as np
@@ -101,5 +101,30 @@ def build_embedding_bank(model, dataloader, device, pool='max', n_batches=None):
     return torch.cat(rows).contiguous()
 
 
-def ft_predict(*a, **k):
-    raise NotImplementedError("ft_predict belongs to the downstream-predictor workload (out of scope, SURVEY.md §2)")
+def ft_predict(model, dataloader, device, num_batches=None, return_images=False, use_label_errs=False):
+    """utils/eval_fns.py:142-192: predictions of a trained predictor (utils.vit) over a labelled loader, in label units
+    (``denormalize_labels``) -> (tgt_labels, pred_labels[, images]) as numpy arrays.  With label errors the second half of the
+    label columns is dropped.  (The reference stops after num_batches + 1 batches: kept.)"""
+    model.eval()
+    net = _net(model)
+    tgt_labels, pred_labels, images = [], [], []
+    if num_batches is None:
+        num_batches = len(dataloader)
+    print(f'Running predictions on {num_batches} batches...')
+    with torch.no_grad():
+        for i, (samples, masks, ra_decs, labels) in enumerate(dataloader):
+            samples = samples.to(device, non_blocking=True)
+            labels = labels.to(device, non_blocking=True)
+            if use_label_errs:
+                labels = labels[:, :labels.size(1) // 2]
+            out = net.denormalize_labels(model(samples, mask=None, ra_dec=ra_decs.to(device, non_blocking=True)))
+            tgt_labels.append(labels.cpu().numpy())
+            pred_labels.append(out.float().cpu().numpy())
+            if return_images:
+                images.append(samples.cpu().numpy())
+            if i == num_batches:
+                break
+    tgt_labels, pred_labels = np.concatenate(tgt_labels), np.concatenate(pred_labels)
+    if return_images:
+        return tgt_labels, pred_labels, np.concatenate(images)
+    return tgt_labels, pred_labels

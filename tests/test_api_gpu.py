@@ -1,6 +1,7 @@
 """GPU: the drop-in module API (utils.mim_vit / utils.similarity / entry points) end to end."""
 import configparser
 import os
+import shutil
 import subprocess
 import sys
 
@@ -402,7 +403,13 @@ def test_train_predictor_entry_point(tmp_path, method, loss_fn):
     dd = tmp_path / "data"
     dd.mkdir()
     hdf5_lite.make_synthetic_cutouts(str(dd / "train.h5"), n=64, seed=11, with_labels=True)
-    hdf5_lite.make_synthetic_cutouts(str(dd / "val.h5"), n=16, seed=12, with_labels=True)
+    # validation objects: twelve with a bright central source (S/N > 5 in every channel: the ones test_predictor.py evaluates), four without
+    rng = np.random.default_rng(12)
+    vcut = rng.standard_normal((16, 5, 64, 64)).astype(np.float32)
+    vcut[:12, :, 28:36, 28:36] += 10.0
+    hdf5_lite.write_datasets(str(dd / "val.h5"), {"cutouts": vcut, "ra": rng.uniform(0, 360, 16).astype(np.float32),
+                                                  "dec": rng.uniform(-90, 90, 16).astype(np.float32), "zspec": rng.uniform(0.2, 1.6, 16).astype(np.float32),
+                                                  "zspec_err": np.full(16, 0.01, np.float32), "class": rng.integers(0, 3, 16).astype(np.int64)})
     work = tmp_path / "work"
     (work / "configs").mkdir(parents=True)
     (work / "models").mkdir()
@@ -439,6 +446,48 @@ def test_train_predictor_entry_point(tmp_path, method, loss_fn):
     assert same == (method == "lp")                                       # the probe leaves the encoder alone, fine-tuning moves it
     out2 = subprocess.run(cmd, cwd=str(work), env=env, capture_output=True, text=True, timeout=600)       # resume: from the best checkpoint
     assert out2.returncode == 0 and "Loading saved model weights..." in out2.stdout, out2.stdout[-1500:] + out2.stderr[-1500:]
+    # ---- python test_predictor.py <ini> (test_predictor.py:12-118): the evaluation of the trained predictor; the numbers of the
+    # reference's figures land in figures/*.npz
+    for name in ("test_predictor.py", "compare_predictors.py"):
+        os.symlink(os.path.join(ROOT, name), work / name)
+    out3 = subprocess.run([sys.executable, str(work / "test_predictor.py"), "pred_t", "-dd", str(dd)], cwd=str(work), env=env,
+                          capture_output=True, text=True, timeout=600)
+    assert out3.returncode == 0 and "Testing complete." in out3.stdout, out3.stdout[-2000:] + out3.stderr[-2000:]
+    prog = np.load(str(work / "figures" / "pred_t_best_progress.npz"))
+    assert "val_loss" in prog.files and len(prog["val_loss"]) >= 1
+    # ... against the predictions of the same checkpoint through the module API
+    from sky_embeddings_amd.utils.vit import build_model as build_vit
+    from sky_embeddings_amd.utils.dataloaders import build_h5_dataloader
+    from sky_embeddings_amd.utils.eval_fns import ft_predict
+    from sky_embeddings_amd.utils.misc import h5_snr
+    from sky_embeddings_amd.utils import plotting_fns as pf
+    model, _, _ = build_vit(cfg, mae_cfg, str(work / "models" / "pred_t_best.pth.tar"), str(work / "models" / "mim_t.pth.tar"), torch.device("cuda"))
+    loader = build_h5_dataloader(str(dd / "val.h5"), batch_size=8, num_workers=1, label_keys=eval(cfg["DATA"]["label_keys"]), img_size=64,
+                                 patch_size=int(mae_cfg["ARCHITECTURE"]["patch_size"]), num_channels=int(mae_cfg["ARCHITECTURE"]["num_channels"]),
+                                 num_patches=model.module.patch_embed.num_patches, shuffle=False)
+    tgt, pred = ft_predict(model, loader, torch.device("cuda"))
+    assert tgt.shape[0] == 16 and pred.shape == (16, 3 if loss_fn == "crossentropy" else 1)
+    keep = np.nanmin(h5_snr(str(dd / "val.h5"))[:, :5], axis=1) > 5
+    assert int(keep.sum()) == 12
+    if loss_fn == "mse":
+        z = np.load(str(work / "figures" / "pred_t_redshift.npz"))
+        _, bias, mad, frac = pf.photoz_prediction_metrics(pred[keep].reshape(-1), tgt[keep].reshape(-1), threshold=0.15)
+        assert np.allclose([z["bias"], z["mad"], z["frac_out"]], [bias, mad, frac], rtol=1e-5, atol=1e-7)
+        assert z["z_bin_counts"].shape == (8,) and z["snr_bin_counts"].shape == (8,)
+        r = np.load(str(work / "figures" / "pred_t_predictions.npz"))
+        assert np.allclose(r["resid"][:, 0], (pred - tgt)[keep, 0], atol=1e-6)
+    else:
+        z = np.load(str(work / "figures" / "pred_t_classes.npz"))
+        cm = pf.confusion_matrix(tgt[keep, 0], pred[keep].argmax(1), n_classes=3)
+        assert np.array_equal(z["confusion_matrix"], cm) and int(cm.sum()) == int(keep.sum())
+        # ---- python compare_predictors.py (compare_predictors.py:150-250): the families' score table; one member present here
+        for src, dst in (("configs/pred_t.ini", "configs/cls_ap_012k.ini"), ("models/pred_t_best.pth.tar", "models/cls_ap_012k_best.pth.tar")):
+            shutil.copy(str(work / src), str(work / dst))
+        out4 = subprocess.run([sys.executable, str(work / "compare_predictors.py"), "x", "-dd", str(dd)], cwd=str(work), env=env,
+                              capture_output=True, text=True, timeout=600)
+        assert out4.returncode == 0 and "Testing complete." in out4.stdout, out4.stdout[-2000:] + out4.stderr[-2000:]
+        sc = np.load(str(work / "figures" / "numsamples_class.npz"))["scores"]
+        assert sc.shape == (5, 3, 8) and np.isclose(sc[2, 0, 0], np.mean(pred.argmax(1) == tgt[:, 0])) and np.isnan(sc[0, 0, 0])
 
 
 def test_compute_similarity_central_patches_matches_reference_goldens():

@@ -88,8 +88,31 @@ def test_product_refuses_cpu_and_never_imports_oracle():
             if fn.endswith(".py"):
                 src = open(os.path.join(base, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
-    for fn in ("pretrain_mim.py", "similarity_search.py", "sky_sim_search.py", "train_predictor.py"):
+    for fn in ("pretrain_mim.py", "similarity_search.py", "sky_sim_search.py", "train_predictor.py", "test_predictor.py", "compare_predictors.py"):
         assert not re.search(r"^\s*(from|import)\s+oracle", open(os.path.join(ROOT, fn)).read(), flags=re.M)
+
+
+def test_evaluation_numbers_of_the_predictor_figures():
+    """utils/plotting_fns.py mirror (numbers only): photo-z metrics (:394-402) by hand, binned metrics, confusion matrix."""
+    from sky_embeddings_amd.utils import plotting_fns as pf
+    rng = np.random.default_rng(3)
+    zt = rng.uniform(0.1, 1.8, 500)
+    zp = zt + rng.normal(0, 0.03, 500) * (1 + zt)
+    zp[:10] += 1.0                                        # outliers
+    resid, bias, mad, frac = pf.photoz_prediction_metrics(zp, zt, threshold=0.15)
+    r = (zp - zt) / (1 + zt)
+    assert np.array_equal(resid, r) and bias == r.mean() and frac == (np.abs(r) > 0.15).sum() / 500
+    assert mad == 1.4826 * np.median(np.abs(r - np.median(r))) and 0.02 < mad < 0.04 and frac >= 0.02
+    res = pf.evaluate_z(zp, zt, n_bins=8, z_range=(0.2, 1.6), threshold=0.1, snr=rng.uniform(0, 30, 500))
+    edges = np.linspace(0.2, 1.6, 9)
+    b3 = np.where((edges[3] <= zt) & (zt < edges[4]))[0]
+    assert res["z_bin_counts"][3] == len(b3) and np.isclose(res["z_bin_bias"][3], r[b3].mean())
+    assert np.isclose(res["z_bin_frac_out"][3], (np.abs(r[b3]) > 0.1).mean()) and res["snr_bin_mids"][0] == 6.25
+    empty = pf.evaluate_z(zp[:5], zt[:5], n_bins=50, z_range=(0.2, 1.6))
+    assert np.isnan(empty["z_bin_bias"]).any()            # empty bins: NaN, not a crash
+    t, p = np.array([0, 0, 1, 2, 2, 2.0]), np.array([0, 1, 1, 2, 0, 2])
+    cm = pf.plot_conf_mat(t, p, ["galaxy", "qso", "star"], None)
+    assert np.array_equal(cm, [[1, 1, 0], [0, 1, 0], [1, 0, 2]])
 
 
 def test_cosine_schedule_and_ini_surface():
