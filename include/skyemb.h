@@ -108,7 +108,7 @@ int skyemb_gemm(const skyemb_gemm_args *args, void *stream);
  * plan returns -1 (with skyemb_last_error set) when a problem is outside the subset: launch them singly then. */
 typedef struct skyemb_gemm_group_info {
     int32_t total_blocks; /* grid size of the launch                                                          */
-    int32_t tile;         /* tile code the plan chose (BM * 1000 + BN): 64064, 128064 or 128128               */
+    int32_t tile;         /* tile code the plan chose (BM * 1000 + BN): 64064, 128064, 128128 or 256256        */
     int32_t class_mask;   /* operand-layout classes present: 1 KC.KC, 2 KC.RC (dgrad), 4 RC.RC (wgrad)        */
     int32_t reserved;     /* 1: the blob carries a skyemb_adamw_desc (skyemb_gemm_group_plan_adamw)                         */
 } skyemb_gemm_group_info;
@@ -119,6 +119,14 @@ int64_t skyemb_gemm_group_blob_bytes(int n);
 int skyemb_gemm_group_plan(const skyemb_gemm_args *args, int n, int tile, void *blob_host, int64_t blob_bytes,
                            skyemb_gemm_group_info *info);
 int skyemb_gemm_group_launch(const void *blob_dev, const skyemb_gemm_group_info *info, void *stream);
+/* Workspace a grouped launch of these problems can use, in bytes (0: none).  Weight gradients of whole 256 x 256 tiles that
+ * leave compute units idle (T tiles on T + H units, T / H whole: the four weight gradients of a ViT-L block are 192 tiles on 256
+ * units) run with SHARED tiles: H helper workgroups multiply the last 1 / (T / H + 1) of every tile's k-range and hand the partial
+ * tile to its owner through this workspace (csrc/gemm_pipe256.h).  Pass it as args[0].ws / ws_bytes to skyemb_gemm_group_plan
+ * (without it the launch is the plain one): device memory, zero-filled ONCE by the caller (the kernels leave it zeroed), and
+ * shared only by launches that do not overlap in time.  Results do not depend on it being used (same k order per
+ * accumulator, one extra fp32 addition per output element). */
+int64_t skyemb_gemm_group_ws_bytes(const skyemb_gemm_args *args, int n, int tile);
 /* The same grouped weight-gradient launch with the optimiser step fused into its epilogue (one process per model replica only:
  * with N > 1 the gradients are summed over the ranks between backward and AdamW).  Every problem's out_f32 points into the flat
  * gradient buffer `g_base`; p / m / v / p_lp are the flat parameter, moment and low-precision-shadow buffers with the SAME element

@@ -62,6 +62,7 @@ PROTOTYPES = {
     "skyemb_debug_skip": (c_i32, [c_i32]),
     "skyemb_gemm": (c_i32, [ctypes.POINTER(GemmArgs), c_vp]),
     "skyemb_gemm_group_blob_bytes": (c_i64, [c_i32]),
+    "skyemb_gemm_group_ws_bytes": (c_i64, [ctypes.POINTER(GemmArgs), c_i32, c_i32]),
     "skyemb_gemm_group_plan": (c_i32, [ctypes.POINTER(GemmArgs), c_i32, c_i32, c_vp, c_i64, ctypes.POINTER(GemmGroupInfo)]),
     "skyemb_set_scalars": (c_i32, [c_vp, c_f32, c_f32, c_f32, c_f32, c_vp]),
     "skyemb_gemm_group_plan_adamw": (c_i32, [ctypes.POINTER(GemmArgs), c_i32, c_i32, ctypes.POINTER(AdamwDesc), c_vp, c_i64,

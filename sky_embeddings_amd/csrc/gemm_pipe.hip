@@ -1053,12 +1053,41 @@ extern "C" int skyemb_gemm_group_plan(const skyemb_gemm_args *args, int n, int t
     }
     hdr[8 + n] = start;
     hdr[0] = n;
+    if (tile == 256256) {
+        // shared tiles (gemm256_group_kernel): the first problem's `ws` carries the workspace (skyemb_gemm_group_ws_bytes)
+        int helpers = 0, r = 0;
+        gemm256_group_split(start, args, n, helpers, r);
+        if (helpers > 0 && args[0].ws && args[0].ws_bytes >= G256GroupWs::bytes(start)) {
+            hdr[2] = helpers;
+            hdr[3] = r;
+            void *ws = args[0].ws;
+            memcpy(hdr + 4, &ws, sizeof ws);
+            start += helpers;
+        }
+    }
     hdr[1] = start;
     info->total_blocks = start;
     info->tile = tile;
     info->class_mask = mask;
     info->reserved = 0;
     return 0;
+}
+
+// bytes of workspace a grouped launch of these problems can use (0: none): the first problem's `ws` / `ws_bytes` carry it into
+// skyemb_gemm_group_plan; zero-filled once, shared by launches that do not overlap in time
+extern "C" int64_t skyemb_gemm_group_ws_bytes(const skyemb_gemm_args *args, int n, int tile) {
+    if (!args || n < 1 || n > GROUP_MAX) return 0;
+    tile = canonical_tile(tile);
+    if (tile != 0 && tile != 256256) return 0;
+    int64_t tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!gemm256_wgrad_applicable(args[i])) return 0;
+        tiles += ((int64_t)(args[i].M / 256) * (args[i].N / 256) + 7) / 8 * 8;
+    }
+    if (tiles > 4096) return 0;
+    int helpers = 0, r = 0;
+    gemm256_group_split((int)tiles, args, n, helpers, r);
+    return helpers > 0 ? G256GroupWs::bytes((int)tiles) : 0;
 }
 
 extern "C" int skyemb_gemm_group_plan_adamw(const skyemb_gemm_args *args, int n, int tile, const skyemb_adamw_desc *adamw, void *blob_host,
