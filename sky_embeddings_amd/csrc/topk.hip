@@ -431,6 +431,22 @@ __global__ __launch_bounds__(1024) void topk_merge_sort_kernel(const float *__re
     // bank-streaming kernel writes one terminator, not k - n padding slots).  With a pruning floor a list holds a few rows: the
     // first HEAD entries of a thread's lists are requested together (one memory round trip instead of one per entry; k >= 1,
     // clamped reads stay inside the list) and kept for the gather below
+    // ... and a list that goes on past its head is walked eight entries per round trip (full lists -- no pruning floor: banks
+    // under 8 x 256 x k rows -- were k dependent loads each)
+    auto list_length = [&](int64_t base, int e) {
+        while (e < k) {
+            int64_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = pi[base + (e + u < k ? e + u : k - 1)];
+            int f = 8;
+#pragma unroll
+            for (int u = 7; u >= 0; --u)
+                if (e + u >= k || v[u] < 0) f = u;
+            e += f;
+            if (f < 8) break;
+        }
+        return e < k ? e : k;
+    };
     constexpr int HEAD = 4, LPT = 2;                          // lists per thread handled with the register heads (nlists <= 2048)
     int64_t hix[LPT][HEAD];
     float hsc[LPT][HEAD];
@@ -454,17 +470,12 @@ __global__ __launch_bounds__(1024) void topk_merge_sort_kernel(const float *__re
             int e = 0;
 #pragma unroll
             for (int h = 0; h < HEAD; ++h) e += (e == h && h < k && hix[j][h] >= 0) ? 1 : 0;
-            if (l < nlists && e == HEAD)
-                while (e < k && pi[(int64_t)l * k + e] >= 0) ++e;
+            if (l < nlists && e == HEAD) e = list_length((int64_t)l * k, e);
             hlen[j] = l < nlists ? e : 0;
             mycount += hlen[j];
         }
     } else {
-        for (int l = tid; l < nlists; l += 1024) {
-            int e = 0;
-            while (e < k && pi[(int64_t)l * k + e] >= 0) ++e;
-            mycount += e;
-        }
+        for (int l = tid; l < nlists; l += 1024) mycount += list_length((int64_t)l * k, 0);
     }
     // block exclusive scan of per-thread counts
     int incl = mycount;
