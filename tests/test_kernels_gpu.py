@@ -455,6 +455,30 @@ def test_grouped_wgrad_256_tile_shared_tiles(ops, shape):
     assert torch.equal(pd, pr) and torch.equal(md, mr) and torch.equal(vd, vr) and torch.equal(pl, plr) and torch.equal(db3, db)
 
 
+def test_vit_l_weight_gradient_group_takes_the_256_tile(ops):
+    """The four weight gradients of a ViT-L block with the tile choice left open (mim_19's shapes, 2112 token rows here): 192 whole
+    256 x 256 tiles, one round -> the plan picks the 256 x 256 group; gradients and bias gradients == the 128 x 128 group's."""
+    from sky_embeddings_amd._lib import RC
+    g = torch.Generator().manual_seed(41)
+    T, dim, hid = 2112, 1024, 4096
+    shapes = [(dim, hid), (hid, dim), (dim, dim), (3 * dim, dim)]
+    dys = [dev(torch.randn(T, o, generator=g), torch.bfloat16) for o, _ in shapes]
+    xs = [dev(torch.randn(T, i, generator=g), torch.bfloat16) for _, i in shapes]
+    res = {}
+    for tile in (0, 128128):
+        dWs = [torch.full((o, i), float("nan"), device=DEV) for o, i in shapes]
+        dbs = [torch.full((o,), float("nan"), device=DEV) for o, _ in shapes]
+        grp = ops.GemmGroup([ops.gemm_args(dys[j], xs[j], M=o, N=i, K=T, a_layout=RC, b_layout=RC, lda=o, ldb=i, out_f32=dWs[j], colsum_a=dbs[j])
+                             for j, (o, i) in enumerate(shapes)], DEV, tile=tile)
+        assert grp.ok
+        grp.launch()
+        res[tile] = (grp.info.tile, grp.total_blocks, dWs, dbs)
+    assert res[0][0] == 256256 and res[0][1] == 192 and res[128128][0] == 128128
+    for j in range(4):
+        assert relerr(res[0][2][j], res[128128][2][j]) < 2e-6 and relerr(res[0][3][j], res[128128][3][j]) < 1e-5
+        assert relerr(res[0][2][j], dys[j].float().t() @ xs[j].float()) < 2e-6
+
+
 # ------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cfg", [(3, 5, 12, 64), (2, 17, 16, 32), (2, 66, 2, 64), (4, 5, 4, 16), (1, 65, 3, 8),
