@@ -693,7 +693,8 @@ def main():
                 "roofline_q_large": {"bound": "mfma_f16", "achieved": ql["effective_tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                      "frac": ql["effective_tflops"] / PEAK_BF16_TFLOPS,
                                      "note": "two-stage exact search (csrc/topk_prefilter.hip); the exact single-stage fp32 kernel on the "
-                                             "same inputs: q_large.kernel_tflops of the 157 TFLOP/s fp32-MFMA peak"},
+                                             "same inputs: q_large.kernel_tflops of the 157 TFLOP/s fp32-MFMA peak",
+                                     **search_pmc_record()},
             }
         if world == 1 and not args.skip_cpu:
             cpre, csea = cpu_baselines(args, search_inputs)
@@ -709,6 +710,20 @@ def main():
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def search_pmc_record():
+    """Matrix-pipe utilisation of the many-query pass by hardware counters (profiles/r04_search_pmc.json: SQ_VALU_MFMA_BUSY_CYCLES over
+    the launch's SIMD-cycles, a separate --pmc pass), or {}."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_search_pmc.json")) as f:
+            ks = json.load(f)["kernels"]
+        k = next(v for n, v in ks.items() if n.startswith("prefilter_kernelILi2ELb0"))
+        return {"mfma_busy_pmc": k["mfma_util"], "l2_hit_rate_pmc": k["l2_hit_rate"], "pmc_source": "profiles/r04_search_pmc.json",
+                "pmc_note": "prefilter_kernel<2,false> (80 % of the search): matrix pipe busy / SIMD-cycles of the launch at the clock the "
+                            "chip ran it at (1.75 GHz in the two long launches: 12.3 / 14.3 M cycles in 6.9 / 8.0 ms); `frac` prices the FLOPs against the 2.4 GHz peak"}
+    except (OSError, KeyError, ValueError, StopIteration):
+        return {}
 
 
 def gemm_pmc_record():
