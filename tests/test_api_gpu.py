@@ -378,6 +378,14 @@ def test_sky_sim_search_entry_point_streams_survey_tiles(tmp_path):
     cfg["DATA"].update(bands="['G','R','I','Z','Y']", min_bands="5", cutouts_per_tile="48", use_calexp="True")
     with open(work / "configs" / "mim_t.ini", "w") as fh:
         cfg.write(fh)
+    # (a checkpoint of a SEEDED random initialisation: the entry point would otherwise draw its own weights, and the margin asserted
+    # at the end would differ from run to run)
+    from sky_embeddings_amd.utils.mim_vit import build_model as build_mae
+    (work / "models").mkdir()
+    torch.manual_seed(20260)
+    mae, _, _ = build_mae(cfg, str(tmp_path / "none.pth.tar"), torch.device("cuda"))
+    torch.save({"batch_iters": 1, "losses": {}, "model": {k: v.cpu() for k, v in mae.module.state_dict().items()}}, str(work / "models" / "mim_t.pth.tar"))
+    del mae
     for name in ("sky_sim_search.py", "utils", "sky_embeddings_amd"):
         os.symlink(os.path.join(ROOT, name), work / name)
     out = subprocess.run([sys.executable, str(work / "sky_sim_search.py"), "mim_t", "-tgt_fn", "targets.h5", "-tst_dirs", str(tiles), "-tgt_i", "[0,1]",
