@@ -350,7 +350,7 @@ def bench_mim19(args, dev):
     res = dict(workload="configs/mim_19.ini: SimMIM ViT-Large/16, 5x128x128, 39 of 64 patches masked per channel (ratio 0.6), "
                         f"bs={B}, L1 + norm-pix, AdamW+cosine, bf16", ms_per_step=ms, images_per_sec=B / ms * 1e3,
                tflops=B / ms * executed / 1e9, frac_of_bf16_peak=B / ms * executed / 1e9 / PEAK_BF16_TFLOPS,
-               flops_per_image_executed=executed, params=int(eng.store.n), loss=float(loss))
+               flops_per_image_executed=executed, params=int(eng.store.n), loss=float(loss), **mim19_pmc_record())
     del step, opt, eng
     torch.cuda.empty_cache()
     return res
@@ -710,6 +710,20 @@ def main():
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def mim19_pmc_record():
+    """Matrix-pipe utilisation of the mim_19 step's GEMM kernels by hardware counters (profiles/r04_mim19_pmc.json: cycle-weighted
+    SQ_VALU_MFMA_BUSY_CYCLES over the launches' SIMD-cycles, a separate --pmc pass over two eager steps), or {}."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_mim19_pmc.json")) as f:
+            ks = {n: v for n, v in json.load(f)["kernels"].items() if n.startswith("gemm")}
+        cyc = {n: v["gpu_cycles_per_launch"] * v["launches"] for n, v in ks.items()}
+        tot = sum(cyc.values())
+        return {"gemm_mfma_busy_pmc": sum(ks[n].get("mfma_util", 0.0) * cyc[n] for n in ks) / tot,
+                "gemm_share_of_gpu_cycles_pmc": sum(v["share_of_gpu_cycles"] for v in ks.values()), "pmc_source": "profiles/r04_mim19_pmc.json"}
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return {}
 
 
 def search_pmc_record():
