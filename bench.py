@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--skip-search", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-feeder", action="store_true")
+    ap.add_argument("--skip-f32", action="store_true", help="skip the timing of the fp32 parity mode (extra.f32_mode)")
     ap.add_argument("--skip-mim19", action="store_true", help="skip the BASELINE configs[4] leg (SimMIM ViT-L/16, 5x128x128)")
     ap.add_argument("--probe", action="store_true", help="also time every GEMM shape of the step alone (HIP-graph probe)")
     ap.add_argument("--bank-rows", type=int, default=1_000_000)
@@ -236,9 +237,91 @@ def bench_pretrain(args, rank, world, dev):
             _, long_ms, _ = timed(step, n_long)
             out["long_run"] = dict(steps=n_long, ms_per_step=long_ms, images_per_sec=B / long_ms * 1e3)
             out["staged"] = staged_schedule_price(eng, opt, sched, B, pool, dev, args)
+            if B == 256 and not args.no_graph:
+                out["batch_sweep"] = batch_sweep(eng, opt, sched, dev, rank, long_ms)
         if world == 1 and not args.skip_feeder:
             out["feeder"] = bench_feeder(args, dev, step, B)
     return out, eng
+
+
+def batch_sweep(eng, opt, sched, dev, rank, ms_256):
+    """The same engine, weights and step at B = 512 and 1024 beside the headline's B = 256: step time against the batch is a straight
+    line T(B) = F + V B -- F the per-launch fixed cost of ~340 dependent launches, V the kernels' throughput -- and the bench line
+    shows both (extra.batch_sweep.fixed_ms / per_image_us).  Not the headline: BASELINE configs[1] prescribes bs = 256 per GPU."""
+    from sky_embeddings_amd.train_step import TrainStep
+    st = eng.store
+    snap = [t.clone() for t in (st.p, st.m, st.v, st.p_lp)]
+    counters = (opt.step_count, sched.last_epoch)
+    res = {"256": dict(ms_per_step=ms_256, images_per_sec=256 / ms_256 * 1e3)}
+    executed, _ = eng.flops_per_image(0.75)
+    try:
+        for Bs in (512, 1024):
+            g = torch.Generator(device="cpu").manual_seed(4321 + rank)
+            batch = torch.randn(Bs, 5, 64, 64, generator=g).clamp_(min=-3.0).to(dev)
+            s = TrainStep(eng, opt, sched, Bs, mask_ratio=0.75, use_graph=True, world_size=1)
+            for _ in range(5):
+                s(batch)
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(30):
+                s(batch)
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1) / 30
+            res[str(Bs)] = dict(ms_per_step=ms, images_per_sec=Bs / ms * 1e3, frac_of_bf16_peak=Bs / ms * executed / 1e9 / PEAK_BF16_TFLOPS)
+            del s, batch
+            for k in [k for k in eng._ws if k[0] == Bs]:
+                del eng._ws[k]
+            torch.cuda.empty_cache()
+    finally:
+        for dst, src in zip((st.p, st.m, st.v, st.p_lp), snap):
+            dst.copy_(src)
+        opt.step_count, sched.last_epoch = counters
+        sched._apply()
+    # least-squares line through the three points
+    xs = [256.0, 512.0, 1024.0]
+    ys = [res[str(int(x))]["ms_per_step"] for x in xs]
+    mx, my = sum(xs) / 3, sum(ys) / 3
+    slope = sum((x - mx) * (y - my) for x, y in zip(xs, ys)) / sum((x - mx) ** 2 for x in xs)
+    res["fixed_ms"], res["per_image_us"] = my - slope * mx, 1e3 * slope
+    res["per_image_frac_of_bf16_peak"] = executed / (slope * 1e-3) / 1e12 / PEAK_BF16_TFLOPS
+    res["note"] = ("T(B) = fixed_ms + per_image_us * B through B = 256 / 512 / 1024 on the same engine (HIP graph, optimiser in the weight-"
+                   "gradient epilogues); per_image_frac_of_bf16_peak = executed FLOPs per image / per_image_us: the kernels' own rate "
+                   "once the per-launch fixed cost is paid")
+    return res
+
+
+def f32_mode_timing(dev, rank, B=256):
+    """The mode that meets north_star's 1e-3 pixel tolerance (exact fp32 MFMA chains, csrc/gemm.hip), timed on the headline's
+    workload: same model, batch and step, HIP graph; its AdamW is the separate launch."""
+    from sky_embeddings_amd.engine import MAEEngine
+    from sky_embeddings_amd.model_config import config_for
+    from sky_embeddings_amd.optim import CosineLR, FusedAdamW
+    from sky_embeddings_amd.train_step import TrainStep
+    cfg = config_for("base", img_size=64, patch_size=16, in_chans=5, embed_dim=768, norm_pix_loss=True, loss_fn="mse")
+    eng = MAEEngine(cfg, device=dev, compute_dtype=torch.float32, seed=0)
+    opt = FusedAdamW(eng, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
+    step = TrainStep(eng, opt, CosineLR(opt, 1_000_000, eta_min=1e-4 / 1e7), B, mask_ratio=0.75, use_graph=True, world_size=1)
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    batch = torch.randn(B, 5, 64, 64, generator=g).clamp_(min=-3.0).to(dev)
+    for _ in range(3):
+        step(batch)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        loss = step(batch)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    executed, _ = eng.flops_per_image(0.75)
+    res = dict(ms_per_step=ms, images_per_sec=B / ms * 1e3, loss=float(loss), tflops=B / ms * executed / 1e9,
+               frac_of_f32_mfma_peak=B / ms * executed / 1e9 / PEAK_F32_MFMA_TFLOPS,
+               note="compute_dtype = f32: v_mfma_f32_16x16x4_f32 GEMMs (exact fp32 fma chains), fp32 attention; parity.f32 is this mode's error")
+    del step, opt, eng
+    torch.cuda.empty_cache()
+    return res
 
 
 def staged_schedule_price(eng, opt, sched, B, pool, dev, args):
@@ -670,9 +753,11 @@ def main():
         line["extra"] = {}
         if mim19 is not None:
             line["extra"]["mim_19"] = mim19
-        for key in ("long_run", "staged"):
+        for key in ("long_run", "staged", "batch_sweep"):
             if key in pre:
                 line["extra"][key] = pre[key]
+        if world == 1 and args.dtype == "bf16" and not args.skip_f32:
+            line["extra"]["f32_mode"] = f32_mode_timing(dev, rank, pre["B"])
         if search is not None:
             ql, qs = search["q_large"], search["q_small"]
             line["search"] = {

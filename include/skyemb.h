@@ -44,7 +44,20 @@ int skyemb_version(void);
 /* Measurement aid for bench.py: entry points of the kernel families in `mask` return 0 without launching (bit 0: the MFMA
  * GEMM launches), so a timed region with and without them gives the family's in-step time.  Returns the previous mask.
  * Not part of the drop-in surface; results are garbage while a bit is set. */
-int skyemb_debug_skip(int mask);
+int skyemb_debug_skip(int mask); /* MEASUREMENT ONLY: process-global, not thread-safe -- a second thread calling into the library
+                                  * while a bit is set gets no-op launches too.  bench.py sets it around one captured replay and
+                                  * clears it in a `finally`; nothing else may. */
+/* Diagnostic: launches issued so far by each GEMM kernel family of this process (out[i] for the slots below; reset != 0 zeroes
+ * them after reading).  Tests use it to assert that a shape ran on the kernel it is meant to exercise (e.g. the 256 x 256 tile
+ * at ViT-L width); no product path reads it. */
+#define SKYEMB_GEMM_COUNT_FALLBACK 0 /* gemm.hip: register-staged kernel (fp32 parity mode, shapes outside the pipe subset) */
+#define SKYEMB_GEMM_COUNT_PIPE 1     /* gemm_pipe_kernel: LDS-DMA ring, every tile shape but 256 x 256                       */
+#define SKYEMB_GEMM_COUNT_256 2      /* gemm256_kernel / gemm256_wgrad_kernel: single 256 x 256 launches                     */
+#define SKYEMB_GEMM_COUNT_GROUP 3    /* gemm_pipe_group_kernel: grouped launches on ring tiles                               */
+#define SKYEMB_GEMM_COUNT_GROUP256 4 /* gemm256_group_kernel: grouped launches on 256 x 256 tiles                            */
+#define SKYEMB_GEMM_COUNT_SPLITK 5   /* splitk_reduce_kernel                                                                 */
+#define SKYEMB_GEMM_COUNT_SLOTS 8
+int skyemb_gemm_launch_counts(long long *out, int n, int reset);
 
 /* ---------------------------------------------------------------- GEMM ----
  * Replaces every nn.Linear / Conv2d(k=s=p) contraction of timm PatchEmbed / Block /
@@ -119,14 +132,6 @@ int64_t skyemb_gemm_group_blob_bytes(int n);
 int skyemb_gemm_group_plan(const skyemb_gemm_args *args, int n, int tile, void *blob_host, int64_t blob_bytes,
                            skyemb_gemm_group_info *info);
 int skyemb_gemm_group_launch(const void *blob_dev, const skyemb_gemm_group_info *info, void *stream);
-/* Workspace a grouped launch of these problems can use, in bytes (0: none).  Weight gradients of whole 256 x 256 tiles that
- * leave compute units idle (T tiles on T + H units, T / H whole: the four weight gradients of a ViT-L block are 192 tiles on 256
- * units) run with SHARED tiles: H helper workgroups multiply the last 1 / (T / H + 1) of every tile's k-range and hand the partial
- * tile to its owner through this workspace (csrc/gemm_pipe256.h).  Pass it as args[0].ws / ws_bytes to skyemb_gemm_group_plan
- * (without it the launch is the plain one): device memory, zero-filled ONCE by the caller (the kernels leave it zeroed), and
- * shared only by launches that do not overlap in time.  Results do not depend on it being used (same k order per
- * accumulator, one extra fp32 addition per output element). */
-int64_t skyemb_gemm_group_ws_bytes(const skyemb_gemm_args *args, int n, int tile);
 /* The same grouped weight-gradient launch with the optimiser step fused into its epilogue (one process per model replica only:
  * with N > 1 the gradients are summed over the ranks between backward and AdamW).  Every problem's out_f32 points into the flat
  * gradient buffer `g_base`; p / m / v / p_lp are the flat parameter, moment and low-precision-shadow buffers with the SAME element

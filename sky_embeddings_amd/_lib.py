@@ -60,9 +60,9 @@ PROTOTYPES = {
     "skyemb_last_error": (ctypes.c_char_p, []),
     "skyemb_version": (c_i32, []),
     "skyemb_debug_skip": (c_i32, [c_i32]),
+    "skyemb_gemm_launch_counts": (c_i32, [c_vp, c_i32, c_i32]),
     "skyemb_gemm": (c_i32, [ctypes.POINTER(GemmArgs), c_vp]),
     "skyemb_gemm_group_blob_bytes": (c_i64, [c_i32]),
-    "skyemb_gemm_group_ws_bytes": (c_i64, [ctypes.POINTER(GemmArgs), c_i32, c_i32]),
     "skyemb_gemm_group_plan": (c_i32, [ctypes.POINTER(GemmArgs), c_i32, c_i32, c_vp, c_i64, ctypes.POINTER(GemmGroupInfo)]),
     "skyemb_set_scalars": (c_i32, [c_vp, c_f32, c_f32, c_f32, c_f32, c_vp]),
     "skyemb_gemm_group_plan_adamw": (c_i32, [ctypes.POINTER(GemmArgs), c_i32, c_i32, ctypes.POINTER(AdamwDesc), c_vp, c_i64,

@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "../../include/skyemb.h"
 
 static thread_local char g_err[512] = "";
@@ -26,3 +28,20 @@ extern "C" int skyemb_debug_skip(int mask) {
     return old;
 }
 int skyemb_skip_mask(void) { return g_skip_mask; }
+
+// Diagnostic: how many launches each GEMM kernel family has issued in this process (relaxed counters; tests assert through
+// them that a configuration really ran on the kernels it is meant to exercise).  Slots: SKYEMB_GEMM_COUNT_* of skyemb.h.
+static std::atomic<long long> g_gemm_counts[SKYEMB_GEMM_COUNT_SLOTS];
+void skyemb_count_gemm(int slot) {
+    if (slot >= 0 && slot < SKYEMB_GEMM_COUNT_SLOTS) g_gemm_counts[slot].fetch_add(1, std::memory_order_relaxed);
+}
+extern "C" int skyemb_gemm_launch_counts(long long *out, int n, int reset) {
+    if (!out || n < 0) {
+        skyemb_set_error("skyemb_gemm_launch_counts: bad arguments");
+        return 1;
+    }
+    for (int i = 0; i < n && i < SKYEMB_GEMM_COUNT_SLOTS; ++i)
+        out[i] = reset ? g_gemm_counts[i].exchange(0, std::memory_order_relaxed) : g_gemm_counts[i].load(std::memory_order_relaxed);
+    for (int i = SKYEMB_GEMM_COUNT_SLOTS; i < n; ++i) out[i] = 0;
+    return 0;
+}

@@ -10,6 +10,7 @@
 namespace {
 
 constexpr int MAXN = 256;   // tokens per sample (cls + RA/Dec + patches)
+constexpr int MAXHD = 512;  // columns per head (the downstream predictor pools with TWO heads: 384 at ViT-B, 512 at ViT-L)
 
 // q[o] = bq[o] + sum_i Wq[o][i] latent[i]; one wave per output
 __global__ __launch_bounds__(256) void attnpool_q_kernel(const float *__restrict__ latent, const float *__restrict__ Wq,
@@ -26,7 +27,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void attnpool_fwd_kernel(const float *__restrict__ q, const T *__restrict__ kv,
                                                            T *__restrict__ out, float *__restrict__ prob, int B, int N, int H,
                                                            int hd) {
-    __shared__ float sq[4][128], sp[4][MAXN];
+    __shared__ float sq[4][MAXHD], sp[4][MAXN];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int bh = blockIdx.x * 4 + wave;
     if (bh >= B * H) return;
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void attnpool_bwd_kernel(const float *__restri
                                                            const T *__restrict__ dout, const float *__restrict__ prob,
                                                            T *__restrict__ dkv, float *__restrict__ dq_part, int B, int N, int H,
                                                            int hd) {
-    __shared__ float sq[4][128], sdo[4][128], sds[4][MAXN];
+    __shared__ float sq[4][MAXHD], sdo[4][MAXHD], sds[4][MAXN];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int bh = blockIdx.x * 4 + wave;
     if (bh >= B * H) return;
@@ -159,8 +160,8 @@ extern "C" int skyemb_attnpool_q(const float *latent, const float *Wq, const flo
 
 extern "C" int skyemb_attnpool_fwd(const float *q, const void *kv, int dtype, void *out, float *prob, int B, int N, int H, int hd,
                                    void *stream) {
-    SKY_CHECK_ARG(q && kv && out && prob && B > 0 && N > 0 && N <= MAXN && H > 0 && hd > 0 && hd <= 128 && hd % 4 == 0,
-                  "skyemb_attnpool_fwd: bad shape B=%d N=%d H=%d hd=%d (N <= %d, hd <= 128, hd %% 4 == 0)", B, N, H, hd, MAXN);
+    SKY_CHECK_ARG(q && kv && out && prob && B > 0 && N > 0 && N <= MAXN && H > 0 && hd > 0 && hd <= MAXHD && hd % 4 == 0,
+                  "skyemb_attnpool_fwd: bad shape B=%d N=%d H=%d hd=%d (N <= %d, hd <= %d, hd %% 4 == 0)", B, N, H, hd, MAXN, MAXHD);
     const dim3 grid((B * H + 3) / 4), block(256);
     if (dtype == SKYEMB_BF16)
         hipLaunchKernelGGL(attnpool_fwd_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, q, (const bf16_t *)kv, (bf16_t *)out, prob, B, N, H, hd);
@@ -172,7 +173,7 @@ extern "C" int skyemb_attnpool_fwd(const float *q, const void *kv, int dtype, vo
 
 extern "C" int skyemb_attnpool_bwd(const float *q, const void *kv, int dtype, const void *dout, const float *prob, void *dkv,
                                    float *dq_part, int B, int N, int H, int hd, void *stream) {
-    SKY_CHECK_ARG(q && kv && dout && prob && dkv && dq_part && B > 0 && N > 0 && N <= MAXN && H > 0 && hd > 0 && hd <= 128 && hd % 4 == 0,
+    SKY_CHECK_ARG(q && kv && dout && prob && dkv && dq_part && B > 0 && N > 0 && N <= MAXN && H > 0 && hd > 0 && hd <= MAXHD && hd % 4 == 0,
                   "skyemb_attnpool_bwd: bad shape B=%d N=%d H=%d hd=%d", B, N, H, hd);
     const dim3 grid((B * H + 3) / 4), block(256);
     if (dtype == SKYEMB_BF16)

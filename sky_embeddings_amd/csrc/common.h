@@ -17,6 +17,7 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 void skyemb_set_error(const char *fmt, ...);
 int skyemb_skip_mask(void);   // api.cpp: measurement aid, see skyemb_debug_skip
+void skyemb_count_gemm(int slot);   // api.cpp: diagnostic launch counters, see skyemb_gemm_launch_counts
 
 // Also drops any stale sticky HIP error left by other code in this thread (e.g. a device probe),
 // so that SKY_LAUNCH_CHECK reports only this call's launches.  Every launching entry point starts

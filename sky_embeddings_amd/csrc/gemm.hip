@@ -284,6 +284,7 @@ int launch(const skyemb_gemm_args &g, hipStream_t st) {
     }
     const int64_t tiles = ceil_div64(g.M, BM) * ceil_div64(g.N, BN);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), smem, st, g);
+    skyemb_count_gemm(SKYEMB_GEMM_COUNT_FALLBACK);
     SKY_LAUNCH_CHECK("skyemb_gemm");
     return 0;
 }

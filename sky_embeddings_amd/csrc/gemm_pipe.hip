@@ -745,10 +745,12 @@ int launch_n(const skyemb_gemm_args &g, hipStream_t st) {
     const int64_t tiles = ceil_div64(g.M, tile_stride_m(BM)) * ceil_div64(g.N, BN);
     const int S = g.split_k > 1 ? g.split_k : 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * S)), dim3(WM * WN * WK * 64), smem, st, g);
+    skyemb_count_gemm(SKYEMB_GEMM_COUNT_PIPE);
     if (S > 1) {
         int64_t blocks = ceil_div64((int64_t)g.M * g.N / 4, 256);
         if (blocks > 1024) blocks = 1024;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, S);
+        skyemb_count_gemm(SKYEMB_GEMM_COUNT_SPLITK);
     }
     SKY_LAUNCH_CHECK("skyemb_gemm(pipe)");
     return 0;
@@ -1053,41 +1055,12 @@ extern "C" int skyemb_gemm_group_plan(const skyemb_gemm_args *args, int n, int t
     }
     hdr[8 + n] = start;
     hdr[0] = n;
-    if (tile == 256256) {
-        // shared tiles (gemm256_group_kernel): the first problem's `ws` carries the workspace (skyemb_gemm_group_ws_bytes)
-        int helpers = 0, r = 0;
-        gemm256_group_split(start, args, n, helpers, r);
-        if (helpers > 0 && args[0].ws && args[0].ws_bytes >= G256GroupWs::bytes(start)) {
-            hdr[2] = helpers;
-            hdr[3] = r;
-            void *ws = args[0].ws;
-            memcpy(hdr + 4, &ws, sizeof ws);
-            start += helpers;
-        }
-    }
     hdr[1] = start;
     info->total_blocks = start;
     info->tile = tile;
     info->class_mask = mask;
     info->reserved = 0;
     return 0;
-}
-
-// bytes of workspace a grouped launch of these problems can use (0: none): the first problem's `ws` / `ws_bytes` carry it into
-// skyemb_gemm_group_plan; zero-filled once, shared by launches that do not overlap in time
-extern "C" int64_t skyemb_gemm_group_ws_bytes(const skyemb_gemm_args *args, int n, int tile) {
-    if (!args || n < 1 || n > GROUP_MAX) return 0;
-    tile = canonical_tile(tile);
-    if (tile != 0 && tile != 256256) return 0;
-    int64_t tiles = 0;
-    for (int i = 0; i < n; ++i) {
-        if (!gemm256_wgrad_applicable(args[i])) return 0;
-        tiles += ((int64_t)(args[i].M / 256) * (args[i].N / 256) + 7) / 8 * 8;
-    }
-    if (tiles > 4096) return 0;
-    int helpers = 0, r = 0;
-    gemm256_group_split((int)tiles, args, n, helpers, r);
-    return helpers > 0 ? G256GroupWs::bytes((int)tiles) : 0;
 }
 
 extern "C" int skyemb_gemm_group_plan_adamw(const skyemb_gemm_args *args, int n, int tile, const skyemb_adamw_desc *adamw, void *blob_host,
@@ -1137,6 +1110,7 @@ static int group_launch_n(const void *blob_dev, int total_blocks, hipStream_t st
         }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)total_blocks), dim3(WM * WN * WK * 64), smem, st, (const char *)blob_dev);
+    skyemb_count_gemm(SKYEMB_GEMM_COUNT_GROUP);
     SKY_LAUNCH_CHECK("skyemb_gemm_group_launch");
     return 0;
 }

@@ -56,29 +56,16 @@ __device__ __forceinline__ int lane_fresh() {
 // One 256 x 256 tile.  A_KC = false: the weight-gradient layout (both operands row-contiguous, contraction over token rows;
 // M, N multiples of 256).  ADAM: the tile is the gradient of a block of parameters in the flat buffers of `ad` and the epilogue is
 // their AdamW step (as in gemm_pipe_body); colsum_a / colsum_parts (row-contiguous A): the bias gradient, as there.
-// A tile's k-tiles shared between two workgroups (grouped weight gradients, gemm256_group_kernel): the HELPER multiplies k-tiles
-// [kt0, kt1), leaves its accumulators (and column sums) in `part` in register order -- [wave][fragment][lane] float4: whole 1 KiB
-// lines per wave-instruction both ways -- and raises `flag`; the OWNER multiplies its k-tiles, waits for the flag, adds the partial
-// tile to its accumulators, clears the flag and runs the epilogue.
-struct G256Split {
-    int role;              // 0: the whole tile   1: owner   2: helper
-    int kt0, kt1;          // k-tiles of this workgroup
-    f32x4 *part;           // 33 x 512 float4 per tile
-    int *flag;
-};
-constexpr int G256_PART_FLOAT4 = 33 * 512;
-
 template <bool A_KC, bool B_KC, bool ADAM>
 __device__ __forceinline__ void gemm256_tile(const skyemb_gemm_args &g, const unsigned int tile, const unsigned int ntiles, char *smem,
-                                             const skyemb_adamw_desc *ad = nullptr, const G256Split sp = G256Split{0, 0, 0, nullptr, nullptr}) {
+                                             const skyemb_adamw_desc *ad = nullptr) {
     static_assert(A_KC || !B_KC, "a row-contiguous A comes with a row-contiguous B (weight gradients)");
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const unsigned int tiles_n = ((unsigned int)g.N + 255u) / 256u, tiles_m = ((unsigned int)g.M + 255u) / 256u;
-    const int kt_first = sp.role ? sp.kt0 : 0;
-    const bf16_t *A = (const bf16_t *)g.A + (A_KC ? (int64_t)kt_first * BK : (int64_t)kt_first * BK * g.lda);
-    const bf16_t *B = (const bf16_t *)g.B + (B_KC ? (int64_t)kt_first * BK : (int64_t)kt_first * BK * g.ldb);
-    const int KT = sp.role ? sp.kt1 - sp.kt0 : g.K / BK, H = 4 * KT;
+    const bf16_t *A = (const bf16_t *)g.A + 0;
+    const bf16_t *B = (const bf16_t *)g.B + 0;
+    const int KT = g.K / BK, H = 4 * KT;
     const bool colmajor = g.N > g.M;
   {
     unsigned int wg;
@@ -221,8 +208,7 @@ __device__ __forceinline__ void gemm256_tile(const skyemb_gemm_args &g, const un
     const bool cs_parts = !A_KC && g.colsum_parts != nullptr;
     const bool do_colsum = !A_KC && (wc == 0) && (cs_parts || (g.colsum_a != nullptr && tile_n == 0));
     const int cs_step = cs_parts ? (int)tiles_n : 1;
-    // (k-tile t of this workgroup is k-tile kt_first + t of the problem: with partial sums, the first one of this tile column)
-    int cs_next = cs_parts ? (tile_n + cs_step - kt_first % cs_step) % cs_step : 0;
+    int cs_next = cs_parts ? tile_n : 0;                  // with partial sums: the first k-tile of this tile column
     f32x4 cacc = (f32x4){0.f, 0.f, 0.f, 0.f};
     // one phase: READ part (fragments of this phase, two half-tiles requested, the counted wait in the last phase of a k-tile),
     // barrier, MFMA part, barrier
@@ -302,50 +288,6 @@ __device__ __forceinline__ void gemm256_tile(const skyemb_gemm_args &g, const un
     const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();
 #endif
 
-    // ---- a tile shared with another workgroup (G256Split)
-    if (sp.role == 2) {
-        // (uniform base per fragment + ONE per-lane byte offset: scalar-base addressing, no address registers beside the accumulators)
-        const unsigned int voff = (unsigned int)(wave * 64 + lane_fresh()) * 16u;
-        char *pbase = (char *)sp.part;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) *(f32x4 *)(pbase + (i * 4 + j) * 8192 + voff) = acc[i][j];
-        *(f32x4 *)(pbase + 32 * 8192 + voff) = cacc;
-        __threadfence();                                  // the partial tile is visible device-wide before the flag
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(sp.flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    if (sp.role == 1) {
-        // (helpers have the lower workgroup numbers: they were dispatched before any owner and wait for nobody, so the flag comes.
-        // The wait is bounded all the same -- ~2 s -- and a tile whose partner never came is poisoned with NaN, not left half-summed.)
-        if (threadIdx.x == 0) {
-            int spins = 0;
-            while (__hip_atomic_load(sp.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0 && spins < (1 << 22)) {
-                __builtin_amdgcn_s_sleep(16);
-                ++spins;
-            }
-            *(volatile int *)smem = spins < (1 << 22);    // (the ring is free: every wave has left the k-loop)
-        }
-        __syncthreads();
-        __threadfence();
-        const bool ok = *(volatile int *)smem != 0;
-        const unsigned int voff = (unsigned int)(wave * 64 + lane_fresh()) * 16u;
-        const char *pbase = (const char *)sp.part;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            f32x4 t[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) t[j] = *(const f32x4 *)(pbase + (i * 4 + j) * 8192 + voff);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] += t[j];
-        }
-        cacc += *(const f32x4 *)(pbase + 32 * 8192 + voff);
-        if (!ok) acc[0][0][0] = __builtin_nanf("");
-        __syncthreads();                                  // every wave has read the partial tile (and `ok`): the flag can go
-        if (threadIdx.x == 0) __hip_atomic_store(sp.flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     // ---- epilogue: two halves of 128 rows through LDS (the ring is free), rows leave in pieces of 8 columns per lane
     constexpr int PITCH = 256 * 4 + 16;
     const int lane_e = lane_fresh(), tid = wave * 64 + lane_e;
@@ -474,73 +416,27 @@ __global__ __launch_bounds__(512) void gemm256_wgrad_kernel(const skyemb_gemm_ar
 }
 
 // Grouped weight gradients (the blob of gemm_pipe_group_kernel below: header with the tile prefix of every problem, then the
-// problems; ADAM: the fused-AdamW descriptor in the header).  Plain: one tile per workgroup.
-// Shared tiles (header word 2 = number of helper workgroups H > 0, word 3 = r, words 4-5 = workspace): a launch of T tiles on a
-// chip of P = T + H compute units (mim_19: 192 tiles, 256 CUs) would leave H units idle for the whole launch.  Instead workgroups
-// 0 .. H-1 are HELPERS: each multiplies the last 1 / (r + 1) of the k-tiles of r tiles, r = T / H, one after the other; workgroup
-// H + t OWNS tile t, multiplies the first r / (r + 1) of its k-tiles, adds its helper's partial tile and runs the epilogue
-// (G256Split above).  Every unit then carries r / (r + 1) of a tile's k-loop.
-// MEASURED (round 4, the four weight gradients of a ViT-L block, 8320 token rows): 413 us per launch against 303 for the plain
-// launch (446 / 330 with the optimiser step) -- the launch is bound by what its tiles miss in the L2s (1.6 GB into LDS per launch,
-// roughly half of it from beyond the L2), not by the idle units: owners and helpers walk different k-ranges, so panels are shared by
-// fewer workgroups at a time.  Used only when the caller hands the plan a workspace (ops.GemmGroup(shared_tiles=True) /
-// SKYEMB_GROUP_SPLIT=1); off by default.
-struct G256GroupWs {
-    static constexpr int64_t PART_BYTES = (int64_t)G256_PART_FLOAT4 * 16;
-    static int64_t bytes(int tiles_padded) { return (int64_t)tiles_padded * (PART_BYTES + 64); }     // partial tiles, then one flag line each
-};
+// problems; ADAM: the fused-AdamW descriptor in the header): one tile per workgroup.
+// (Round 4 also built tiles SHARED between an owner and a helper workgroup for launches with idle compute units -- mim_19: 192
+// tiles on 256 CUs -- and measured them a third slower, 413 against 303 us per launch: the launch is bound by what its tiles miss in
+// the L2s, and owners and helpers on different k-ranges share fewer panels.  Removed in round 5; profiles/HISTORY.md keeps the numbers.)
 template <bool ADAM>
 __global__ __launch_bounds__(512) void gemm256_group_kernel(const char *__restrict__ blob) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int *hdr = (const int *)blob;
-    const int n = hdr[0], helpers = hdr[2], r = hdr[3];
-    const int tiles_padded = hdr[1] - helpers;
-    // tiles of this workgroup (index in the padded tile list) and its role.  Helper h takes tiles h, h + H, h + 2 H, ...: with H a
-    // multiple of 8 they are tiles of the helper's own XCD (tile & 7 == workgroup & 7), whose L2 holds their operand panels
-    int gt, gt_end, gt_step, role;
-    if (helpers == 0) { gt = blockIdx.x; gt_end = gt + 1; gt_step = 1; role = 0; }
-    else if ((int)blockIdx.x < helpers) { gt = blockIdx.x; gt_end = tiles_padded; gt_step = helpers; role = 2; }
-    else { gt = blockIdx.x - helpers; gt_end = gt + 1; gt_step = 1; role = 1; }
+    const int n = hdr[0];
+    const int gt = blockIdx.x;
+    int p = 0, first = 0;                                 // (the tile prefix is walked in memory: n <= 32 scalar loads per tile)
 #pragma unroll 1
-    for (; gt < gt_end; gt += gt_step) {
-        int p = 0, first = 0;                             // (the tile prefix is walked in memory: n <= 32 scalar loads per tile)
-#pragma unroll 1
-        for (int i = 1; i < n; ++i) {
-            const int s_i = hdr[8 + i];
-            if (gt >= s_i) { p = i; first = s_i; }
-        }
-        const skyemb_gemm_args g = ((const skyemb_gemm_args *)(blob + GROUP_HEADER_BYTES))[p];
-        const unsigned int tb = gt - first;
-        const unsigned int ntiles = ((unsigned int)g.M / 256u) * ((unsigned int)g.N / 256u);
-        if (tb >= ntiles) continue;                       // padding up to the next multiple of 8 (keeps tb & 7 == XCD)
-        G256Split sp = {role, 0, 0, nullptr, nullptr};
-        if (role) {
-            const int KT = g.K / BK, ko = (KT * r + r) / (r + 1);          // the owner's k-tiles: ceil(KT r / (r + 1))
-            sp.kt0 = role == 1 ? 0 : ko;
-            sp.kt1 = role == 1 ? ko : KT;
-            char *ws = *(char *const *)(hdr + 4);
-            sp.part = (f32x4 *)(ws + (int64_t)gt * G256GroupWs::PART_BYTES);
-            sp.flag = (int *)(ws + (int64_t)tiles_padded * G256GroupWs::PART_BYTES + (int64_t)gt * 64);
-        }
-        gemm256_tile<false, false, ADAM>(g, tb, ntiles, smem, ADAM ? (const skyemb_adamw_desc *)(blob + GROUP_ADAMW_OFFSET) : nullptr, sp);
+    for (int i = 1; i < n; ++i) {
+        const int s_i = hdr[8 + i];
+        if (gt >= s_i) { p = i; first = s_i; }
     }
-}
-
-// Shared tiles for a grouped launch of `tiles_padded` tiles whose problems have K / 64 = kt[i] k-tiles: helper count H and r, or
-// H = 0 (plain launch): the chip must have more compute units than tiles, r = tiles / H whole, and both shares >= 2 k-tiles.
-void gemm256_group_split(int tiles_padded, const skyemb_gemm_args *args, int n, int &helpers, int &r) {
-    helpers = r = 0;
-    int dev = 0, ncu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return;
-    const int h = ncu - tiles_padded;
-    if (h <= 0 || tiles_padded % h != 0 || tiles_padded / h > 8) return;
-    const int rr = tiles_padded / h;
-    for (int i = 0; i < n; ++i) {
-        const int KT = args[i].K / BK, ko = (KT * rr + rr) / (rr + 1);
-        if (ko < 2 || KT - ko < 2) return;
-    }
-    helpers = h;
-    r = rr;
+    const skyemb_gemm_args g = ((const skyemb_gemm_args *)(blob + GROUP_HEADER_BYTES))[p];
+    const unsigned int tb = gt - first;
+    const unsigned int ntiles = ((unsigned int)g.M / 256u) * ((unsigned int)g.N / 256u);
+    if (tb >= ntiles) return;                             // padding up to the next multiple of 8 (keeps tb & 7 == XCD)
+    gemm256_tile<false, false, ADAM>(g, tb, ntiles, smem, ADAM ? (const skyemb_adamw_desc *)(blob + GROUP_ADAMW_OFFSET) : nullptr);
 }
 
 // the weight-gradient variant: both operands row-contiguous, whole tiles, K a multiple of 64 with at least two k-tiles
@@ -570,6 +466,7 @@ int gemm256_group_launch(const void *blob_dev, int total_blocks, hipStream_t st)
         }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)total_blocks), dim3(512), smem, st, (const char *)blob_dev);
+    skyemb_count_gemm(SKYEMB_GEMM_COUNT_GROUP256);
     SKY_LAUNCH_CHECK("skyemb_gemm_group_launch(256x256)");
     return 0;
 }
@@ -608,6 +505,7 @@ int gemm256_launch_n(const skyemb_gemm_args &g, hipStream_t st) {
     }();
     static const bool persist = []() { const char *e = getenv("SKYEMB_GEMM_256_PERSIST"); return !(e && e[0] == '0'); }();
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles < ncu || !persist ? tiles : ncu)), dim3(512), smem, st, g);
+    skyemb_count_gemm(SKYEMB_GEMM_COUNT_256);
     SKY_LAUNCH_CHECK("skyemb_gemm(256x256)");
     return 0;
 }
@@ -630,6 +528,7 @@ int gemm256_wgrad_launch(const skyemb_gemm_args &g, hipStream_t st) {
         }
     }
     hipLaunchKernelGGL(gemm256_wgrad_kernel, dim3((unsigned)((g.M / 256) * (g.N / 256))), dim3(512), smem, st, g);
+    skyemb_count_gemm(SKYEMB_GEMM_COUNT_256);
     SKY_LAUNCH_CHECK("skyemb_gemm(256x256, weight gradient)");
     return 0;
 }

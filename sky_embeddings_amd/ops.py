@@ -64,34 +64,17 @@ def gemm(A, B, **kw):
     check(lib().skyemb_gemm(ctypes.byref(g), _stream()), "skyemb_gemm")
 
 
-_GROUP_WS = {}          # device index -> workspace of the grouped launches with shared tiles
-
-
 class GemmGroup:
     """Several independent GEMMs as ONE launch (skyemb_gemm_group_*): one tile shape (``tile`` = 0 lets the plan choose),
     data-gradient (KC.RC) and weight-gradient (RC.RC) problems may share a launch.  Built once from gemm_args(...)
     structs -- the device blob holds the raw pointers, so the operand buffers must stay allocated -- and replayed with
     launch().  `ok` is False when a problem is outside the grouped subset (launch them singly)."""
 
-    def __init__(self, args, device, tile=0, adamw=None, shared_tiles=None):
+    def __init__(self, args, device, tile=0, adamw=None):
         """adamw: an _lib.AdamwDesc -- the optimiser step fused into the launch's epilogue (weight-gradient groups of a
-        single-process run: skyemb_gemm_group_plan_adamw).  shared_tiles: hand the plan the workspace that lets a 256 x 256
-        group with idle compute units share tiles between workgroups (include/skyemb.h, skyemb_gemm_group_ws_bytes; measured
-        slower than the plain launch at ViT-L size, so off unless asked for: SKYEMB_GROUP_SPLIT=1)."""
+        single-process run: skyemb_gemm_group_plan_adamw)."""
         n = len(args)
         arr = (GemmArgs * n)(*args)
-        if shared_tiles is None:
-            shared_tiles = os.environ.get("SKYEMB_GROUP_SPLIT", "0") == "1"
-        ws_bytes = lib().skyemb_gemm_group_ws_bytes(arr, n, tile) if shared_tiles else 0
-        if ws_bytes > 0 and not arr[0].ws:
-            # shared 256 x 256 tiles (include/skyemb.h): one zero-filled workspace per device, shared by every group -- their
-            # launches are ordered on one stream (the engine's backward, or its weight-gradient side stream)
-            key = torch.device(device).index or 0
-            ws = _GROUP_WS.get(key)
-            if ws is None or ws.numel() < ws_bytes:
-                ws = _GROUP_WS[key] = torch.zeros(ws_bytes, dtype=torch.uint8, device=device)
-            arr[0].ws, arr[0].ws_bytes = ws.data_ptr(), ws.numel()
-            self._ws = ws
         nbytes = lib().skyemb_gemm_group_blob_bytes(n)
         host = torch.zeros(nbytes, dtype=torch.uint8)
         self.info = GemmGroupInfo()
@@ -107,6 +90,16 @@ class GemmGroup:
 
     def launch(self):
         check(lib().skyemb_gemm_group_launch(self.blob.data_ptr(), ctypes.byref(self.info), _stream()), "skyemb_gemm_group_launch")
+
+
+GEMM_COUNT_NAMES = ("fallback", "pipe", "tile256", "group", "group256", "splitk")
+
+
+def gemm_launch_counts(reset=False):
+    """{family: launches so far in this process} (include/skyemb.h, SKYEMB_GEMM_COUNT_*): a diagnostic the parity tests read."""
+    buf = (ctypes.c_longlong * 8)()
+    check(lib().skyemb_gemm_launch_counts(ctypes.cast(buf, ctypes.c_void_p), 8, int(reset)), "skyemb_gemm_launch_counts")
+    return dict(zip(GEMM_COUNT_NAMES, list(buf)))
 
 
 def colsum(X, M, N, out, ldx=None):

@@ -2,15 +2,18 @@
 TRAINED through the reference's API (``build_model`` with ``build_optimizer``, ``load_model``, ``model.module.*``).
 
 The encoder (patch embedding, Blocks, final norm) runs forward AND backward in the HIP engine (``MAEEngine``: the same kernels
-as pre-training; tokens in raster order, nothing masked); the head -- pooling, ``fc_norm``, one Linear -- is a few kilobytes of
-torch on the same device, joined to the engine by an autograd node whose backward runs the engine's backward schedule.
+as pre-training; tokens in raster order, nothing masked), and so does the head -- pooling, ``fc_norm``, one Linear
+(``sky_embeddings_amd.predictor_head.PredictorHead``: GEMM, attention-pool, LayerNorm and AdamW kernels of the library on the
+head's own flat buffers).  One autograd node joins the predictions to the caller's loss: its backward runs the head's backward
+schedule and then the engine's.
 Training methods of utils/vit.py:134-172: ``ft`` (fine-tuning with layer-wise lr decay), ``lp`` (linear probe: final norm,
 ``fc_norm`` and head only; the encoder backward is not run at all), anything else "fully supervised" (timm's weight-decay split,
-one lr); schedule = the LinearLR the reference ends up with (its OneCycleLR is overwritten, utils/vit.py:174-186).
+one lr); schedule = the LinearLR the reference ends up with -- starting from what its discarded OneCycleLR left in the
+optimiser: lr = init_lr / 25, beta1 = 0.95 (utils/vit.py:174-186, ``apply_onecycle_side_effects``).
 Pooling: ``token`` (class token), ``avg`` (mean of the patch tokens + ``fc_norm``; timm then has no final norm), ``map`` (timm's
 ``AttentionPoolLatent`` with two heads, as every shipped predictor config asks for: one learned query over the encoder's tokens,
-projection, LayerNorm + MLP residual -- evaluated in torch like the rest of the head, ~1.5 % of the encoder's FLOPs; its gradient
-with respect to ALL tokens enters the engine's backward), ``''``.
+projection, LayerNorm + MLP residual; its gradient with respect to ALL tokens enters the engine's backward as the final norm's
+incoming gradient), ``''``.
 """
 from __future__ import annotations
 
@@ -24,6 +27,7 @@ import torch
 from .. import ops
 from ..engine import MAEEngine
 from ..model_config import MODEL_TYPES, config_for
+from ..predictor_head import PredictorHead
 from .lr_decay import param_groups_lrd
 from .mim_vit import _DataParallelShim, _PatchEmbedInfo, _compute_dtype
 from .misc import str2bool
@@ -32,20 +36,20 @@ from .pos_embed import interpolate_pos_embed
 _ENCODER_KEYS = ("cls_token", "pos_embed", "patch_mask_values", "patch_embed.", "blocks.", "norm.", "ra_dec_embed.")
 
 
-class _EncoderFeatures(torch.autograd.Function):
-    """HIP encoder forward -> the pooled-from tensor (class-token rows after the final norm, or the patch-token mean of the
-    un-normalised stream); backward hands d features to the engine's backward schedule (parameter gradients land in the flat
-    gradient buffer) -- or only to the final norm's when the encoder is frozen (linear probe)."""
+class _Predict(torch.autograd.Function):
+    """HIP encoder + head forward -> predictions [B, num_classes]; backward hands d predictions to the head's backward schedule and
+    what that leaves (d features / d tokens) to the engine's (parameter gradients land in the flat gradient buffers) -- or only to
+    the final norm's when the encoder is frozen (linear probe)."""
 
     @staticmethod
     def forward(ctx, hook, model, x, ra_dec):
         ctx.model = model
-        return model._encode_train(x, ra_dec)
+        return model._predict_train(x, ra_dec)
 
     @staticmethod
-    def backward(ctx, dfeat):
-        ctx.model._encode_backward(dfeat.contiguous())
-        return torch.zeros(1, device=dfeat.device), None, None, None
+    def backward(ctx, dpred):
+        ctx.model._predict_backward(dpred.contiguous())
+        return torch.zeros(1, device=dpred.device), None, None, None
 
 
 class VisionTransformer:
@@ -68,26 +72,13 @@ class VisionTransformer:
         self.num_blocks = cfg.depth
         D = cfg.embed_dim
         gen = torch.Generator().manual_seed(0 if seed is None else seed)
-        # head-side tensors (torch, fp32): timm's names.  'avg' pooling normalises the POOLED features (fc_norm) and has no final norm
-        self.head = OrderedDict()
-        if global_pool == 'avg':
-            self.head["fc_norm.weight"], self.head["fc_norm.bias"] = torch.ones(D, device=dev), torch.zeros(D, device=dev)
-        if global_pool == 'map':
-            # timm AttentionPoolLatent(embed_dim, num_heads=2, mlp_ratio, norm_layer) (utils/vit.py:303-309): trunc-normal latent, Linear init
-            hid = int(D * cfg.mlp_ratio)
-
-            def lin(o, i):
-                return (torch.randn(o, i, generator=gen) * 0.02).clamp_(-0.04, 0.04).to(dev), torch.zeros(o, device=dev)
-            self.pool_heads = 2
-            self.head["attn_pool.latent"] = (torch.randn(1, 1, D, generator=gen) * D ** -0.5).clamp_(-2 * D ** -0.5, 2 * D ** -0.5).to(dev)
-            for name, (o, i) in (("q", (D, D)), ("kv", (2 * D, D)), ("proj", (D, D))):
-                self.head[f"attn_pool.{name}.weight"], self.head[f"attn_pool.{name}.bias"] = lin(o, i)
-            self.head["attn_pool.norm.weight"], self.head["attn_pool.norm.bias"] = torch.ones(D, device=dev), torch.zeros(D, device=dev)
-            self.head["attn_pool.mlp.fc1.weight"], self.head["attn_pool.mlp.fc1.bias"] = lin(hid, D)
-            self.head["attn_pool.mlp.fc2.weight"], self.head["attn_pool.mlp.fc2.bias"] = lin(D, hid)
-        if self.num_classes > 0:
-            self.head["head.weight"] = (torch.randn(self.num_classes, D, generator=gen) * 0.02).clamp_(-0.04, 0.04).to(dev)
-            self.head["head.bias"] = torch.zeros(self.num_classes, device=dev)
+        # head-side tensors under timm's names: views of the head's flat fp32 buffer (predictor_head.PredictorHead).  'avg' pooling
+        # normalises the POOLED features (fc_norm) and has no final norm; 'map' = timm AttentionPoolLatent(embed_dim, num_heads=2,
+        # mlp_ratio, norm_layer) (utils/vit.py:303-309)
+        self.pool_heads = 2
+        self._head_mod = PredictorHead(D, cfg.mlp_ratio, cfg.ln_eps, global_pool, self.num_classes, dev, compute_dtype, gen,
+                                       splitk_ws=self.engine._splitk_ws)
+        self.head = self._head_mod.tensors
         self.training = False
         self.frozen_encoder = False                # linear probe: only norm / fc_norm / head receive gradients
         self.trainable = None                      # names with requires_grad (None = everything but pos_embed)
@@ -137,7 +128,12 @@ class VisionTransformer:
         for k in self.head:
             if k in sd:
                 self.head[k].copy_(torch.as_tensor(sd[k]).to(torch.float32).reshape(self.head[k].shape))
+        self.sync_head()
         return type("Keys", (), {"missing_keys": missing, "unexpected_keys": unexpected})()
+
+    def sync_head(self):
+        """Refresh the compute-dtype shadow the head's GEMMs read (after anything wrote the fp32 head tensors directly)."""
+        self._head_mod.store.refresh_lp()
 
     def load_encoder_state(self, sd):
         own = self.engine.state_dict()
@@ -182,52 +178,36 @@ class VisionTransformer:
             lat = lat.permute(0, 2, 1).reshape(B, -1, H, W)
         return lat, None, None
 
-    def _pool(self, tokens):
-        if self.global_pool == 'avg':
-            return tokens[:, 1:].mean(dim=1)      # timm: x[:, num_prefix_tokens:] with ONE prefix token (the RA/Dec token is averaged in)
-        if self.global_pool == 'token':
-            return tokens[:, 0]
-        if self.global_pool == 'map':
-            return self._attn_pool(tokens)
-        return tokens
-
-    def _attn_pool(self, x):
-        """timm.layers.AttentionPoolLatent.forward (latent_len 1, pool 'token', no q / k norm, no positional table)."""
-        F, P = torch.nn.functional, self.head
-        B, N, C = x.shape
-        H = self.pool_heads
-        hd = C // H
-        q = F.linear(P["attn_pool.latent"].expand(B, -1, -1), P["attn_pool.q.weight"], P["attn_pool.q.bias"]).reshape(B, 1, H, hd).transpose(1, 2)
-        kv = F.linear(x, P["attn_pool.kv.weight"], P["attn_pool.kv.bias"]).reshape(B, N, 2, H, hd).permute(2, 0, 3, 1, 4)
-        k, v = kv.unbind(0)
-        attn = ((q * hd ** -0.5) @ k.transpose(-2, -1)).softmax(dim=-1)
-        y = F.linear((attn @ v).transpose(1, 2).reshape(B, 1, C), P["attn_pool.proj.weight"], P["attn_pool.proj.bias"])
-        z = F.layer_norm(y, (C,), P["attn_pool.norm.weight"], P["attn_pool.norm.bias"], 1e-6)
-        z = F.linear(F.gelu(F.linear(z, P["attn_pool.mlp.fc1.weight"], P["attn_pool.mlp.fc1.bias"])), P["attn_pool.mlp.fc2.weight"], P["attn_pool.mlp.fc2.bias"])
-        return (y + z)[:, 0]
-
-    def _encode_train(self, x, ra_dec):
-        """Encoder forward with activations kept; -> what the head starts from: [B, D] (token / avg: already pooled) or every
-        token [B, N, D] (map: the attention pool is part of the torch head)."""
-        eng, cfg = self.engine, self.cfg
+    def _predict_train(self, x, ra_dec):
+        """Encoder forward with activations kept, then the head: -> predictions [B, num_classes] (pooled features when the model
+        has no classifier)."""
+        eng, cfg, hd = self.engine, self.cfg, self._head_mod
         B, L = x.shape[0], cfg.num_patches
         w = eng._workspace(B, L, True)
         eng._encoder_fwd(x, self._ramp, L, w, True, ra_dec)
         eng._last = (x, B, L)
         Ne, D = cfg.num_extra_tokens + L, cfg.embed_dim
-        if self.global_pool == 'avg':
-            return w["xs"][cfg.depth].view(B, Ne, D)[:, 1:].mean(dim=1)
         if self.global_pool == 'map':
-            return w["latent32"].view(B, Ne, D).clone()
-        return w["latent32"].view(B, Ne, D)[:, 0].clone()
+            out = hd.forward(B, Ne, tokens_lp=w["lat_lp"])          # the final norm's output in the compute dtype: every token
+        elif self.global_pool == 'avg':
+            out = hd.forward(B, Ne, feat=w["xs"][cfg.depth].view(B, Ne, D)[:, 1:].mean(dim=1))
+        elif self.global_pool == 'token':
+            out = hd.forward(B, Ne, feat=w["latent32"].view(B, Ne, D)[:, 0])
+        else:
+            raise NotImplementedError("training needs a pooled head (global_pool = token | avg | map)")
+        return out.clone()
 
-    def _encode_backward(self, dfeat):
-        eng, cfg = self.engine, self.cfg
+    def _predict_backward(self, dpred):
+        eng, cfg, hd = self.engine, self.cfg, self._head_mod
         x, B, L = eng._last
         w = eng._ws[(B, L, True)]
         Ne, D = cfg.num_extra_tokens + L, cfg.embed_dim
         Me = B * Ne
         st = eng.store
+        dlat = w["dln"][:Me * D].view(Me, D)                      # the final norm's incoming gradient (compute dtype)
+        if self.num_classes <= 0:
+            raise NotImplementedError("backward through a model without a classifier")
+        dfeat = hd.backward(dpred, B, Ne, tokens_lp=w["lat_lp"], dtokens_lp=dlat)
         if self.global_pool == 'avg':
             if self.frozen_encoder:
                 return                                 # nothing inside the engine trains (fc_norm and the head live outside it)
@@ -239,16 +219,13 @@ class VisionTransformer:
             eng.backward_encoder(hi=cfg.depth, lo=0)   # (hi given: the final norm is not part of this configuration)
             eng.backward_embed()
             return
-        dlat = w["dln"][:Me * D].view(B, Ne, D)
-        if self.global_pool == 'map':
-            dlat.copy_(dfeat)                          # d loss / d every token
-        else:
+        if self.global_pool != 'map':                  # class token: d loss / d (row 0 of every sample), zero elsewhere
             dlat.zero_()
-            dlat[:, 0] = dfeat
+            dlat.view(B, Ne, D)[:, 0] = dfeat
         if self.frozen_encoder:
             # linear probe: the final norm's own gradients, nothing below it (utils/vit.py:145-160)
             tmp = w["g"][:Me * D].view(Me, D)
-            ops.layernorm_bwd(dlat.view(Me, D), w["xs"][cfg.depth], st.param("norm.weight"), w["lat_mean"], w["lat_rstd"], None, tmp, None,
+            ops.layernorm_bwd(dlat, w["xs"][cfg.depth], st.param("norm.weight"), w["lat_mean"], w["lat_rstd"], None, tmp, None,
                               w["ln_parts"]["norm"], st.grad("norm.weight"), st.grad("norm.bias"), Me, D, eng.code)
             return
         eng._ln_first, eng._ln_count = w["ln_index"]["norm"], 0
@@ -256,27 +233,27 @@ class VisionTransformer:
         eng.backward_embed()
 
     def forward_head(self, x, pre_logits=False):
-        """timm VisionTransformer.forward_head on a token tensor [B, N, D] (inference)."""
-        return self._head(self._pool(x), pre_logits)
-
-    def _head(self, f, pre_logits=False):
-        if f.dim() == 3:                                # (training path with global_pool = map: f holds every token)
-            f = self._attn_pool(f)
+        """timm VisionTransformer.forward_head on a token tensor [B, N, D] (inference): pooling, fc_norm, classifier -- the head's
+        forward schedule on the library's kernels."""
+        hd = self._head_mod
+        B, N, D = x.shape
+        x = x.to(self.engine.device, torch.float32).contiguous()
+        if self.global_pool == 'map':
+            w = hd._workspace(B, N)
+            ops.cast(x.view(-1), w["x_lp"], B * N * D)
+            return hd.forward(B, N, tokens_lp=w["x_lp"], pre_logits=pre_logits).clone()
         if self.global_pool == 'avg':
-            f = torch.nn.functional.layer_norm(f, (f.shape[-1],), self.head["fc_norm.weight"], self.head["fc_norm.bias"], 1e-6)
-        if pre_logits or self.num_classes <= 0:
-            return f
-        return torch.nn.functional.linear(f, self.head["head.weight"], self.head["head.bias"])
+            return hd.forward(B, N, feat=x[:, 1:].mean(dim=1), pre_logits=pre_logits).clone()     # timm: ONE prefix token (the RA/Dec token is averaged in)
+        if self.global_pool == 'token':
+            return hd.forward(B, N, feat=x[:, 0], pre_logits=pre_logits).clone()
+        return x
 
     def forward(self, x, mask=None, ra_dec=None):
-        """utils/vit.py:390-393 -> predictions [B, num_classes].  In training mode the result carries the autograd graph of the
-        head and the node that runs the engine's backward."""
+        """utils/vit.py:390-393 -> predictions [B, num_classes].  In training mode the result is the output of the autograd node
+        whose backward runs the head's and the engine's backward schedules."""
         if self.training and torch.is_grad_enabled():
             x, ra_dec = self._inputs(x, ra_dec)
-            for k, v in self.head.items():
-                v.requires_grad_(self.trainable is None or k in self.trainable)
-            f = _EncoderFeatures.apply(self._hook, self, x, ra_dec)
-            return self._head(f)
+            return _Predict.apply(self._hook, self, x, ra_dec)
         with torch.no_grad():
             tokens, _, _ = self.forward_features(x, ra_dec=ra_dec)
             return self.forward_head(tokens)
@@ -285,9 +262,11 @@ class VisionTransformer:
 
 
 class PredictorOptimizer:
-    """torch.optim.AdamW over named parameter groups of a downstream ViT: engine tensors are stepped by the AdamW kernel on
-    their slices of the flat buffers (fp32 master + the compute-dtype shadow the GEMMs read), head-side tensors by the same
-    formula in torch.  groups: [{'params': [names], 'lr', 'weight_decay'}]; betas / eps = torch's defaults, as the reference."""
+    """torch.optim.AdamW over named parameter groups of a downstream ViT: every tensor -- the engine's and the head's -- is
+    stepped by the AdamW kernel on its slice of the flat buffers it lives in (fp32 master + the compute-dtype shadow the GEMMs
+    read).  groups: [{'params': [names], 'lr', 'weight_decay'(, 'betas')}]; eps = torch's default, as the reference.
+    state_dict / load_state_dict use torch.optim.AdamW's layout (integer parameter ids in group order, per-parameter
+    'step' / 'exp_avg' / 'exp_avg_sq'), so predictor checkpoints interchange with the reference's."""
 
     def __init__(self, model, groups, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         self.model = model
@@ -297,61 +276,92 @@ class PredictorOptimizer:
             g = dict(g)
             g.setdefault("lr", lr)
             g.setdefault("weight_decay", weight_decay)
+            g.setdefault("betas", tuple(betas))
             g["initial_lr"] = g["lr"]
             self.param_groups.append(g)
         self.step_count = 0
-        self.head_state = {}
 
     def zero_grad(self, set_to_none=True):
-        for v in self.model.head.values():
-            v.grad = None
+        """Nothing to do: every backward overwrites the gradient buffers (engine and head) it computes."""
+
+    def _buffers(self, name):
+        """(p, g, m, v, p_lp) slices of the flat buffers `name` lives in, padded run included."""
+        hs = self.model._head_mod.store
+        if name in hs.offsets:
+            o, n = hs.offsets[name], hs.sizes[name]
+            return tuple(b[o:o + n] for b in (hs.p, hs.g, hs.m, hs.v, hs.p_lp)), hs
+        st = self.model.engine.store
+        o = st.offsets[name]
+        n = (int(np.prod(st.shapes[name])) + 7) // 8 * 8
+        return tuple(b[o:o + n] for b in (st.p, st.g, st.m, st.v, st.p_lp)), st
 
     def step(self):
         self.step_count += 1
         t = self.step_count
-        b1, b2 = self.defaults["betas"]
         eps = self.defaults["eps"]
-        bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
-        st = self.model.engine.store
         for g in self.param_groups:
             lr, wd = g["lr"], g["weight_decay"]
+            b1, b2 = g["betas"]
+            bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
             for name in g["params"]:
-                if name in self.model.head:
-                    p = self.model.head[name]
-                    if p.grad is None:
-                        continue
-                    s = self.head_state.setdefault(name, dict(m=torch.zeros_like(p), v=torch.zeros_like(p)))
-                    with torch.no_grad():
-                        p.mul_(1.0 - lr * wd)
-                        s["m"].mul_(b1).add_(p.grad, alpha=1.0 - b1)
-                        s["v"].mul_(b2).addcmul_(p.grad, p.grad, value=1.0 - b2)
-                        p.addcdiv_(s["m"], (s["v"].sqrt() / math.sqrt(bc2)).add_(eps), value=-lr / bc1)
-                    continue
-                o = st.offsets[name]
-                n = (int(np.prod(st.shapes[name])) + 7) // 8 * 8
-                sl = slice(o, o + n)
-                ops.adamw(st.p[sl], st.g[sl], st.m[sl], st.v[sl], st.p_lp[sl], n, n if wd != 0.0 else 0, None, b1, b2, eps, wd,
-                          lr=lr, bc1=bc1, bc2=bc2)
+                (p, gr, m, v, p_lp), _ = self._buffers(name)
+                n = p.numel()
+                ops.adamw(p, gr, m, v, p_lp, n, n if wd != 0.0 else 0, None, b1, b2, eps, wd, lr=lr, bc1=bc1, bc2=bc2)
+
+    def _names(self):
+        return [n for g in self.param_groups for n in g["params"]]
 
     def state_dict(self):
-        st = self.model.engine.store
-        eng = {n: dict(exp_avg=st._view(st.m, n).detach().clone(), exp_avg_sq=st._view(st.v, n).detach().clone())
-               for g in self.param_groups for n in g["params"] if n not in self.model.head} if self.step_count else {}
-        head = {n: dict(exp_avg=s["m"].clone(), exp_avg_sq=s["v"].clone()) for n, s in self.head_state.items()}
-        return {"state": {**eng, **head}, "step": self.step_count,
-                "param_groups": [{k: (list(v) if k == "params" else v) for k, v in g.items()} for g in self.param_groups]}
+        """torch.optim.AdamW.state_dict(): {'state': {id: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [... 'params': [ids]]};
+        'param_names' (ids -> names) rides along for readers of this repo and is ignored by torch."""
+        names = self._names()
+        state = {}
+        if self.step_count:
+            for i, n in enumerate(names):
+                _, store = self._buffers(n)
+                state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": store._view(store.m, n).detach().clone().cpu(),
+                            "exp_avg_sq": store._view(store.v, n).detach().clone().cpu()}
+        groups, k = [], 0
+        for g in self.param_groups:
+            d = {key: v for key, v in g.items() if key != "params"}
+            d.update(eps=self.defaults["eps"], amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False,
+                     fused=None, decoupled_weight_decay=True)
+            d["params"] = list(range(k, k + len(g["params"])))
+            k += len(g["params"])
+            groups.append(d)
+        return {"state": state, "param_groups": groups, "param_names": names}
 
     def load_state_dict(self, sd):
-        st = self.model.engine.store
-        self.step_count = int(sd.get("step", 0))
-        for n, s in sd["state"].items():
-            if n in self.model.head:
-                self.head_state[n] = dict(m=s["exp_avg"].to(self.model.head[n].device).clone(), v=s["exp_avg_sq"].to(self.model.head[n].device).clone())
-            else:
-                st._view(st.m, n).copy_(s["exp_avg"])
-                st._view(st.v, n).copy_(s["exp_avg_sq"])
+        """Accepts torch's layout (the reference's checkpoints: ids in group order) and this repo's earlier name-keyed one."""
+        names = self._names()
+        steps = []
+        for key, s in sd["state"].items():
+            n = names[int(key)] if not isinstance(key, str) else key
+            _, store = self._buffers(n)
+            store._view(store.m, n).copy_(torch.as_tensor(s["exp_avg"]).reshape(store.shapes[n]))
+            store._view(store.v, n).copy_(torch.as_tensor(s["exp_avg_sq"]).reshape(store.shapes[n]))
+            if "step" in s:
+                steps.append(int(float(s["step"])))
+        self.step_count = int(sd["step"]) if "step" in sd else (max(steps) if steps else 0)
         for g, saved in zip(self.param_groups, sd["param_groups"]):
-            g.update({k: v for k, v in saved.items() if k != "params"})
+            for k in ("lr", "initial_lr", "weight_decay", "betas"):
+                if k in saved:
+                    g[k] = tuple(saved[k]) if k == "betas" else saved[k]
+
+
+def apply_onecycle_side_effects(optimizer, max_lr, div_factor=25.0, max_momentum=0.95, final_div_factor=1e4):
+    """utils/vit.py:174-182 constructs a OneCycleLR and throws it away (:183-186 overwrites it with LinearLR) -- but the constructor
+    has already rewritten the optimiser: every group's ``initial_lr = lr = max_lr / div_factor`` and, with cycle_momentum,
+    ``betas = (max_momentum, beta2)``; LinearLR then keeps that ``initial_lr`` (torch's LRScheduler uses setdefault).  So the
+    reference trains from init_lr / 25 with beta1 = 0.95.  max_lr: one value or one per group (the fine-tuning branch hands over
+    the groups' own scaled rates)."""
+    per_group = list(max_lr) if isinstance(max_lr, (list, tuple)) else [max_lr] * len(optimizer.param_groups)
+    assert len(per_group) == len(optimizer.param_groups)
+    for g, mx in zip(optimizer.param_groups, per_group):
+        g["initial_lr"] = g["lr"] = mx / div_factor
+        g["max_lr"], g["min_lr"] = mx, mx / div_factor / final_div_factor     # (bookkeeping torch leaves in the group; unused afterwards)
+        g["betas"] = (max_momentum, g["betas"][1])
+        g["max_momentum"], g["base_momentum"] = max_momentum, 0.85
 
 
 class LinearLR:
@@ -359,6 +369,7 @@ class LinearLR:
 
     def __init__(self, optimizer, start_factor=1.0, end_factor=1.0, total_iters=5):
         self.optimizer, self.start_factor, self.end_factor, self.total_iters = optimizer, start_factor, end_factor, int(total_iters)
+        self.base_lrs = [g["initial_lr"] for g in optimizer.param_groups]
         self.last_epoch = 0
         self._apply()
 
@@ -367,8 +378,8 @@ class LinearLR:
         return self.start_factor + (self.end_factor - self.start_factor) * t / self.total_iters
 
     def _apply(self):
-        for g in self.optimizer.param_groups:
-            g["lr"] = g["initial_lr"] * self._factor()
+        for g, base in zip(self.optimizer.param_groups, self.base_lrs):
+            g["lr"] = base * self._factor()
 
     def step(self):
         self.last_epoch += 1
@@ -378,11 +389,15 @@ class LinearLR:
         return [g["lr"] for g in self.optimizer.param_groups]
 
     def state_dict(self):
+        """torch's keys (base_lrs, last_epoch, _step_count, _last_lr, ...)."""
         return {"start_factor": self.start_factor, "end_factor": self.end_factor, "total_iters": self.total_iters,
-                "last_epoch": self.last_epoch, "_last_lr": self.get_last_lr()}
+                "base_lrs": list(self.base_lrs), "last_epoch": self.last_epoch, "_step_count": self.last_epoch + 1,
+                "_is_initial": False, "_get_lr_called_within_step": False, "_last_lr": self.get_last_lr()}
 
     def load_state_dict(self, sd):
         self.last_epoch = int(sd["last_epoch"])
+        if "base_lrs" in sd and len(sd["base_lrs"]) == len(self.base_lrs):
+            self.base_lrs = [float(v) for v in sd["base_lrs"]]
         self._apply()
 
 
@@ -393,7 +408,7 @@ def build_optimizer(model, train_method, init_lr, weight_decay, layer_decay):
         # utils/vit.py:141-143 passes (model, weight_decay, ...) POSITIONALLY to param_groups_lrd(model, init_lr, weight_decay=0.05, ...):
         # the configured weight decay becomes the base lr of the groups and their weight decay stays 0.05.  Mirrored as written.
         groups, _ = param_groups_lrd(model, weight_decay, no_weight_decay_list=model.no_weight_decay(), layer_decay=layer_decay)
-        return PredictorOptimizer(model, groups)
+        return PredictorOptimizer(model, groups)                 # (the groups' own rates are what utils/vit.py:174 hands OneCycleLR)
     if train_method in ('linearprobe', 'lp'):
         print('\nUsing the linear probing training method...')
         comps = ["norm.", "fc_norm.", "head."]
@@ -434,8 +449,10 @@ def build_model(config, mae_config, model_filename, mae_filename, device, build_
         num_labels = 0                           # similarity_search.py routes through forward_features only
     model = VisionTransformer(cfg, device, _compute_dtype(mae_config), num_classes=num_labels,
                               global_pool=config['ARCHITECTURE'].get('global_pool', 'token'),
-                              label_means=eval(data['label_means']) if 'label_means' in data else (0.0,),
-                              label_stds=eval(data['label_stds']) if 'label_stds' in data else (1.0,),
+                              # utils/vit.py:38-39 as written: the LENGTHS of the configured lists -- 1 for every shipped ini, so
+                              # labels are normalised as (y - 1) / 1 whatever the ini says (label_stds = [0] in all cls_*.ini)
+                              label_means=len(eval(data['label_means'])) if 'label_means' in data else 1,
+                              label_stds=len(eval(data['label_stds'])) if 'label_stds' in data else 1,
                               drop_rate=float(eval(config['ARCHITECTURE'].get('dropout', '0.0'))))
     model = _DataParallelShim(model)
     if not build_optimizer:
@@ -444,6 +461,11 @@ def build_model(config, mae_config, model_filename, mae_filename, device, build_
     total = int(float(tr['total_batch_iters']))
     optimizer = globals()['build_optimizer'](model.module, tr['train_method'], float(tr['init_lr']), float(tr['weight_decay']),
                                              float(tr['layer_decay']))
+    # utils/vit.py:174-182: the discarded OneCycleLR's constructor (max_lr = the groups' scaled rates when fine-tuning -- the
+    # `init_lr` param_groups_lrd returned -- else the configured init_lr)
+    finetune = tr['train_method'] in ('finetune', 'ft')
+    apply_onecycle_side_effects(optimizer, [g["lr"] for g in optimizer.param_groups] if finetune else float(tr['init_lr']),
+                                final_div_factor=float(tr['final_lr_factor']))
     lr_scheduler = LinearLR(optimizer, start_factor=1.0, end_factor=1 / float(tr['final_lr_factor']), total_iters=total)
     model, losses, cur_iter = load_model(model, model_filename, mae_filename, optimizer, lr_scheduler)
     return model, losses, cur_iter, optimizer, lr_scheduler
@@ -480,6 +502,7 @@ def load_model(model, model_filename, mae_filename='None', optimizer=None, lr_sc
         m.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)
         if "head.weight" in m.head:
             torch.nn.init.trunc_normal_(m.head["head.weight"], std=2e-5)
+            m.sync_head()
         losses, cur_iter = defaultdict(list), 1
     else:
         print('\nStarting fresh model to train...')

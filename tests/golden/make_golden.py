@@ -530,6 +530,9 @@ def predictor_cases():
       fs_token_mse  "fully supervised" branch: timm's weight-decay split, one lr
       lp_map_ce     attentive probe (the shipped cls_ap_*.ini): the two-head AttentionPoolLatent + norm + head trained, encoder frozen
       ft_map_mse    fine-tuning through the attention pool (z_ft_2.ini)
+      lp_map_ce_oc, ft_map_mse_oc   the same two with the optimiser EXACTLY as utils/vit.py:174-186 leaves it: a OneCycleLR is constructed
+                    first (its constructor rewrites every group's lr / initial_lr to max_lr / 25 and beta1 to 0.95) and then
+                    replaced by the LinearLR
     plus the checkpoint surgery of load_model on an MAE checkpoint of another image size (bicubic pos_embed interpolation)."""
     import importlib
     vit = importlib.import_module("utils.vit")
@@ -540,8 +543,10 @@ def predictor_cases():
     img, patch, C, D, depth, heads = 32, 8, 5, 32, 2, 2
     for case, method, pool, loss_fn, ncls in (("lp_token_ce", "lp", "token", "crossentropy", 3), ("ft_avg_mse", "ft", "avg", "mse", 2),
                                               ("fs_token_mse", "fs", "token", "mse", 1), ("lp_map_ce", "lp", "map", "crossentropy", 3),
-                                              ("ft_map_mse", "ft", "map", "mse", 1)):
-        torch.manual_seed({"lp_token_ce": 21, "ft_avg_mse": 22, "fs_token_mse": 23, "lp_map_ce": 24, "ft_map_mse": 25}[case])
+                                              ("ft_map_mse", "ft", "map", "mse", 1), ("lp_map_ce_oc", "lp", "map", "crossentropy", 3),
+                                              ("ft_map_mse_oc", "ft", "map", "mse", 1)):
+        torch.manual_seed({"lp_token_ce": 21, "ft_avg_mse": 22, "fs_token_mse": 23, "lp_map_ce": 24, "ft_map_mse": 25, "lp_map_ce_oc": 26,
+                           "ft_map_mse_oc": 27}[case])
         label_means, label_stds = ([0.5, -1.0][:ncls], [2.0, 0.5][:ncls]) if loss_fn == "mse" else ([0.0], [1.0])
         model = vit.VisionTransformer(label_means, label_stds, 0.1, 1.7, False, ra_dec=False, depth=depth, num_heads=heads, mlp_ratio=4,
                                       qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), img_size=img, in_chans=C, embed_dim=D,
@@ -557,8 +562,8 @@ def predictor_cases():
         model = nn.DataParallel(model)
         init_lr, weight_decay, layer_decay, total, final_lr_factor = 2e-3, 0.03, 0.7, 50, 100.0
         if method == "ft":                                      # utils/vit.py:138-143 (positional call: weight_decay lands in init_lr)
-            groups, _ = lrd.param_groups_lrd(model.module, weight_decay, no_weight_decay_list=model.module.no_weight_decay(),
-                                             layer_decay=layer_decay)
+            groups, max_lr = lrd.param_groups_lrd(model.module, weight_decay, no_weight_decay_list=model.module.no_weight_decay(),
+                                                  layer_decay=layer_decay)
             opt = torch.optim.AdamW(groups)
         elif method == "lp":                                    # utils/vit.py:145-160
             comps = [model.module.norm, model.module.fc_norm, model.module.head]
@@ -573,7 +578,14 @@ def predictor_cases():
         else:                                                   # utils/vit.py:162-171 (the split sees the DataParallel wrapper's names)
             import timm.optim.optim_factory as of
             opt = torch.optim.AdamW(of.param_groups_weight_decay(model, weight_decay), lr=init_lr)
+        if case.endswith("_oc"):                                # utils/vit.py:174-182, argument for argument; the object is discarded
+            torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=max_lr if method == "ft" else init_lr, total_steps=int(total), pct_start=0.05,
+                                                anneal_strategy='cos', cycle_momentum=True, base_momentum=0.85, max_momentum=0.95,
+                                                div_factor=25.0, final_div_factor=final_lr_factor, three_phase=False)
         sched = torch.optim.lr_scheduler.LinearLR(opt, start_factor=1.0, end_factor=1 / final_lr_factor, total_iters=total)
+        if case.endswith("_oc"):
+            out[f"{case}/opt_groups"] = np.array([[gp["lr"], gp["initial_lr"], gp["betas"][0], gp["betas"][1], gp["weight_decay"]]
+                                                  for gp in opt.param_groups])
         out[f"{case}/hyper"] = np.array([init_lr, weight_decay, layer_decay, total, final_lr_factor])
         out[f"{case}/cfg"] = np.array([img, patch, C, D, depth, heads, ncls])
         out[f"{case}/label_means"], out[f"{case}/label_stds"] = np.array(label_means, np.float32), np.array(label_stds, np.float32)
@@ -599,6 +611,15 @@ def predictor_cases():
         out[f"{case}/train_loss"] = np.array(cp["train_loss"])
         out[f"{case}/train_metric"] = np.array(cp["train_acc" if loss_fn == "crossentropy" else "train_mae"])
         out[f"{case}/lr_after"] = np.array([gp["lr"] for gp in opt.param_groups])
+        if case.endswith("_oc"):
+            # the optimiser / scheduler state dicts' STRUCTURE (what a predictor checkpoint of the reference holds)
+            osd = opt.state_dict()
+            out[f"{case}/opt_state_ids"] = np.array(sorted(osd["state"].keys()))
+            out[f"{case}/opt_group_param_ids"] = np.array([len(gp["params"]) for gp in osd["param_groups"]])
+            first = osd["state"][osd["param_groups"][0]["params"][0]]
+            out[f"{case}/opt_state_keys"] = np.array(sorted(first.keys()))
+            out[f"{case}/opt_state_step"] = np.array(float(first["step"]))
+            out[f"{case}/sched_keys"] = np.array(sorted(sched.state_dict().keys()))
         print("wrote predictor", case, "losses", cp["train_loss"])
     # checkpoint surgery: an MAE checkpoint made at 32x32 (16 patches) loaded into a 48x48 model (36 patches)
     torch.manual_seed(31)

@@ -429,7 +429,10 @@ def test_train_predictor_entry_point(tmp_path, method, loss_fn):
     mae, _, _ = build_mae(mae_cfg, str(tmp_path / "none.pth.tar"), torch.device("cuda"))
     torch.save({"batch_iters": 5, "losses": {}, "model": {k: v.cpu() for k, v in mae.module.state_dict().items()}}, str(work / "models" / "mim_t.pth.tar"))
     cfg = configparser.ConfigParser()
-    cfg["DATA"] = {"train_data_file": "train.h5", "val_data_file": "val.h5", "label_means": "[1.0]", "label_stds": "[0.6]"}
+    # (the shipped cls_*.ini all say label_means = [0], label_stds = [0]: utils/vit.py:38-39 only takes their LENGTH, so predictions
+    # are never multiplied by that zero -- the confusion matrix below would be degenerate otherwise)
+    cfg["DATA"] = {"train_data_file": "train.h5", "val_data_file": "val.h5", "label_means": "[0]" if loss_fn == "crossentropy" else "[1.0]",
+                   "label_stds": "[0]" if loss_fn == "crossentropy" else "[0.6]"}
     cfg["DATA"].update({"label_keys": "['class']", "num_classes": "3"} if loss_fn == "crossentropy" else {"label_keys": "['zspec']"})
     cfg["TRAINING"] = {"train_method": method, "pretained_mae": "mim_t", "num_train": "40", "batch_size": "8", "total_batch_iters": "6", "layer_decay": "0.7",
                        "weight_decay": "0.05", "init_lr": "0.001", "final_lr_factor": "10", "augment": "False", "brightness": "0.8", "noise": "0.1",
@@ -490,6 +493,7 @@ def test_train_predictor_entry_point(tmp_path, method, loss_fn):
         z = np.load(str(work / "figures" / "pred_t_classes.npz"))
         cm = pf.confusion_matrix(tgt[keep, 0], pred[keep].argmax(1), n_classes=3)
         assert np.array_equal(z["confusion_matrix"], cm) and int(cm.sum()) == int(keep.sum())
+        assert float(np.abs(pred - pred[:1]).max()) > 0                   # label_stds = [0] did not zero the predictions (see cfg["DATA"])
         # ---- python compare_predictors.py (compare_predictors.py:150-250): the families' score table; one member present here
         for src, dst in (("configs/pred_t.ini", "configs/cls_ap_012k.ini"), ("models/pred_t_best.pth.tar", "models/cls_ap_012k_best.pth.tar")):
             shutil.copy(str(work / src), str(work / dst))

@@ -402,59 +402,6 @@ def test_grouped_wgrad_256_tile(ops):
         assert torch.equal(dbs[j], res[256256][1][j])
 
 
-@pytest.mark.parametrize("shape", [(2048, 4096, 512), (3072, 4096, 704)])
-def test_grouped_wgrad_256_tile_shared_tiles(ops, shape):
-    """Grouped 256 x 256 weight gradients that leave compute units idle can run with SHARED tiles (a switch, off by default: include/skyemb.h,
-    skyemb_gemm_group_ws_bytes; csrc/gemm_pipe256.h): 128 tiles on 256 units -> every tile's k-range is halved between an owner and
-    a helper workgroup; 192 tiles (the ViT-L block's count) -> owners take 3/4, 64 helpers the last quarter of three tiles each.
-    Gradient and bias gradient against torch and the 128 x 128 tile, run-to-run identical, workspace left zeroed, and with the
-    optimiser step in the epilogue == the separate AdamW launch on the stored gradient."""
-    from sky_embeddings_amd._lib import RC, AdamwDesc
-    n_out, k_in, T = shape
-    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
-        pytest.skip("the tile counts of this test share tiles on a 256-CU device")
-    g = torch.Generator().manual_seed(n_out + T)
-    dy = dev(torch.randn(T, n_out, generator=g), torch.bfloat16)
-    x = dev(torch.randn(T, k_in, generator=g), torch.bfloat16)
-    n = n_out * k_in
-
-    def launch(flat, db, tile, adamw=None):
-        grp = ops.GemmGroup([ops.gemm_args(dy, x, M=n_out, N=k_in, K=T, a_layout=RC, b_layout=RC, lda=n_out, ldb=k_in,
-                                           out_f32=flat.view(n_out, k_in), colsum_a=db)], DEV, tile=tile, adamw=adamw, shared_tiles=True)
-        assert grp.ok and grp.info.tile == tile
-        grp.launch()
-        return grp
-    ref_flat, ref_db = torch.empty(n, device=DEV), torch.empty(n_out, device=DEV)
-    launch(ref_flat, ref_db, 128128)
-    flat, db = torch.full((n,), float("nan"), device=DEV), torch.full((n_out,), float("nan"), device=DEV)
-    grp = launch(flat, db, 256256)
-    tiles = (n_out // 256) * (k_in // 256)
-    assert grp.total_blocks == 256 and tiles in (128, 192)            # tiles + helpers = the device's compute units
-    assert relerr(flat.view(n_out, k_in), dy.float().t() @ x.float()) < 2e-6 and relerr(flat, ref_flat) < 2e-6
-    assert relerr(db, dy.float().sum(0)) < 1e-5 and relerr(db, ref_db) < 1e-5
-    flat2, db2 = torch.full((n,), float("nan"), device=DEV), torch.full((n_out,), float("nan"), device=DEV)
-    launch(flat2, db2, 256256)
-    assert torch.equal(flat, flat2) and torch.equal(db, db2)
-    torch.cuda.synchronize()
-    ws = grp._ws
-    assert not bool(ws[tiles * 33 * 512 * 16:].any())                 # every flag is down again
-    # optimiser step in the owners' epilogue
-    step, lr, wd, n_decay = 2, 1e-3, 0.05, n - 4096
-    p0, m0, v0 = torch.randn(n, generator=g), torch.randn(n, generator=g) * 0.01, torch.rand(n, generator=g) * 0.01
-    hyper = dev(torch.tensor([lr, 1 - 0.9 ** step, 1 - 0.95 ** step, 0.0]))
-    pr, mr, vr, gr = dev(p0.clone()), dev(m0.clone()), dev(v0.clone()), flat.clone()
-    plr = torch.empty(n, device=DEV, dtype=torch.bfloat16)
-    ops.adamw(pr, gr, mr, vr, plr, n, n_decay, hyper, 0.9, 0.95, 1e-8, wd, grad_scale=1.0)
-    pd, md, vd, gd = dev(p0.clone()), dev(m0.clone()), dev(v0.clone()), torch.zeros(n, device=DEV)
-    pl = torch.empty(n, device=DEV, dtype=torch.bfloat16)
-    d = AdamwDesc()
-    d.g_base, d.p, d.m, d.v, d.p_lp, d.hyper = (t.data_ptr() for t in (gd, pd, md, vd, pl, hyper))
-    d.n_decay, d.beta1, d.beta2, d.eps, d.weight_decay, d.grad_scale = n_decay, 0.9, 0.95, 1e-8, wd, 1.0
-    db3 = torch.full((n_out,), float("nan"), device=DEV)
-    launch(gd, db3, 256256, adamw=d)
-    assert torch.equal(pd, pr) and torch.equal(md, mr) and torch.equal(vd, vr) and torch.equal(pl, plr) and torch.equal(db3, db)
-
-
 def test_vit_l_weight_gradient_group_takes_the_256_tile(ops):
     """The four weight gradients of a ViT-L block with the tile choice left open (mim_19's shapes, 2112 token rows here): 192 whole
     256 x 256 tiles, one round -> the plan picks the 256 x 256 group; gradients and bias gradients == the 128 x 128 group's."""

@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = {"lp_token_ce": ("lp", "token", "crossentropy"), "ft_avg_mse": ("ft", "avg", "mse"), "fs_token_mse": ("fs", "token", "mse"),
-         "lp_map_ce": ("lp", "map", "crossentropy"), "ft_map_mse": ("ft", "map", "mse")}
+         "lp_map_ce": ("lp", "map", "crossentropy"), "ft_map_mse": ("ft", "map", "mse"),
+         # ... and with the optimiser as utils/vit.py:174-186 really leaves it (lr / 25 and beta1 = 0.95 from the discarded OneCycleLR)
+         "lp_map_ce_oc": ("lp", "map", "crossentropy"), "ft_map_mse_oc": ("ft", "map", "mse")}
 
 
 def build(z, case, dtype):
@@ -54,8 +56,13 @@ def test_predictor_training_steps_match_reference(case):
     model, m = build(z, case, torch.float32)
     init_lr, wd, layer_decay, total, flf = [float(v) for v in z[f"{case}/hyper"]]
     opt = build_optimizer(m, method, init_lr, wd, layer_decay)
+    if case.endswith("_oc"):
+        from sky_embeddings_amd.utils.vit import apply_onecycle_side_effects
+        apply_onecycle_side_effects(opt, [g["lr"] for g in opt.param_groups] if method == "ft" else init_lr)
+        got = np.array([[g["lr"], g["initial_lr"], g["betas"][0], g["betas"][1], g["weight_decay"]] for g in opt.param_groups])
+        assert got.shape == z[f"{case}/opt_groups"].shape and np.allclose(got, z[f"{case}/opt_groups"], rtol=1e-12, atol=0)
     sched = LinearLR(opt, start_factor=1.0, end_factor=1 / flf, total_iters=int(total))
-    if method == "ft":
+    if method == "ft" and not case.endswith("_oc"):
         # utils/vit.py:141-143 as written: the groups' base lr is the configured WEIGHT DECAY, scaled per layer; decay 0.05 / 0
         lrs = sorted({round(g["initial_lr"], 12) for g in opt.param_groups})
         assert lrs == sorted({round(wd * layer_decay ** (m.num_blocks + 1 - i), 12) for i in range(m.num_blocks + 2)})
@@ -102,6 +109,18 @@ def test_predictor_training_steps_match_reference(case):
     run_iter(model, x[0].cuda(), None, None, labels[0].cuda(), opt, sched, cp, loss_fn=loss_fn, mode="val")
     assert len(cp["val_loss"]) == 1 and opt.step_count == 3
     sd_o, sd_s = opt.state_dict(), sched.state_dict()
+    if case.endswith("_oc"):
+        # the layout of torch.optim.AdamW / LinearLR state dicts, as the reference's predictor checkpoints hold them
+        assert sorted(sd_o["state"].keys()) == z[f"{case}/opt_state_ids"].tolist()
+        assert [len(g["params"]) for g in sd_o["param_groups"]] == z[f"{case}/opt_group_param_ids"].tolist()
+        assert sorted(sd_o["state"][0].keys()) == z[f"{case}/opt_state_keys"].tolist() and float(sd_o["state"][0]["step"]) == float(z[f"{case}/opt_state_step"])
+        assert set(z[f"{case}/sched_keys"].tolist()) <= set(sd_s.keys())
+        # ... and torch's own AdamW accepts it
+        tp = [torch.nn.Parameter(torch.zeros(tuple(v.shape))) for k, v in m.state_dict().items() if k in opt._names()]
+        by_name = dict(zip([k for k in m.state_dict() if k in opt._names()], tp))
+        topt = torch.optim.AdamW([{"params": [by_name[n] for n in g["params"]]} for g in opt.param_groups])
+        topt.load_state_dict({k: v for k, v in sd_o.items() if k in ("state", "param_groups")})
+        assert topt.param_groups[0]["betas"][0] == 0.95 and torch.equal(topt.state[by_name[opt._names()[0]]]["exp_avg"], sd_o["state"][0]["exp_avg"])
     opt2 = build_optimizer(m, method, init_lr, wd, layer_decay)
     sched2 = LinearLR(opt2, start_factor=1.0, end_factor=1 / flf, total_iters=int(total))
     opt2.load_state_dict(sd_o)

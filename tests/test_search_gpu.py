@@ -62,7 +62,10 @@ def test_sharded_bank_merge_equals_single_bank():
 def test_full_size_bank_1m_x_768_against_oracle():
     """BASELINE configs[3] at full size on one GPU: 1,000,000 x 768 fp32 bank, k = 100, weighted.  The Q = 16 launch
     (bank-streaming kernel) and a 32-query sample of the Q = 10,000 launch (tiled many-query kernel, whatever stages it
-    runs) must equal oracle/topk_oracle.c bit for bit: scores and indices."""
+    runs) must equal oracle/topk_oracle.c bit for bit: scores and indices.  ALL 10,000 answers of the two-stage (prefiltered)
+    path are then compared with the exact single-stage kernel's on the same bank (0.2 s on the device; itself oracle-checked
+    through the sample and the Q = 16 launch)."""
+    import os
     from sky_embeddings_amd import search
     N, D, k, Q = 1_000_000, 768, 100, 10_000
     g = torch.Generator(device="cuda").manual_seed(2024)
@@ -79,8 +82,18 @@ def test_full_size_bank_1m_x_768_against_oracle():
     w = w / w.sum()
     pb = search.PreparedBank(bank, w)
     s16, i16 = search.cosine_topk(queries[:16], pb, k)
-    sL, iL = search.cosine_topk(queries, pb, k)
+    stL = {}
+    sL, iL = search.cosine_topk(queries, pb, k, stats=stL)
+    assert stL["path"] == "prefiltered"
+    os.environ["SKYEMB_TOPK_PREFILTER"] = "0"
+    try:
+        stE = {}
+        sE, iE = search.cosine_topk(queries, pb, k, stats=stE)
+    finally:
+        del os.environ["SKYEMB_TOPK_PREFILTER"]
     torch.cuda.synchronize()
+    assert stE["path"] == "exact"
+    assert torch.equal(iL, iE) and torch.equal(sL, sE), (iL != iE).any(dim=1).nonzero()[:5]      # every one of the 10,000 queries
     sample = np.unique(np.concatenate(([0, 5, 15, 16, 63, 64, 4242, Q - 1], np.random.default_rng(1).integers(0, Q, 24))))[:32]
     x = bank.cpu().numpy()
     qh = queries.cpu().numpy()

@@ -171,6 +171,66 @@ def test_mim19_geometry_against_oracle():
                 assert grel[k] < BF16_GRAD_REL_BAR or gmax[k] < BF16_GRAD_MAX_BAR, (k, grel[k], gmax[k])
 
 
+# bf16 bars of the ViT-L-width test = 2x the errors measured on MI355X (profiles/r05_parity_errors.json)
+VITL_BF16_LOSS_BAR, VITL_BF16_PRED_BAR, VITL_BF16_GRAD_REL_BAR, VITL_BF16_GRAD_MAX_BAR = 2e-4, 2e-2, 1.2e-1, 8e-2
+
+
+def test_mim19_vit_large_width_against_oracle():
+    """BASELINE configs[4] at its real WIDTH and batch (ViT-L/16: 1024 columns, 16 heads, 5x128x128 cutouts, B = 128 -> 8320 token
+    rows), cut to depth 2 so the CPU oracle finishes in seconds: loss, prediction image and every gradient against
+    oracle/mae_oracle.py, f32 and bf16.  In bf16 these are the launches mim_19.ini itself runs -- the 256 x 256 tile for the
+    [8320 x 4096 x 1024] forward / data-gradient GEMMs, the 256 x 256 grouped weight gradients, the 65-token strip attention, the
+    four-vector LayerNorm -- and the test asserts through the library's launch counters that those kernels were the ones selected."""
+    from oracle import mae_oracle as mo
+    from sky_embeddings_amd import ops
+    kw = dict(img_size=128, patch_size=16, in_chans=5, embed_dim=1024, depth=2, num_heads=16, norm_pix_loss=True, loss_fn="L1")
+    cfg_o = mo.config_for("simmim", **kw)
+    assert (cfg_o.embed_dim, cfg_o.num_heads, cfg_o.num_patches) == (1024, 16, 64)
+    st = mo.init_state(cfg_o, seed=7)
+    B = 128
+    x, m, _ = _mim19_batch(cfg_o, B, seed=23)
+    x[3, 1] = float("nan")
+    x[77, 4, 40:70, 5:90] = float("nan")
+    loss_o, pred_o, _, _, _, grads_o = mo.loss_and_grads(st, x, cfg_o, None, None, mask=m)
+    for dtype in (torch.float32, torch.bfloat16):
+        f32 = dtype == torch.float32
+        eng = make_engine(cfg_o, st, dtype)
+        ops.gemm_launch_counts(reset=True)
+        loss, pred, _ = eng.forward_train(x.cuda(), mask=m.cuda())
+        eng.backward()
+        torch.cuda.synchronize()
+        counts = ops.gemm_launch_counts()
+        if f32:
+            assert counts["tile256"] == 0 and counts["group256"] == 0 and counts["fallback"] > 0, counts
+        else:
+            # per block: fc1 forward + fc2 data gradient on the 256 x 256 tile, the four weight gradients as one 256 x 256 group
+            assert counts["tile256"] >= 2 * cfg_o.depth and counts["group256"] == cfg_o.depth and counts["fallback"] == 0, counts
+            w = eng._ws[(B, cfg_o.num_patches, True)]
+            assert all(g.info.tile == 256256 for g in w["wgrad_groups"].values()), [g.info.tile for g in w["wgrad_groups"].values()]
+        loss_rel = abs(float(loss) - float(loss_o)) / abs(float(loss_o))
+        pred_rel = rel_err(pred.cpu().numpy(), pred_o.numpy())
+        grel, gmax = {}, {}
+        for k in eng.store.order:
+            r = grads_o[k].numpy()
+            gk = eng.store.grad(k).cpu().numpy().reshape(r.shape)
+            assert np.isfinite(gk).all(), k
+            grel[k] = rel_err(gk, r)
+            gmax[k] = float(np.abs(gk - r).max()) / max(float(np.abs(r).max()), 1e-6)
+        wk = max(grel, key=grel.get)
+        record_parity(f"mim19_vitl_width_{'f32' if f32 else 'bf16'}",
+                      dict(loss_rel=loss_rel, pred_rel_l2=pred_rel, grad_rel_l2_max=grel[wk], grad_worst_tensor=wk,
+                           grad_max_abs_over_max_max=max(gmax.values()), gemm_launches=counts))
+        assert loss_rel <= (2e-5 if f32 else VITL_BF16_LOSS_BAR), loss_rel
+        assert pred_rel < (2e-5 if f32 else VITL_BF16_PRED_BAR), pred_rel
+        for k in eng.store.order:
+            if f32:
+                assert gmax[k] <= 2e-4, (k, gmax[k])
+            else:
+                assert grel[k] < VITL_BF16_GRAD_REL_BAR or gmax[k] < VITL_BF16_GRAD_MAX_BAR, (k, grel[k], gmax[k])
+        del eng
+        torch.cuda.empty_cache()
+
+
 def test_simmim_bf16_gradient_mirror_written_by_the_weight_gradient_launches(monkeypatch):
     """SimMIM mode of the data-parallel schedule with bf16 gradient communication (mim_19 geometry at a narrow width, 64 x 65 token
     rows so that the grouped launches apply): bf16 gradients written straight into the mirror == fp32 gradients + cast, bit for bit."""
