@@ -194,7 +194,7 @@ def bench_pretrain(args, rank, world, dev):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
     executed, algorithmic = eng.flops_per_image(0.75)
-    out = dict(fused_adamw=step.fused_adamw, ms_per_step=1e3 * dt / args.steps, images_per_sec=world * B * args.steps / dt, gpu_ms_per_step=gpu_ms,
+    out = dict(fused_adamw=step.fused_adamw, adamw_side=getattr(step, "adamw_side", None), ms_per_step=1e3 * dt / args.steps, images_per_sec=world * B * args.steps / dt, gpu_ms_per_step=gpu_ms,
                loss=float(loss), flops_per_image_executed=executed, flops_per_image_reference=algorithmic, B=B)
     if rank == 0:
         # In-step time of the dominant kernel family: the same step with the MFMA GEMM launches left out (the C ABI's
@@ -239,9 +239,55 @@ def bench_pretrain(args, rank, world, dev):
             out["staged"] = staged_schedule_price(eng, opt, sched, B, pool, dev, args)
             if B == 256 and not args.no_graph:
                 out["batch_sweep"] = batch_sweep(eng, opt, sched, dev, rank, long_ms)
+            if step.fused_adamw and not args.no_graph:
+                out["optimizer_placement"] = placement_ab(lambda: MAEEngine(cfg, device=dev, compute_dtype=dtype, seed=0), B, pool, dev, step,
+                                                          ["1", "dec"] if os.environ.get("SKYEMB_BENCH_PLACEMENT_ALL") else ["1"])
         if world == 1 and not args.skip_feeder:
             out["feeder"] = bench_feeder(args, dev, step, B)
     return out, eng
+
+
+def placement_ab(make_engine, B, pool, dev, step_default, others, load=None, rounds=3, n=30):
+    """Interleaved A/B, one process: where the AdamW step of the transformer blocks' weights runs.  `step_default` is the TrainStep the
+    headline timed (policy "auto": side jobs where the carrying launch leaves compute units idle -- the 256 x 256 groups of ViT-L --
+    and the launch's own epilogue elsewhere); `others` are policies built on further engines with the same weights: "0" = epilogue
+    everywhere (the round 3-4 form), "1" = side jobs everywhere, "dec" = side jobs carried by the decoder's launches only.
+    HIP events, `rounds` x `n` steps each, alternating."""
+    from sky_embeddings_amd.optim import CosineLR, FusedAdamW
+    from sky_embeddings_amd.train_step import TrainStep
+    steps = {"auto": (step_default, None)}
+    for pol in others:
+        eng2 = make_engine()
+        opt2 = FusedAdamW(eng2, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
+        s2 = TrainStep(eng2, opt2, CosineLR(opt2, 1_000_000, eta_min=1e-4 / 1e7), B, mask_ratio=0.75, use_graph=True, world_size=1, adamw_side=pol)
+        if load is not None:
+            load(s2)
+        steps[pol] = (s2, (eng2, opt2))
+    call = (lambda s, i: s(pool[i % 2])) if pool is not None else (lambda s, i: s())
+    for name, (s, _) in steps.items():
+        for i in range(5):
+            call(s, i)
+    res = {k: [] for k in steps}
+    for _ in range(rounds):
+        for name, (s, _) in steps.items():
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(n):
+                call(s, i)
+            e1.record()
+            e1.synchronize()
+            res[name].append(e0.elapsed_time(e1) / n)
+    side_launches = {}
+    for name, (s, _) in steps.items():
+        ws = [w for k, w in s.engine._ws.items() if k[-1] is True]
+        side_launches[name] = int(ws[-1].get("adamw_side_launches", 0)) if ws else None
+    steps.clear()
+    torch.cuda.empty_cache()
+    return dict(ms_per_step={k: v for k, v in res.items()}, mean_ms={k: sum(v) / len(v) for k, v in res.items()}, side_launches_per_step=side_launches,
+                note="AdamW of the transformer blocks' weights: 'auto' (shipped) = side job of the NEXT block's grouped weight-gradient launch where "
+                     "that launch leaves compute units idle (256 x 256 tiles), else the epilogue of the block's own launch; '0' = epilogue everywhere; "
+                     "'1' = side jobs everywhere; 'dec' = carried by the decoder's launches only.  Interleaved rounds in one process")
 
 
 def batch_sweep(eng, opt, sched, dev, rank, ms_256):
@@ -430,8 +476,12 @@ def bench_mim19(args, dev):
     e1.synchronize()
     ms = e0.elapsed_time(e1) / n
     executed, algorithmic = eng.flops_per_image()
+    placement = None
+    if step.fused_adamw:
+        placement = placement_ab(lambda: SimMIMEngine(cfg, device=dev, compute_dtype=torch.bfloat16, seed=0), B, None, dev, step, ["0"],
+                                 load=lambda s: s.load_batch(x, m), rounds=2, n=10)
     res = dict(workload="configs/mim_19.ini: SimMIM ViT-Large/16, 5x128x128, 39 of 64 patches masked per channel (ratio 0.6), "
-                        f"bs={B}, L1 + norm-pix, AdamW+cosine, bf16", ms_per_step=ms, images_per_sec=B / ms * 1e3,
+                        f"bs={B}, L1 + norm-pix, AdamW+cosine, bf16", ms_per_step=ms, images_per_sec=B / ms * 1e3, optimizer_placement=placement,
                tflops=B / ms * executed / 1e9, frac_of_bf16_peak=B / ms * executed / 1e9 / PEAK_BF16_TFLOPS,
                flops_per_image_executed=executed, params=int(eng.store.n), loss=float(loss), **mim19_pmc_record())
     del step, opt, eng
@@ -727,7 +777,10 @@ def main():
                        "rccl_ranks": 0 if rehearsal else torch.distributed.get_world_size() if world > 1 else 1,
                        **({"rehearsal": "SKYEMB_BENCH_REHEARSAL=1: all ranks on cuda:0 over gloo; a walk through the N > 1 code path, "
                                         "NOT a measurement"} if rehearsal else {}),
-                       "graph": not args.no_graph, "adamw_in_wgrad_epilogue": bool(pre.get("fused_adamw"))},
+                       "graph": not args.no_graph, "adamw_in_wgrad_epilogue": bool(pre.get("fused_adamw")),
+                       "adamw_placement": (f"policy {pre.get('adamw_side')}: epilogue of each block's own grouped weight-gradient launch at this size "
+                                           "(side jobs of the next block's launch where launches leave compute units idle: ViT-L, extra.mim_19)"
+                                           if pre.get("fused_adamw") else "separate launch")},
             "roofline": {"bound": "mfma", "achieved": gi["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": gi["tflops"] / peak,
                          # the same family with AdamW as its own launch (no optimiser bytes in the weight-gradient epilogues): the figure
                          # comparable with rounds 1-2, whose `frac` had no optimiser traffic in it
@@ -753,7 +806,7 @@ def main():
         line["extra"] = {}
         if mim19 is not None:
             line["extra"]["mim_19"] = mim19
-        for key in ("long_run", "staged", "batch_sweep"):
+        for key in ("long_run", "staged", "batch_sweep", "optimizer_placement"):
             if key in pre:
                 line["extra"][key] = pre[key]
         if world == 1 and args.dtype == "bf16" and not args.skip_f32:

@@ -123,7 +123,7 @@ typedef struct skyemb_gemm_group_info {
     int32_t total_blocks; /* grid size of the launch                                                          */
     int32_t tile;         /* tile code the plan chose (BM * 1000 + BN): 64064, 128064, 128128 or 256256        */
     int32_t class_mask;   /* operand-layout classes present: 1 KC.KC, 2 KC.RC (dgrad), 4 RC.RC (wgrad)        */
-    int32_t reserved;     /* 1: the blob carries a skyemb_adamw_desc (skyemb_gemm_group_plan_adamw)                         */
+    int32_t reserved;     /* bit 0: the tiles' epilogue is the AdamW step (plan_adamw); bit 1: side optimiser job (plan_side_adamw) */
 } skyemb_gemm_group_info;
 int64_t skyemb_gemm_group_blob_bytes(int n);
 /* tile = 0: chosen from the total tile count.  The problems share ONE tile shape and may mix the data-gradient
@@ -151,6 +151,19 @@ typedef struct skyemb_adamw_desc {
 } skyemb_adamw_desc;
 int skyemb_gemm_group_plan_adamw(const skyemb_gemm_args *args, int n, int tile, const skyemb_adamw_desc *adamw, void *blob_host,
                                  int64_t blob_bytes, skyemb_gemm_group_info *info);
+/* The optimiser step as a SIDE JOB of a grouped weight-gradient launch (round 5).  In the epilogue form above a tile's parameters are
+ * stepped after that tile's own k-loop: every tile ends at the same moment, so the launch is a matrix phase followed by an HBM
+ * phase.  Here `side_blocks` extra workgroups behind the launch's tiles step the slice [side_lo, side_hi) of the flat buffers --
+ * the weights whose gradients the PREVIOUS grouped launch of the backward pass stored in g_base (skyemb_adamw on that slice, bit
+ * for bit) -- while the tile workgroups multiply: they are dispatched into the slots the tiles leave free (a grouped launch
+ * rarely fills the chip evenly: 192 tiles of 256 x 256 for 256 compute units at ViT-L) and into the tiles' slots as those finish.
+ * own_step = 0: the launch's own tiles are stored as gradients (a later launch's side job, or skyemb_adamw, steps them);
+ * own_step = 1: they are stepped in the epilogue as with skyemb_gemm_group_plan_adamw (the LAST block of a backward pass: nothing
+ * follows it that could carry its step).  An empty side range (side_lo == side_hi, side_blocks = 0) is allowed.  RC.RC problems
+ * only; launch with skyemb_gemm_group_launch.  info->reserved: bit 0 = own_step, bit 1 = side job. */
+int skyemb_gemm_group_plan_side_adamw(const skyemb_gemm_args *args, int n, int tile, const skyemb_adamw_desc *adamw, int own_step,
+                                      int64_t side_lo, int64_t side_hi, int side_blocks, void *blob_host, int64_t blob_bytes,
+                                      skyemb_gemm_group_info *info);
 
 /* column sums: out[n] = sum_m X[m,n]; X is `dtype` (bias gradients) or fp32 partials
  * (LayerNorm dgamma/dbeta second stage).  Replaces autograd's bias-gradient reductions. */

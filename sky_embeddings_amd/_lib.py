@@ -67,6 +67,8 @@ PROTOTYPES = {
     "skyemb_set_scalars": (c_i32, [c_vp, c_f32, c_f32, c_f32, c_f32, c_vp]),
     "skyemb_gemm_group_plan_adamw": (c_i32, [ctypes.POINTER(GemmArgs), c_i32, c_i32, ctypes.POINTER(AdamwDesc), c_vp, c_i64,
                                              ctypes.POINTER(GemmGroupInfo)]),
+    "skyemb_gemm_group_plan_side_adamw": (c_i32, [ctypes.POINTER(GemmArgs), c_i32, c_i32, ctypes.POINTER(AdamwDesc), c_i32, c_i64, c_i64, c_i32,
+                                                  c_vp, c_i64, ctypes.POINTER(GemmGroupInfo)]),
     "skyemb_gemm_group_launch": (c_i32, [c_vp, ctypes.POINTER(GemmGroupInfo), c_vp]),
     "skyemb_colsum": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "skyemb_random_mask_from_noise": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),

@@ -640,9 +640,70 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm_pipe_kernel(const skye
 constexpr int GROUP_HEADER_BYTES = 256, GROUP_MAX = 32;
 constexpr int GROUP_ADAMW_OFFSET = 176;                  // skyemb_adamw_desc (80 bytes) ends the 256-byte header
 static_assert(sizeof(skyemb_adamw_desc) == 80, "the blob header reserves 80 bytes for the fused-AdamW descriptor");
-template <int BM, int BN, int NSTAGE, int WM, int WN, int CLASSES, int WK = 1, bool ADAM = false>
+
+// SIDE job of a grouped weight-gradient launch (skyemb_gemm_group_plan_side_adamw): the workgroups behind the launch's tiles
+// (header words 2 / 3: first side workgroup, their count) stream the AdamW step of ANOTHER slice of the flat buffers -- [lo, hi),
+// header words 4-7: the tensors whose gradients the PREVIOUS grouped launch of the backward pass stored -- while the tile
+// workgroups run their k-loops.  Why: a grouped launch rarely fills the chip evenly (440 tiles on 512 slots at ViT-B, 384 on
+// 512 in the decoder, 192 tiles of 256 x 256 on 256 CUs at ViT-L), its k-loops leave HBM idle, and an optimiser pass that waits
+// for every tile's own k-loop (the epilogue form: ADAM) cannot overlap anything; side workgroups have the highest workgroup
+// numbers, so they are dispatched into whatever slots the tiles leave free and, as tiles finish, into theirs.  One thread = 8
+// consecutive elements per turn (two float4 of p, g, m, v in; p, m, v and the bf16 shadow out), U turns in flight.
+template <int THREADS, int U>
+__device__ __forceinline__ void side_adamw_job(const char *__restrict__ blob, const int wg, const int nwg) {
+    const skyemb_adamw_desc *ad = (const skyemb_adamw_desc *)(blob + GROUP_ADAMW_OFFSET);
+    const long long *range = (const long long *)(blob + 16);
+    const int64_t lo = range[0], hi = range[1];
+    const float lr = ad->hyper[0], bc1 = ad->hyper[1], bc2 = ad->hyper[2];
+    const SkyAdamScalars sc = sky_adam_scalars(lr, bc1, bc2, ad->beta1, ad->beta2, ad->eps, ad->weight_decay, ad->grad_scale);
+    const int64_t n8 = (hi - lo) >> 3, stride = (int64_t)nwg * THREADS, n_decay = ad->n_decay;
+    float *__restrict__ P = ad->p, *__restrict__ M = ad->m, *__restrict__ V = ad->v;
+    const float *__restrict__ G = ad->g_base;
+    bf16_t *__restrict__ PL = (bf16_t *)ad->p_lp;
+    for (int64_t i0 = (int64_t)wg * THREADS + threadIdx.x; i0 < n8; i0 += U * stride) {
+        float4 p4[U][2], g4[U][2], m4[U][2], v4[U][2];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int64_t i = i0 + u * stride;
+            i = i < n8 ? i : n8 - 1;                      // clamped request, skipped store
+            const int64_t o = lo + 8 * i;
+            p4[u][0] = gload4(P + o); p4[u][1] = gload4(P + o + 4);
+            g4[u][0] = gload4(G + o); g4[u][1] = gload4(G + o + 4);
+            m4[u][0] = gload4(M + o); m4[u][1] = gload4(M + o + 4);
+            v4[u][0] = gload4(V + o); v4[u][1] = gload4(V + o + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i >= n8) break;
+            const int64_t o = lo + 8 * i;
+            float pp[8] = {p4[u][0].x, p4[u][0].y, p4[u][0].z, p4[u][0].w, p4[u][1].x, p4[u][1].y, p4[u][1].z, p4[u][1].w};
+            float gg[8] = {g4[u][0].x, g4[u][0].y, g4[u][0].z, g4[u][0].w, g4[u][1].x, g4[u][1].y, g4[u][1].z, g4[u][1].w};
+            float mm[8] = {m4[u][0].x, m4[u][0].y, m4[u][0].z, m4[u][0].w, m4[u][1].x, m4[u][1].y, m4[u][1].z, m4[u][1].w};
+            float vv[8] = {v4[u][0].x, v4[u][0].y, v4[u][0].z, v4[u][0].w, v4[u][1].x, v4[u][1].y, v4[u][1].z, v4[u][1].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sky_adamw_update(gg[e], pp[e], mm[e], vv[e], o + e < n_decay, sc);
+            *(float4 *)(P + o) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+            *(float4 *)(P + o + 4) = make_float4(pp[4], pp[5], pp[6], pp[7]);
+            *(float4 *)(M + o) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+            *(float4 *)(M + o + 4) = make_float4(mm[4], mm[5], mm[6], mm[7]);
+            *(float4 *)(V + o) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            *(float4 *)(V + o + 4) = make_float4(vv[4], vv[5], vv[6], vv[7]);
+            store8(PL + o, pp);
+        }
+    }
+}
+
+template <int BM, int BN, int NSTAGE, int WM, int WN, int CLASSES, int WK = 1, bool ADAM = false, bool SIDE = false>
 __global__ __launch_bounds__(WM * WN * WK * 64) void gemm_pipe_group_kernel(const char *__restrict__ blob) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if constexpr (SIDE) {
+        const int side_first = ((const int *)blob)[2];
+        if ((int)blockIdx.x >= side_first) {
+            __builtin_amdgcn_s_setprio(0);
+            return side_adamw_job<WM * WN * WK * 64, 2>(blob, (int)blockIdx.x - side_first, ((const int *)blob)[3]);
+        }
+    }
     // the tile prefix of every problem in one scalar request (the walk `while (blockIdx.x >= hdr[9 + p]) ++p` was one dependent
     // scalar load per problem in front of every workgroup's first operand load); unused slots hold 0 and never match
     const int *hdr = (const int *)blob;
@@ -661,6 +722,7 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm_pipe_group_kernel(cons
     const bool a = g.a_layout == SKYEMB_KC, b = g.b_layout == SKYEMB_KC;   // workgroup-uniform
     if constexpr (CLASSES & 1) if (a && b) return gemm_pipe_body<BM, BN, true, true, NSTAGE, WM, WN, WK>(g, tb, ntiles, 0, 1, smem);
     if constexpr (CLASSES & 2) if (a && !b) return gemm_pipe_body<BM, BN, true, false, NSTAGE, WM, WN, WK>(g, tb, ntiles, 0, 1, smem);
+    if constexpr (SIDE) static_assert(CLASSES == 4, "side optimiser jobs ride in weight-gradient (RC.RC) groups only");
     if constexpr (ADAM) {
         static_assert(CLASSES == 4, "the fused optimiser step exists for weight-gradient (RC.RC) groups only");
         return gemm_pipe_body<BM, BN, false, false, NSTAGE, WM, WN, WK, true>(g, tb, ntiles, 0, 1, smem,
@@ -1089,11 +1151,46 @@ extern "C" int skyemb_gemm_group_plan_adamw(const skyemb_gemm_args *args, int n,
     return 0;
 }
 
-template <int BM, int BN, int NSTAGE, int WM, int WN, int CLASSES, int WK = 1, bool ADAM = false>
+extern "C" int skyemb_gemm_group_plan_side_adamw(const skyemb_gemm_args *args, int n, int tile, const skyemb_adamw_desc *adamw, int own_step,
+                                                 int64_t side_lo, int64_t side_hi, int side_blocks, void *blob_host, int64_t blob_bytes,
+                                                 skyemb_gemm_group_info *info) {
+    SKY_CHECK_ARG(adamw && adamw->g_base && adamw->p && adamw->m && adamw->v && adamw->p_lp && adamw->hyper,
+                  "skyemb_gemm_group_plan_side_adamw: incomplete descriptor");
+    SKY_CHECK_ARG(side_lo >= 0 && side_hi >= side_lo && side_lo % 8 == 0 && side_hi % 8 == 0 && side_blocks >= 0 && side_blocks <= 65536 &&
+                      (side_hi == side_lo) == (side_blocks == 0),
+                  "skyemb_gemm_group_plan_side_adamw: side range [%lld, %lld) must be whole 8-element pieces with >= 1 workgroup (or empty with none)",
+                  (long long)side_lo, (long long)side_hi);
+    int rc = own_step ? skyemb_gemm_group_plan_adamw(args, n, tile, adamw, blob_host, blob_bytes, info)
+                      : skyemb_gemm_group_plan(args, n, tile, blob_host, blob_bytes, info);
+    if (rc != 0) return rc;
+    if (info->class_mask != 4 || !(info->tile == 64064 || info->tile == 128064 || info->tile == 128128 || info->tile == 256256)) {
+        skyemb_set_error("skyemb_gemm_group_plan_side_adamw: weight-gradient (RC.RC) problems on the 64x64 / 128x64 / 128x128 / 256x256 tiles only");
+        return -1;
+    }
+    for (int i = 0; i < n && !own_step; ++i)
+        if (args[i].colsum_parts) {
+            skyemb_set_error("skyemb_gemm_group_plan_side_adamw: problem %d: colsum_parts is not built with a side job", i);
+            return -1;
+        }
+    skyemb_adamw_desc d = *adamw;
+    d.enabled = own_step ? 1 : 0;
+    memcpy((char *)blob_host + GROUP_ADAMW_OFFSET, &d, sizeof d);
+    int *hdr = (int *)blob_host;
+    hdr[2] = info->total_blocks;                          // first side workgroup
+    hdr[3] = side_blocks;
+    const long long range[2] = {(long long)side_lo, (long long)side_hi};
+    memcpy(hdr + 4, range, sizeof range);
+    info->total_blocks += side_blocks;
+    hdr[1] = info->total_blocks;
+    info->reserved = (own_step ? 1 : 0) | 2;
+    return 0;
+}
+
+template <int BM, int BN, int NSTAGE, int WM, int WN, int CLASSES, int WK = 1, bool ADAM = false, bool SIDE = false>
 static int group_launch_n(const void *blob_dev, int total_blocks, hipStream_t st) {
     constexpr size_t ring = (size_t)NSTAGE * (BM + BN) * BK * 2 * WK, image = (size_t)BM * (BN * 4 + 16) + (WK > 1 ? BM * 4 : 0);
     constexpr size_t smem = ring > image ? ring : image;
-    auto kern = gemm_pipe_group_kernel<BM, BN, NSTAGE, WM, WN, CLASSES, WK, ADAM>;
+    auto kern = gemm_pipe_group_kernel<BM, BN, NSTAGE, WM, WN, CLASSES, WK, ADAM, SIDE>;
     static std::mutex attr_mutex;
     static bool attr_done[64] = {};
     int dev = 0;
@@ -1130,6 +1227,21 @@ extern "C" int skyemb_gemm_group_launch(const void *blob_dev, const skyemb_gemm_
     SKY_CHECK_ARG(blob_dev && info && info->total_blocks > 0, "skyemb_gemm_group_launch: bad arguments");
     if (skyemb_skip_mask() & 1) return 0;
     hipStream_t st = (hipStream_t)stream;
+    if (info->reserved == 2 || info->reserved == 3) {          // side optimiser job (plan_side_adamw), own tiles stored (2) or stepped (3)
+        const bool own = info->reserved == 3;
+        switch (info->tile) {
+            case 64064: return own ? group_launch_n<64, 64, 3, 2, 2, 4, 1, true, true>(blob_dev, info->total_blocks, st)
+                                   : group_launch_n<64, 64, 3, 2, 2, 4, 1, false, true>(blob_dev, info->total_blocks, st);
+            case 128064: return own ? group_launch_n<128, 64, 3, 4, 2, 4, 1, true, true>(blob_dev, info->total_blocks, st)
+                                    : group_launch_n<128, 64, 3, 4, 2, 4, 1, false, true>(blob_dev, info->total_blocks, st);
+            case 128128: return own ? group_launch_n<128, 128, 2, 4, 2, 4, 1, true, true>(blob_dev, info->total_blocks, st)
+                                    : group_launch_n<128, 128, 2, 4, 2, 4, 1, false, true>(blob_dev, info->total_blocks, st);
+            case 256256: return own ? gemm256_group_launch<true, true>(blob_dev, info->total_blocks, st)
+                                    : gemm256_group_launch<false, true>(blob_dev, info->total_blocks, st);
+        }
+        skyemb_set_error("skyemb_gemm_group_launch: tile %d not built with a side optimiser job", info->tile);
+        return 1;
+    }
     if (info->reserved == 1) {                                 // optimiser step fused into the epilogue (plan_adamw: class 4 only)
         switch (info->tile) {
             case 64064: return group_launch_n<64, 64, 3, 2, 2, 4, 1, true>(blob_dev, info->total_blocks, st);

@@ -420,10 +420,18 @@ __global__ __launch_bounds__(512) void gemm256_wgrad_kernel(const skyemb_gemm_ar
 // (Round 4 also built tiles SHARED between an owner and a helper workgroup for launches with idle compute units -- mim_19: 192
 // tiles on 256 CUs -- and measured them a third slower, 413 against 303 us per launch: the launch is bound by what its tiles miss in
 // the L2s, and owners and helpers on different k-ranges share fewer panels.  Removed in round 5; profiles/HISTORY.md keeps the numbers.)
-template <bool ADAM>
+// SIDE: workgroups behind the tiles stream another slice's AdamW step (side_adamw_job, gemm_pipe.hip): at ViT-L a block's four weight
+// gradients are 192 tiles for 256 compute units -- 64 units idle for the whole launch, and HBM idle under everybody's k-loops.
+template <bool ADAM, bool SIDE = false>
 __global__ __launch_bounds__(512) void gemm256_group_kernel(const char *__restrict__ blob) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int *hdr = (const int *)blob;
+    if constexpr (SIDE) {
+        if ((int)blockIdx.x >= hdr[2]) {
+            __builtin_amdgcn_s_setprio(0);
+            return side_adamw_job<512, 4>(blob, (int)blockIdx.x - hdr[2], hdr[3]);
+        }
+    }
     const int n = hdr[0];
     const int gt = blockIdx.x;
     int p = 0, first = 0;                                 // (the tile prefix is walked in memory: n <= 32 scalar loads per tile)
@@ -446,10 +454,10 @@ bool gemm256_wgrad_applicable(const skyemb_gemm_args &g) {
            g.lda * 2 * 4 < (1ll << 31) && g.ldb * 2 * 4 < (1ll << 31);
 }
 
-template <bool ADAM>
+template <bool ADAM, bool SIDE = false>
 int gemm256_group_launch(const void *blob_dev, int total_blocks, hipStream_t st) {
     constexpr int smem = G256_RING * G256_HT;
-    auto kern = gemm256_group_kernel<ADAM>;
+    auto kern = gemm256_group_kernel<ADAM, SIDE>;
     static std::mutex attr_mutex;
     static bool attr_done[64] = {};
     int dev = 0;

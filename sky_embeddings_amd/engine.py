@@ -501,7 +501,7 @@ class MAEEngine:
         return [(g_lp, bufs["hact"], f"{prefix}.mlp.fc2", dim, hidden), (dh, bufs["ln2"], f"{prefix}.mlp.fc1", hidden, dim),
                 (g_lp2, bufs["att"], f"{prefix}.attn.proj", dim, dim), (dqkv, bufs["ln1"], f"{prefix}.attn.qkv", 3 * dim, dim)]
 
-    def _make_wgrad_group(self, prefix, bufs, M, dim, w, adamw=None, g16=None):
+    def _make_wgrad_group(self, prefix, bufs, M, dim, w, adamw=None, g16=None, side=None):
         st = self.store
 
         def dst(name, n_out, k_in):
@@ -519,7 +519,7 @@ class MAEEngine:
                                   colsum_a=None if parts else st.grad(f"{name}.bias"), colsum_parts=parts[j] if parts else None,
                                   **dst(name, n_out, k_in))
                     for j, (dy, x_in, name, n_out, k_in) in enumerate(layers)]
-            return ops.GemmGroup(args, self.device, tile=tile, adamw=adamw)
+            return ops.GemmGroup(args, self.device, tile=tile, adamw=adamw, side=side)
         if prefix not in w["bias_parts"] and adamw is None and g16 is None:
             # the plain group is planned first: its tile shape fixes how many tile columns share a bias gradient's partial sums
             # (experiments: SKYEMB_WGRAD_TILE_ENC / _DEC force the grouped launch's tile code for one stack; SKYEMB_BIAS_PARTS=0
@@ -550,15 +550,26 @@ class MAEEngine:
         return grp if grp.ok else None
 
     # -- optimiser step fused into the weight-gradient launches (one process per replica: TrainStep(fused_adamw=True)) --
-    def enable_fused_adamw(self, optimizer, on=True):
-        """The grouped weight-gradient launch of every transformer block applies AdamW to its four weight matrices in its
-        epilogue instead of storing their gradients (include/skyemb.h, skyemb_gemm_group_plan_adamw).  Returns the slices of
-        the flat buffers those launches update -- the caller runs the ordinary AdamW on the rest (embeddings, biases,
-        LayerNorms, the single weight gradients): fused_adamw_ranges(workspace).  The gradient buffer is then NOT written for
-        the fused tensors."""
+    def enable_fused_adamw(self, optimizer, on=True, side=None):
+        """The grouped weight-gradient launches of the transformer blocks carry the AdamW step of the blocks' weight matrices
+        (include/skyemb.h).  Epilogue form: a launch steps its OWN four matrices in its epilogue instead of storing their
+        gradients (skyemb_gemm_group_plan_adamw: the gradient buffer is then not written for them).  Side form: a launch
+        stores its gradients, and the launch that FOLLOWS it in the backward pass carries their step as a side job of extra
+        workgroups (skyemb_gemm_group_plan_side_adamw: HBM-bound work beside the k-loops instead of behind them).  side = None:
+        SKYEMB_ADAMW_SIDE, default "auto" -- the side form where the carrying launch leaves compute units idle (the 256 x 256
+        groups of a ViT-L block: 192 tiles for 256 units; measured mim_19 26.9 -> 25.8 ms), the epilogue form elsewhere (at
+        ViT-B the launches fill the chip and the side form LOSES: 5.49 against 5.28 ms per step).  Either way fused_adamw_ranges(workspace) are the slices of the flat buffers these launches update -- the
+        caller runs the ordinary AdamW on the rest (embeddings, biases, LayerNorms, the single weight gradients)."""
         self._fused_adamw = None
         if not on:
             return
+        import os
+        # placement policy: "auto" (default) = side jobs where the carrying launch leaves compute units idle (256 x 256 tiles:
+        # ViT-L), epilogue elsewhere; "1" / True = side jobs everywhere; "0" / False = epilogue everywhere; "dec" / "enc" =
+        # side jobs carried by the decoder's / encoder's launches only (experiments)
+        self._adamw_side = os.environ.get("SKYEMB_ADAMW_SIDE", "auto") if side is None else ("1" if side is True else "0" if side is False else str(side))
+        assert self._adamw_side in ("auto", "0", "1", "dec", "enc"), self._adamw_side
+        self._adamw_side_blocks = int(os.environ.get("SKYEMB_SIDE_BLOCKS", "256"))
         assert self.dtype == torch.bfloat16, "the fused optimiser step exists on the bf16 path (grouped weight gradients)"
         from ._lib import AdamwDesc
         st = self.store
@@ -593,20 +604,53 @@ class MAEEngine:
     def _build_adamw_groups(self, w):
         self._build_variant_groups(w, "adamw")
 
+    def _wgrad_launch_order(self, w):
+        """Prefixes of the blocks in the order backward() launches their grouped weight gradients."""
+        order = [f"decoder_blocks.{i}" for i in reversed(range(len(w.get("dec", []))))]
+        return order + [f"blocks.{i}" for i in reversed(range(self.cfg.depth))]
+
+    def _block_weight_span(self, prefix):
+        """[lo, hi) of the flat buffers holding a block's four weight matrices (layout order keeps them together)."""
+        st = self.store
+        spans = sorted((st.offsets[f"{prefix}.{n}.weight"], st.offsets[f"{prefix}.{n}.weight"] + _pad8(int(np.prod(st.shapes[f"{prefix}.{n}.weight"]))))
+                       for n in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2"))
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:])), "a block's weight matrices are not contiguous in the flat buffers"
+        return spans[0][0], spans[-1][1]
+
     def _build_variant_groups(self, w, kind):
-        """A second set of the blocks' grouped weight-gradient launches: kind 'adamw' (optimiser step in the epilogue; ranges in
-        w['fused_ranges']) or 'g16' (bf16 output into the communication mirror; w['g16_ranges'])."""
+        """A second set of the blocks' grouped weight-gradient launches: kind 'adamw' (optimiser step carried by the launches -- in
+        the epilogue, or as the side job of the following launch: enable_fused_adamw; ranges in w['fused_ranges']) or 'g16' (bf16
+        output into the communication mirror; w['g16_ranges'])."""
         st = self.store
         groups, spans = {}, []
-        for prefix, plain in w["wgrad_groups"].items():
-            if plain is None:                                 # (token counts the grouped kernel does not take: single launches)
-                continue
+        order = [p for p in self._wgrad_launch_order(w) if w["wgrad_groups"].get(p) is not None]
+        # carry[k]: launch k carries the step of launch k-1's block as a side job (launch k-1 then STORES its gradients)
+        carry = [False] * len(order)
+        if kind == "adamw":
+            mode = getattr(self, "_adamw_side", "0")
+            for k in range(1, len(order)):
+                tile = w["wgrad_groups"][order[k]].info.tile
+                carry[k] = (mode == "1" or (mode == "auto" and tile == 256256) or (mode == "dec" and order[k].startswith("decoder_blocks")) or
+                            (mode == "enc" and order[k].startswith("blocks")))
+        w["adamw_side_launches"] = sum(carry)
+        for k, prefix in enumerate(order):
             tag, i = prefix.rsplit(".", 1)
             bufs = (w["enc"] if tag == "blocks" else w["dec"])[int(i)]
             M, dim = bufs["ln1"].shape
-            grp = (self._make_wgrad_group(prefix, bufs, M, dim, w, adamw=self._fused_adamw) if kind == "adamw"
-                   else self._make_wgrad_group(prefix, bufs, M, dim, w, g16=self._g16))
+            stores = k + 1 < len(order) and carry[k + 1]
+            if kind == "adamw" and (carry[k] or stores):
+                lo, hi = self._block_weight_span(order[k - 1]) if carry[k] else (0, 0)
+                side = (not stores, lo, hi, self._adamw_side_blocks if hi > lo else 0)
+                grp = self._make_wgrad_group(prefix, bufs, M, dim, w, adamw=self._fused_adamw, side=side)
+                side_mode = True
+            elif kind == "adamw":
+                grp = self._make_wgrad_group(prefix, bufs, M, dim, w, adamw=self._fused_adamw)
+                side_mode = False
+            else:
+                grp = self._make_wgrad_group(prefix, bufs, M, dim, w, g16=self._g16)
+                side_mode = False
             if grp is None:
+                assert not side_mode, f"side optimiser jobs: the grouped launch of {prefix} could not be planned"
                 continue
             groups[prefix] = grp
             for name in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2"):

@@ -24,6 +24,13 @@ from . import hdf5_lite
 from ._lib import check, lib
 
 
+def batches_per_epoch(n, batch_size, rank=0, world=1, drop_last=True):
+    """Minibatches a rank draws per epoch from n cutouts: the same number on EVERY rank -- with several ranks the shards are cut
+    to the common length n // world before batching (ranks take every world-th index, so low ranks would otherwise own one more)."""
+    n_local = n // world if world > 1 else n
+    return n_local // batch_size if (drop_last or world > 1) else (n_local + batch_size - 1) // batch_size
+
+
 class CutoutFeeder:
     def __init__(self, path, batch_size, img_size=64, device="cuda", indices=None, shuffle=True, seed=0, pixel_min=-3.0,
                  pixel_max=None, depth=3, threads=4, drop_last=True, rank=0, world_size=1, epochs=1):
@@ -50,8 +57,7 @@ class CutoutFeeder:
         self.dataset = self
         # every rank must run the SAME number of steps per epoch (each step issues collectives): with several ranks the
         # shards are cut to the common length len // world before batching (DistributedIndexSampler does the same)
-        n_local = len(self.indices) // self.world if self.world > 1 else len(self.indices)
-        self._nb = n_local // self.B if (drop_last or self.world > 1) else (n_local + self.B - 1) // self.B
+        self._nb = batches_per_epoch(len(self.indices), self.B, self.rank, self.world, drop_last)
         # ring: pinned host slots, device staging + device output per slot
         self._pinned = [torch.empty(self.B, self.C, self.Hs, self.Ws, dtype=torch.float32).pin_memory() for _ in range(self.depth)]
         self._radec_pin = [torch.empty(self.B, 2, dtype=torch.float32).pin_memory() for _ in range(self.depth)]

@@ -70,15 +70,21 @@ class GemmGroup:
     structs -- the device blob holds the raw pointers, so the operand buffers must stay allocated -- and replayed with
     launch().  `ok` is False when a problem is outside the grouped subset (launch them singly)."""
 
-    def __init__(self, args, device, tile=0, adamw=None):
+    def __init__(self, args, device, tile=0, adamw=None, side=None):
         """adamw: an _lib.AdamwDesc -- the optimiser step fused into the launch's epilogue (weight-gradient groups of a
-        single-process run: skyemb_gemm_group_plan_adamw)."""
+        single-process run: skyemb_gemm_group_plan_adamw).  side = (own_step, lo, hi, blocks) with adamw: the step of the flat
+        slice [lo, hi) rides in the launch as a side job of `blocks` extra workgroups (skyemb_gemm_group_plan_side_adamw);
+        own_step: the launch's own tiles are stepped in their epilogue too, else stored as gradients."""
         n = len(args)
         arr = (GemmArgs * n)(*args)
         nbytes = lib().skyemb_gemm_group_blob_bytes(n)
         host = torch.zeros(nbytes, dtype=torch.uint8)
         self.info = GemmGroupInfo()
-        if adamw is not None:
+        if side is not None:
+            own, lo, hi, blocks = side
+            rc = lib().skyemb_gemm_group_plan_side_adamw(arr, n, tile, ctypes.byref(adamw), int(bool(own)), int(lo), int(hi), int(blocks),
+                                                         host.data_ptr(), nbytes, ctypes.byref(self.info))
+        elif adamw is not None:
             rc = lib().skyemb_gemm_group_plan_adamw(arr, n, tile, ctypes.byref(adamw), host.data_ptr(), nbytes, ctypes.byref(self.info))
         else:
             rc = lib().skyemb_gemm_group_plan(arr, n, tile, host.data_ptr(), nbytes, ctypes.byref(self.info))

@@ -49,7 +49,8 @@ class TrainStep:
                  use_graph: bool = True, process_group=None, world_size: int = 1, warmup_iters: int = 2,
                  staged: bool | None = None, n_encoder_groups: int | None = None, bucket_elems: int = 32 * 1024 * 1024,
                  wgrad_overlap: bool | None = None, optimizer_overlap: bool | None = None, grad_comm: str | None = None,
-                 external_noise: bool = False, max_mask_ratio: float | None = None, fused_adamw: bool | None = None):
+                 external_noise: bool = False, max_mask_ratio: float | None = None, fused_adamw: bool | None = None,
+                 adamw_side: bool | None = None):
         self.engine, self.optimizer, self.scheduler = engine, optimizer, scheduler
         self.mask_ratio = mask_ratio
         self.world_size = world_size
@@ -152,7 +153,10 @@ class TrainStep:
         snap = None
         if self.fused_adamw:
             optimizer.use_device_scalars(dev)
-            engine.enable_fused_adamw(optimizer)
+            # (adamw_side: the step of a block's weights as a side job of the NEXT block's weight-gradient launch instead of its own
+            # launch's epilogue -- engine.enable_fused_adamw; None = the default, SKYEMB_ADAMW_SIDE)
+            engine.enable_fused_adamw(optimizer, side=adamw_side)
+            self.adamw_side = engine._adamw_side          # placement policy: 'auto' | '0' | '1' | 'dec' | 'enc'
             # (the warm-up launches below would already step the fused tensors: restore them afterwards)
             st = engine.store
             snap = [t.clone() for t in (st.p, st.m, st.v, st.p_lp)]

@@ -14,10 +14,10 @@ pytestmark = pytest.mark.gpu
 STEPS, B_RANK, WORLD, LR = 3, 4, 2, 1e-3
 
 
-def _data():
+def _data(world=WORLD):
     g = torch.Generator().manual_seed(42)
-    imgs = torch.randn(WORLD * B_RANK, 5, 64, 64, generator=g).clamp_(min=-3.0)
-    noise = torch.rand(STEPS, WORLD * B_RANK, 16, generator=g)
+    imgs = torch.randn(world * B_RANK, 5, 64, 64, generator=g).clamp_(min=-3.0)
+    noise = torch.rand(STEPS, world * B_RANK, 16, generator=g)
     return imgs, noise
 
 
@@ -33,17 +33,17 @@ def _make(dev, B, world, **kw):
     return eng, step
 
 
-def _rank_main(rank, port, out_dir, grad_comm, use_nccl):
+def _rank_main(rank, port, out_dir, grad_comm, use_nccl, world=WORLD):
     import torch.distributed as dist
     dev = torch.device("cuda", rank if use_nccl else 0)
     torch.cuda.set_device(dev)
     if use_nccl:
-        dist.init_process_group("nccl", rank=rank, world_size=WORLD, init_method=f"tcp://127.0.0.1:{port}", device_id=dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, init_method=f"tcp://127.0.0.1:{port}", device_id=dev)
     else:
-        dist.init_process_group("gloo", rank=rank, world_size=WORLD, init_method=f"tcp://127.0.0.1:{port}")
-    imgs, noise = _data()
+        dist.init_process_group("gloo", rank=rank, world_size=world, init_method=f"tcp://127.0.0.1:{port}")
+    imgs, noise = _data(world)
     rows = slice(rank * B_RANK, (rank + 1) * B_RANK)
-    eng, step = _make(dev, B_RANK, WORLD, grad_comm=grad_comm)
+    eng, step = _make(dev, B_RANK, world, grad_comm=grad_comm)
     assert step.staged and len(step.stages) >= 4          # decoder | encoder groups | embedding: comm overlaps backward
     losses = []
     for it in range(STEPS):
@@ -55,20 +55,21 @@ def _rank_main(rank, port, out_dir, grad_comm, use_nccl):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("grad_comm", ["f32", "bf16"])
-def test_two_rank_training_step_matches_one_rank_on_the_concatenated_batch(tmp_path, grad_comm):
+# world 4 = the most ranks a one-GPU box lets a test start next to the test process itself (six GPU processes per card)
+@pytest.mark.parametrize("grad_comm,world", [("f32", 2), ("bf16", 2), ("bf16", 4)])
+def test_n_rank_training_step_matches_one_rank_on_the_concatenated_batch(tmp_path, grad_comm, world):
     import torch.multiprocessing as mp
-    use_nccl = torch.cuda.device_count() >= WORLD
+    use_nccl = torch.cuda.device_count() >= world
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    mp.spawn(_rank_main, args=(port, str(tmp_path), grad_comm, use_nccl), nprocs=WORLD, join=True)
-    r = [torch.load(tmp_path / f"rank{k}.pt") for k in range(WORLD)]
+    mp.spawn(_rank_main, args=(port, str(tmp_path), grad_comm, use_nccl, world), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"rank{k}.pt") for k in range(world)]
     # the replicas stay identical, bit for bit
-    assert torch.equal(r[0]["p"], r[1]["p"])
+    assert all(torch.equal(r[0]["p"], rk["p"]) for rk in r[1:])
     # one process, the whole batch, fp32 gradients
-    imgs, noise = _data()
-    eng, step = _make(torch.device("cuda", 0), WORLD * B_RANK, 1)
+    imgs, noise = _data(world)
+    eng, step = _make(torch.device("cuda", 0), world * B_RANK, 1)
     p0 = eng.store.p.cpu().clone()
     ref_losses = []
     for it in range(STEPS):
@@ -76,7 +77,7 @@ def test_two_rank_training_step_matches_one_rank_on_the_concatenated_batch(tmp_p
         ref_losses.append(float(step(imgs.cuda())))
     torch.cuda.synchronize()
     ref = eng.store.p.cpu()
-    mean_losses = np.mean([r[0]["losses"], r[1]["losses"]], axis=0)
+    mean_losses = np.mean([rk["losses"] for rk in r], axis=0)
     # MAE mode masks the same number of patches per sample, so the mean of the rank losses is the global loss and the mean of
     # the rank gradients the global gradient
     # (bars = 2x the errors measured on MI355X, profiles/r03_parity_errors.json: losses 1.0e-5 / 4.5e-5 relative, 99.98 % of the
@@ -88,13 +89,133 @@ def test_two_rank_training_step_matches_one_rank_on_the_concatenated_batch(tmp_p
     # move of an element whose gradient is rounding noise, but not the bulk
     frac_close = float((err <= (0.05 if grad_comm == "f32" else 0.25) * LR * STEPS).float().mean())
     from tests.helpers import record_parity
-    record_parity(f"ddp_two_ranks_vs_one_{grad_comm}",
+    record_parity(f"ddp_{world}_ranks_vs_one_{grad_comm}",
                   dict(loss_rel_max=float(np.max(np.abs(mean_losses - np.asarray(ref_losses)) / np.abs(ref_losses))),
                        frac_within_band=frac_close, band_in_lr_steps=0.05 if grad_comm == "f32" else 0.25,
                        err_max_in_lr_steps=float(err.max()) / (LR * STEPS), err_mean_in_lr_steps=float(err.mean()) / (LR * STEPS),
                        comm_dtype=grad_comm, backend="nccl" if use_nccl else "gloo (both ranks on cuda:0)"))
-    assert frac_close > 0.9995, frac_close
+    assert frac_close > (0.9995 if world == 2 else 0.999), frac_close
     assert float(err.max()) <= 2.5 * LR * STEPS and float(moved.max()) > 0.5 * LR
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# world size 8 (BASELINE configs[2] / [3]) walked in ONE process: a one-GPU box admits six GPU processes, so the eight ranks'
+# arithmetic is run rank after rank on the same card -- every kernel and every reduction order of the 8-rank job, no collective
+# ----------------------------------------------------------------------------------------------------------------
+# bars = 2x the drift measured on MI355X (profiles/r05_parity_errors.json)
+# (measured: 99.988 % of the parameters within a quarter lr-step between the two sums, 99.933 % against one rank; largest 1.45 lr-steps; losses 6.3e-5)
+W8_FRAC_BAR, W8_MAX_BAR_LR_STEPS, W8_LOSS_BAR = 0.9986, 3.0, 1.3e-4
+
+
+def test_world_8_gradient_sums_bf16_against_fp32_three_steps():
+    """Eight ranks' gradients of three optimiser steps, summed (a) in fp32 -- nn.DataParallel's reduction, utils/mim_vit.py:117 -- and
+    (b) the way the default bf16 gradient communication does: every rank's gradient rounded to bf16 (what the weight-gradient
+    launches write into the mirror), partial sums rounded to bf16 after every addition (a ring all-reduce's seven roundings), AdamW
+    reading the bf16 sum with grad_scale = 1/8.  Recorded and enforced: the parameter drift between the two after 3 steps, and
+    both against one rank on the concatenated batch."""
+    from tests.helpers import record_parity
+    world = 8
+    imgs, noise = _data(world)
+    dev = torch.device("cuda", 0)
+    finals, losses = {}, {}
+    for comm in ("f32", "bf16"):
+        eng, step = _make(dev, B_RANK, 1, fused_adamw=False, use_graph=False)
+        opt = step.optimizer
+        opt.grad_scale = 1.0 / world
+        g16 = torch.zeros(eng.store.n, device=dev, dtype=torch.bfloat16)
+        ls = []
+        for it in range(STEPS):
+            acc32 = torch.zeros_like(eng.store.g)
+            acc16 = None
+            rank_losses = []
+            for rk in range(world):
+                rows = slice(rk * B_RANK, (rk + 1) * B_RANK)
+                loss, _, _ = eng.forward_train(imgs[rows].to(dev), 0.75, noise[it][rows].to(dev))
+                eng.backward()
+                rank_losses.append(float(loss))
+                if comm == "f32":
+                    acc32 += eng.store.g
+                else:
+                    mine = eng.store.g.bfloat16()
+                    acc16 = mine if acc16 is None else (acc16.float() + mine.float()).bfloat16()
+            ls.append(float(np.mean(rank_losses)))
+            if comm == "f32":
+                eng.store.g.copy_(acc32)
+                opt.grad_buffer = None
+            else:
+                g16.copy_(acc16)
+                opt.grad_buffer = g16
+            opt.step()
+            opt.grad_buffer = None
+            step.scheduler.step()
+        torch.cuda.synchronize()
+        finals[comm], losses[comm] = eng.store.p.cpu().clone(), ls
+        del eng, step
+    eng, step = _make(dev, world * B_RANK, 1)
+    p0 = eng.store.p.cpu().clone()
+    ref_losses = []
+    for it in range(STEPS):
+        step.noise.copy_(noise[it])
+        ref_losses.append(float(step(imgs.cuda())))
+    torch.cuda.synchronize()
+    ref = eng.store.p.cpu()
+    band = LR * STEPS
+    rec = {}
+    for name, a, b in (("bf16_vs_f32", finals["bf16"], finals["f32"]), ("f32_vs_one_rank", finals["f32"], ref), ("bf16_vs_one_rank", finals["bf16"], ref)):
+        err = (a - b).abs()
+        rec[name] = dict(frac_within_quarter_lr_step=float((err <= 0.25 * band).float().mean()), err_max_in_lr_steps=float(err.max()) / band,
+                         err_mean_in_lr_steps=float(err.mean()) / band)
+    rec["loss_rel_max_bf16"] = float(np.max(np.abs(np.asarray(losses["bf16"]) - np.asarray(ref_losses)) / np.abs(ref_losses)))
+    rec["loss_rel_max_f32"] = float(np.max(np.abs(np.asarray(losses["f32"]) - np.asarray(ref_losses)) / np.abs(ref_losses)))
+    record_parity("ddp_world8_emulated_three_steps", rec)
+    assert float((ref - p0).abs().max()) > 0.5 * LR
+    for name in ("bf16_vs_f32", "f32_vs_one_rank", "bf16_vs_one_rank"):
+        assert rec[name]["frac_within_quarter_lr_step"] > W8_FRAC_BAR, (name, rec[name])
+        assert rec[name]["err_max_in_lr_steps"] <= W8_MAX_BAR_LR_STEPS, (name, rec[name])
+    assert rec["loss_rel_max_bf16"] <= W8_LOSS_BAR and rec["loss_rel_max_f32"] <= W8_LOSS_BAR, rec
+
+
+@pytest.mark.parametrize("Q", [16, 512])
+def test_world_8_sharded_search_at_the_real_shard_size(Q):
+    """BASELINE configs[3]'s split at its real shard size: 8 shards of 125,000 x 768 rows (the sizes at which the per-rank path choices
+    -- streaming kernel + sample floor for Q <= 16, the two-stage prefilter above -- are made), each shard searched as its rank
+    would (global indices through idx_offset), the eight [Q, k] lists merged by the HIP k-way merge: == the single 1M-row bank bit
+    for bit, == the CPU oracle on sampled queries, with one row's copies planted in FOUR different shards (ties -> ascending index)."""
+    from oracle import similarity_oracle as so
+    from sky_embeddings_amd import ops, search
+    from sky_embeddings_amd.distributed import shard_rows
+    N, D, k, world = 1_000_000, 768, 100, 8
+    g = torch.Generator(device="cuda").manual_seed(88)
+    bank = torch.empty(N, D, device="cuda")
+    for s0 in range(0, N, 50_000):
+        bank[s0:s0 + 50_000] = torch.randn(50_000, D, device="cuda", generator=g)
+    queries = torch.randn(Q, D, device="cuda", generator=g)
+    queries[0] = bank[31] + 0.01 * queries[0]
+    for row in (130_000, 400_017, 999_990):                  # shards 1, 3 and 7 hold a copy of shard 0's row 31
+        bank[row] = bank[31]
+    w = 1.0 / (torch.rand(D, device="cuda", generator=g) + 0.5) ** 2
+    w = w / w.sum()
+    parts, paths = [], set()
+    for rk in range(world):
+        lo, hi = shard_rows(N, rk, world)
+        assert hi - lo == 125_000
+        st = {}
+        pb = search.PreparedBank(bank[lo:hi], w, idx_offset=lo)
+        parts.append(search.cosine_topk(queries, pb, k, stats=st))
+        paths.add(st["path"])
+        del pb
+    assert paths == ({"exact"} if Q <= 16 else {"prefiltered"}), paths
+    gs = torch.stack([p[0] for p in parts], dim=1).contiguous()
+    gi = torch.stack([p[1] for p in parts], dim=1).contiguous()
+    out_s, out_i = torch.empty(Q, k, device="cuda"), torch.empty(Q, k, device="cuda", dtype=torch.int64)
+    ops.topk_merge(gs, gi, Q, world, k, out_s, out_i)
+    whole_s, whole_i = search.cosine_topk(queries, search.PreparedBank(bank, w), k)
+    torch.cuda.synchronize()
+    assert torch.equal(out_i, whole_i) and torch.equal(out_s, whole_s)
+    assert out_i[0, :4].tolist() == [31, 130_000, 400_017, 999_990]
+    sample = np.unique(np.concatenate(([0, Q - 1], np.random.default_rng(2).integers(0, Q, 6))))
+    ref_s, ref_i = so.cosine_topk_np(queries.cpu().numpy()[sample], bank.cpu().numpy(), k, w.cpu().numpy())
+    assert np.array_equal(out_i.cpu().numpy()[sample], ref_i) and np.array_equal(out_s.cpu().numpy()[sample], ref_s)
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -305,9 +305,9 @@ def test_feeder_batch_count_is_equal_on_every_rank():
     import inspect
     from sky_embeddings_amd import feeder
     src = inspect.getsource(feeder.CutoutFeeder.__init__)
-    assert "len(self.indices) // self.world" in src
+    assert "batches_per_epoch(len(self.indices), self.B, self.rank, self.world, drop_last)" in src
     for n, world, B in ((1030, 4, 8), (257, 2, 128), (1000, 8, 125), (7, 8, 1)):
-        per_rank = [(n // world) // B for _ in range(world)]
+        per_rank = [feeder.batches_per_epoch(n, B, r, world) for r in range(world)]
         longest = len(np.arange(n)[0::world])
         assert len(set(per_rank)) == 1 and per_rank[0] * B <= n // world <= longest
 
@@ -548,6 +548,81 @@ def test_hdf5_lite_unchunk_cache_is_built_once_by_concurrent_openers(tmp_path):
     left = sorted(os.listdir(cache))
     assert not [p for p in left if p.endswith(".tmp")], left
     assert [p for p in left if p.endswith(".contig")] and [p for p in left if p.endswith(".contig.json")]
+
+
+def _worker8(rank, world, port, tmp):
+    """The host-side logic of the N = 8 splits BASELINE configs[2] / [3] name, over gloo with eight CPU processes (no node with eight
+    GPUs is available to the build, and a GPU box admits at most six GPU processes)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    r, w, _ = sdist.init_from_env("gloo")
+    assert (r, w) == (rank, world) and world == 8
+    from oracle import similarity_oracle as so
+    # (1) bucketed all-reduce of the flat gradient buffer over eight ranks, fp32 and bf16 (the default communication dtype): the bf16
+    # ring sum stays within 8 bf16 roundings of the fp32 mean
+    n = 20_000 + 8
+    grads = [torch.randn(n, generator=torch.Generator().manual_seed(200 + k)) for k in range(world)]
+    g32 = grads[rank].clone()
+    sdist.allreduce_flat_gradients(g32, world, bucket_elems=4096)
+    want = torch.stack(grads).double().sum(0)
+    assert torch.allclose(g32.double(), want, atol=1e-5)
+    g16 = grads[rank].bfloat16()
+    sdist.allreduce_flat_gradients(g16, world, bucket_elems=4096)
+    rel = ((g16.double() - want).abs() / (torch.stack(grads).abs().double().sum(0) + 1e-30)).max()
+    assert float(rel) < 8 * 2.0 ** -8, float(rel)
+    every = [torch.zeros_like(g16) for _ in range(world)]
+    dist.all_gather(every, g16)
+    assert all(torch.equal(every[0], e) for e in every)                       # replicas see the same sum, bit for bit
+    # (2) bank sharded eight ways with ragged last shards, ties planted in THREE different shards: gather + merge == one bank
+    rng = np.random.default_rng(8)
+    Q, N, D, k = 9, 12_345, 64, 25
+    q = rng.standard_normal((Q, D), dtype=np.float32)
+    x = rng.standard_normal((N, D), dtype=np.float32)
+    w8 = rng.random(D, dtype=np.float32) + 0.1
+    best = int(np.argmax(so.cosine_scores_np(q[:1], x, w8)[0]))
+    for row in (37, 5_000, 12_300):                                          # shards 0, 3 and 7 hold a copy of query 0's best row
+        x[row] = x[best]
+    lo, hi = sdist.shard_rows(N, rank, world)
+    assert hi - lo == (1544 if rank < 7 else N - 7 * 1544)
+    s_loc, i_loc = so.cosine_topk_np(q, x[lo:hi], k, w8)
+    i_loc = np.where(i_loc >= 0, i_loc + lo, -1)
+    gs, gi = sdist.gather_topk(torch.from_numpy(s_loc), torch.from_numpy(i_loc), world)
+    assert gs.shape == (Q, world, k)
+    cs, ci = gs.reshape(Q, -1).numpy(), gi.reshape(Q, -1).numpy()
+    order = np.lexsort((ci, -cs), axis=1)[:, :k]
+    ms, mi = np.take_along_axis(cs, order, 1), np.take_along_axis(ci, order, 1)
+    rs, ri = so.cosine_topk_np(q, x, k, w8)
+    assert np.array_equal(mi, ri) and np.array_equal(ms, rs)
+    tied = sorted({37, 5_000, 12_300, best})
+    assert ri[0, :len(tied)].tolist() == tied                                # equal scores: ascending global index across shards
+    # (3) index shards with a remainder: 8 x 12 of 101 samples, disjoint, a fresh permutation per epoch, the same 96 on every rank's view
+    samp = sdist.DistributedIndexSampler(101, rank, world, shuffle=True, seed=3)
+    seen = []
+    for epoch in range(2):
+        samp.set_epoch(epoch)
+        mine_idx = torch.tensor(list(samp))
+        allr = [torch.zeros_like(mine_idx) for _ in range(world)]
+        dist.all_gather(allr, mine_idx)
+        flat = torch.cat(allr).tolist()
+        assert len(mine_idx) == len(samp) == 12 and len(set(flat)) == 96 and max(flat) < 101
+        seen.append(flat)
+    assert seen[0] != seen[1]
+    # (4) the feeder's batch count is the same on every rank (the step's collectives would deadlock otherwise)
+    from sky_embeddings_amd.feeder import batches_per_epoch
+    counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([batches_per_epoch(1001, 16, rank, world)]))
+    assert len({int(c) for c in counts}) == 1 and int(counts[0]) == 1001 // world // 16
+    sdist.host_barrier(timeout_s=60.0)
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+
+
+def test_eight_process_gloo_paths(tmp_path):
+    """World size 8 -- the split BASELINE.json names -- over gloo on CPU: all-reduce (fp32 / bf16), sharded search with ties in three
+    shards, index shards with a remainder, the feeder's batch count, the store barrier."""
+    port = _free_port()
+    mp.spawn(_worker8, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{k}") for k in range(8))
 
 
 def test_predictor_schedule_and_layer_decay_groups_match_torch_and_the_reference_recipe():

@@ -231,9 +231,11 @@ def test_bf16_gradient_mirror_written_by_the_weight_gradient_launches(monkeypatc
         assert torch.equal(r[1], results[0][1]) and torch.equal(r[2], results[0][2])
 
 
-def test_fused_adamw_step_at_the_benchmark_size():
+@pytest.mark.parametrize("side", [False, True])
+def test_fused_adamw_step_at_the_benchmark_size(side):
     """The same bit-equality at BASELINE configs[1] (ViT-B/16, B = 256): the 128x128 (encoder) and 128x64 (decoder) grouped
-    launches with the optimiser step in their epilogue against the separate AdamW launch, four steps, no host sync in between."""
+    launches with the optimiser step in their epilogue (side = False) or as the side job of the following block's launch
+    (side = True: the default) against the separate AdamW launch, four steps, no host sync in between."""
     from sky_embeddings_amd.engine import MAEEngine
     from sky_embeddings_amd.model_config import config_for
     from sky_embeddings_amd.optim import CosineLR, FusedAdamW
@@ -244,7 +246,8 @@ def test_fused_adamw_step_at_the_benchmark_size():
     for fused in (False, True):
         eng = MAEEngine(cfg, compute_dtype=torch.bfloat16, seed=0)
         opt = FusedAdamW(eng, lr=1e-4, weight_decay=0.05)
-        step = TrainStep(eng, opt, CosineLR(opt, 1000), 256, fused_adamw=fused)
+        step = TrainStep(eng, opt, CosineLR(opt, 1000), 256, fused_adamw=fused, adamw_side=side)
+        assert not fused or step.adamw_side == ("1" if side else "0")
         torch.manual_seed(5)
         ls = [step(imgs).clone() for _ in range(4)]
         torch.cuda.synchronize()
@@ -258,8 +261,9 @@ def test_fused_adamw_step_at_the_benchmark_size():
         assert torch.equal(res[0][k], res[1][k]), k
 
 
+@pytest.mark.parametrize("side", [False, True])
 @pytest.mark.parametrize("graph", [True, False])
-def test_fused_adamw_step_equals_the_separate_optimiser_launch(graph):
+def test_fused_adamw_step_equals_the_separate_optimiser_launch(graph, side):
     """TrainStep(fused_adamw=True): the AdamW step of every transformer block's weight matrices runs in the epilogue of the
     block's grouped weight-gradient launch.  Parameters, both moments and the bf16 shadow are bit-identical to the schedule
     with the separate optimiser launch after ten steps; engine.backward() outside the step still stores plain gradients."""
@@ -274,7 +278,7 @@ def test_fused_adamw_step_equals_the_separate_optimiser_launch(graph):
     for fused in (False, True):
         eng = MAEEngine(cfg, compute_dtype=torch.bfloat16, seed=1)
         opt = FusedAdamW(eng, lr=1e-3, weight_decay=0.05)
-        step = TrainStep(eng, opt, CosineLR(opt, 100), 64, use_graph=graph, fused_adamw=fused)
+        step = TrainStep(eng, opt, CosineLR(opt, 100), 64, use_graph=graph, fused_adamw=fused, adamw_side=side)
         assert step.fused_adamw == fused
         torch.manual_seed(123)
         # ten steps WITHOUT a host sync in between: the host runs ahead of the GPU, so step t's launches must still read step t's

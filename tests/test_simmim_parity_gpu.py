@@ -178,21 +178,33 @@ VITL_BF16_LOSS_BAR, VITL_BF16_PRED_BAR, VITL_BF16_GRAD_REL_BAR, VITL_BF16_GRAD_M
 def test_mim19_vit_large_width_against_oracle():
     """BASELINE configs[4] at its real WIDTH and batch (ViT-L/16: 1024 columns, 16 heads, 5x128x128 cutouts, B = 128 -> 8320 token
     rows), cut to depth 2 so the CPU oracle finishes in seconds: loss, prediction image and every gradient against
-    oracle/mae_oracle.py, f32 and bf16.  In bf16 these are the launches mim_19.ini itself runs -- the 256 x 256 tile for the
+    oracle/mae_oracle.py.  In bf16 these are the launches mim_19.ini itself runs -- the 256 x 256 tile for the
     [8320 x 4096 x 1024] forward / data-gradient GEMMs, the 256 x 256 grouped weight gradients, the 65-token strip attention, the
-    four-vector LayerNorm -- and the test asserts through the library's launch counters that those kernels were the ones selected."""
+    four-vector LayerNorm -- and the test asserts through the library's launch counters that those kernels were the ones selected.
+    Three legs: f32 + MSE (smooth loss: the engine's arithmetic at this width to fp32 rounding), f32 + L1 and bf16 + L1 (the ini's
+    loss).  L1's gradient is sign(pred - target): at 6.4 M masked pixels a handful of them have |pred - target| below the two
+    implementations' 1e-6 disagreement and flip, and k flips move d loss / d pred by 2 sqrt(k / 6.4e6) in relative L2 (five flips:
+    1.8e-3) -- every gradient inherits that, so the f32 + L1 leg is held to 4e-3, not to fp32 rounding."""
     from oracle import mae_oracle as mo
     from sky_embeddings_amd import ops
-    kw = dict(img_size=128, patch_size=16, in_chans=5, embed_dim=1024, depth=2, num_heads=16, norm_pix_loss=True, loss_fn="L1")
-    cfg_o = mo.config_for("simmim", **kw)
-    assert (cfg_o.embed_dim, cfg_o.num_heads, cfg_o.num_patches) == (1024, 16, 64)
-    st = mo.init_state(cfg_o, seed=7)
     B = 128
-    x, m, _ = _mim19_batch(cfg_o, B, seed=23)
-    x[3, 1] = float("nan")
-    x[77, 4, 40:70, 5:90] = float("nan")
-    loss_o, pred_o, _, _, _, grads_o = mo.loss_and_grads(st, x, cfg_o, None, None, mask=m)
-    for dtype in (torch.float32, torch.bfloat16):
+    oracle, batch = {}, None
+    for dtype, loss_fn in ((torch.float32, "mse"), (torch.float32, "L1"), (torch.bfloat16, "L1")):
+        kw = dict(img_size=128, patch_size=16, in_chans=5, embed_dim=1024, depth=2, num_heads=16, norm_pix_loss=True, loss_fn=loss_fn)
+        cfg_o = mo.config_for("simmim", **kw)
+        assert (cfg_o.embed_dim, cfg_o.num_heads, cfg_o.num_patches) == (1024, 16, 64)
+        st = mo.init_state(cfg_o, seed=7)
+        if batch is None:
+            x, m, _ = _mim19_batch(cfg_o, B, seed=23)
+            x[3, 1] = float("nan")
+            x[77, 4, 40:70, 5:90] = float("nan")
+            batch = (x, m)
+        x, m = batch
+        if loss_fn not in oracle:
+            # (MSE on NaN target pixels: the reference's backward is NaN for every parameter, DESIGN.md deviation 1 -- the oracle's
+            # nan_safe form gives those pixels the zero gradient the library gives them)
+            oracle[loss_fn] = mo.loss_and_grads(st, x, cfg_o, None, None, mask=m, nan_safe=loss_fn == "mse")
+        loss_o, pred_o, _, _, _, grads_o = oracle[loss_fn]
         f32 = dtype == torch.float32
         eng = make_engine(cfg_o, st, dtype)
         ops.gemm_launch_counts(reset=True)
@@ -217,14 +229,16 @@ def test_mim19_vit_large_width_against_oracle():
             grel[k] = rel_err(gk, r)
             gmax[k] = float(np.abs(gk - r).max()) / max(float(np.abs(r).max()), 1e-6)
         wk = max(grel, key=grel.get)
-        record_parity(f"mim19_vitl_width_{'f32' if f32 else 'bf16'}",
+        record_parity(f"mim19_vitl_width_{'f32' if f32 else 'bf16'}_{loss_fn.lower()}",
                       dict(loss_rel=loss_rel, pred_rel_l2=pred_rel, grad_rel_l2_max=grel[wk], grad_worst_tensor=wk,
                            grad_max_abs_over_max_max=max(gmax.values()), gemm_launches=counts))
         assert loss_rel <= (2e-5 if f32 else VITL_BF16_LOSS_BAR), loss_rel
         assert pred_rel < (2e-5 if f32 else VITL_BF16_PRED_BAR), pred_rel
         for k in eng.store.order:
-            if f32:
+            if f32 and loss_fn == "mse":
                 assert gmax[k] <= 2e-4, (k, gmax[k])
+            elif f32:
+                assert grel[k] <= 4e-3, (k, grel[k], gmax[k])
             else:
                 assert grel[k] < VITL_BF16_GRAD_REL_BAR or gmax[k] < VITL_BF16_GRAD_MAX_BAR, (k, grel[k], gmax[k])
         del eng
