@@ -257,12 +257,26 @@ def placement_ab(make_engine, B, pool, dev, step_default, others, load=None, rou
     from sky_embeddings_amd.train_step import TrainStep
     steps = {"auto": (step_default, None)}
     for pol in others:
-        eng2 = make_engine()
-        opt2 = FusedAdamW(eng2, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
-        s2 = TrainStep(eng2, opt2, CosineLR(opt2, 1_000_000, eta_min=1e-4 / 1e7), B, mask_ratio=0.75, use_graph=True, world_size=1, adamw_side=pol)
-        if load is not None:
-            load(s2)
-        steps[pol] = (s2, (eng2, opt2))
+        # ("name=ENV=value": the shipped policy with one library switch flipped while the variant's launches are planned)
+        env = dict([pol.split("=", 2)[1:]]) if "=" in pol else {}
+        saved = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            eng2 = make_engine()
+            opt2 = FusedAdamW(eng2, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
+            s2 = TrainStep(eng2, opt2, CosineLR(opt2, 1_000_000, eta_min=1e-4 / 1e7), B, mask_ratio=0.75, use_graph=True, world_size=1,
+                           adamw_side=None if env else pol)
+            if load is not None:
+                load(s2)
+            for i in range(2):                       # (plans are made when the first step builds the workspace)
+                s2(pool[i % 2]) if pool is not None else s2()
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        steps[pol.split("=")[0]] = (s2, (eng2, opt2))
     call = (lambda s, i: s(pool[i % 2])) if pool is not None else (lambda s, i: s())
     for name, (s, _) in steps.items():
         for i in range(5):
@@ -287,7 +301,8 @@ def placement_ab(make_engine, B, pool, dev, step_default, others, load=None, rou
     return dict(ms_per_step={k: v for k, v in res.items()}, mean_ms={k: sum(v) / len(v) for k, v in res.items()}, side_launches_per_step=side_launches,
                 note="AdamW of the transformer blocks' weights: 'auto' (shipped) = side job of the NEXT block's grouped weight-gradient launch where "
                      "that launch leaves compute units idle (256 x 256 tiles), else the epilogue of the block's own launch; '0' = epilogue everywhere; "
-                     "'1' = side jobs everywhere; 'dec' = carried by the decoder's launches only.  Interleaved rounds in one process")
+                     "'1' = side jobs everywhere; 'dec' = carried by the decoder's launches only; 'tiles_per_problem' = the shipped policy with the 256 x 256 "
+                     "groups' tiles laid out per problem instead of per XCD (SKYEMB_GROUP_XCD_ORDER=0).  Interleaved rounds in one process")
 
 
 def batch_sweep(eng, opt, sched, dev, rank, ms_256):
@@ -477,9 +492,9 @@ def bench_mim19(args, dev):
     ms = e0.elapsed_time(e1) / n
     executed, algorithmic = eng.flops_per_image()
     placement = None
-    if step.fused_adamw:
-        placement = placement_ab(lambda: SimMIMEngine(cfg, device=dev, compute_dtype=torch.bfloat16, seed=0), B, None, dev, step, ["0"],
-                                 load=lambda s: s.load_batch(x, m), rounds=2, n=10)
+    if step.fused_adamw and not os.environ.get("SKYEMB_BENCH_NO_AB"):       # (tools/mim19_bench.py under the profiler: the shipped step alone)
+        placement = placement_ab(lambda: SimMIMEngine(cfg, device=dev, compute_dtype=torch.bfloat16, seed=0), B, None, dev, step,
+                                 ["0", "tiles_per_problem=SKYEMB_GROUP_XCD_ORDER=0"], load=lambda s: s.load_batch(x, m), rounds=2, n=10)
     res = dict(workload="configs/mim_19.ini: SimMIM ViT-Large/16, 5x128x128, 39 of 64 patches masked per channel (ratio 0.6), "
                         f"bs={B}, L1 + norm-pix, AdamW+cosine, bf16", ms_per_step=ms, images_per_sec=B / ms * 1e3, optimizer_placement=placement,
                tflops=B / ms * executed / 1e9, frac_of_bf16_peak=B / ms * executed / 1e9 / PEAK_BF16_TFLOPS,

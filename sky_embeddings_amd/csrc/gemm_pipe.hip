@@ -1118,6 +1118,12 @@ extern "C" int skyemb_gemm_group_plan(const skyemb_gemm_args *args, int n, int t
     hdr[8 + n] = start;
     hdr[0] = n;
     hdr[1] = start;
+    if (tile == 256256) {
+        // tile order across the group (gemm256_group_kernel): an XCD takes consecutive tiles of the concatenated list
+        // (read per plan, not once per process: bench.py builds both orders in one process for its interleaved A/B)
+        const char *e = getenv("SKYEMB_GROUP_XCD_ORDER");
+        if (!(e && e[0] == '0')) hdr[1] |= 1 << 30;
+    }
     info->total_blocks = start;
     info->tile = tile;
     info->class_mask = mask;
@@ -1181,7 +1187,7 @@ extern "C" int skyemb_gemm_group_plan_side_adamw(const skyemb_gemm_args *args, i
     const long long range[2] = {(long long)side_lo, (long long)side_hi};
     memcpy(hdr + 4, range, sizeof range);
     info->total_blocks += side_blocks;
-    hdr[1] = info->total_blocks;
+    hdr[1] = (hdr[1] & (1 << 30)) | info->total_blocks;
     info->reserved = (own_step ? 1 : 0) | 2;
     return 0;
 }

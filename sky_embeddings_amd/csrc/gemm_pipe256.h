@@ -58,7 +58,7 @@ __device__ __forceinline__ int lane_fresh() {
 // their AdamW step (as in gemm_pipe_body); colsum_a / colsum_parts (row-contiguous A): the bias gradient, as there.
 template <bool A_KC, bool B_KC, bool ADAM>
 __device__ __forceinline__ void gemm256_tile(const skyemb_gemm_args &g, const unsigned int tile, const unsigned int ntiles, char *smem,
-                                             const skyemb_adamw_desc *ad = nullptr) {
+                                             const skyemb_adamw_desc *ad = nullptr, const bool linear = false) {
     static_assert(A_KC || !B_KC, "a row-contiguous A comes with a row-contiguous B (weight gradients)");
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -73,6 +73,7 @@ __device__ __forceinline__ void gemm256_tile(const skyemb_gemm_args &g, const un
         const unsigned int nwg = ntiles, xcd = tile & 7u, local = tile >> 3;
         const unsigned int q = nwg >> 3, r = nwg & 7u;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+        if (linear) wg = tile;                            // (grouped launches: the caller has already laid the tiles out per XCD)
     }
     const unsigned int div = colmajor ? tiles_m : tiles_n, quo = wg / div, rem = wg - quo * div;
     const int m0 = (int)(colmajor ? rem : quo) * 256, n0 = (int)(colmajor ? quo : rem) * 256;
@@ -433,7 +434,13 @@ __global__ __launch_bounds__(512) void gemm256_group_kernel(const char *__restri
         }
     }
     const int n = hdr[0];
-    const int gt = blockIdx.x;
+    // Tile order across the GROUP (round 5; header word 1 bit 30 = on): workgroup b runs on XCD b & 7, and XCD x takes the x-th
+    // EIGHTH of the concatenated tile list -- 24 consecutive tiles of (mostly) one problem: a 6 x 4 block sharing 10 operand panels
+    // per k-tile -- instead of an eighth of EVERY problem (8 + 8 + 6 + 2 tiles of the four weight gradients of a ViT-L block: 21
+    // panels per k-tile for the same 48 panel loads; PMC round 4: 62 % L2 hits, 2.6 x the operand bytes from beyond the L2).
+    const bool by_xcd = (hdr[1] >> 30) & 1;
+    int gt = blockIdx.x;
+    if (by_xcd) gt = (gt & 7) * (hdr[8 + n] >> 3) + (gt >> 3);
     int p = 0, first = 0;                                 // (the tile prefix is walked in memory: n <= 32 scalar loads per tile)
 #pragma unroll 1
     for (int i = 1; i < n; ++i) {
@@ -444,7 +451,7 @@ __global__ __launch_bounds__(512) void gemm256_group_kernel(const char *__restri
     const unsigned int tb = gt - first;
     const unsigned int ntiles = ((unsigned int)g.M / 256u) * ((unsigned int)g.N / 256u);
     if (tb >= ntiles) return;                             // padding up to the next multiple of 8 (keeps tb & 7 == XCD)
-    gemm256_tile<false, false, ADAM>(g, tb, ntiles, smem, ADAM ? (const skyemb_adamw_desc *)(blob + GROUP_ADAMW_OFFSET) : nullptr);
+    gemm256_tile<false, false, ADAM>(g, tb, ntiles, smem, ADAM ? (const skyemb_adamw_desc *)(blob + GROUP_ADAMW_OFFSET) : nullptr, by_xcd);
 }
 
 // the weight-gradient variant: both operands row-contiguous, whole tiles, K a multiple of 64 with at least two k-tiles

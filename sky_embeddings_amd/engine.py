@@ -556,9 +556,10 @@ class MAEEngine:
         gradients (skyemb_gemm_group_plan_adamw: the gradient buffer is then not written for them).  Side form: a launch
         stores its gradients, and the launch that FOLLOWS it in the backward pass carries their step as a side job of extra
         workgroups (skyemb_gemm_group_plan_side_adamw: HBM-bound work beside the k-loops instead of behind them).  side = None:
-        SKYEMB_ADAMW_SIDE, default "auto" -- the side form where the carrying launch leaves compute units idle (the 256 x 256
-        groups of a ViT-L block: 192 tiles for 256 units; measured mim_19 26.9 -> 25.8 ms), the epilogue form elsewhere (at
-        ViT-B the launches fill the chip and the side form LOSES: 5.49 against 5.28 ms per step).  Either way fused_adamw_ranges(workspace) are the slices of the flat buffers these launches update -- the
+        SKYEMB_ADAMW_SIDE, default "auto" -- the side form where the carrying launch leaves a quarter of the device's workgroup
+        slots free (the 256 x 256 groups of a ViT-L block: 192 tiles for 256 units, mim_19 26.5 -> 25.5 ms; the ViT-B decoder's
+        384 tiles for 512 slots), the epilogue form elsewhere (the ViT-B encoder's launches fill the chip and the side form
+        LOSES there).  Either way fused_adamw_ranges(workspace) are the slices of the flat buffers these launches update -- the
         caller runs the ordinary AdamW on the rest (embeddings, biases, LayerNorms, the single weight gradients)."""
         self._fused_adamw = None
         if not on:
@@ -628,10 +629,17 @@ class MAEEngine:
         carry = [False] * len(order)
         if kind == "adamw":
             mode = getattr(self, "_adamw_side", "0")
+            ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
             for k in range(1, len(order)):
-                tile = w["wgrad_groups"][order[k]].info.tile
-                carry[k] = (mode == "1" or (mode == "auto" and tile == 256256) or (mode == "dec" and order[k].startswith("decoder_blocks")) or
-                            (mode == "enc" and order[k].startswith("blocks")))
+                info = w["wgrad_groups"][order[k]].info
+                # "auto": the carrying launch must leave a quarter of the device's workgroup slots free (slots per compute unit
+                # follow from the tile's LDS ring: one 256 x 256, two 128 x 128 / 128 x 64, three 64 x 64).  Measured (bench.py
+                # extra.optimizer_placement): ViT-L, 192 tiles of 256 x 256 on 256 units: 26.5 -> 25.5 ms per step; ViT-B decoder,
+                # 384 tiles of 128 x 64 on 512 slots: 5.24 -> 5.21; ViT-B encoder, 440 of 512: side jobs LOSE (5.24 -> 5.47 with
+                # every launch carrying one: they start when the tiles end, and move 34 instead of 26 bytes per parameter)
+                slots = ncu * {256256: 1, 128128: 2, 9128128: 1, 128064: 2, 64064: 3}.get(info.tile, 1)
+                carry[k] = (mode == "1" or (mode == "auto" and info.total_blocks <= 0.76 * slots) or
+                            (mode == "dec" and order[k].startswith("decoder_blocks")) or (mode == "enc" and order[k].startswith("blocks")))
         w["adamw_side_launches"] = sum(carry)
         for k, prefix in enumerate(order):
             tag, i = prefix.rsplit(".", 1)

@@ -172,7 +172,8 @@ def test_mim19_geometry_against_oracle():
 
 
 # bf16 bars of the ViT-L-width test = 2x the errors measured on MI355X (profiles/r05_parity_errors.json)
-VITL_BF16_LOSS_BAR, VITL_BF16_PRED_BAR, VITL_BF16_GRAD_REL_BAR, VITL_BF16_GRAD_MAX_BAR = 2e-4, 2e-2, 1.2e-1, 8e-2
+# (measured: loss 2.0e-5, prediction image 3.9e-3 rel-L2, worst gradient 4.1e-2 rel-L2 / 3.6e-2 of its maximum: patch_embed.proj.weight)
+VITL_BF16_LOSS_BAR, VITL_BF16_PRED_BAR, VITL_BF16_GRAD_REL_BAR, VITL_BF16_GRAD_MAX_BAR = 4e-5, 8e-3, 8.5e-2, 7.5e-2
 
 
 def test_mim19_vit_large_width_against_oracle():
