@@ -251,7 +251,7 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
     constexpr int NI = (issue_per_wave<BM, NW>() + issue_per_wave<BN, NW>()) * WK;   // LDS-DMA instructions per wave per stage
     static_assert(BM % 8 == 0 && BN % 8 == 0 && SM % 16 == 0 && SN % 16 == 0 && SM * WM == BM && SN * WN == BN, "tile / wave grid mismatch");
     static_assert(WK == 1 || WK == 2, "one or two k-groups");
-    static_assert(BMS <= BM && BMS % 8 == 0 && (BMS == BM || A_KC), "overlapping row blocks: k-contiguous A only");
+    static_assert(BMS <= BM && BMS % 2 == 0 && (BMS == BM || A_KC), "overlapping row blocks: k-contiguous A only (any even row stride: rows are addressed one by one)");
 
     GSTAMP(st_entry);
 #ifdef GEMM_STAMP
@@ -614,8 +614,10 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
 #endif
 }
 
-// row stride of a tile shape: the 144-row image steps by 136 rows (gemm_pipe_body, BMS)
-constexpr int tile_stride_m(int bm) { return bm == 144 ? 136 : bm; }
+// row stride of a tile shape (gemm_pipe_body, BMS): the 144-row image steps by 136 rows with 64 columns (the ViT-B decoder's
+// 4352 = 32 x 136 token rows) and by 130 rows with 256 columns (ViT-L: 8320 = 64 x 130 token rows -- [8320 x 1024] outputs are
+// exactly 256 tiles, [8320 x 3072] 768, [8320 x 4096] 1024: whole rounds of a 256-CU device, no row tail)
+constexpr int tile_stride_m(int bm, int bn) { return bm == 144 ? (bn == 256 ? 130 : 136) : bm; }
 constexpr bool pow2_rows(int r) { return r == 64 || r == 128 || r == 256; }
 
 template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int WM, int WN, int WK = 1>
@@ -627,7 +629,7 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm_pipe_kernel(const skye
         ntiles = gridDim.x / (unsigned int)S;
         split = blockIdx.x / ntiles;
     }
-    gemm_pipe_body<BM, BN, A_KC, B_KC, NSTAGE, WM, WN, WK, false, tile_stride_m(BM)>(g, (int)(blockIdx.x - split * ntiles), (int)ntiles,
+    gemm_pipe_body<BM, BN, A_KC, B_KC, NSTAGE, WM, WN, WK, false, tile_stride_m(BM, BN)>(g, (int)(blockIdx.x - split * ntiles), (int)ntiles,
                                                                                       (int)split, S, smem);
 }
 
@@ -804,7 +806,7 @@ int launch_n(const skyemb_gemm_args &g, hipStream_t st) {
             attr_done[dev & 63] = true;
         }
     }
-    const int64_t tiles = ceil_div64(g.M, tile_stride_m(BM)) * ceil_div64(g.N, BN);
+    const int64_t tiles = ceil_div64(g.M, tile_stride_m(BM, BN)) * ceil_div64(g.N, BN);
     const int S = g.split_k > 1 ? g.split_k : 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * S)), dim3(WM * WN * WK * 64), smem, st, g);
     skyemb_count_gemm(SKYEMB_GEMM_COUNT_PIPE);
@@ -858,7 +860,8 @@ int dispatch(const skyemb_gemm_args &g, hipStream_t st) {
     X(6, 64, 64, 2, 2, 2, 1)         \
     X(9, 64, 64, 3, 2, 2, 2)         \
     X(9, 128, 128, 2, 4, 2, 2)       \
-    X(9, 144, 64, 3, 3, 2, 2)
+    X(9, 144, 64, 3, 3, 2, 2)        \
+    X(13, 144, 256, 3, 3, 4, 1)
 #ifdef SKY_GEMM_LAB   // experiment builds (tools/ubench/gemm_lab.hip): every shape under study
 #define SKY_GEMM_VARIANTS(X) SKY_GEMM_PRODUCT_VARIANTS(X) SKY_GEMM_LAB_VARIANTS(X)
 #else
@@ -874,8 +877,8 @@ int dispatch_code(int code, const skyemb_gemm_args &g, hipStream_t st) {
     return 1;
 }
 void tile_dims(int code, int &bm, int &bn) {   // bm = the row STRIDE of the tiles (136 for the 144-row image)
-    bm = tile_stride_m((code % 1000000) / 1000);
     bn = code % 1000;
+    bm = tile_stride_m((code % 1000000) / 1000, bn);
 }
 int canonical_tile(int tile) {   // legacy codes of the round-1 ABI
     return tile == 64 ? 64064 : tile == 128 ? 128128 : tile == 12864 ? 128064 : tile;

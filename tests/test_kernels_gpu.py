@@ -71,11 +71,13 @@ def test_gemm_layouts(ops, dtype, layouts, tile, shape):
 
 
 @pytest.mark.parametrize("b_l", [0, 1])
-@pytest.mark.parametrize("tile", [9064064, 0])
-@pytest.mark.parametrize("shape", [(200, 136, 256), (1280, 768, 768), (70, 264, 384), (64, 64, 128)])
+@pytest.mark.parametrize("tile", [9064064, 0, 9144064, 13144256])
+@pytest.mark.parametrize("shape", [(200, 136, 256), (1280, 768, 768), (70, 264, 384), (64, 64, 128), (407, 520, 128)])
 def test_gemm_two_k_group_tile(ops, b_l, tile, shape):
-    """The 64x64 tile with two wave groups over k (launches of <= 256 tiles; picked by the heuristic when tile = 0): both
-    operand classes with a k-contiguous A, every fused epilogue, ragged tile edges -- against fp64."""
+    """The 64x64 tile with two wave groups over k (launches of <= 256 tiles; picked by the heuristic when tile = 0) and the tiles
+    whose row STRIDE is below their height (a 144-row image stepping by 136 rows x 64 columns on twelve waves in two k-groups; by
+    130 rows x 256 columns on twelve waves: ViT-L's 8320 = 64 x 130 token rows): both operand classes with a k-contiguous A, every
+    fused epilogue, ragged tile edges (row counts that are and are not multiples of the stride) -- against fp64."""
     M, N, K = shape
     g = torch.Generator().manual_seed(M + 3 * N + K + b_l)
     A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.2
@@ -117,7 +119,7 @@ def test_gemm_two_k_group_tile(ops, b_l, tile, shape):
     refd = prod.float() * auxr.grad
     assert float((dg.float().cpu() - refd).abs().max()) <= 1e-2 * float(refd.abs().max())
     # an odd number of k-tiles is refused by the explicit tile and served by the one-group tile when the choice is left open
-    if tile:
+    if tile in (9064064, 9144064):
         with pytest.raises(Exception):
             ops.gemm(Ad[:, :64].contiguous(), dev(B[:, :64].contiguous(), T), M=M, N=N, K=64, out_f32=out, tile=tile)
 
