@@ -636,13 +636,11 @@ def pmc_traffic(args):
     """HBM-side bytes per Q = 16 bank-pass launch from the newest committed PMC summary (profiles/rNN_topk_stream_pmc.json), or None."""
     if args.bank_rows != 1_000_000 or args.topk != 100 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
         return None                                        # (counters cannot be read from inside the timed process: the profiles/ figure of the same workload)
-    for name in ("r04_topk_stream_pmc.json", "r03_topk_stream_pmc.json"):
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                return json.load(f)["kernels"]["cosine_topk_stream_kernel<8>"]["traffic_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            continue
-    return None
+    rec, _, _ = _pmc_load(("r05_topk_stream_pmc.json", "r04_topk_stream_pmc.json", "r03_topk_stream_pmc.json"))
+    try:
+        return rec["kernels"]["cosine_topk_stream_kernel<8>"]["traffic_bytes_per_launch"]
+    except (TypeError, KeyError):
+        return None
 
 
 def parity_of_timed_mode(args, mo, cfg_o, st):
@@ -865,17 +863,37 @@ def main():
         torch.distributed.destroy_process_group()
 
 
+def _pmc_load(names):
+    """(record, file, current) of the newest committed PMC summary among `names`; current = its `csrc_sha16` stamp equals the
+    fingerprint of the kernel sources this process runs (tools/fingerprint.py) -- hardware-counter figures of older kernels are
+    reported with pmc_current = false instead of sitting beside fresh timings as if they were theirs."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from fingerprint import csrc_sha16
+        now = csrc_sha16(ROOT)
+    except Exception:
+        now = None
+    for name in names:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                rec = json.load(f)
+            return rec, "profiles/" + name, bool(now and rec.get("csrc_sha16") == now)
+        except (OSError, ValueError):
+            continue
+    return None, None, False
+
+
 def mim19_pmc_record():
     """Matrix-pipe utilisation of the mim_19 step's GEMM kernels by hardware counters (profiles/r04_mim19_pmc.json: cycle-weighted
     SQ_VALU_MFMA_BUSY_CYCLES over the launches' SIMD-cycles, a separate --pmc pass over two eager steps), or {}."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r04_mim19_pmc.json")) as f:
-            ks = {n: v for n, v in json.load(f)["kernels"].items() if n.startswith("gemm")}
+        rec, src, cur = _pmc_load(("r05_mim19_pmc.json", "r04_mim19_pmc.json"))
+        ks = {n: v for n, v in rec["kernels"].items() if n.startswith("gemm")}
         cyc = {n: v["gpu_cycles_per_launch"] * v["launches"] for n, v in ks.items()}
         tot = sum(cyc.values())
         return {"gemm_mfma_busy_pmc": sum(ks[n].get("mfma_util", 0.0) * cyc[n] for n in ks) / tot,
-                "gemm_share_of_gpu_cycles_pmc": sum(v["share_of_gpu_cycles"] for v in ks.values()), "pmc_source": "profiles/r04_mim19_pmc.json"}
-    except (OSError, KeyError, ValueError, ZeroDivisionError):
+                "gemm_share_of_gpu_cycles_pmc": sum(v["share_of_gpu_cycles"] for v in ks.values()), "pmc_source": src, "pmc_current": cur}
+    except (TypeError, KeyError, ValueError, ZeroDivisionError):
         return {}
 
 
@@ -883,28 +901,26 @@ def search_pmc_record():
     """Matrix-pipe utilisation of the many-query pass by hardware counters (profiles/r04_search_pmc.json: SQ_VALU_MFMA_BUSY_CYCLES over
     the launch's SIMD-cycles, a separate --pmc pass), or {}."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r04_search_pmc.json")) as f:
-            ks = json.load(f)["kernels"]
+        rec, src, cur = _pmc_load(("r05_search_pmc.json", "r04_search_pmc.json"))
+        ks = rec["kernels"]
         k = next(v for n, v in ks.items() if n.startswith("prefilter_kernelILi2ELb0"))
-        return {"mfma_busy_pmc": k["mfma_util"], "l2_hit_rate_pmc": k["l2_hit_rate"], "pmc_source": "profiles/r04_search_pmc.json",
+        return {"mfma_busy_pmc": k["mfma_util"], "l2_hit_rate_pmc": k["l2_hit_rate"], "pmc_source": src, "pmc_current": cur,
                 "pmc_note": "prefilter_kernel<2,false> (80 % of the search): matrix pipe busy / SIMD-cycles of the launch at the clock the "
                             "chip ran it at (1.75 GHz in the two long launches: 12.3 / 14.3 M cycles in 6.9 / 8.0 ms); `frac` prices the FLOPs against the 2.4 GHz peak"}
-    except (OSError, KeyError, ValueError, StopIteration):
+    except (TypeError, KeyError, ValueError, StopIteration):
         return {}
 
 
 def gemm_pmc_record():
     """The GEMM family's record of the newest committed PMC summary (profiles/rNN_mfma_pmc.json: FETCH_SIZE doubled per the
     gfx950 correction + WRITE_SIZE, separate --pmc passes), or None."""
-    for name in ("r04_mfma_pmc.json", "r03_mfma_pmc.json"):
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                rec = json.load(f)["gemm_family_total"]
-            rec["file"] = "profiles/" + name
-            return rec
-        except (OSError, KeyError, ValueError):
-            continue
-    return None
+    rec, src, cur = _pmc_load(("r05_mfma_pmc.json", "r04_mfma_pmc.json", "r03_mfma_pmc.json"))
+    try:
+        rec = dict(rec["gemm_family_total"])
+    except (TypeError, KeyError):
+        return None
+    rec["file"], rec["current"] = src, cur
+    return rec
 
 
 def traffic_ratio():
@@ -915,7 +931,7 @@ def traffic_ratio():
         return {}
     alg = rec["algorithmic_bytes_per_step_gemm_operands"] + rec.get("optimizer_bytes_in_weight_gradient_epilogues", 0)
     return {"traffic_algorithmic": alg / rec["launches_per_step"], "traffic_ratio": rec["hbm_side_bytes_per_step"] / alg,
-            "traffic_source": rec["file"]}
+            "traffic_source": rec["file"], "traffic_pmc_current": rec["current"]}
 
 
 def gemm_pmc_traffic():
