@@ -103,13 +103,6 @@ typedef struct skyemb_gemm_args {
                                    the epilogue.  One workspace per stream. */
     int64_t ws_bytes;
     int32_t split_k;            /* 0 = auto (1 when ws == NULL), 1 = off, n = force n-way */
-    float *colsum_parts;        /* optional (A must be RC, unsplit launches): the column sums of A as PARTIAL sums spread over the
-                                   tile columns -- colsum_parts[j * M + m] = sum of A(m, k) over the 64-wide k-tiles kt with
-                                   kt % tiles_n == j, j = 0 .. tiles_n - 1, tiles_n = ceil(N / tile columns); the caller adds the
-                                   tiles_n rows in order (skyemb_layernorm_bwd_reduce_batch does, with dbeta = NULL).  With
-                                   colsum_a alone the first tile column carries all of it: that column's tiles are the launch's
-                                   stragglers (one more matrix instruction per A fragment and k-step).  colsum_a is ignored when
-                                   this is set. */
 } skyemb_gemm_args;
 
 int skyemb_gemm(const skyemb_gemm_args *args, void *stream);
@@ -229,7 +222,7 @@ int skyemb_layernorm_bwd_blocks(int M);
  * dgamma / dbeta of many LayerNorms (e.g. all of one backward stage) in ONE launch; `items` is a DEVICE array. */
 typedef struct {
     const float *part;   /* [2, nblk, D] written by skyemb_layernorm_bwd */
-    float *dgamma, *dbeta;      /* dbeta == NULL: a single vector (part [nblk][D] -> dgamma), e.g. skyemb_gemm_args.colsum_parts */
+    float *dgamma, *dbeta;      /* dbeta == NULL: a single vector (part [nblk][D] -> dgamma) */
     int32_t nblk, D;
 } skyemb_ln_reduce_item;
 /* blocks: device int32 pairs {item index into `items`, x | y << 16}, one per workgroup: columns [32 x, +32) of half y (0 = dgamma,

@@ -319,7 +319,6 @@ extern "C" int skyemb_gemm(const skyemb_gemm_args *args, void *stream) {
     SKY_CHECK_ARG(g.act != SKYEMB_ACT_DGELU || g.aux, "skyemb_gemm: ACT_DGELU needs aux");
     SKY_CHECK_ARG(!g.table || g.tab_row, "skyemb_gemm: table without tab_row");
     SKY_CHECK_ARG(!g.colsum_a || g.a_layout == SKYEMB_RC, "skyemb_gemm: colsum_a needs an RC A operand");
-    SKY_CHECK_ARG(!g.colsum_parts, "skyemb_gemm: colsum_parts exists in grouped launches (skyemb_gemm_group_plan) only");
     hipStream_t st = (hipStream_t)stream;
     if (skyemb_skip_mask() & 1) return 0;
     static const bool use_pipe = []() { const char *e = getenv("SKYEMB_GEMM_PIPE"); return !(e && e[0] == '0'); }();

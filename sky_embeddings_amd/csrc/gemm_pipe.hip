@@ -314,13 +314,11 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
 
     // bias gradient = column sums of the RC A tile, taken by the waves of the first tile column with one extra MFMA
     // per A fragment against a fragment of ones (exact products, fp32 accumulation in k order)
-    // ... or, with colsum_parts, by EVERY tile column for the k-tiles kt % tiles_n == its index: partial sums the caller adds up.
-    // The first column alone made its tiles the stragglers of every weight-gradient launch (0.52 -> 0.44 us per k-step without
-    // the sums on the 64x64 tile, 0.66 -> 0.60 on 128x128: tools/ubench/gemm_lab, LAB_NOCOLSUM).
-    const bool cs_parts = !A_KC && S == 1 && g.colsum_parts != nullptr;
-    const bool do_colsum = !A_KC && wn == 0 && (cs_parts || (g.colsum_a != nullptr && tile_n == 0));
-    int cs_next = cs_parts ? tile_n : 0;                 // the next stage whose column sums this tile takes (every stage without parts)
-    const int cs_step = cs_parts ? (int)tiles_n : 1;
+    // (The first column's tiles are the stragglers of every weight-gradient launch: 0.52 -> 0.44 us per k-step without the sums on
+    // the 64x64 tile, 0.66 -> 0.60 on 128x128 -- tools/ubench/gemm_lab, LAB_NOCOLSUM.  Spreading the sums over all tile columns as
+    // partial sums was built in round 4 and returned nothing in the step -- the extra reduce items cost what was gained --
+    // and was removed in round 5: profiles/HISTORY.md, round 4 item 2.)
+    const bool do_colsum = !A_KC && wn == 0 && g.colsum_a != nullptr && tile_n == 0;
     f32x4 cacc[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) cacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -395,11 +393,10 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);  // D[n][m]
 #endif
-                if (!A_KC && do_colsum && kt == cs_next) {
+                if (!A_KC && do_colsum) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
                         cacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[kk][i], cacc[i], 0, 0, 0);
-                    if (kk == 1) cs_next += cs_step;
                 }
             }
         }
@@ -413,8 +410,7 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
     // through LDS (the ring is free now) and written in pieces of 8 consecutive columns per lane, consecutive lanes on
     // consecutive pieces of a row: every wave-instruction writes whole 128-byte lines.  The fused inputs (bias, table
     // rows, residual, dGELU operand) are read in the same lane order.
-    float *cs_out = cs_parts ? g.colsum_parts + (int64_t)tile_n * g.M
-                             : S > 1 ? (float *)g.ws + (int64_t)S * g.M * g.N + (int64_t)split * g.M : g.colsum_a;
+    float *cs_out = S > 1 ? (float *)g.ws + (int64_t)S * g.M * g.N + (int64_t)split * g.M : g.colsum_a;
     constexpr int PITCH = BN * 4 + 16;                   // bytes per tile row in LDS (+16: conflict-free b128 writes)
     float *cs_lds = (float *)(smem + BM * PITCH);        // (two k-groups) the odd k-tiles' column sums, BM floats behind the image
     // The fused inputs of this thread's pieces (8 consecutive columns of a row each) are requested HERE, all of them, before
@@ -978,7 +974,7 @@ int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
     // rest of the chip idles.  The row blocks that fill whole rounds go as one launch; the remaining rows as a second,
     // finely split launch (64x64 tiles, split-K) that is over in a fraction of a round.
     static const bool tail_on = []() { const char *e = getenv("SKYEMB_GEMM_TAIL"); return !(e && e[0] == '0'); }();
-    if (tile == 256256 && (g_in.split_k > 1 || !(gemm256_applicable(g) || (gemm256_wgrad_applicable(g) && !g.colsum_parts)))) {
+    if (tile == 256256 && (g_in.split_k > 1 || !(gemm256_applicable(g) || gemm256_wgrad_applicable(g)))) {
         skyemb_set_error("skyemb_gemm(256x256): the problem is outside this tile's subset (k-contiguous A, or a weight gradient of whole tiles; plain epilogue, K >= 128, no split-K)");
         return 1;
     }
@@ -1101,10 +1097,6 @@ extern "C" int skyemb_gemm_group_plan(const skyemb_gemm_args *args, int n, int t
             skyemb_set_error("skyemb_gemm_group_plan: problem %d is outside the pipelined bf16 subset", i);
             return -1;
         }
-        if (g.colsum_parts && g.a_layout != SKYEMB_RC) {
-            skyemb_set_error("skyemb_gemm_group_plan: problem %d: colsum_parts needs an RC A operand", i);
-            return -1;
-        }
         g.split_k = 1;
         g.tile = tile;
         out[i] = g;
@@ -1176,11 +1168,6 @@ extern "C" int skyemb_gemm_group_plan_side_adamw(const skyemb_gemm_args *args, i
         skyemb_set_error("skyemb_gemm_group_plan_side_adamw: weight-gradient (RC.RC) problems on the 64x64 / 128x64 / 128x128 / 256x256 tiles only");
         return -1;
     }
-    for (int i = 0; i < n && !own_step; ++i)
-        if (args[i].colsum_parts) {
-            skyemb_set_error("skyemb_gemm_group_plan_side_adamw: problem %d: colsum_parts is not built with a side job", i);
-            return -1;
-        }
     skyemb_adamw_desc d = *adamw;
     d.enabled = own_step ? 1 : 0;
     memcpy((char *)blob_host + GROUP_ADAMW_OFFSET, &d, sizeof d);

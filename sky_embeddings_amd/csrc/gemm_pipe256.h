@@ -55,7 +55,7 @@ __device__ __forceinline__ int lane_fresh() {
 
 // One 256 x 256 tile.  A_KC = false: the weight-gradient layout (both operands row-contiguous, contraction over token rows;
 // M, N multiples of 256).  ADAM: the tile is the gradient of a block of parameters in the flat buffers of `ad` and the epilogue is
-// their AdamW step (as in gemm_pipe_body); colsum_a / colsum_parts (row-contiguous A): the bias gradient, as there.
+// their AdamW step (as in gemm_pipe_body); colsum_a (row-contiguous A): the bias gradient, as there.
 template <bool A_KC, bool B_KC, bool ADAM>
 __device__ __forceinline__ void gemm256_tile(const skyemb_gemm_args &g, const unsigned int tile, const unsigned int ntiles, char *smem,
                                              const skyemb_adamw_desc *ad = nullptr, const bool linear = false) {
@@ -200,16 +200,13 @@ __device__ __forceinline__ void gemm256_tile(const skyemb_gemm_args &g, const un
         __builtin_amdgcn_s_setprio(0);
 #endif
     };
-    // Bias gradient (row-contiguous A only) = column sums of the A tile over k: waves of the first tile column (or, with
-    // colsum_parts, of every tile column for the k-tiles t % tiles_n == its index).  ONE accumulator collects the wave's eight
+    // Bias gradient (row-contiguous A only) = column sums of the A tile over k: waves of the first tile column.  ONE accumulator
+    // collects the wave's eight
     // 16-row blocks: block b's fragment is multiplied by an operand that is 1 in row b and 0 elsewhere, so D[b][m] += sum_k A[m][k]
     // (4 + 4 registers; a ones-operand per block, as in the ring kernels, would be eight accumulators = 32 registers this kernel
     // does not have).
     const int tile_n = n0 >> 8;
-    const bool cs_parts = !A_KC && g.colsum_parts != nullptr;
-    const bool do_colsum = !A_KC && (wc == 0) && (cs_parts || (g.colsum_a != nullptr && tile_n == 0));
-    const int cs_step = cs_parts ? (int)tiles_n : 1;
-    int cs_next = cs_parts ? tile_n : 0;                  // with partial sums: the first k-tile of this tile column
+    const bool do_colsum = !A_KC && (wc == 0) && g.colsum_a != nullptr && tile_n == 0;
     f32x4 cacc = (f32x4){0.f, 0.f, 0.f, 0.f};
     // one phase: READ part (fragments of this phase, two half-tiles requested, the counted wait in the last phase of a k-tile),
     // barrier, MFMA part, barrier
@@ -260,7 +257,7 @@ __device__ __forceinline__ void gemm256_tile(const skyemb_gemm_args &g, const un
         }
         mfma_half(q);
         if constexpr (!A_KC) {
-            if (do_colsum && t == cs_next) {
+            if (do_colsum) {
                 const int row = lane_fresh() & 15;
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
@@ -270,7 +267,6 @@ __device__ __forceinline__ void gemm256_tile(const skyemb_gemm_args &g, const un
 #pragma unroll
                     for (int kk = 0; kk < 2; ++kk) cacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel, fa[ii][kk], cacc, 0, 0, 0);
                 }
-                if constexpr (q == 1) cs_next += cs_step;
             }
         }
         G256_STAMP(2);
@@ -294,7 +290,7 @@ __device__ __forceinline__ void gemm256_tile(const skyemb_gemm_args &g, const un
     const int lane_e = lane_fresh(), tid = wave * 64 + lane_e;
     if constexpr (!A_KC) {
         if (do_colsum && lane_e < 32) {                   // D[b][m]: lane (m = lane & 15, rows 4 (lane >> 4) + r) -> blocks 0-3 / 4-7
-            float *cs_out = cs_parts ? g.colsum_parts + (int64_t)tile_n * g.M : g.colsum_a;
+            float *cs_out = g.colsum_a;
 #pragma unroll
             for (int r = 0; r < 4; ++r) cs_out[m0 + wr * 128 + (4 * (lane_e >> 4) + r) * 16 + (lane_e & 15)] = cacc[r];
         }
@@ -488,7 +484,7 @@ int gemm256_group_launch(const void *blob_dev, int total_blocks, hipStream_t st)
 
 // what the 256 x 256 kernel takes: k-contiguous A, no row maps / column sums / split-K, K a multiple of 64 with at least two k-tiles
 bool gemm256_applicable(const skyemb_gemm_args &g) {
-    return g.a_layout == SKYEMB_KC && !g.dst_row && !g.tab_row && !g.table && !g.colsum_a && !g.colsum_parts && g.split_k <= 1 &&
+    return g.a_layout == SKYEMB_KC && !g.dst_row && !g.tab_row && !g.table && !g.colsum_a && g.split_k <= 1 &&
            g.K % BK == 0 && g.K >= 2 * BK && g.M % 8 == 0 && g.M >= 8 && g.N % 8 == 0 && (g.b_layout == SKYEMB_KC || g.N % 128 == 0) &&
            g.lda * 2 * 8 < (1ll << 31) && g.ldb * 2 * 8 < (1ll << 31);
 }
@@ -549,7 +545,7 @@ int gemm256_wgrad_launch(const skyemb_gemm_args &g, hipStream_t st) {
 }
 
 int gemm256_launch(const skyemb_gemm_args &g, hipStream_t st) {
-    if (gemm256_wgrad_applicable(g) && !g.colsum_parts) return gemm256_wgrad_launch(g, st);
+    if (gemm256_wgrad_applicable(g)) return gemm256_wgrad_launch(g, st);
     if (!gemm256_applicable(g)) {
         skyemb_set_error("skyemb_gemm(256x256): the problem is outside this tile's subset (k-contiguous A, plain epilogue, K >= 128)");
         return 1;

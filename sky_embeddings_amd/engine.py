@@ -236,15 +236,13 @@ class MAEEngine:
             # the four weight-gradient GEMMs of a block as ONE grouped launch (ops.GemmGroup): together they fill the
             # chip, so none needs split-K slabs or a reduce launch.  bf16 path only; pointers are fixed from here on.
             w["splitk_ws"] = self._splitk_ws
-            w["wgrad_groups"], w["bias_parts"] = {}, {}
+            w["wgrad_groups"] = {}
             if self.dtype == torch.bfloat16:
                 for tag, blocks, M_, dim in (("blocks", w["enc"], Me, D), ("decoder_blocks", w["dec"], Md, Dd)):
                     for i, bufs in enumerate(blocks):
                         w["wgrad_groups"][f"{tag}.{i}"] = self._make_wgrad_group(f"{tag}.{i}", bufs, M_, dim, w)
             # LayerNorm dgamma/dbeta: every LN keeps its own partial sums; ONE batched launch per backward stage
-            # finishes them (42 reduce launches -> 3-6).  Table order = the order backward visits the LNs.  The same launch adds
-            # up the bias gradients of the grouped weight-gradient launches, which leave them as partial sums per tile column
-            # (skyemb_gemm_args.colsum_parts): four single-vector items per block, between its norm2 and norm1.
+            # finishes them (42 reduce launches -> 3-6).  Table order = the order backward visits the LNs.
             order = [("ln", "decoder_norm", Md, Dd)]
             for i in reversed(range(cfg.decoder_depth)):
                 order.append(("block", f"decoder_blocks.{i}", w["dec"][i], Md, Dd))
@@ -267,8 +265,7 @@ class MAEEngine:
     def _build_reduce_table(self, w, order):
         """Device table of the batched column reduces of backward (ops.layernorm_bwd_reduce_batch), in the order backward visits
         its entries: ("ln", name, M, D) = one LayerNorm's dgamma / dbeta partial sums; ("block", prefix, bufs, M, dim) = a
-        transformer block: norm2, the four bias gradients of its grouped weight-gradient launch (when that launch leaves them
-        as partial sums per tile column: w["bias_parts"]), norm1."""
+        transformer block: norm2, then norm1."""
         f32 = dict(device=self.device, dtype=torch.float32)
         entries = []
         w["ln_index"], w["ln_parts"] = {}, {}
@@ -285,10 +282,6 @@ class MAEEngine:
                 continue
             _, prefix, bufs, M_, dim = item
             ln(f"{prefix}.norm2", M_, dim)
-            if prefix in w["bias_parts"]:
-                w["ln_index"][prefix + ".bias"] = len(entries)
-                for (dy, x_in, lname, n_out, k_in), part in zip(self._wgrad_layers(prefix, bufs, M_, dim, w), w["bias_parts"][prefix][1]):
-                    entries.append((part, self.store.grad(f"{lname}.bias"), None, part.shape[0], n_out))
             ln(f"{prefix}.norm1", M_, dim)
         w["ln_items"] = ops.ln_reduce_items(entries, self.device)
 
@@ -513,40 +506,12 @@ class MAEEngine:
             return dict(out=g16[o:o + n_out * k_in].view(n_out, k_in))
         layers = self._wgrad_layers(prefix, bufs, M, dim, w)
         import os
-
-        def build(tile, parts):
-            args = [ops.gemm_args(dy, x_in, M=n_out, N=k_in, K=M, a_layout=RC, b_layout=RC, lda=n_out, ldb=k_in,
-                                  colsum_a=None if parts else st.grad(f"{name}.bias"), colsum_parts=parts[j] if parts else None,
-                                  **dst(name, n_out, k_in))
-                    for j, (dy, x_in, name, n_out, k_in) in enumerate(layers)]
-            return ops.GemmGroup(args, self.device, tile=tile, adamw=adamw, side=side)
-        if prefix not in w["bias_parts"] and adamw is None and g16 is None:
-            # the plain group is planned first: its tile shape fixes how many tile columns share a bias gradient's partial sums
-            # (experiments: SKYEMB_WGRAD_TILE_ENC / _DEC force the grouped launch's tile code for one stack; SKYEMB_BIAS_PARTS=0
-            # keeps the column sums on the first tile column, as before round 4)
-            tile = int(os.environ.get("SKYEMB_WGRAD_TILE_DEC" if prefix.startswith("decoder") else "SKYEMB_WGRAD_TILE_ENC", "0"))
-            probe = build(tile, None)
-            if not probe.ok:
-                return None
-            # measured at config A (round 4): the 128x128 groups of the encoder gain 2.3 us per launch, the 128x64 groups of the
-            # decoder nothing, and every group adds four items to its stage's batched reduce -- "auto" uses the partial sums on
-            # the 128x128 tile only
-            # Measured at config A (round 4, interleaved A/B of the whole step): OFF wins by 0.004-0.02 ms.  The 128x128 groups of
-            # the encoder do gain 2.3 us per launch (755 -> 727 us per step), the 128x64 groups of the decoder nothing, and the
-            # four extra items per block in the stage's batched reduce cost what was gained.  Kept behind the switch ("1": every
-            # group, "auto": 128x128 tiles only) for shapes where the first tile column is a larger share of the launch.
-            mode = os.environ.get("SKYEMB_BIAS_PARTS", "0")
-            if mode == "0" or (mode == "auto" and probe.info.tile % 1000000 != 128128):
-                return probe
-            bn = probe.info.tile % 1000
-            w["bias_parts"][prefix] = (probe.info.tile, [torch.empty((k_in + bn - 1) // bn, n_out, device=self.device, dtype=torch.float32)
-                                                       for _, _, _, n_out, k_in in layers])
-        if prefix in w["bias_parts"]:
-            tile, parts = w["bias_parts"][prefix]
-            grp = build(tile, parts)
-        else:
-            tile = int(os.environ.get("SKYEMB_WGRAD_TILE_DEC" if prefix.startswith("decoder") else "SKYEMB_WGRAD_TILE_ENC", "0"))
-            grp = build(tile, None)
+        # (experiments: SKYEMB_WGRAD_TILE_ENC / _DEC force the grouped launch's tile code for one stack)
+        tile = int(os.environ.get("SKYEMB_WGRAD_TILE_DEC" if prefix.startswith("decoder") else "SKYEMB_WGRAD_TILE_ENC", "0"))
+        args = [ops.gemm_args(dy, x_in, M=n_out, N=k_in, K=M, a_layout=RC, b_layout=RC, lda=n_out, ldb=k_in,
+                              colsum_a=st.grad(f"{name}.bias"), **dst(name, n_out, k_in))
+                for dy, x_in, name, n_out, k_in in layers]
+        grp = ops.GemmGroup(args, self.device, tile=tile, adamw=adamw, side=side)
         return grp if grp.ok else None
 
     # -- optimiser step fused into the weight-gradient launches (one process per replica: TrainStep(fused_adamw=True)) --
@@ -709,10 +674,6 @@ class MAEEngine:
         self._linear_bwd(dqkv, bufs["ln1"], f"{prefix}.attn.qkv.weight", f"{prefix}.attn.qkv.bias", M, 3 * dim, dim, w,
                          dx_out=dln, wgrad=single)
         prev_done = self._group_done
-        if group is not None and prefix in w["bias_parts"]:
-            # the launch leaves the four bias gradients as partial sums: their items of the stage's batched reduce come next
-            assert w["ln_index"][prefix + ".bias"] == self._ln_first + self._ln_count, "bias-gradient items out of table order"
-            self._ln_count += 4
         if group is not None:
             # all four dW / db of the block in ONE launch.  With the side stream it runs under the next block's dgrad
             # chain (a bandwidth-bound launch next to a chain of latency-bound ones); its four dy live in this block's

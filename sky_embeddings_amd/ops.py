@@ -37,7 +37,7 @@ def _p(t):
 
 def gemm_args(A, B, *, M, N, K, a_layout=KC, b_layout=KC, lda=None, ldb=None, alpha=1.0, bias=None, table=None,
               tab_row=None, ldt=0, dst_row=None, resid=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, out_f32=None, ldo32=0,
-              out=None, ldo=0, out2=None, ldo2=0, tile=0, colsum_a=None, ws=None, split_k=0, colsum_parts=None):
+              out=None, ldo=0, out2=None, ldo2=0, tile=0, colsum_a=None, ws=None, split_k=0):
     """skyemb_gemm_args for C[M,N] = alpha * A[M,K] B[N,K]^T with fused epilogue (see include/skyemb.h)."""
     g = GemmArgs()
     g.A, g.B = _p(A), _p(B)
@@ -53,7 +53,6 @@ def gemm_args(A, B, *, M, N, K, a_layout=KC, b_layout=KC, lda=None, ldb=None, al
     g.out_f32, g.ldo32, g.out, g.ldo, g.out2, g.ldo2 = _p(out_f32), ldo32 or N, _p(out), ldo or N, _p(out2), ldo2 or N
     g.tile = tile
     g.colsum_a = _p(colsum_a)
-    g.colsum_parts = _p(colsum_parts)
     g.ws, g.ws_bytes, g.split_k = _p(ws), (ws.numel() * ws.element_size() if ws is not None else 0), split_k
     return g
 

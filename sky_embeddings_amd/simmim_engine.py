@@ -121,7 +121,7 @@ class SimMIMEngine(MAEEngine):
             w["pmv_part"] = torch.empty(B, pv, **f32)
             w["rs_part"] = torch.empty(256, D, **f32)
             w["splitk_ws"] = self._splitk_ws
-            w["wgrad_groups"], w["bias_parts"] = {}, {}
+            w["wgrad_groups"] = {}
             if self.dtype == torch.bfloat16:
                 for i, bufs in enumerate(w["enc"]):
                     w["wgrad_groups"][f"blocks.{i}"] = self._make_wgrad_group(f"blocks.{i}", bufs, M, D, w)

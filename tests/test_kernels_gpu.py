@@ -282,7 +282,7 @@ def test_layernorm_bwd_batched_reduce(ops):
             outs.append((part, dgam, dbet, nblk, D))
         direct.append(outs[0])
         entries.append(outs[1])
-    # a single-vector item of another width (the bias-gradient partial sums of a grouped weight-gradient launch): [nblk, D] -> [D]
+    # a single-vector item of another width (dbeta = NULL: any [nblk, D] stack of partial rows -> [D])
     parts = dev(torch.randn(6, 3072, generator=g))
     vec = torch.full((3072,), float("nan"), device=DEV)
     entries.append((parts, vec, None, 6, 3072))
@@ -299,41 +299,9 @@ def test_layernorm_bwd_batched_reduce(ops):
     assert torch.equal(vec, ref)
 
 
-def test_grouped_wgrad_bias_partial_sums(ops):
-    """skyemb_gemm_args.colsum_parts: the column sums of dy spread over the tile columns of a grouped weight-gradient launch,
-    added up afterwards == colsum_a of the same launch (same products; fp32 sums in another order) == torch."""
-    g = torch.Generator().manual_seed(11)
-    T, n_out, k_in = 1280, 768, 512                      # tokens, dW [n_out, k_in]
-    dy = dev(torch.randn(T, n_out, generator=g), torch.bfloat16)
-    x = dev(torch.randn(T, k_in, generator=g), torch.bfloat16)
-    from sky_embeddings_amd._lib import RC
-    outs = {}
-    for mode in ("first_column", "parts"):
-        dW = torch.empty(n_out, k_in, device=DEV)
-        db = torch.full((n_out,), float("nan"), device=DEV)
-        probe = ops.GemmGroup([ops.gemm_args(dy, x, M=n_out, N=k_in, K=T, a_layout=RC, b_layout=RC, lda=n_out, ldb=k_in, out_f32=dW, colsum_a=db)], DEV)
-        assert probe.ok
-        if mode == "first_column":
-            probe.launch()
-        else:
-            bn = probe.info.tile % 1000
-            parts = torch.full(((k_in + bn - 1) // bn, n_out), float("nan"), device=DEV)
-            grp = ops.GemmGroup([ops.gemm_args(dy, x, M=n_out, N=k_in, K=T, a_layout=RC, b_layout=RC, lda=n_out, ldb=k_in, out_f32=dW,
-                                               colsum_parts=parts)], DEV, tile=probe.info.tile)
-            assert grp.ok
-            grp.launch()
-            assert not bool(torch.isnan(parts).any())
-            table = ops.ln_reduce_items([(parts, db, None, parts.shape[0], n_out)], DEV)
-            ops.layernorm_bwd_reduce_batch(table, 0, 1)
-        outs[mode] = (dW, db)
-    assert torch.equal(outs["parts"][0], outs["first_column"][0])
-    ref = dy.float().sum(0)
-    assert relerr(outs["first_column"][1], ref) < 1e-5 and relerr(outs["parts"][1], ref) < 1e-5
-
-
 def test_grouped_wgrad_256_tile(ops):
     """The 256 x 256 weight-gradient tile (both operands row-contiguous; csrc/gemm_pipe256.h) in a grouped launch: gradients and
-    bias gradients (first tile column / partial sums) against torch and against the 128 x 128 tile; with the optimiser step in its
+    bias gradients against torch and against the 128 x 128 tile; with the optimiser step in its
     epilogue against the separate AdamW launch on the same gradient."""
     from sky_embeddings_amd._lib import RC, AdamwDesc
     g = torch.Generator().manual_seed(23)
@@ -345,14 +313,12 @@ def test_grouped_wgrad_256_tile(ops):
     offs = [0, sizes[0]]
     n = sum(sizes)
 
-    def problems(flat, dbs=None, parts=None):
+    def problems(flat, dbs=None):
         out = []
         for j, (o, i) in enumerate(shapes):
             kw = {}
             if dbs is not None:
                 kw["colsum_a"] = dbs[j]
-            if parts is not None:
-                kw["colsum_parts"] = parts[j]
             out.append(ops.gemm_args(dys[j], xs[j], M=o, N=i, K=T, a_layout=RC, b_layout=RC, lda=o, ldb=i,
                                      out_f32=flat[offs[j]:offs[j] + sizes[j]].view(o, i), **kw))
         return out
@@ -371,16 +337,6 @@ def test_grouped_wgrad_256_tile(ops):
         assert relerr(got, ref) < 2e-6
         assert relerr(got, res[128128][0][offs[j]:offs[j] + sizes[j]].view(o, i)) < 2e-6
         assert relerr(res[256256][1][j], dys[j].float().sum(0)) < 1e-5
-    # bias gradients as partial sums over the tile columns
-    flat2 = torch.full((n,), float("nan"), device=DEV)
-    parts = [torch.full((i // 256, o), float("nan"), device=DEV) for o, i in shapes]
-    grp = ops.GemmGroup(problems(flat2, parts=parts), DEV, tile=256256)
-    assert grp.ok
-    grp.launch()
-    assert torch.equal(flat2, res[256256][0])
-    for j in range(2):
-        assert not bool(torch.isnan(parts[j]).any())
-        assert relerr(parts[j].sum(0), dys[j].float().sum(0)) < 1e-5
     # optimiser step in the epilogue
     step, lr, wd, n_decay = 3, 1e-3, 0.05, sizes[0] + 1000
     p0, m0, v0 = torch.randn(n, generator=g), torch.randn(n, generator=g) * 0.01, torch.rand(n, generator=g) * 0.01

@@ -246,6 +246,44 @@ def test_mim19_vit_large_width_against_oracle():
         torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("policy", ["auto", "0"])
+def test_vit_large_width_optimiser_in_the_weight_gradient_launches_equals_the_separate_launch(policy):
+    """ViT-L width (1024 columns, B = 128: 8320 token rows, depth 3): three TrainStep steps with the AdamW step of the blocks' weights
+    carried by the 256 x 256 grouped weight-gradient launches -- policy "auto": as SIDE JOBS of the following block's launch (192
+    tiles for 256 compute units leave a quarter of the device free), the last launch stepping its own tiles in its epilogue;
+    policy "0": every launch in its own epilogue -- against the schedule with the separate AdamW launch: parameters, both moments
+    and the bf16 shadow bit for bit."""
+    from sky_embeddings_amd.model_config import config_for
+    from sky_embeddings_amd.optim import CosineLR, FusedAdamW
+    from sky_embeddings_amd.simmim_engine import SimMIMEngine
+    from sky_embeddings_amd.train_step import TrainStep
+    cfg = config_for("simmim", img_size=128, patch_size=16, in_chans=5, embed_dim=1024, depth=3, num_heads=16, norm_pix_loss=True, loss_fn="L1")
+    B = 128
+    x, m, _ = _mim19_batch(cfg, B, seed=31)
+    out = []
+    for fused in (False, True):
+        eng = SimMIMEngine(cfg, device="cuda", compute_dtype=torch.bfloat16, seed=0)
+        opt = FusedAdamW(eng, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
+        step = TrainStep(eng, opt, CosineLR(opt, 1000), B, fused_adamw=fused, adamw_side=policy)
+        assert step.fused_adamw == fused
+        losses = [float(step(x.cuda(), m.cuda())) for _ in range(3)]
+        torch.cuda.synchronize()
+        if fused:
+            w = eng._ws[(B, cfg.num_patches, True)]
+            assert all(g.info.tile == 256256 for g in w["wgrad_groups_adamw"].values())
+            assert w["adamw_side_launches"] == (cfg.depth - 1 if policy == "auto" else 0)
+            # launch order blocks.2, blocks.1, blocks.0; info.reserved: bit 0 = own tiles stepped in the epilogue, bit 1 = side-job form
+            assert list(w["wgrad_groups_adamw"]) == ["blocks.2", "blocks.1", "blocks.0"]
+            assert [g.info.reserved for g in w["wgrad_groups_adamw"].values()] == ([2, 2, 3] if policy == "auto" else [1, 1, 1])
+        st = eng.store
+        out.append((losses, st.p.clone(), st.m.clone(), st.v.clone(), st.p_lp.clone()))
+        del step, opt, eng
+        torch.cuda.empty_cache()
+    assert out[0][0] == out[1][0]
+    for k in range(1, 5):
+        assert torch.equal(out[0][k], out[1][k]), k
+
+
 def test_simmim_bf16_gradient_mirror_written_by_the_weight_gradient_launches(monkeypatch):
     """SimMIM mode of the data-parallel schedule with bf16 gradient communication (mim_19 geometry at a narrow width, 64 x 65 token
     rows so that the grouped launches apply): bf16 gradients written straight into the mirror == fp32 gradients + cast, bit for bit."""
