@@ -67,7 +67,7 @@ if g and all("mfma_busy_cycles_per_step" in v for v in g):
                                 "expected_busy_cycles_from_flops": round(1.3356e12 / 16384 * 16)}
     # HBM-side traffic of the family (the GEMM launches + the split-K reduce launches that finish them) against its algorithmic bytes:
     # every operand and output once (4.653 GB per step at config A, B = 256: tools/gemm_bench.py shapes) + the optimiser state the fused
-    # weight-gradient epilogues move (26 B for each of the 110.1 M block-weight parameters)
+    # weight-gradient launches move (round 5: 26 B per parameter in the epilogue form, 34 B as side jobs: 3.04 GB per step at config A)
     fam = [v for k, v in res["families"].items() if k.startswith("gemm") or k == "splitk_reduce"]
     if all("hbm_side_read_bytes_per_step" in v and "hbm_side_write_bytes_per_step" in v for v in fam):
         tot = sum(v["hbm_side_read_bytes_per_step"] + v["hbm_side_write_bytes_per_step"] for v in fam)
@@ -75,10 +75,11 @@ if g and all("mfma_busy_cycles_per_step" in v for v in g):
         res["gemm_family_total"].update({"hbm_side_bytes_per_step": tot, "launches_per_step": launches,
                                          "hbm_side_bytes_per_launch": round(tot / launches),
                                          "algorithmic_bytes_per_step_gemm_operands": 4653449216,
-                                         "optimizer_bytes_in_weight_gradient_epilogues": 2862612480,
+                                         "optimizer_bytes_in_weight_gradient_epilogues": 3038773248,
                                          "note": "tools/pmc_step.py runs TrainStep(use_graph=False): with one process the AdamW step of the transformer blocks' weights "
-                                                 "(110.1 M of 112.3 M parameters) runs in the grouped weight-gradient launches: 26 B per parameter of optimiser traffic "
-                                                 "is inside this family's bytes (and no gradient store)"})
+                                                 "(110.1 M of 112.3 M parameters) runs in the grouped weight-gradient launches: 26 B per parameter in the epilogue form (the "
+                                                 "encoder's twelve blocks and decoder block 0), 34 B per parameter as side jobs (decoder blocks 7..1: gradient stored and read "
+                                                 "back) -- inside this family's bytes"})
         if "adamw" in res["families"] and "hbm_side_read_bytes_per_step" in res["families"]["adamw"]:
             a = res["families"]["adamw"]
             res["gemm_family_total"]["adamw_rest"] = {"measured_bytes": a["hbm_side_read_bytes_per_step"] + a["hbm_side_write_bytes_per_step"]}
