@@ -157,6 +157,22 @@ int skyemb_gemm_group_plan_adamw(const skyemb_gemm_args *args, int n, int tile, 
 int skyemb_gemm_group_plan_side_adamw(const skyemb_gemm_args *args, int n, int tile, const skyemb_adamw_desc *adamw, int own_step,
                                       int64_t side_lo, int64_t side_hi, int side_blocks, void *blob_host, int64_t blob_bytes,
                                       skyemb_gemm_group_info *info);
+/* A LayerNorm backward as a SIDE JOB of a planned grouped weight-gradient launch (round 5): the backward of a transformer block's
+ * norm1 (timm Block: x + attn(norm1(x)); utils/mim_vit.py:231-233 through autograd) depends on the block's qkv data gradient only,
+ * not on its weight gradients -- so instead of a launch of its own behind the grouped launch, its rows are taken by extra workgroups
+ * inside it (bf16 compute dtype; same rows per four-wave block, same partial-sum table and same bits as skyemb_layernorm_bwd with
+ * dgamma = dbeta = NULL: the caller reduces `part` as before).  Call AFTER skyemb_gemm_group_plan / _plan_adamw / _plan_side_adamw
+ * on the same host blob (weight-gradient groups only); grows info->total_blocks and sets bit 1 of info->reserved.  D <= 1024 on 256 x 256 tiles, <= 768 on the ring tiles. */
+typedef struct skyemb_ln_bwd_side {
+    const void *dy;             /* [M, D] bf16: d loss / d (LayerNorm output) */
+    const float *x, *gamma, *mean, *rstd;
+    const float *g_in;          /* fp32 residual gradient added to the result (may equal g_out), or NULL */
+    float *g_out;               /* [M, D] fp32 */
+    void *g_lp;                 /* [M, D] bf16 copy of g_out, or NULL */
+    float *part;                /* [2, skyemb_layernorm_bwd_blocks(M), D] */
+    int32_t M, D;
+} skyemb_ln_bwd_side;
+int skyemb_gemm_group_attach_ln_bwd(void *blob_host, int64_t blob_bytes, skyemb_gemm_group_info *info, const skyemb_ln_bwd_side *ln);
 
 /* column sums: out[n] = sum_m X[m,n]; X is `dtype` (bias gradients) or fp32 partials
  * (LayerNorm dgamma/dbeta second stage).  Replaces autograd's bias-gradient reductions. */

@@ -51,6 +51,12 @@ class AdamwDesc(ctypes.Structure):
                 ("beta1", c_f32), ("beta2", c_f32), ("eps", c_f32), ("weight_decay", c_f32), ("grad_scale", c_f32), ("enabled", c_i32)]
 
 
+class LnBwdSide(ctypes.Structure):
+    """skyemb_ln_bwd_side (include/skyemb.h): a LayerNorm backward riding in a grouped weight-gradient launch."""
+    _fields_ = [("dy", c_vp), ("x", c_vp), ("gamma", c_vp), ("mean", c_vp), ("rstd", c_vp), ("g_in", c_vp), ("g_out", c_vp), ("g_lp", c_vp),
+                ("part", c_vp), ("M", c_i32), ("D", c_i32)]
+
+
 class GemmGroupInfo(ctypes.Structure):
     _fields_ = [("total_blocks", c_i32), ("tile", c_i32), ("class_mask", c_i32), ("reserved", c_i32)]
 
@@ -69,6 +75,7 @@ PROTOTYPES = {
                                              ctypes.POINTER(GemmGroupInfo)]),
     "skyemb_gemm_group_plan_side_adamw": (c_i32, [ctypes.POINTER(GemmArgs), c_i32, c_i32, ctypes.POINTER(AdamwDesc), c_i32, c_i64, c_i64, c_i32,
                                                   c_vp, c_i64, ctypes.POINTER(GemmGroupInfo)]),
+    "skyemb_gemm_group_attach_ln_bwd": (c_i32, [c_vp, c_i64, ctypes.POINTER(GemmGroupInfo), ctypes.POINTER(LnBwdSide)]),
     "skyemb_gemm_group_launch": (c_i32, [c_vp, ctypes.POINTER(GemmGroupInfo), c_vp]),
     "skyemb_colsum": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "skyemb_random_mask_from_noise": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),

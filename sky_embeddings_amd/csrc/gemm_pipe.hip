@@ -13,6 +13,7 @@
 // consecutive output COLUMNS of one row: 16-byte fp32 / 8-byte bf16 stores, float4 bias loads.
 #include "common.h"
 #include "adamw_math.h"
+#include "ln_bwd_body.h"
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
@@ -692,15 +693,59 @@ __device__ __forceinline__ void side_adamw_job(const char *__restrict__ blob, co
     }
 }
 
+// The other side job (skyemb_gemm_group_attach_ln_bwd): a LayerNorm backward whose rows do not depend on this launch's tiles -- the
+// block's norm1, which needs the qkv data gradient only -- taken by side workgroups (header word 41 = their count, word 42 = byte
+// offset of the skyemb_ln_bwd_side record in the blob; they come before the optimiser's).  A workgroup of W waves is W / 4 blocks of
+// the stand-alone kernel's partial-sum table (ln_bwd_body.h): same rows, same sums, same bits.
+constexpr int GROUP_LN_COUNT_WORD = 41, GROUP_LN_OFFSET_WORD = 42;
+__host__ __device__ inline int sky_ln_bwd_blocks(int M) {   // == skyemb_layernorm_bwd_blocks (layernorm.hip)
+    int nb = (M + 3) / 4;
+    if (nb < 1) nb = 1;
+    const int rounds = (nb + 575) / 576;
+    return (nb + rounds - 1) / rounds;
+}
+// MAXNV = widest row in 256-column units the instance carries: 4 (D <= 1024) in the 256 x 256 kernel, whose waves own 236 registers
+// anyway; 3 (D <= 768) in the ring-tile kernels -- a row of 1024 held in registers took them from 110 to 168 registers and the
+// 128 x 128 tile from two workgroups per CU to one.
+template <int THREADS, int MAXNV>
+__device__ __forceinline__ void side_ln_bwd_job(const char *__restrict__ blob, const int wg, char *smem) {
+    static_assert(THREADS % 256 == 0, "LayerNorm side workgroups are whole blocks of four waves");
+    const skyemb_ln_bwd_side ln = *(const skyemb_ln_bwd_side *)(blob + ((const int *)blob)[GROUP_LN_OFFSET_WORD]);
+    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    const int nblk = sky_ln_bwd_blocks(ln.M);
+    const int blk = wg * (THREADS / 256) + (wave >> 2);
+    float *red = (float *)smem + (wave >> 2) * 1024;
+    // gamma once into LDS behind the reduce slots (read from there row by row: ln_bwd_body.h, GAMMA_LDS)
+    float *gam_lds = (float *)smem + (THREADS / 256) * 1024;
+    for (int c = (int)threadIdx.x; c < ln.D; c += THREADS) gam_lds[c] = ln.gamma[c];
+    __syncthreads();
+    const bf16_t *dy = (const bf16_t *)ln.dy;
+    bf16_t *g_lp = (bf16_t *)ln.g_lp;
+    switch ((ln.D + 255) / 256) {                           // (workgroup-uniform)
+        case 1: return sky_ln_bwd_rows<bf16_t, bf16_t, 1, true>(dy, ln.x, ln.gamma, ln.mean, ln.rstd, ln.g_in, ln.g_out, g_lp, ln.part, ln.M, ln.D, nblk, blk, wave & 3, lane, red, gam_lds);
+        case 2: return sky_ln_bwd_rows<bf16_t, bf16_t, 2, true>(dy, ln.x, ln.gamma, ln.mean, ln.rstd, ln.g_in, ln.g_out, g_lp, ln.part, ln.M, ln.D, nblk, blk, wave & 3, lane, red, gam_lds);
+        case 3: return sky_ln_bwd_rows<bf16_t, bf16_t, 3, true>(dy, ln.x, ln.gamma, ln.mean, ln.rstd, ln.g_in, ln.g_out, g_lp, ln.part, ln.M, ln.D, nblk, blk, wave & 3, lane, red, gam_lds);
+        default:
+            if constexpr (MAXNV >= 4)
+                return sky_ln_bwd_rows<bf16_t, bf16_t, 4, true>(dy, ln.x, ln.gamma, ln.mean, ln.rstd, ln.g_in, ln.g_out, g_lp, ln.part, ln.M, ln.D, nblk, blk, wave & 3, lane, red, gam_lds);
+    }
+}
+// which side job a workgroup behind the tiles runs: LayerNorm rows first, then the optimiser's slice
+template <int THREADS, int U, int MAXNV>
+__device__ __forceinline__ void side_job(const char *__restrict__ blob, char *smem) {
+    const int *hdr = (const int *)blob;
+    int s = (int)blockIdx.x - hdr[2];
+    __builtin_amdgcn_s_setprio(0);
+    const int n_ln = hdr[GROUP_LN_COUNT_WORD];
+    if (s < n_ln) return side_ln_bwd_job<THREADS, MAXNV>(blob, s, smem);
+    return side_adamw_job<THREADS, U>(blob, s - n_ln, hdr[3]);
+}
+
 template <int BM, int BN, int NSTAGE, int WM, int WN, int CLASSES, int WK = 1, bool ADAM = false, bool SIDE = false>
 __global__ __launch_bounds__(WM * WN * WK * 64) void gemm_pipe_group_kernel(const char *__restrict__ blob) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if constexpr (SIDE) {
-        const int side_first = ((const int *)blob)[2];
-        if ((int)blockIdx.x >= side_first) {
-            __builtin_amdgcn_s_setprio(0);
-            return side_adamw_job<WM * WN * WK * 64, 2>(blob, (int)blockIdx.x - side_first, ((const int *)blob)[3]);
-        }
+        if ((int)blockIdx.x >= ((const int *)blob)[2]) return side_job<WM * WN * WK * 64, 2, 3>(blob, smem);
     }
     // the tile prefix of every problem in one scalar request (the walk `while (blockIdx.x >= hdr[9 + p]) ++p` was one dependent
     // scalar load per problem in front of every workgroup's first operand load); unused slots hold 0 and never match
@@ -1026,7 +1071,10 @@ int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
 }
 
 // ---- grouped launch (see gemm_pipe_group_kernel) -------------------------------------------------------
-extern "C" int64_t skyemb_gemm_group_blob_bytes(int n) { return GROUP_HEADER_BYTES + (int64_t)n * sizeof(skyemb_gemm_args); }
+// [header 256 B][n problems][skyemb_ln_bwd_side, 128 B reserved]
+constexpr int GROUP_TAIL_BYTES = 128;
+static_assert(sizeof(skyemb_ln_bwd_side) <= GROUP_TAIL_BYTES, "the blob's tail holds the LayerNorm side job's record");
+extern "C" int64_t skyemb_gemm_group_blob_bytes(int n) { return GROUP_HEADER_BYTES + (int64_t)n * sizeof(skyemb_gemm_args) + GROUP_TAIL_BYTES; }
 
 static int class_bit(const skyemb_gemm_args &g) {
     const bool a = g.a_layout == SKYEMB_KC, b = g.b_layout == SKYEMB_KC;
@@ -1179,6 +1227,36 @@ extern "C" int skyemb_gemm_group_plan_side_adamw(const skyemb_gemm_args *args, i
     info->total_blocks += side_blocks;
     hdr[1] = (hdr[1] & (1 << 30)) | info->total_blocks;
     info->reserved = (own_step ? 1 : 0) | 2;
+    return 0;
+}
+
+extern "C" int skyemb_gemm_group_attach_ln_bwd(void *blob_host, int64_t blob_bytes, skyemb_gemm_group_info *info, const skyemb_ln_bwd_side *ln) {
+    SKY_CHECK_ARG(blob_host && info && ln && info->total_blocks > 0, "skyemb_gemm_group_attach_ln_bwd: bad arguments");
+    int *hdr = (int *)blob_host;
+    const int n = hdr[0];
+    SKY_CHECK_ARG(n >= 1 && n <= GROUP_MAX && blob_bytes >= skyemb_gemm_group_blob_bytes(n), "skyemb_gemm_group_attach_ln_bwd: not a planned blob");
+    SKY_CHECK_ARG(hdr[GROUP_LN_COUNT_WORD] == 0, "skyemb_gemm_group_attach_ln_bwd: the launch already carries a LayerNorm");
+    if (info->class_mask != 4 || !(info->tile == 64064 || info->tile == 128064 || info->tile == 128128 || info->tile == 256256)) {
+        skyemb_set_error("skyemb_gemm_group_attach_ln_bwd: weight-gradient (RC.RC) groups on the 64x64 / 128x64 / 128x128 / 256x256 tiles only");
+        return -1;
+    }
+    SKY_CHECK_ARG(ln->dy && ln->x && ln->gamma && ln->mean && ln->rstd && ln->g_out && ln->part && ln->M > 0 && ln->D > 0 && ln->D % 4 == 0 &&
+                      ln->D <= (info->tile == 256256 ? 1024 : 768) && aligned16(ln->dy) && aligned16(ln->x) && aligned16(ln->gamma) && aligned16(ln->g_out) && aligned16(ln->g_in) &&
+                      aligned16(ln->g_lp) && aligned16(ln->part),
+                  "skyemb_gemm_group_attach_ln_bwd: bad LayerNorm record (M=%d D=%d; D <= 1024 on 256 x 256 tiles, <= 768 on the others; 16-byte aligned rows)", ln->M, ln->D);
+    const int per_wg = info->tile == 64064 ? 1 : 2;          // four-wave blocks of the partial-sum table per side workgroup (256 / 512 threads)
+    const int n_ln = (sky_ln_bwd_blocks(ln->M) + per_wg - 1) / per_wg;
+    const int off = GROUP_HEADER_BYTES + n * (int)sizeof(skyemb_gemm_args);
+    memcpy((char *)blob_host + off, ln, sizeof *ln);
+    if (!(info->reserved & 2)) {                             // a launch without an optimiser side job: the side workgroups start behind its tiles
+        hdr[2] = info->total_blocks;
+        hdr[3] = 0;
+    }
+    hdr[GROUP_LN_COUNT_WORD] = n_ln;
+    hdr[GROUP_LN_OFFSET_WORD] = off;
+    info->total_blocks += n_ln;
+    hdr[1] = (hdr[1] & (1 << 30)) | info->total_blocks;
+    info->reserved |= 2;
     return 0;
 }
 

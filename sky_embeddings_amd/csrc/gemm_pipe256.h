@@ -424,10 +424,7 @@ __global__ __launch_bounds__(512) void gemm256_group_kernel(const char *__restri
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int *hdr = (const int *)blob;
     if constexpr (SIDE) {
-        if ((int)blockIdx.x >= hdr[2]) {
-            __builtin_amdgcn_s_setprio(0);
-            return side_adamw_job<512, 4>(blob, (int)blockIdx.x - hdr[2], hdr[3]);
-        }
+        if ((int)blockIdx.x >= hdr[2]) return side_job<512, 4, 4>(blob, smem);
     }
     const int n = hdr[0];
     // Tile order across the GROUP (round 5; header word 1 bit 30 = on): workgroup b runs on XCD b & 7, and XCD x takes the x-th

@@ -1,6 +1,7 @@
 // LayerNorm forward / backward (fp32 statistics, wavefront-shuffle reductions).
 // One 64-lane wave per token row; a row of D <= 2048 floats lives in registers as float4s.
 #include "common.h"
+#include "ln_bwd_body.h"
 
 namespace {
 
@@ -65,89 +66,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD *__restrict__ dy, 
                                                      const float *__restrict__ rstd, const float *g_in, float *g_out,
                                                      T *__restrict__ g_lp, float *__restrict__ part, int M, int D,
                                                      int nblk) {
-    __shared__ float red[4][64 * 4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nv = D >> 2;
-    float4 dgam[NV], dbet[NV], gam[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        dgam[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        dbet[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int c = lane + i * 64;
-        gam[i] = *(const float4 *)(gamma + 4 * (c < nv ? c : nv - 1));      // (columns past the row are never used)
-    }
-    const float *gsrc = g_in ? g_in : x;                      // (no incoming gradient: a harmless second read of x, selected away)
-    for (int row = blockIdx.x * 4 + wave; row < M; row += nblk * 4) {
-        const float mu = mean[row], rs = rstd[row];
-        float4 xh[NV], dyv[NV], gi[NV];
-        float s1 = 0.f, s2 = 0.f;
-        // the row of x, of dy and of the incoming residual gradient: all requested together, unconditionally, at clamped columns
-        // (loads under `if (c < nv)` were waited for one by one: 3 NV dependent memory round trips per row)
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = lane + i * 64, cc = c < nv ? c : nv - 1;
-            xh[i] = *(const float4 *)(x + (int64_t)row * D + 4 * cc);
-            dyv[i] = load4<TD>(dy + (int64_t)row * D + 4 * cc);
-            gi[i] = *(const float4 *)(gsrc + (int64_t)row * D + 4 * cc);
-        }
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = lane + i * 64;
-            if (c < nv) {
-                const float4 xv = xh[i];
-                if (!g_in) gi[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-                const float a0 = dyv[i].x * gam[i].x, a1 = dyv[i].y * gam[i].y, a2 = dyv[i].z * gam[i].z,
-                            a3 = dyv[i].w * gam[i].w;
-                s1 += (a0 + a1) + (a2 + a3);
-                s2 += (a0 * xh[i].x + a1 * xh[i].y) + (a2 * xh[i].z + a3 * xh[i].w);
-                dgam[i].x += dyv[i].x * xh[i].x; dgam[i].y += dyv[i].y * xh[i].y;
-                dgam[i].z += dyv[i].z * xh[i].z; dgam[i].w += dyv[i].w * xh[i].w;
-                dbet[i].x += dyv[i].x; dbet[i].y += dyv[i].y; dbet[i].z += dyv[i].z; dbet[i].w += dyv[i].w;
-            }
-        }
-        const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = lane + i * 64;
-            if (c < nv) {
-                float4 o;
-                o.x = rs * (dyv[i].x * gam[i].x - m1 - xh[i].x * m2);
-                o.y = rs * (dyv[i].y * gam[i].y - m1 - xh[i].y * m2);
-                o.z = rs * (dyv[i].z * gam[i].z - m1 - xh[i].z * m2);
-                o.w = rs * (dyv[i].w * gam[i].w - m1 - xh[i].w * m2);
-                const int64_t off = (int64_t)row * D + 4 * c;
-                if (g_in) {
-                    o.x += gi[i].x; o.y += gi[i].y; o.z += gi[i].z; o.w += gi[i].w;
-                }
-                *(float4 *)(g_out + off) = o;
-                if (g_lp) store4<T>(g_lp + off, o.x, o.y, o.z, o.w);
-            }
-        }
-    }
-    // reduce the 4 waves' column partials through LDS, one float4 slot at a time
-    float *pg = part + (int64_t)blockIdx.x * D;
-    float *pb = part + (int64_t)nblk * D + (int64_t)blockIdx.x * D;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = lane + i * 64;
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            const float4 val = pass == 0 ? dgam[i] : dbet[i];
-            __syncthreads();
-            *(float4 *)&red[wave][lane * 4] = val;
-            __syncthreads();
-            if (wave == 0 && c < nv) {
-                float4 a = *(float4 *)&red[0][lane * 4];
-#pragma unroll
-                for (int w = 1; w < 4; ++w) {
-                    const float4 b = *(float4 *)&red[w][lane * 4];
-                    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-                }
-                *(float4 *)((pass == 0 ? pg : pb) + 4 * c) = a;
-            }
-        }
-    }
+    __shared__ float red[4 * 256];
+    // (the rows and the partial sums: ln_bwd_body.h -- shared with the side job of the grouped weight-gradient launches)
+    sky_ln_bwd_rows<TD, T, NV>(dy, x, gamma, mean, rstd, g_in, g_out, g_lp, part, M, D, nblk, (int)blockIdx.x, (int)(threadIdx.x >> 6),
+                               (int)(threadIdx.x & 63), red);
 }
 
 // second stage: out[which][d] = sum_b part[which][b][d]; block = 32 columns x 32 row groups, grid = (D/32, 2)

@@ -233,14 +233,6 @@ class MAEEngine:
             w["datt"] = torch.empty(Mx * Dx, **lp)
             w["dh"] = torch.empty(Hx, **lp)
             w["dqkv"] = torch.empty(3 * Mx * Dx, **lp)
-            # the four weight-gradient GEMMs of a block as ONE grouped launch (ops.GemmGroup): together they fill the
-            # chip, so none needs split-K slabs or a reduce launch.  bf16 path only; pointers are fixed from here on.
-            w["splitk_ws"] = self._splitk_ws
-            w["wgrad_groups"] = {}
-            if self.dtype == torch.bfloat16:
-                for tag, blocks, M_, dim in (("blocks", w["enc"], Me, D), ("decoder_blocks", w["dec"], Md, Dd)):
-                    for i, bufs in enumerate(blocks):
-                        w["wgrad_groups"][f"{tag}.{i}"] = self._make_wgrad_group(f"{tag}.{i}", bufs, M_, dim, w)
             # LayerNorm dgamma/dbeta: every LN keeps its own partial sums; ONE batched launch per backward stage
             # finishes them (42 reduce launches -> 3-6).  Table order = the order backward visits the LNs.
             order = [("ln", "decoder_norm", Md, Dd)]
@@ -250,6 +242,15 @@ class MAEEngine:
             for i in reversed(range(cfg.depth)):
                 order.append(("block", f"blocks.{i}", w["enc"][i], Me, D))
             self._build_reduce_table(w, order)
+            # the four weight-gradient GEMMs of a block as ONE grouped launch (ops.GemmGroup): together they fill the
+            # chip, so none needs split-K slabs or a reduce launch.  bf16 path only; pointers are fixed from here on.
+            # (the block's norm1 backward rides in the same launch as a side job: _make_wgrad_group)
+            w["splitk_ws"] = self._splitk_ws
+            w["wgrad_groups"] = {}
+            if self.dtype == torch.bfloat16:
+                for tag, blocks, M_, dim in (("blocks", w["enc"], Me, D), ("decoder_blocks", w["dec"], Md, Dd)):
+                    for i, bufs in enumerate(blocks):
+                        w["wgrad_groups"][f"{tag}.{i}"] = self._make_wgrad_group(f"{tag}.{i}", bufs, M_, dim, w)
             w["dE"] = torch.empty(Me, Dd, **lp)
             w["dT"] = torch.empty(B * keep, D, **lp)
             w["drows"] = torch.empty(B * keep, pv, **f32)
@@ -511,8 +512,28 @@ class MAEEngine:
         args = [ops.gemm_args(dy, x_in, M=n_out, N=k_in, K=M, a_layout=RC, b_layout=RC, lda=n_out, ldb=k_in,
                               colsum_a=st.grad(f"{name}.bias"), **dst(name, n_out, k_in))
                 for dy, x_in, name, n_out, k_in in layers]
-        grp = ops.GemmGroup(args, self.device, tile=tile, adamw=adamw, side=side)
+        grp = ops.GemmGroup(args, self.device, tile=tile, adamw=adamw, side=side, ln_bwd=self._norm1_side_record(prefix, bufs, M, dim, w))
         return grp if grp.ok else None
+
+    def _block_input(self, prefix, w):
+        """fp32 residual stream a block reads (saved by the training forward)."""
+        tag, i = prefix.rsplit(".", 1)
+        return (w["xs"] if tag == "blocks" else w["xd"])[int(i)]
+
+    def _norm1_side_record(self, prefix, bufs, M, dim, w):
+        """The backward of the block's norm1 as a side job of its grouped weight-gradient launch (skyemb_gemm_group_attach_ln_bwd):
+        it needs the qkv data gradient (in w['dln'] by then) and the residual gradient, not the weight gradients -- as a launch
+        of its own it sat BEHIND the grouped launch, 7-11 us at ViT-B and 29 us at ViT-L per block on the step's critical path.
+        Same buffers _block_bwd would hand ops.layernorm_bwd; None when the schedule cannot take it (weight gradients on a side
+        stream: the next block would read the residual gradient before this launch is done; SKYEMB_LN_SIDE=0)."""
+        import os
+        if self._side is not None or os.environ.get("SKYEMB_LN_SIDE", "1") == "0" or "ln_parts" not in w:
+            return None
+        s = self._bwd_set(prefix)
+        g = w["g"][:M * dim].view(M, dim)
+        return dict(dy=w["dln"][:M * dim].view(M, dim), x=self._block_input(prefix, w), gamma=self.store.param(f"{prefix}.norm1.weight"),
+                    mean=bufs["mean1"], rstd=bufs["rstd1"], g_in=g, g_out=g, g_lp=self._scratch(w, "g_lp", s ^ 1, M * dim).view(M, dim),
+                    part=w["ln_parts"][f"{prefix}.norm1"], M=M, D=dim)
 
     # -- optimiser step fused into the weight-gradient launches (one process per replica: TrainStep(fused_adamw=True)) --
     def enable_fused_adamw(self, optimizer, on=True, side=None):
@@ -596,14 +617,15 @@ class MAEEngine:
             mode = getattr(self, "_adamw_side", "0")
             ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
             for k in range(1, len(order)):
-                info = w["wgrad_groups"][order[k]].info
+                grp0 = w["wgrad_groups"][order[k]]
+                info = grp0.info
                 # "auto": the carrying launch must leave a quarter of the device's workgroup slots free (slots per compute unit
                 # follow from the tile's LDS ring: one 256 x 256, two 128 x 128 / 128 x 64, three 64 x 64).  Measured (bench.py
                 # extra.optimizer_placement): ViT-L, 192 tiles of 256 x 256 on 256 units: 26.5 -> 25.5 ms per step; ViT-B decoder,
                 # 384 tiles of 128 x 64 on 512 slots: 5.24 -> 5.21; ViT-B encoder, 440 of 512: side jobs LOSE (5.24 -> 5.47 with
                 # every launch carrying one: they start when the tiles end, and move 34 instead of 26 bytes per parameter)
                 slots = ncu * {256256: 1, 128128: 2, 9128128: 1, 128064: 2, 64064: 3}.get(info.tile, 1)
-                carry[k] = (mode == "1" or (mode == "auto" and info.total_blocks <= 0.76 * slots) or
+                carry[k] = (mode == "1" or (mode == "auto" and grp0.tile_blocks <= 0.76 * slots) or
                             (mode == "dec" and order[k].startswith("decoder_blocks")) or (mode == "enc" and order[k].startswith("blocks")))
         w["adamw_side_launches"] = sum(carry)
         for k, prefix in enumerate(order):
@@ -690,7 +712,13 @@ class MAEEngine:
                     self._group_done.record()
         if prev_done is not None:
             torch.cuda.current_stream().wait_event(prev_done)   # the previous block's launch still reads g_lp_next
-        self._ln_bwd(dln, x_in, f"{prefix}.norm1", bufs["mean1"], bufs["rstd1"], g, g, g_lp_next, M, dim, w)
+        if group is not None and group.ln_side:
+            # norm1's backward rode in the grouped launch (side workgroups): only the stage's reduce table moves on
+            assert w["ln_index"][f"{prefix}.norm1"] == self._ln_first + self._ln_count, "LayerNorm backward visited out of table order"
+            assert x_in.data_ptr() == self._block_input(prefix, w).data_ptr()
+            self._ln_count += 1
+        else:
+            self._ln_bwd(dln, x_in, f"{prefix}.norm1", bufs["mean1"], bufs["rstd1"], g, g, g_lp_next, M, dim, w)
 
     def _last_key(self):
         """Workspace key of the last forward_train() call."""

@@ -11,7 +11,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ACT_DGELU, ACT_GELU, ACT_NONE, BF16, F32, KC, RC, AdamwDesc, GemmArgs, GemmGroupInfo, check, lib
+from ._lib import ACT_DGELU, ACT_GELU, ACT_NONE, BF16, F32, KC, RC, AdamwDesc, GemmArgs, GemmGroupInfo, LnBwdSide, check, lib
 
 TORCH_DTYPE = {BF16: torch.bfloat16, F32: torch.float32}
 
@@ -69,11 +69,14 @@ class GemmGroup:
     structs -- the device blob holds the raw pointers, so the operand buffers must stay allocated -- and replayed with
     launch().  `ok` is False when a problem is outside the grouped subset (launch them singly)."""
 
-    def __init__(self, args, device, tile=0, adamw=None, side=None):
+    def __init__(self, args, device, tile=0, adamw=None, side=None, ln_bwd=None):
         """adamw: an _lib.AdamwDesc -- the optimiser step fused into the launch's epilogue (weight-gradient groups of a
         single-process run: skyemb_gemm_group_plan_adamw).  side = (own_step, lo, hi, blocks) with adamw: the step of the flat
         slice [lo, hi) rides in the launch as a side job of `blocks` extra workgroups (skyemb_gemm_group_plan_side_adamw);
-        own_step: the launch's own tiles are stepped in their epilogue too, else stored as gradients."""
+        own_step: the launch's own tiles are stepped in their epilogue too, else stored as gradients.  ln_bwd = dict(dy, x, gamma,
+        mean, rstd, g_in, g_out, g_lp, part, M, D): a LayerNorm backward that does not depend on the launch's tiles (a block's
+        norm1) rides in it as a side job instead of a launch of its own (skyemb_gemm_group_attach_ln_bwd); `ln_side` says whether
+        the plan took it (else the caller launches ops.layernorm_bwd as before)."""
         n = len(args)
         arr = (GemmArgs * n)(*args)
         nbytes = lib().skyemb_gemm_group_blob_bytes(n)
@@ -90,6 +93,18 @@ class GemmGroup:
         self.ok = rc == 0
         if rc > 0:
             check(rc, "skyemb_gemm_group_plan")
+        # workgroups that compute TILES (the grid also holds the side jobs' workgroups)
+        self.tile_blocks = self.info.total_blocks - (int(side[3]) if side is not None else 0)
+        self.ln_side = False
+        if self.ok and ln_bwd is not None and ln_bwd["dy"].dtype == torch.bfloat16:
+            rec = LnBwdSide()
+            for k in ("dy", "x", "gamma", "mean", "rstd", "g_in", "g_out", "g_lp", "part"):
+                setattr(rec, k, _p(ln_bwd[k]))
+            rec.M, rec.D = ln_bwd["M"], ln_bwd["D"]
+            rc2 = lib().skyemb_gemm_group_attach_ln_bwd(host.data_ptr(), nbytes, ctypes.byref(self.info), ctypes.byref(rec))
+            if rc2 > 0:
+                check(rc2, "skyemb_gemm_group_attach_ln_bwd")
+            self.ln_side = rc2 == 0
         self.total_blocks = self.info.total_blocks
         self.blob = host.to(device) if self.ok else None
 

@@ -121,14 +121,14 @@ class SimMIMEngine(MAEEngine):
             w["pmv_part"] = torch.empty(B, pv, **f32)
             w["rs_part"] = torch.empty(256, D, **f32)
             w["splitk_ws"] = self._splitk_ws
-            w["wgrad_groups"] = {}
-            if self.dtype == torch.bfloat16:
-                for i, bufs in enumerate(w["enc"]):
-                    w["wgrad_groups"][f"blocks.{i}"] = self._make_wgrad_group(f"blocks.{i}", bufs, M, D, w)
             order = [("ln", "norm", R, D)] + ([("ln", "attn_pool.norm", B, D)] if pool else [])
             for i in reversed(range(cfg.depth)):
                 order.append(("block", f"blocks.{i}", w["enc"][i], M, D))
             self._build_reduce_table(w, order)
+            w["wgrad_groups"] = {}            # (built after the reduce table: every group carries its block's norm1 backward)
+            if self.dtype == torch.bfloat16:
+                for i, bufs in enumerate(w["enc"]):
+                    w["wgrad_groups"][f"blocks.{i}"] = self._make_wgrad_group(f"blocks.{i}", bufs, M, D, w)
         if train and getattr(self, "_fused_adamw", None) is not None and w.get("wgrad_groups"):
             self._build_adamw_groups(w)
         if train and getattr(self, "_g16", None) is not None and w.get("wgrad_groups"):
