@@ -231,6 +231,35 @@ def test_bf16_gradient_mirror_written_by_the_weight_gradient_launches(monkeypatc
         assert torch.equal(r[1], results[0][1]) and torch.equal(r[2], results[0][2])
 
 
+@pytest.mark.parametrize("size", ["tiny", "base"])
+def test_norm1_backward_inside_the_weight_gradient_launch_equals_its_own_launch(size, monkeypatch):
+    """Every block's norm1 backward rides in the block's grouped weight-gradient launch as side workgroups
+    (skyemb_gemm_group_attach_ln_bwd; SKYEMB_LN_SIDE=0 keeps it a launch of its own): same rows per four-wave block, same
+    partial-sum table -- every gradient of the step bit for bit, ViT-B/16 at B = 256 (768- and 512-wide rows) and the tiny model."""
+    from sky_embeddings_amd.engine import MAEEngine
+    from sky_embeddings_amd.model_config import config_for
+    cfg = (config_for("base", img_size=64, patch_size=16, in_chans=5, embed_dim=768, norm_pix_loss=True, loss_fn="mse") if size == "base"
+           else config_for("tiny", img_size=64, patch_size=16, in_chans=5, embed_dim=192))
+    B = 256 if size == "base" else 64
+    g = torch.Generator().manual_seed(3)
+    imgs = torch.randn(B, 5, 64, 64, generator=g).clamp_(min=-3).cuda()
+    noise = torch.rand(B, 16, generator=g).cuda()
+    out = []
+    for side in ("1", "0"):
+        monkeypatch.setenv("SKYEMB_LN_SIDE", side)
+        eng = MAEEngine(cfg, compute_dtype=torch.bfloat16, seed=0)
+        loss, _, _ = eng.forward_train(imgs, 0.75, noise)
+        eng.backward()
+        torch.cuda.synchronize()
+        w = eng._ws[(B, 4, True)]
+        carried = [grp.ln_side for grp in w["wgrad_groups"].values() if grp is not None]
+        assert len(carried) == cfg.depth + cfg.decoder_depth and all(c == (side == "1") for c in carried), carried
+        out.append((float(loss), eng.store.g.clone()))
+        del eng
+        torch.cuda.empty_cache()
+    assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1])
+
+
 @pytest.mark.parametrize("side", [False, True])
 def test_fused_adamw_step_at_the_benchmark_size(side):
     """The same bit-equality at BASELINE configs[1] (ViT-B/16, B = 256): the 128x128 (encoder) and 128x64 (decoder) grouped
