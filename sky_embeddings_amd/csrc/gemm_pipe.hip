@@ -1241,9 +1241,13 @@ extern "C" int skyemb_gemm_group_attach_ln_bwd(void *blob_host, int64_t blob_byt
         return -1;
     }
     SKY_CHECK_ARG(ln->dy && ln->x && ln->gamma && ln->mean && ln->rstd && ln->g_out && ln->part && ln->M > 0 && ln->D > 0 && ln->D % 4 == 0 &&
-                      ln->D <= (info->tile == 256256 ? 1024 : 768) && aligned16(ln->dy) && aligned16(ln->x) && aligned16(ln->gamma) && aligned16(ln->g_out) && aligned16(ln->g_in) &&
-                      aligned16(ln->g_lp) && aligned16(ln->part),
-                  "skyemb_gemm_group_attach_ln_bwd: bad LayerNorm record (M=%d D=%d; D <= 1024 on 256 x 256 tiles, <= 768 on the others; 16-byte aligned rows)", ln->M, ln->D);
+                      aligned16(ln->dy) && aligned16(ln->x) && aligned16(ln->gamma) && aligned16(ln->g_out) && aligned16(ln->g_in) && aligned16(ln->g_lp) &&
+                      aligned16(ln->part),
+                  "skyemb_gemm_group_attach_ln_bwd: bad LayerNorm record (M=%d D=%d; 16-byte aligned rows)", ln->M, ln->D);
+    if (ln->D > (info->tile == 256256 ? 1024 : 768)) {       // (not an error: the caller launches skyemb_layernorm_bwd itself)
+        skyemb_set_error("skyemb_gemm_group_attach_ln_bwd: rows of %d columns are wider than this tile's instance carries (1024 on 256 x 256 tiles, 768 on the others)", ln->D);
+        return -1;
+    }
     const int per_wg = info->tile == 64064 ? 1 : 2;          // four-wave blocks of the partial-sum table per side workgroup (256 / 512 threads)
     const int n_ln = (sky_ln_bwd_blocks(ln->M) + per_wg - 1) / per_wg;
     const int off = GROUP_HEADER_BYTES + n * (int)sizeof(skyemb_gemm_args);

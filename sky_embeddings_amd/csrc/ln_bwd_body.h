@@ -15,6 +15,10 @@ __device__ __forceinline__ void sky_ln_bwd_rows(const TD *__restrict__ dy, const
                                                 float *g_out, T *__restrict__ g_lp, float *__restrict__ part, const int M, const int D,
                                                 const int nblk, const int blk, const int wave, const int lane, float *red,
                                                 const float *gam_lds = nullptr) {
+    // every rounding pinned (no compiler contraction of a * b + c into an fma): the stand-alone kernel and the side job are two
+    // instantiations of this text with different surroundings, and hipcc's default -ffp-contract=fast fused them differently at
+    // D = 192 (gradients apart in the last bit); with contraction off both are the same sequence of multiplies and adds
+#pragma clang fp contract(off)
     const int nv = D >> 2;
     float4 dgam[NV], dbet[NV], gam_r[GAMMA_LDS ? 1 : NV];
 #pragma unroll

@@ -299,6 +299,47 @@ def test_layernorm_bwd_batched_reduce(ops):
     assert torch.equal(vec, ref)
 
 
+@pytest.mark.parametrize("shape", [(320, 192, 192, 768, 0), (1088, 512, 512, 2048, 0), (1280, 768, 768, 3072, 0), (4352, 512, 2048, 512, 128064),
+                                   (1280, 768, 3072, 768, 128128), (2112, 1024, 1024, 1024, 256256), (333, 192, 768, 192, 0)])
+def test_layernorm_backward_as_a_side_job_of_a_grouped_launch(ops, shape):
+    """skyemb_gemm_group_attach_ln_bwd: a LayerNorm backward riding in a grouped weight-gradient launch as side workgroups (a
+    block's norm1: it does not depend on the launch's tiles) == skyemb_layernorm_bwd as its own launch, bit for bit -- residual
+    gradient, its bf16 copy and the dgamma / dbeta partial-sum table -- on every tile shape that carries it (64 x 64: one
+    four-wave block per side workgroup; 128 x 64 / 128 x 128 / 256 x 256: two), rows from 192 to 1024 wide, a row count that is
+    not a multiple of the block size; the weight gradient of the same launch is unaffected."""
+    from sky_embeddings_amd._lib import BF16, RC
+    M, D, n_out, k_in, tile = shape
+    g = torch.Generator().manual_seed(M + D)
+    x = dev(torch.randn(M, D, generator=g))
+    dy = dev(torch.randn(M, D, generator=g), torch.bfloat16)
+    gam = dev(1 + 0.1 * torch.randn(D, generator=g))
+    g_in = dev(torch.randn(M, D, generator=g))
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    ops.layernorm_fwd(x, gam, dev(torch.zeros(D)), torch.empty(M, D, device=DEV, dtype=torch.bfloat16), mean, rstd, M, D, 1e-6)
+    nb = ops.layernorm_bwd_blocks(M)
+    go_a, glp_a, part_a = g_in.clone(), torch.empty(M, D, device=DEV, dtype=torch.bfloat16), torch.full((2, nb, D), float("nan"), device=DEV)
+    ops.layernorm_bwd(dy, x, gam, mean, rstd, go_a, go_a, glp_a, part_a, None, None, M, D, BF16)
+    T = (M + 63) // 64 * 64                                   # token rows of the weight gradient (a multiple of the k-tile)
+    dyw = dev(torch.randn(T, n_out, generator=g), torch.bfloat16)
+    xw = dev(torch.randn(T, k_in, generator=g), torch.bfloat16)
+    dW, db = torch.empty(n_out, k_in, device=DEV), torch.empty(n_out, device=DEV)
+    go_b, glp_b, part_b = g_in.clone(), torch.empty(M, D, device=DEV, dtype=torch.bfloat16), torch.full((2, nb, D), float("nan"), device=DEV)
+    grp = ops.GemmGroup([ops.gemm_args(dyw, xw, M=n_out, N=k_in, K=T, a_layout=RC, b_layout=RC, lda=n_out, ldb=k_in, out_f32=dW, colsum_a=db)], DEV,
+                        tile=tile, ln_bwd=dict(dy=dy, x=x, gamma=gam, mean=mean, rstd=rstd, g_in=go_b, g_out=go_b, g_lp=glp_b, part=part_b, M=M, D=D))
+    assert grp.ok and grp.ln_side and (tile == 0 or grp.info.tile == tile) and grp.total_blocks > grp.tile_blocks
+    grp.launch()
+    torch.cuda.synchronize()
+    assert torch.equal(go_a, go_b) and torch.equal(glp_a, glp_b) and torch.equal(part_a, part_b)
+    assert relerr(dW, dyw.float().t() @ xw.float()) < 2e-6 and relerr(db, dyw.float().sum(0)) < 1e-5
+    # wider rows than the instance carries are declined by the plan, not mis-served: the caller launches the LayerNorm itself
+    if grp.info.tile != 256256:
+        wide = dict(dy=torch.empty(8, 1024, device=DEV, dtype=torch.bfloat16), x=torch.empty(8, 1024, device=DEV), gamma=torch.empty(1024, device=DEV),
+                    mean=mean, rstd=rstd, g_in=None, g_out=torch.empty(8, 1024, device=DEV), g_lp=None, part=torch.empty(2, 2, 1024, device=DEV), M=8, D=1024)
+        g2 = ops.GemmGroup([ops.gemm_args(dyw, xw, M=n_out, N=k_in, K=T, a_layout=RC, b_layout=RC, lda=n_out, ldb=k_in, out_f32=dW, colsum_a=db)], DEV,
+                           tile=grp.info.tile, ln_bwd=wide)
+        assert g2.ok and not g2.ln_side and g2.total_blocks == g2.tile_blocks
+
+
 def test_grouped_wgrad_256_tile(ops):
     """The 256 x 256 weight-gradient tile (both operands row-contiguous; csrc/gemm_pipe256.h) in a grouped launch: gradients and
     bias gradients against torch and against the 128 x 128 tile; with the optimiser step in its
