@@ -242,6 +242,7 @@ class MAEEngine:
             for i in reversed(range(cfg.depth)):
                 order.append(("block", f"blocks.{i}", w["enc"][i], Me, D))
             self._build_reduce_table(w, order)
+            w["dE"] = torch.empty(Me, Dd, **lp)
             # the four weight-gradient GEMMs of a block as ONE grouped launch (ops.GemmGroup): together they fill the
             # chip, so none needs split-K slabs or a reduce launch.  bf16 path only; pointers are fixed from here on.
             # (the block's norm1 backward rides in the same launch as a side job: _make_wgrad_group)
@@ -251,7 +252,6 @@ class MAEEngine:
                 for tag, blocks, M_, dim in (("blocks", w["enc"], Me, D), ("decoder_blocks", w["dec"], Md, Dd)):
                     for i, bufs in enumerate(blocks):
                         w["wgrad_groups"][f"{tag}.{i}"] = self._make_wgrad_group(f"{tag}.{i}", bufs, M_, dim, w)
-            w["dE"] = torch.empty(Me, Dd, **lp)
             w["dT"] = torch.empty(B * keep, D, **lp)
             w["drows"] = torch.empty(B * keep, pv, **f32)
             w["pmv_part"] = torch.empty(B, pv, **f32)
@@ -505,7 +505,7 @@ class MAEEngine:
                 return dict(out_f32=st.grad(f"{name}.weight"))
             o = st.offsets[f"{name}.weight"]
             return dict(out=g16[o:o + n_out * k_in].view(n_out, k_in))
-        layers = self._wgrad_layers(prefix, bufs, M, dim, w)
+        layers = self._wgrad_layers(prefix, bufs, M, dim, w) + self._extra_wgrad_layers(prefix, M, w)
         import os
         # (experiments: SKYEMB_WGRAD_TILE_ENC / _DEC force the grouped launch's tile code for one stack)
         tile = int(os.environ.get("SKYEMB_WGRAD_TILE_DEC" if prefix.startswith("decoder") else "SKYEMB_WGRAD_TILE_ENC", "0"))
@@ -513,7 +513,27 @@ class MAEEngine:
                               colsum_a=st.grad(f"{name}.bias"), **dst(name, n_out, k_in))
                 for dy, x_in, name, n_out, k_in in layers]
         grp = ops.GemmGroup(args, self.device, tile=tile, adamw=adamw, side=side, ln_bwd=self._norm1_side_record(prefix, bufs, M, dim, w))
+        if grp.ok:
+            grp.extra_layers = [name for _, _, name, _, _ in layers[4:]]
+            if adamw is None and g16 is None:                 # (the plain group is planned first: it decides what the call sites skip)
+                w.setdefault("folded_wgrads", set()).update(grp.extra_layers)
         return grp if grp.ok else None
+
+    def _extra_wgrad_layers(self, prefix, M, w):
+        """Single weight gradients that nothing in backward waits for, folded into a block's grouped launch as further problems
+        (same token rows = same contraction length; round 5): `decoder_pred` into the first decoder block's launch, `decoder_embed`
+        into the first encoder block's.  As launches of their own (a split-K GEMM + its reduce each) they were 25 and 14 us of the
+        step's dependent chain.  -> [(dy, x_in, layer name, n_out, k_in)]; the names are recorded in w['folded_wgrads']."""
+        import os
+        if os.environ.get("SKYEMB_FOLD_WGRADS", "1") == "0" or self._side is not None or "dpred" not in w:
+            return []
+        cfg = self.cfg
+        out = []
+        if prefix == f"decoder_blocks.{cfg.decoder_depth - 1}" and w["dpred"].shape[0] == M:
+            out.append((w["dpred"], w["dlat_lp"], "decoder_pred", cfg.patch_dim, cfg.decoder_embed_dim))
+        if prefix == f"blocks.{cfg.depth - 1}" and "dE" in w and w["dE"].shape[0] == M:
+            out.append((w["dE"], w["lat_lp"], "decoder_embed", cfg.decoder_embed_dim, cfg.embed_dim))
+        return out
 
     def _block_input(self, prefix, w):
         """fp32 residual stream a block reads (saved by the training forward)."""
@@ -651,6 +671,12 @@ class MAEEngine:
             for name in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2"):
                 o = st.offsets[f"{prefix}.{name}.weight"]
                 spans.append((o, o + _pad8(int(np.prod(st.shapes[f"{prefix}.{name}.weight"])))))
+            # folded single weight gradients: written to the mirror / stepped in the epilogue with the launch's own tiles; where the
+            # launch only STORES gradients they stay with the ordinary AdamW launch like every tensor outside the blocks
+            if kind != "adamw" or not stores:
+                for name in getattr(grp, "extra_layers", []):
+                    o = st.offsets[f"{name}.weight"]
+                    spans.append((o, o + _pad8(int(np.prod(st.shapes[f"{name}.weight"])))))
         spans.sort()
         merged = []
         for s_, e_ in spans:
@@ -740,7 +766,9 @@ class MAEEngine:
         Me, Md = B * Ne, B * Nd
         self._ln_first = self._ln_count = 0
         dln = w["dln"][:Md * Dd].view(Md, Dd)
-        self._linear_bwd(w["dpred"], w["dlat_lp"], "decoder_pred.weight", "decoder_pred.bias", Md, pv, Dd, w, dx_out=dln)
+        # (decoder_pred's weight gradient rides in the first decoder block's grouped launch when that launch exists: _extra_wgrad_layers)
+        self._linear_bwd(w["dpred"], w["dlat_lp"], "decoder_pred.weight", "decoder_pred.bias", Md, pv, Dd, w, dx_out=dln,
+                         wgrad="decoder_pred" not in w.get("folded_wgrads", ()))
         g = w["g"][:Md * Dd].view(Md, Dd)
         g_lp = w["g_lp"][:Md * Dd].view(Md, Dd)
         self._ln_bwd(dln, w["xd"][-1], "decoder_norm", w["dlat_mean"], w["dlat_rstd"], None, g, g_lp, Md, Dd, w)
@@ -751,7 +779,8 @@ class MAEEngine:
         ops.rowsum_select(g, Dd, w["mask"], cfg.num_extra_tokens, L, Nd, B * L, Dd, w["rs_part"], st.grad("mask_token").view(Dd))
         ops.gather_rows(g, w["dec_dst"], None, w["dE"], Me, Dd)
         dln_e = w["dln"][:Me * D].view(Me, D)
-        self._linear_bwd(w["dE"], w["lat_lp"], "decoder_embed.weight", "decoder_embed.bias", Me, Dd, D, w, dx_out=dln_e)
+        self._linear_bwd(w["dE"], w["lat_lp"], "decoder_embed.weight", "decoder_embed.bias", Me, Dd, D, w, dx_out=dln_e,
+                         wgrad="decoder_embed" not in w.get("folded_wgrads", ()))     # (... in the first encoder block's)
         self._end_stage(w)
 
     def backward_encoder(self, hi=None, lo=0):

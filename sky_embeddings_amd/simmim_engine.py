@@ -241,6 +241,17 @@ class SimMIMEngine(MAEEngine):
         imgs, B, L, mask = self._last
         return imgs, B, mask, self._ws[(B, L, True)]
 
+    def _extra_wgrad_layers(self, prefix, M, w):
+        """The pixel head's weight gradient (Conv2d 1x1 = a linear over the token rows, utils/mim_vit.py:244-249) as a fifth problem
+        of the last block's grouped weight-gradient launch -- the first grouped launch of backward, same token rows (engine.py
+        _extra_wgrad_layers).  Not with the pooled head: its rows are the images, not the tokens."""
+        import os
+        cfg = self.cfg
+        if (os.environ.get("SKYEMB_FOLD_WGRADS", "1") == "0" or self._side is not None or cfg.attn_pool or "dpred" not in w
+                or prefix != f"blocks.{cfg.depth - 1}" or w["dpred"].shape[0] != M):
+            return []
+        return [(w["dpred"], w["lat_lp"], "decoder.0", w["dpred"].shape[1], cfg.embed_dim)]
+
     def backward_decoder(self):
         """Stage 0: the head (decoder.0) and the final norm; leaves d(block output) in g / g_lp."""
         imgs, B, mask, w = self._ctx()
@@ -254,7 +265,8 @@ class SimMIMEngine(MAEEngine):
             self._end_stage(w)
             return
         dln = w["dln"][:M * D].view(M, D)
-        self._linear_bwd(w["dpred"], w["lat_lp"], "decoder.0.weight", "decoder.0.bias", M, pv, D, w, dx_out=dln)
+        self._linear_bwd(w["dpred"], w["lat_lp"], "decoder.0.weight", "decoder.0.bias", M, pv, D, w, dx_out=dln,
+                         wgrad="decoder.0" not in w.get("folded_wgrads", ()))
         self._ln_bwd(dln, w["xs"][cfg.depth], "norm", w["lat_mean"], w["lat_rstd"], None, g, g_lp, M, D, w)
         self._end_stage(w)
 

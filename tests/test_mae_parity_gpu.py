@@ -260,6 +260,40 @@ def test_norm1_backward_inside_the_weight_gradient_launch_equals_its_own_launch(
     assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1])
 
 
+@pytest.mark.parametrize("size", ["tiny", "base"])
+def test_single_weight_gradients_folded_into_the_grouped_launches(size, monkeypatch):
+    """decoder_pred's and decoder_embed's weight gradients ride as fifth problems in the first decoder / encoder block's grouped
+    launch (engine._extra_wgrad_layers; SKYEMB_FOLD_WGRADS=0 keeps their own split-K launches).  The two forms add the same fp32
+    products in a different order: those four tensors agree to 2e-6 of their norm, every other gradient bit for bit."""
+    from sky_embeddings_amd.engine import MAEEngine
+    from sky_embeddings_amd.model_config import config_for
+    cfg = (config_for("base", img_size=64, patch_size=16, in_chans=5, embed_dim=768, norm_pix_loss=True, loss_fn="mse") if size == "base"
+           else config_for("tiny", img_size=64, patch_size=16, in_chans=5, embed_dim=192))
+    B = 256 if size == "base" else 64
+    g = torch.Generator().manual_seed(4)
+    imgs = torch.randn(B, 5, 64, 64, generator=g).clamp_(min=-3).cuda()
+    noise = torch.rand(B, 16, generator=g).cuda()
+    out = []
+    for fold in ("1", "0"):
+        monkeypatch.setenv("SKYEMB_FOLD_WGRADS", fold)
+        eng = MAEEngine(cfg, compute_dtype=torch.bfloat16, seed=0)
+        loss, _, _ = eng.forward_train(imgs, 0.75, noise)
+        eng.backward()
+        torch.cuda.synchronize()
+        w = eng._ws[(B, 4, True)]
+        assert w.get("folded_wgrads", set()) == ({"decoder_pred", "decoder_embed"} if fold == "1" else set())
+        out.append((float(loss), {k: eng.store.grad(k).clone() for k in eng.store.offsets}))
+        del eng
+        torch.cuda.empty_cache()
+    assert out[0][0] == out[1][0]
+    for k, a in out[0][1].items():
+        b = out[1][1][k]
+        if k.split(".")[0] in ("decoder_pred", "decoder_embed"):
+            assert float((a - b).norm() / b.norm()) < 2e-6, k
+        else:
+            assert torch.equal(a, b), k
+
+
 @pytest.mark.parametrize("side", [False, True])
 def test_fused_adamw_step_at_the_benchmark_size(side):
     """The same bit-equality at BASELINE configs[1] (ViT-B/16, B = 256): the 128x128 (encoder) and 128x64 (decoder) grouped

@@ -286,6 +286,38 @@ def test_vit_large_width_optimiser_in_the_weight_gradient_launches_equals_the_se
         assert torch.equal(out[0][k], out[1][k]), k
 
 
+def test_vit_large_width_head_weight_gradient_folded_into_the_last_blocks_launch(monkeypatch):
+    """ViT-L width, 8320 token rows: the pixel head's weight gradient (1280 x 1024 over the same rows) as the fifth problem of the
+    last block's 256 x 256 grouped launch (192 + 20 tiles on 256 compute units; simmim_engine._extra_wgrad_layers) against its own
+    launch (SKYEMB_FOLD_WGRADS=0): head gradients to 2e-6 of their norm (another order of the same fp32 sums), the rest bit for bit."""
+    from sky_embeddings_amd.model_config import config_for
+    from sky_embeddings_amd.simmim_engine import SimMIMEngine
+    cfg = config_for("simmim", img_size=128, patch_size=16, in_chans=5, embed_dim=1024, depth=2, num_heads=16, norm_pix_loss=True, loss_fn="L1")
+    B = 128
+    x, m, _ = _mim19_batch(cfg, B, seed=37)
+    out = []
+    for fold in ("1", "0"):
+        monkeypatch.setenv("SKYEMB_FOLD_WGRADS", fold)
+        eng = SimMIMEngine(cfg, device="cuda", compute_dtype=torch.bfloat16, seed=0)
+        loss = eng.forward_train(x.cuda(), m.cuda())[0]
+        eng.backward()
+        torch.cuda.synchronize()
+        w = eng._ws[(B, cfg.num_patches, True)]
+        assert w.get("folded_wgrads", set()) == ({"decoder.0"} if fold == "1" else set())
+        grp = w["wgrad_groups"]["blocks.1"]
+        assert grp.info.tile == 256256 and grp.tile_blocks == (212 if fold == "1" else 192)
+        out.append((float(loss), {k: eng.store.grad(k).clone() for k in eng.store.offsets}))
+        del eng
+        torch.cuda.empty_cache()
+    assert out[0][0] == out[1][0]
+    for k, a in out[0][1].items():
+        b = out[1][1][k]
+        if k.startswith("decoder.0."):
+            assert float((a - b).norm() / b.norm()) < 2e-6, k
+        else:
+            assert torch.equal(a, b), k
+
+
 def test_simmim_bf16_gradient_mirror_written_by_the_weight_gradient_launches(monkeypatch):
     """SimMIM mode of the data-parallel schedule with bf16 gradient communication (mim_19 geometry at a narrow width, 64 x 65 token
     rows so that the grouped launches apply): bf16 gradients written straight into the mirror == fp32 gradients + cast, bit for bit."""
