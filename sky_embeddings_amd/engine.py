@@ -83,7 +83,9 @@ def stage_gradient_ranges(store: ParamStore, cfg: MAEConfig, n_encoder_groups: i
     the front tensors (cls, patch_mask_values, mask_token, patch embedding) go with the last stage.
     Returns (encoder groups [(hi, lo), ...], ranges per stage)."""
     off = store.offsets
-    dec0 = off["decoder_embed.weight"]
+    # decoder_embed.weight, the first tensor of the decoder's run, goes with the TOP ENCODER stage: its gradient may be a problem of
+    # blocks.{depth-1}'s grouped weight-gradient launch (MAEEngine._extra_wgrad_layers), i.e. written after the decoder stage ended
+    dec0 = off["decoder_embed.weight"] + _pad8(int(np.prod(store.shapes["decoder_embed.weight"])))
     ranges = [[(dec0, store.n_decay)]]
     bounds = sorted({round(cfg.depth * k / n_encoder_groups) for k in range(n_encoder_groups + 1)}, reverse=True)
     groups = []
@@ -425,6 +427,10 @@ class MAEEngine:
     # ramp / tail bubbles of the dgrad chain.  dy lives in scratch that later layers overwrite: every writer of such a
     # buffer first waits for the wgrad that still reads it (_before_write).
     def enable_wgrad_overlap(self, on=True):
+        if bool(on) != (self._side is not None):
+            # workspaces are planned for one of the two schedules (side workgroups and folded problems of the grouped launches exist
+            # only without the side stream: _norm1_side_record, _extra_wgrad_layers): rebuild them on the next forward
+            self._ws, self._last = {}, None
         if on and self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
             self._splitk_ws_side = torch.zeros_like(self._splitk_ws)

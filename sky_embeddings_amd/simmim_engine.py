@@ -14,6 +14,7 @@ one "patch" the size of the image).
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 from . import ops
@@ -26,8 +27,11 @@ def simmim_stage_ranges(store, cfg: MAEConfig, n_encoder_groups: int = 3):
     """Backward stages [head, encoder block groups (top first) ..., embedding] -> slices of the flat gradient buffer
     that are final after each (cf. engine.stage_gradient_ranges)."""
     off = store.offsets
-    head0 = off["attn_pool.latent"] if cfg.attn_pool else off["decoder.0.weight"]    # (layout order: the pool precedes the head)
-    ranges = [[(head0, store.n_decay)]]
+    # (layout order: the pool precedes the head.  Without the pool the head's weight gradient may be a problem of the last block's
+    # grouped launch -- _extra_wgrad_layers -- so it belongs to the top encoder stage and the head stage finishes no decayed tensor)
+    head0 = off["attn_pool.latent"] if cfg.attn_pool else store.n_decay
+    assert cfg.attn_pool or off["decoder.0.weight"] + int(np.prod(store.shapes["decoder.0.weight"])) <= store.n_decay
+    ranges = [[(head0, store.n_decay)] if head0 < store.n_decay else []]
     bounds = sorted({round(cfg.depth * k / n_encoder_groups) for k in range(n_encoder_groups + 1)}, reverse=True)
     groups = []
     for hi, lo in zip(bounds[:-1], bounds[1:]):

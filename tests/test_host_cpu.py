@@ -232,10 +232,33 @@ def test_backward_stage_ranges_tile_the_gradient_buffer():
         assert flat[0][0] == 0 and flat[-1][1] == st.n
         for (a0, a1), (b0, b1) in zip(flat[:-1], flat[1:]):
             assert a1 == b0 and a0 < a1
-        # a stage's slice holds exactly the weights of its own blocks
+        # a stage's slice holds exactly the weights of its own blocks; the top encoder stage also owns decoder_embed.weight, whose
+        # gradient may ride in blocks.{depth-1}'s grouped weight-gradient launch (engine._extra_wgrad_layers)
         hi, lo = enc_groups[0]
         s, e = ranges[1][0]
-        assert s == st.offsets[f"blocks.{lo}.attn.qkv.weight"] and e == st.offsets["decoder_embed.weight"]
+        assert s == st.offsets[f"blocks.{lo}.attn.qkv.weight"]
+        assert e == st.offsets["decoder_embed.weight"] + cfg.decoder_embed_dim * cfg.embed_dim == ranges[0][0][0]
+        assert ranges[0][0][0] == st.offsets["decoder_blocks.0.attn.qkv.weight"]
+
+
+def test_simmim_stage_ranges_put_the_head_weight_with_the_top_encoder_stage():
+    """SimMIM without the pool: the head's weight gradient may be a problem of the last block's grouped launch
+    (simmim_engine._extra_wgrad_layers): the head stage then finishes no decayed tensor; with the pool it keeps pool + head."""
+    import dataclasses
+    from sky_embeddings_amd.engine import ParamStore
+    from sky_embeddings_amd.simmim_engine import simmim_stage_ranges
+    base = mc.config_for("simmim", img_size=128, patch_size=16, in_chans=5, embed_dim=64, depth=4, num_heads=4)
+    for cfg in (base, dataclasses.replace(base, attn_pool=True)):
+        st = ParamStore(cfg, "cpu", torch.bfloat16)
+        for groups in (1, 2, 4):
+            enc_groups, ranges = simmim_stage_ranges(st, cfg, groups)
+            flat = sorted(r for stage in ranges for r in stage)
+            assert flat[0][0] == 0 and flat[-1][1] == st.n
+            for (a0, a1), (b0, b1) in zip(flat[:-1], flat[1:]):
+                assert a1 == b0 and a0 < a1
+            o = st.offsets["decoder.0.weight"]
+            owner = [k for k, stage in enumerate(ranges) for (s, e) in stage if s <= o < e]
+            assert owner == [0 if cfg.attn_pool else 1]
 
 
 def test_native_host_gather_rows():
