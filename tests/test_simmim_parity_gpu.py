@@ -305,7 +305,8 @@ def test_vit_large_width_head_weight_gradient_folded_into_the_last_blocks_launch
         w = eng._ws[(B, cfg.num_patches, True)]
         assert w.get("folded_wgrads", set()) == ({"decoder.0"} if fold == "1" else set())
         grp = w["wgrad_groups"]["blocks.1"]
-        assert grp.info.tile == 256256 and grp.tile_blocks == (212 if fold == "1" else 192)
+        # 192 / 192 + 20 tiles; the per-XCD tile order rounds the launch's tile slots up to a multiple of 8
+        assert grp.info.tile == 256256 and grp.tile_blocks == (216 if fold == "1" else 192)
         out.append((float(loss), {k: eng.store.grad(k).clone() for k in eng.store.offsets}))
         del eng
         torch.cuda.empty_cache()
