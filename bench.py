@@ -225,7 +225,10 @@ def bench_pretrain(args, rank, world, dev):
         del bare, snap
         gf = gemm_flops_per_step(cfg, B)
         gemm_ms = gpu_ms - bare_ms
-        launches = 83 * 2 + 23                       # forward, dgrad singles; 20 grouped + 3 single wgrad launches
+        # forward, dgrad singles; 20 grouped weight-gradient launches + the single ones (patch_embed; decoder_pred / decoder_embed unless
+        # they ride in a grouped launch as further problems: engine._extra_wgrad_layers)
+        folded = max((len(w_.get("folded_wgrads", ())) for k_, w_ in eng._ws.items() if k_[-1] is True), default=0)
+        launches = 83 * 2 + 20 + 3 - folded
         out["gemm_in_step"] = dict(ms_per_step=gemm_ms, step_without_gemm_ms=bare_ms, flop_per_step=gf, launches_per_step=launches,
                                    avg_launch_us=1e3 * gemm_ms / launches, tflops=gf / gemm_ms / 1e9)
         if args.probe:

@@ -7,9 +7,14 @@ mkdir -p $O
 cd $R
 timeout -k 10 500 bash tools/r05_pmc.sh > $O/pmc.txt 2>&1; echo "pmc rc=$?"
 cp gpurun_out/r05pmc/summary.json $O/mfma_pmc_summary.json 2>/dev/null
+rm -f gpurun_out/r05pmc/pmc_*.csv          # (raw per-dispatch counter rows: tens of MB; gpurun brings back at most 64 MiB)
 timeout -k 10 600 bash tools/r05_pmc_extra.sh > $O/pmc_extra.txt 2>&1; echo "pmc extra rc=$?"
 cp gpurun_out/r05x_search/summary.json $O/search_pmc_summary.json 2>/dev/null; cp gpurun_out/r05x_mim19/summary.json $O/mim19_pmc_summary.json 2>/dev/null
+rm -f gpurun_out/r05x_search/pmc_*.csv gpurun_out/r05x_mim19/pmc_*.csv
 timeout -k 10 200 bash tools/r05_search_pmc.sh > $O/pmc_q16.txt 2>&1; echo "pmc q16 rc=$?"
 cp gpurun_out/r05spmc/r05_topk_stream_pmc.json $O/ 2>/dev/null
+rm -f gpurun_out/r05spmc/pmc_*.csv
 bash tools/prof_cmd.sh r05f/bench bench.py --skip-cpu > $O/bench_prof.txt 2>&1; echo "bench prof rc=$?"
+rm -rf $O/bench/prof
 python3 bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -c 300 $O/bench.err
+du -sh gpurun_out | tail -1
