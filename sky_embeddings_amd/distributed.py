@@ -104,6 +104,11 @@ def gather_topk(scores: torch.Tensor, idx: torch.Tensor, world: int, group=None)
     """All-gather per-rank [Q,k] results into [Q, world, k] lists ready for the k-way merge."""
     if world <= 1:
         return scores.unsqueeze(1), idx.unsqueeze(1)
+    return _gather_lists(scores, idx, world, group)
+
+
+def _gather_lists(scores, idx, world, group=None):
+    """The collective part of :func:`gather_topk` (also called with world = 1 by the one-rank RCCL test)."""
     Q, k = scores.shape
     gs = torch.empty(world, Q, k, dtype=scores.dtype, device=scores.device)
     gi = torch.empty(world, Q, k, dtype=idx.dtype, device=idx.device)

@@ -55,6 +55,10 @@ class TrainStep:
         self.mask_ratio = mask_ratio
         self.world_size = world_size
         self.process_group = process_group
+        # SKYEMB_DIST_FORCE=1: issue the per-stage collectives with ONE rank too (an initialised process group of size 1): the RCCL
+        # calls, their stream ordering against the stage graphs and the optimiser stream, on a box with one GPU (tests/test_ddp_gpu.py)
+        self.collectives = world_size > 1 or (os.environ.get("SKYEMB_DIST_FORCE", "0") == "1" and torch.distributed.is_available()
+                                              and torch.distributed.is_initialized())
         self.bucket_elems = bucket_elems
         cfg = engine.cfg
         dev = engine.device
@@ -276,7 +280,7 @@ class TrainStep:
             else:
                 fn()
             stage_works = []
-            if self.world_size > 1:
+            if self.collectives:
                 for (s, e) in ranges:
                     for (bs, be) in bucket_bounds(e - s, self.bucket_elems):
                         stage_works.append(torch.distributed.all_reduce(g[s + bs:s + be], group=self.process_group,

@@ -99,6 +99,66 @@ def test_n_rank_training_step_matches_one_rank_on_the_concatenated_batch(tmp_pat
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# RCCL itself, with the one rank a one-GPU box allows (two ranks on one card are refused by RCCL: "duplicate GPU"): the "nccl"
+# branches of the package -- process-group start-up with device_id, bf16 / fp32 all-reduce of mirror slices issued async between the
+# stage graphs, their waits on the optimiser stream, all_gather_into_tensor of the search lists, barrier + float64 MAX as bench.py
+# uses them -- run on the real library; a sum over one rank is the identity, so every result must equal the collective-free run
+# ----------------------------------------------------------------------------------------------------------------
+def _rccl_one_rank_main(rank, port, out_dir):
+    import torch.distributed as dist
+    from sky_embeddings_amd import distributed as skd
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, init_method=f"tcp://127.0.0.1:{port}", device_id=dev)
+    assert dist.get_backend() == "nccl"
+    imgs, noise = _data(1)
+    res = {}
+    # (default schedule of an N > 1 job: waits on the compute stream, one AdamW launch; and the optimiser-stream overlap)
+    for comm, overlap in (("bf16", False), ("bf16", True), ("f32", False)):
+        for force in ("1", "0"):
+            os.environ["SKYEMB_DIST_FORCE"] = force
+            eng, step = _make(dev, B_RANK, 1, staged=True, grad_comm=comm, n_encoder_groups=6, optimizer_overlap=overlap)
+            assert step.collectives == (force == "1") and step.staged and len(step.stages) >= 4
+            assert (step.g16 is not None) == (comm == "bf16") and step.optimizer_overlap == overlap
+            losses = []
+            for it in range(STEPS):
+                step.noise.copy_(noise[it][:B_RANK])
+                losses.append(float(step(imgs[:B_RANK].to(dev))))
+            torch.cuda.synchronize(dev)
+            res[force] = (losses, eng.store.p.clone(), eng.store.m.clone())
+            del eng, step
+        a, b = res["1"], res["0"]
+        assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), (comm, overlap)
+    # the search lists: all_gather_into_tensor (the branch gloo never takes), [Q, k] -> [Q, world, k]
+    g = torch.Generator().manual_seed(5)
+    scores = torch.rand(33, 100, generator=g).to(dev)
+    idx = torch.randint(0, 10 ** 6, (33, 100), generator=g).to(dev)
+    gs, gi = skd._gather_lists(scores, idx, 1)
+    assert gs.shape == (33, 1, 100) and torch.equal(gs[:, 0], scores) and torch.equal(gi[:, 0], idx)
+    # bench.py's bracket: barrier, then the MAX over ranks of a float64 wall time
+    dist.barrier()
+    t = torch.tensor([1.25], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert float(t) == 1.25
+    works = skd.allreduce_flat_gradients(torch.ones(3 * 1024 * 1024 + 5, device=dev), 2, bucket_elems=1024 * 1024, async_op=True)
+    assert len(works) == 4
+    for w in works:
+        w.wait()
+    with open(os.path.join(out_dir, "ok"), "w") as f:
+        f.write("ok")
+    dist.destroy_process_group()
+
+
+def test_rccl_one_rank_runs_the_nccl_branches(tmp_path):
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_rccl_one_rank_main, args=(port, str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / "ok").exists()
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # world size 8 (BASELINE configs[2] / [3]) walked in ONE process: a one-GPU box admits six GPU processes, so the eight ranks'
 # arithmetic is run rank after rank on the same card -- every kernel and every reduction order of the 8-rank job, no collective
 # ----------------------------------------------------------------------------------------------------------------
