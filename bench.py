@@ -245,7 +245,7 @@ def bench_pretrain(args, rank, world, dev):
             if step.fused_adamw and not args.no_graph:
                 out["optimizer_placement"] = placement_ab(lambda: MAEEngine(cfg, device=dev, compute_dtype=dtype, seed=0), B, pool, dev, step,
                                                           ["1", "0", "ln_separate=SKYEMB_LN_SIDE=0"] if os.environ.get("SKYEMB_BENCH_PLACEMENT_ALL")
-                                                          else ["0", "ln_separate=SKYEMB_LN_SIDE=0", "no_fold=SKYEMB_FOLD_WGRADS=0"])
+                                                          else ["0", "ln_separate=SKYEMB_LN_SIDE=0", "no_fold=SKYEMB_FOLD_WGRADS=0", "no_prefetch=SKYEMB_PREFETCH=0"])
         if world == 1 and not args.skip_feeder:
             out["feeder"] = bench_feeder(args, dev, step, B)
     return out, eng
@@ -309,7 +309,8 @@ def placement_ab(make_engine, B, pool, dev, step_default, others, load=None, rou
                      "groups' tiles laid out per problem instead of per XCD (SKYEMB_GROUP_XCD_ORDER=0); 'ln_separate' = the shipped policy with every block's norm1 "
                      "backward as its own launch behind the grouped weight-gradient launch instead of side workgroups inside it (SKYEMB_LN_SIDE=0); 'no_fold' = the "
                      "shipped policy with the single weight gradients outside the blocks (decoder_pred, decoder_embed / the SimMIM head) as their own "
-                     "split-K launches instead of fifth problems of a grouped launch (SKYEMB_FOLD_WGRADS=0).  "
+                     "split-K launches instead of fifth problems of a grouped launch (SKYEMB_FOLD_WGRADS=0); 'no_prefetch' = the shipped policy without the "
+                     "prefetch hints (every GEMM launch touching the next GEMM's weights: skyemb_gemm_args.prefetch; SKYEMB_PREFETCH=0).  "
                      "Interleaved rounds in one process")
 
 
@@ -502,7 +503,7 @@ def bench_mim19(args, dev):
     placement = None
     if step.fused_adamw and not os.environ.get("SKYEMB_BENCH_NO_AB"):       # (tools/mim19_bench.py under the profiler: the shipped step alone)
         placement = placement_ab(lambda: SimMIMEngine(cfg, device=dev, compute_dtype=torch.bfloat16, seed=0), B, None, dev, step,
-                                 ["0", "ln_separate=SKYEMB_LN_SIDE=0", "no_fold=SKYEMB_FOLD_WGRADS=0"] + (["tiles_per_problem=SKYEMB_GROUP_XCD_ORDER=0"] if os.environ.get("SKYEMB_BENCH_PLACEMENT_ALL") else []),
+                                 ["0", "ln_separate=SKYEMB_LN_SIDE=0", "no_fold=SKYEMB_FOLD_WGRADS=0", "no_prefetch=SKYEMB_PREFETCH=0"] + (["tiles_per_problem=SKYEMB_GROUP_XCD_ORDER=0"] if os.environ.get("SKYEMB_BENCH_PLACEMENT_ALL") else []),
                                  load=lambda s: s.load_batch(x, m), rounds=2, n=10)
     res = dict(workload="configs/mim_19.ini: SimMIM ViT-Large/16, 5x128x128, 39 of 64 patches masked per channel (ratio 0.6), "
                         f"bs={B}, L1 + norm-pix, AdamW+cosine, bf16", ms_per_step=ms, images_per_sec=B / ms * 1e3, optimizer_placement=placement,

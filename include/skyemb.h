@@ -103,6 +103,12 @@ typedef struct skyemb_gemm_args {
                                    the epilogue.  One workspace per stream. */
     int64_t ws_bytes;
     int32_t split_k;            /* 0 = auto (1 when ws == NULL), 1 = off, n = force n-way */
+    const void *prefetch;       /* optional hint, no effect on results: `prefetch_bytes` bytes (a multiple of 4, 4-byte aligned) that a LATER
+                                   launch will read -- the next layer's weight matrix -- are touched once by this launch's workgroups
+                                   (one 4-byte LDS-DMA read per 128-byte line, ahead of their first operand loads), so that they sit in
+                                   the memory-side cache when that launch starts instead of coming from HBM inside its k-loops.
+                                   Honoured by the pipelined bf16 kernels (gemm_pipe.hip); ignored elsewhere. */
+    int64_t prefetch_bytes;
 } skyemb_gemm_args;
 
 int skyemb_gemm(const skyemb_gemm_args *args, void *stream);

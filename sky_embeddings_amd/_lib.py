@@ -42,6 +42,7 @@ class GemmArgs(ctypes.Structure):
         ("resid", c_vp), ("ldr", c_i64), ("aux", c_vp), ("ldaux", c_i64), ("act", c_i32),
         ("out_f32", c_vp), ("ldo32", c_i64), ("out", c_vp), ("ldo", c_i64), ("out2", c_vp), ("ldo2", c_i64),
         ("tile", c_i32), ("colsum_a", c_vp), ("ws", c_vp), ("ws_bytes", c_i64), ("split_k", c_i32),
+        ("prefetch", c_vp), ("prefetch_bytes", c_i64),
     ]
 
 

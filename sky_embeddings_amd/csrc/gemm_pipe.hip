@@ -93,6 +93,17 @@ __device__ __forceinline__ void store8(bf16_t *p, const float (&v)[8]) {
     *(bf16x8 *)p = o;
 }
 
+// One 4-byte LDS-DMA read per lane from a workgroup-uniform base + a 32-bit lane offset into the 256 bytes at `lds_wave_base`: the
+// prefetch hint of skyemb_gemm_args (a wave touches 64 lines of 128 bytes = 8 KiB per instruction; the data is never used -- it
+// lands where the wave's own first operand piece of stage 0 lands AFTER it, the wave's requests completing in order).
+__device__ __forceinline__ void glds4_sbase(const void *base_uniform, unsigned int lane_off, char *lds_wave_base) {
+    const unsigned int dst = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) void *)lds_wave_base;
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
+                 :
+                 : "v"(lane_off), "s"(base_uniform), "s"(dst)
+                 : "memory", "m0");
+}
+
 // ---- stage issue -----------------------------------------------------------------------------
 // KC operand: R rows x 64 k.  One wave-instruction = 8 rows x 128 B.
 // Instructions of one operand tile per wave: R / 8 of them over NW waves, rounded up.  When they do not divide (144-row tiles,
@@ -328,6 +339,25 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
     for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
 
     constexpr int AHEAD = NSTAGE - 1;
+    // The prefetch hint (skyemb.h): this workgroup's share of the lines a later launch will read, requested BEFORE its own first
+    // operand loads -- the oldest requests of every wave, so the counted waits below cover them and they cost no wait of their own:
+    // they return with the first stage (both are HBM / memory-side-cache misses issued at the same moment).
+    if (g.prefetch != nullptr && split == 0 && KT > 0) {
+        constexpr int PA = issue_per_wave<BM, NW>();
+        const int piece = wave * PA < BM / 8 ? wave * PA : BM / 8 - 1;          // the wave's first A piece of stage 0, k-group 0
+        const unsigned int nchunk = (unsigned int)((g.prefetch_bytes + 8191) >> 13);
+        const unsigned int slot = (unsigned int)tb * NW + (unsigned int)wave, nslot = (unsigned int)ntiles * NW;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned int c = slot + (unsigned int)j * nslot;               // wave-uniform
+            if (c < nchunk) {
+                const long long left = g.prefetch_bytes - ((long long)c << 13);
+                const unsigned int last = (unsigned int)(left < 8192 ? left : 8192) - 4u;
+                const unsigned int off = (unsigned int)lane * 128u;
+                glds4_sbase((const char *)g.prefetch + ((size_t)c << 13), off < last ? off : last, smem + piece * 1024);
+            }
+        }
+    }
 #pragma unroll
     for (int p = 0; p < AHEAD; ++p)
         if (p < KT) issue(p, p);

@@ -288,6 +288,41 @@ class MAEEngine:
             ln(f"{prefix}.norm1", M_, dim)
         w["ln_items"] = ops.ln_reduce_items(entries, self.device)
 
+    # ------------------------------------------------------------------ prefetch hints
+    # Between two uses of a weight matrix a step moves far more than the 256 MB memory-side cache holds (activations, 2.9 GB of
+    # optimiser state), so every GEMM of the chain found its weights in HBM and paid that latency inside its first k-steps
+    # (tools/ubench/cold_weights_probe.py: [1280 x 3072 x 768] 12.2 us with the weights cached, 14.6 from HBM -- the in-step figure).
+    # Every GEMM launch therefore names the weights the NEXT GEMM of the chain will read (skyemb_gemm_args.prefetch): its workgroups
+    # touch them before their own first loads, and the lines are in the memory-side cache when the next launch asks.
+    def _weight_chain(self):
+        """Weight names in the order the forward GEMMs read them (backward's data gradients read them in reverse)."""
+        cfg = self.cfg
+        blk = lambda p: [f"{p}.attn.qkv.weight", f"{p}.attn.proj.weight", f"{p}.mlp.fc1.weight", f"{p}.mlp.fc2.weight"]
+        names = ["patch_embed.proj.weight"]
+        for i in range(cfg.depth):
+            names += blk(f"blocks.{i}")
+        names += self._decoder_weight_chain()
+        return [n for n in names if n in self.store.offsets]
+
+    def _decoder_weight_chain(self):
+        cfg = self.cfg
+        names = ["decoder_embed.weight"]
+        for i in range(cfg.decoder_depth):
+            names += [f"decoder_blocks.{i}.attn.qkv.weight", f"decoder_blocks.{i}.attn.proj.weight", f"decoder_blocks.{i}.mlp.fc1.weight",
+                      f"decoder_blocks.{i}.mlp.fc2.weight"]
+        return names + ["decoder_pred.weight"]
+
+    def _pf(self, direction, wname):
+        """The bf16 weights the GEMM after the one reading `wname` will read (forward chain / backward's data-gradient chain), or None."""
+        maps = getattr(self, "_pf_maps", None)
+        if maps is None:
+            chain = self._weight_chain()
+            maps = self._pf_maps = {"fwd": dict(zip(chain[:-1], chain[1:])), "bwd": dict(zip(chain[1:], chain[:-1]))}
+        if self.dtype != torch.bfloat16:
+            return None
+        nxt = maps[direction].get(wname)
+        return None if nxt is None else self.store.lp(nxt)
+
     # ------------------------------------------------------------------ forward pieces
     def _embed(self, imgs, noise, keep, w, ra_dec=None):
         """a3-a6: mask from noise, fused normalise/NaN-fill/gather of the kept patches, patch-embed
@@ -303,7 +338,7 @@ class MAEEngine:
         pos = st.frozen["pos_embed"].view(-1, D)
         ops.gemm(w["patches"], st.lp("patch_embed.proj.weight"), M=B * keep, N=D, K=pv,
                  bias=st.param("patch_embed.proj.bias"), table=pos[E:], tab_row=w["ids_keep"], ldt=D,
-                 dst_row=w["pe_dst"], out_f32=x0, ldo32=D)
+                 dst_row=w["pe_dst"], out_f32=x0, ldo32=D, prefetch=self._pf("fwd", "patch_embed.proj.weight"))
         # cls_token + pos_embed[:, :1] (utils/mim_vit.py:417-419): B tiny row copies (host glue)
         x0.view(B, Ne, D)[:, 0, :] = st.param("cls_token").view(D) + pos[0]
         if cfg.ra_dec:
@@ -322,17 +357,18 @@ class MAEEngine:
         P, LP = st.param, st.lp
         ops.layernorm_fwd(x_in, P(f"{prefix}.norm1.weight"), P(f"{prefix}.norm1.bias"), bufs["ln1"], bufs["mean1"],
                           bufs["rstd1"], M, dim, eps)
+        PF = lambda name: self._pf("fwd", f"{prefix}.{name}.weight")     # (the next GEMM's weights: _pf)
         ops.gemm(bufs["ln1"], LP(f"{prefix}.attn.qkv.weight"), M=M, N=3 * dim, K=dim, bias=P(f"{prefix}.attn.qkv.bias"),
-                 out=bufs["qkv"])
+                 out=bufs["qkv"], prefetch=PF("attn.qkv"))
         ops.mha_fwd(bufs["qkv"], bufs["att"], Bsz, N, heads, hd)
         ops.gemm(bufs["att"], LP(f"{prefix}.attn.proj.weight"), M=M, N=dim, K=dim, bias=P(f"{prefix}.attn.proj.bias"),
-                 resid=x_in, ldr=dim, out_f32=bufs["xmid"], ws=self._splitk_ws)
+                 resid=x_in, ldr=dim, out_f32=bufs["xmid"], ws=self._splitk_ws, prefetch=PF("attn.proj"))
         ops.layernorm_fwd(bufs["xmid"], P(f"{prefix}.norm2.weight"), P(f"{prefix}.norm2.bias"), bufs["ln2"],
                           bufs["mean2"], bufs["rstd2"], M, dim, eps)
         ops.gemm(bufs["ln2"], LP(f"{prefix}.mlp.fc1.weight"), M=M, N=hidden, K=dim, bias=P(f"{prefix}.mlp.fc1.bias"),
-                 act=ACT_GELU, out=bufs["hact"], out2=bufs["hpre"])
+                 act=ACT_GELU, out=bufs["hact"], out2=bufs["hpre"], prefetch=PF("mlp.fc1"))
         ops.gemm(bufs["hact"], LP(f"{prefix}.mlp.fc2.weight"), M=M, N=dim, K=hidden, bias=P(f"{prefix}.mlp.fc2.bias"),
-                 resid=bufs["xmid"], ldr=dim, out_f32=x_out, ws=self._splitk_ws)
+                 resid=bufs["xmid"], ldr=dim, out_f32=x_out, ws=self._splitk_ws, prefetch=PF("mlp.fc2"))
 
     def _encoder_fwd(self, imgs, noise, keep, w, train, ra_dec=None):
         cfg, st = self.cfg, self.store
@@ -397,7 +433,8 @@ class MAEEngine:
         xd = w["xd"]
         dpos = st.frozen["decoder_pos_embed"].view(-1, Dd)
         ops.gemm(w["lat_lp"], st.lp("decoder_embed.weight"), M=Me, N=Dd, K=D, bias=st.param("decoder_embed.bias"),
-                 table=dpos, tab_row=w["dec_tab"], ldt=Dd, dst_row=w["dec_dst"], out_f32=xd[0], ldo32=Dd)
+                 table=dpos, tab_row=w["dec_tab"], ldt=Dd, dst_row=w["dec_dst"], out_f32=xd[0], ldo32=Dd,
+                 prefetch=self._pf("fwd", "decoder_embed.weight"))
         ops.fill_mask_tokens(xd[0], w["mask"], st.param("mask_token"), dpos, B, L, Dd, n_extra=E)
         for i in range(cfg.decoder_depth):
             self._block_fwd(xd[i], xd[i + 1], w["dec"][i], f"decoder_blocks.{i}", Md, Dd, cfg.decoder_num_heads, B, Nd)
@@ -412,7 +449,7 @@ class MAEEngine:
         return w["loss"], w["pred"][:, E:, :], w["mask"]
 
     # ------------------------------------------------------------------ backward
-    def _linear_bwd(self, dy, x_in, wname, bname, M, N, K, w, dx_out=None, dx_act=0, dx_aux=None, wgrad=True):
+    def _linear_bwd(self, dy, x_in, wname, bname, M, N, K, w, dx_out=None, dx_act=0, dx_aux=None, wgrad=True, prefetch="chain"):
         """dy [M,N] (lp), x_in [M,K] (lp): dW[N,K] = dy^T x, db = colsum(dy), optional dx = dy W."""
         st = self.store
         # wgrad; the bias gradient (column sums of dy) rides along in the same launch
@@ -420,8 +457,9 @@ class MAEEngine:
             self._wgrad(dy, x_in, N, K, M, st.grad(wname), st.grad(bname), w)
         if dx_out is not None:
             self._before_write(dx_out)
+            # (prefetch: the weights of the next data gradient of the chain -- _pf -- unless the caller names a tensor or None)
             ops.gemm(dy, st.lp(wname), M=M, N=K, K=N, a_layout=KC, b_layout=RC, lda=N, ldb=K, act=dx_act, aux=dx_aux,
-                     ldaux=K, out=dx_out, ws=w["splitk_ws"])
+                     ldaux=K, out=dx_out, ws=w["splitk_ws"], prefetch=self._pf("bwd", wname) if isinstance(prefetch, str) else prefetch)
 
     # -- weight gradients on a side stream: nothing downstream in backward depends on them, so they fill the
     # ramp / tail bubbles of the dgrad chain.  dy lives in scratch that later layers overwrite: every writer of such a
@@ -515,9 +553,12 @@ class MAEEngine:
         import os
         # (experiments: SKYEMB_WGRAD_TILE_ENC / _DEC force the grouped launch's tile code for one stack)
         tile = int(os.environ.get("SKYEMB_WGRAD_TILE_DEC" if prefix.startswith("decoder") else "SKYEMB_WGRAD_TILE_ENC", "0"))
+        # (the launch sits between the data-gradient chains of two blocks: its first problem touches the weights the next chain starts
+        # with -- the block below's fc2 -- and this block's qkv data gradient, right in front of it, names nothing: _block_bwd)
+        hint = self._pf("bwd", f"{prefix}.attn.qkv.weight")
         args = [ops.gemm_args(dy, x_in, M=n_out, N=k_in, K=M, a_layout=RC, b_layout=RC, lda=n_out, ldb=k_in,
-                              colsum_a=st.grad(f"{name}.bias"), **dst(name, n_out, k_in))
-                for dy, x_in, name, n_out, k_in in layers]
+                              colsum_a=st.grad(f"{name}.bias"), prefetch=hint if j == 0 else None, **dst(name, n_out, k_in))
+                for j, (dy, x_in, name, n_out, k_in) in enumerate(layers)]
         grp = ops.GemmGroup(args, self.device, tile=tile, adamw=adamw, side=side, ln_bwd=self._norm1_side_record(prefix, bufs, M, dim, w))
         if grp.ok:
             grp.extra_layers = [name for _, _, name, _, _ in layers[4:]]
@@ -726,7 +767,7 @@ class MAEEngine:
         self._before_write(dqkv)
         ops.mha_bwd(bufs["qkv"], datt, dqkv, Bsz, N, heads, hd)
         self._linear_bwd(dqkv, bufs["ln1"], f"{prefix}.attn.qkv.weight", f"{prefix}.attn.qkv.bias", M, 3 * dim, dim, w,
-                         dx_out=dln, wgrad=single)
+                         dx_out=dln, wgrad=single, prefetch="chain" if group is None else None)
         prev_done = self._group_done
         if group is not None:
             # all four dW / db of the block in ONE launch.  With the side stream it runs under the next block's dgrad

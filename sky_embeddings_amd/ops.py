@@ -35,10 +35,18 @@ def _p(t):
     return t.data_ptr()
 
 
+# SKYEMB_PREFETCH=0: no prefetch hints in the launches' arguments (read whenever an argument struct is built -- once per launch of a
+# captured step -- so that bench.py can A/B the hint inside one process)
+def _prefetch_on():
+    import os
+    return os.environ.get("SKYEMB_PREFETCH", "1") != "0"
+
+
 def gemm_args(A, B, *, M, N, K, a_layout=KC, b_layout=KC, lda=None, ldb=None, alpha=1.0, bias=None, table=None,
               tab_row=None, ldt=0, dst_row=None, resid=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, out_f32=None, ldo32=0,
-              out=None, ldo=0, out2=None, ldo2=0, tile=0, colsum_a=None, ws=None, split_k=0):
-    """skyemb_gemm_args for C[M,N] = alpha * A[M,K] B[N,K]^T with fused epilogue (see include/skyemb.h)."""
+              out=None, ldo=0, out2=None, ldo2=0, tile=0, colsum_a=None, ws=None, split_k=0, prefetch=None):
+    """skyemb_gemm_args for C[M,N] = alpha * A[M,K] B[N,K]^T with fused epilogue (see include/skyemb.h).  prefetch: a tensor a LATER
+    launch reads (the next layer's weights): touched by this launch so that it is in the memory-side cache by then (a hint)."""
     g = GemmArgs()
     g.A, g.B = _p(A), _p(B)
     g.lda = lda if lda is not None else (K if a_layout == KC else M)
@@ -54,6 +62,8 @@ def gemm_args(A, B, *, M, N, K, a_layout=KC, b_layout=KC, lda=None, ldb=None, al
     g.tile = tile
     g.colsum_a = _p(colsum_a)
     g.ws, g.ws_bytes, g.split_k = _p(ws), (ws.numel() * ws.element_size() if ws is not None else 0), split_k
+    if prefetch is not None and _prefetch_on():
+        g.prefetch, g.prefetch_bytes = _p(prefetch), prefetch.numel() * prefetch.element_size() // 4 * 4
     return g
 
 

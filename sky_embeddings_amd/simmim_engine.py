@@ -167,7 +167,8 @@ class SimMIMEngine(MAEEngine):
         x0 = xs[0]
         pos = st.frozen["pos_embed"].view(-1, D)
         ops.gemm(w["patches"], st.lp("patch_embed.proj.weight"), M=B * L, N=D, K=pv, bias=st.param("patch_embed.proj.bias"),
-                 table=pos[E:], tab_row=w["pe_tab"], ldt=D, dst_row=w["pe_dst"], out_f32=x0, ldo32=D)
+                 table=pos[E:], tab_row=w["pe_tab"], ldt=D, dst_row=w["pe_dst"], out_f32=x0, ldo32=D,
+                 prefetch=self._pf("fwd", "patch_embed.proj.weight"))
         x0.view(B, Ne, D)[:, 0, :] = st.param("cls_token").view(D) + pos[0]        # utils/mim_vit.py:417-419 (host glue)
         if cfg.ra_dec:
             P = st.param
@@ -244,6 +245,10 @@ class SimMIMEngine(MAEEngine):
         assert self._last is not None, "backward() without forward_train()"
         imgs, B, L, mask = self._last
         return imgs, B, mask, self._ws[(B, L, True)]
+
+    def _decoder_weight_chain(self):
+        # (prefetch hints, engine._pf: behind the blocks the forward chain reads the pixel head; the pooled variant's small GEMMs name nothing)
+        return [] if self.cfg.attn_pool else ["decoder.0.weight"]
 
     def _extra_wgrad_layers(self, prefix, M, w):
         """The pixel head's weight gradient (Conv2d 1x1 = a linear over the token rows, utils/mim_vit.py:244-249) as a fifth problem
