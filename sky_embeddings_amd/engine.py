@@ -294,6 +294,10 @@ class MAEEngine:
     # (tools/ubench/cold_weights_probe.py: [1280 x 3072 x 768] 12.2 us with the weights cached, 14.6 from HBM -- the in-step figure).
     # Every GEMM launch therefore names the weights the NEXT GEMM of the chain will read (skyemb_gemm_args.prefetch): its workgroups
     # touch them before their own first loads, and the lines are in the memory-side cache when the next launch asks.
+    # Measured (bench.py extra.optimizer_placement, interleaved): config A 5.08 -> 4.74 ms; forward hints alone 4.95, backward alone 4.90.
+    # WEIGHTS only: naming saved activations as well (the dGELU operand, norm2's input, the attention backward's qkv rows, the grouped
+    # launch's operands) made the step slower again (4.83; 4.79 for the grouped launch's operand alone) -- those are streamed by
+    # bandwidth-type kernels that gain nothing, while the extra lines sit in front of the naming launch's own first stage.
     def _weight_chain(self):
         """Weight names in the order the forward GEMMs read them (backward's data gradients read them in reverse)."""
         cfg = self.cfg
@@ -319,6 +323,10 @@ class MAEEngine:
             chain = self._weight_chain()
             maps = self._pf_maps = {"fwd": dict(zip(chain[:-1], chain[1:])), "bwd": dict(zip(chain[1:], chain[:-1]))}
         if self.dtype != torch.bfloat16:
+            return None
+        import os
+        only = os.environ.get("SKYEMB_PF_ONLY", "")        # (bench.py's A/B: hints in one direction only)
+        if only and only != direction:
             return None
         nxt = maps[direction].get(wname)
         return None if nxt is None else self.store.lp(nxt)

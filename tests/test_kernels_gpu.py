@@ -197,6 +197,41 @@ def test_gemm_epilogues(ops, dtype):
     assert float((dg.float().cpu() - refd).abs().max()) < tol * float(refd.abs().max())
 
 
+@pytest.mark.parametrize("tile", [0, 64064, 128064, 6128064, 128128, 9064064, 9144064, 13144256, 2256128])
+@pytest.mark.parametrize("layouts", [(0, 0), (0, 1), (1, 1)])
+def test_gemm_prefetch_hint_changes_no_result(ops, tile, layouts):
+    """skyemb_gemm_args.prefetch: the launch's workgroups touch a range a LATER launch will read (one 4-byte LDS-DMA read per 128-byte
+    line, requested before their first operand loads and landing where the wave's own first operand piece lands after it).  A hint:
+    the output must equal the launch without it bit for bit -- every ring tile, every operand class, ranges of 4 bytes, of a ragged
+    number of 8 KiB chunks, and far more chunks than the launch has waves (only the first two per wave are taken)."""
+    a_l, b_l = layouts
+    if a_l == 1 and tile in (9144064, 13144256, 2256128, 9064064):
+        pytest.skip("k-contiguous A only")
+    M, N, K = 407, 520, 256
+    g = torch.Generator().manual_seed(tile % 1000 + 7 * a_l + b_l)
+    A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.2
+    T = torch.bfloat16
+    Ad = dev(A.T.contiguous() if a_l else A, T)
+    Bd = dev(B.T.contiguous() if b_l else B, T)
+    if a_l:                                                  # row-contiguous operands: whole 8-row chunks
+        M, N = 400, 520
+        Ad, Bd = dev(A[:M].T.contiguous(), T), dev(B.T.contiguous() if b_l else B, T)
+    kw = dict(M=M, N=N, K=K, a_layout=a_l, b_layout=b_l, tile=tile, lda=M if a_l else K, ldb=N if b_l else K)
+    bias = dev(torch.randn(N, generator=g))
+    ref = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(Ad, Bd, out_f32=ref, bias=bias, **kw)
+    pool = torch.randn(6 * 1024 * 1024, device=DEV)          # 24 MB the hints point into
+    for nbytes in (4, 8192 * 3 + 132, 24 * 1024 * 1024):
+        out = torch.full((M, N), float("nan"), device=DEV)
+        ops.gemm(Ad, Bd, out_f32=out, bias=bias, prefetch=pool[: nbytes // 4], **kw)
+        assert torch.equal(out, ref), (tile, layouts, nbytes)
+    # the end of an allocation: the last chunk's lanes are clamped inside the range
+    tail = torch.randn(2048 + 33, device=DEV)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(Ad, Bd, out_f32=out, bias=bias, prefetch=tail, **kw)
+    assert torch.equal(out, ref)
+
+
 def test_gemm_group_equals_single_launches(ops):
     """Four wgrad-shaped problems (different output sizes, shared contraction length) as ONE grouped launch give the
     same bits as four single launches without split-K; a problem outside the bf16 subset makes the plan refuse."""
@@ -220,6 +255,16 @@ def test_gemm_group_equals_single_launches(ops):
     assert grp.ok and grp.total_blocks % 8 == 0
     grp.launch()
     grp.launch()      # replayable
+    for (dw, db), (dw1, db1) in zip(outs, refs):
+        assert torch.equal(dw, dw1) and torch.equal(db, db1)
+    # the same launch with a prefetch hint on its first problem (what the engine's grouped launches carry): same bits
+    hint = torch.randn(1 << 20, device=DEV)
+    args[0].prefetch, args[0].prefetch_bytes = hint.data_ptr(), hint.numel() * 4 - 12
+    for dw, db in outs:
+        dw.fill_(float("nan"))
+        db.fill_(float("nan"))
+    grp2 = ops.GemmGroup(args, DEV)
+    grp2.launch()
     for (dw, db), (dw1, db1) in zip(outs, refs):
         assert torch.equal(dw, dw1) and torch.equal(db, db1)
     bad = ops.gemm_args(keep[0][0].float(), keep[0][1].float(), M=192, N=768, K=tokens, a_layout=ops.RC, b_layout=ops.RC,

@@ -261,6 +261,34 @@ def test_norm1_backward_inside_the_weight_gradient_launch_equals_its_own_launch(
 
 
 @pytest.mark.parametrize("size", ["tiny", "base"])
+def test_prefetch_hints_change_no_bit_of_the_step(size, monkeypatch):
+    """Every GEMM launch of the step names the next GEMM's weights as a prefetch hint (engine._pf, skyemb_gemm_args.prefetch);
+    SKYEMB_PREFETCH=0 builds the same launches without it: loss and every gradient bit for bit, ViT-B/16 at B = 256 and the tiny model."""
+    from sky_embeddings_amd.engine import MAEEngine
+    from sky_embeddings_amd.model_config import config_for
+    cfg = (config_for("base", img_size=64, patch_size=16, in_chans=5, embed_dim=768, norm_pix_loss=True, loss_fn="mse") if size == "base"
+           else config_for("tiny", img_size=64, patch_size=16, in_chans=5, embed_dim=192))
+    B = 256 if size == "base" else 64
+    g = torch.Generator().manual_seed(6)
+    imgs = torch.randn(B, 5, 64, 64, generator=g).clamp_(min=-3).cuda()
+    noise = torch.rand(B, 16, generator=g).cuda()
+    out = []
+    for hints in ("1", "0"):
+        monkeypatch.setenv("SKYEMB_PREFETCH", hints)
+        eng = MAEEngine(cfg, compute_dtype=torch.bfloat16, seed=0)
+        assert (eng._pf("fwd", "blocks.0.mlp.fc2.weight").data_ptr() == eng.store.lp("blocks.1.attn.qkv.weight").data_ptr()
+                and eng._pf("bwd", "blocks.1.attn.qkv.weight").data_ptr() == eng.store.lp("blocks.0.mlp.fc2.weight").data_ptr()
+                and eng._pf("fwd", "decoder_pred.weight") is None and eng._pf("bwd", "patch_embed.proj.weight") is None)
+        loss, pred, _ = eng.forward_train(imgs, 0.75, noise)
+        eng.backward()
+        torch.cuda.synchronize()
+        out.append((float(loss), pred.clone(), eng.store.g.clone()))
+        del eng
+        torch.cuda.empty_cache()
+    assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+
+
+@pytest.mark.parametrize("size", ["tiny", "base"])
 def test_single_weight_gradients_folded_into_the_grouped_launches(size, monkeypatch):
     """decoder_pred's and decoder_embed's weight gradients ride as fifth problems in the first decoder / encoder block's grouped
     launch (engine._extra_wgrad_layers; SKYEMB_FOLD_WGRADS=0 keeps their own split-K launches).  The two forms add the same fp32
