@@ -316,8 +316,15 @@ class MAEEngine:
                       f"decoder_blocks.{i}.mlp.fc2.weight"]
         return names + ["decoder_pred.weight"]
 
-    def _pf(self, direction, wname):
-        """The bf16 weights the GEMM after the one reading `wname` will read (forward chain / backward's data-gradient chain), or None."""
+    PF_MAX_ROWS = 8192     # token rows above which launches name nothing: ViT-L at B = 128 (8320 rows) has k-loops of tens of us that
+                           # re-read a weight panel from the L2 thirty times -- its first touch is amortised, and the hint's lines in front of
+                           # every workgroup's first stage cost more than they return there (mim_19: 24.91 without, 25.05 ms with)
+
+    def _pf(self, direction, wname, rows=0):
+        """The bf16 weights the GEMM after the one reading `wname` will read (forward chain / backward's data-gradient chain), or None.
+        rows: token rows of the naming launch."""
+        if rows >= self.PF_MAX_ROWS:
+            return None
         maps = getattr(self, "_pf_maps", None)
         if maps is None:
             chain = self._weight_chain()
@@ -346,7 +353,7 @@ class MAEEngine:
         pos = st.frozen["pos_embed"].view(-1, D)
         ops.gemm(w["patches"], st.lp("patch_embed.proj.weight"), M=B * keep, N=D, K=pv,
                  bias=st.param("patch_embed.proj.bias"), table=pos[E:], tab_row=w["ids_keep"], ldt=D,
-                 dst_row=w["pe_dst"], out_f32=x0, ldo32=D, prefetch=self._pf("fwd", "patch_embed.proj.weight"))
+                 dst_row=w["pe_dst"], out_f32=x0, ldo32=D, prefetch=self._pf("fwd", "patch_embed.proj.weight", B * keep))
         # cls_token + pos_embed[:, :1] (utils/mim_vit.py:417-419): B tiny row copies (host glue)
         x0.view(B, Ne, D)[:, 0, :] = st.param("cls_token").view(D) + pos[0]
         if cfg.ra_dec:
@@ -365,7 +372,7 @@ class MAEEngine:
         P, LP = st.param, st.lp
         ops.layernorm_fwd(x_in, P(f"{prefix}.norm1.weight"), P(f"{prefix}.norm1.bias"), bufs["ln1"], bufs["mean1"],
                           bufs["rstd1"], M, dim, eps)
-        PF = lambda name: self._pf("fwd", f"{prefix}.{name}.weight")     # (the next GEMM's weights: _pf)
+        PF = lambda name: self._pf("fwd", f"{prefix}.{name}.weight", M)     # (the next GEMM's weights: _pf)
         ops.gemm(bufs["ln1"], LP(f"{prefix}.attn.qkv.weight"), M=M, N=3 * dim, K=dim, bias=P(f"{prefix}.attn.qkv.bias"),
                  out=bufs["qkv"], prefetch=PF("attn.qkv"))
         ops.mha_fwd(bufs["qkv"], bufs["att"], Bsz, N, heads, hd)
@@ -442,7 +449,7 @@ class MAEEngine:
         dpos = st.frozen["decoder_pos_embed"].view(-1, Dd)
         ops.gemm(w["lat_lp"], st.lp("decoder_embed.weight"), M=Me, N=Dd, K=D, bias=st.param("decoder_embed.bias"),
                  table=dpos, tab_row=w["dec_tab"], ldt=Dd, dst_row=w["dec_dst"], out_f32=xd[0], ldo32=Dd,
-                 prefetch=self._pf("fwd", "decoder_embed.weight"))
+                 prefetch=self._pf("fwd", "decoder_embed.weight", Me))
         ops.fill_mask_tokens(xd[0], w["mask"], st.param("mask_token"), dpos, B, L, Dd, n_extra=E)
         for i in range(cfg.decoder_depth):
             self._block_fwd(xd[i], xd[i + 1], w["dec"][i], f"decoder_blocks.{i}", Md, Dd, cfg.decoder_num_heads, B, Nd)
@@ -467,7 +474,7 @@ class MAEEngine:
             self._before_write(dx_out)
             # (prefetch: the weights of the next data gradient of the chain -- _pf -- unless the caller names a tensor or None)
             ops.gemm(dy, st.lp(wname), M=M, N=K, K=N, a_layout=KC, b_layout=RC, lda=N, ldb=K, act=dx_act, aux=dx_aux,
-                     ldaux=K, out=dx_out, ws=w["splitk_ws"], prefetch=self._pf("bwd", wname) if isinstance(prefetch, str) else prefetch)
+                     ldaux=K, out=dx_out, ws=w["splitk_ws"], prefetch=self._pf("bwd", wname, M) if isinstance(prefetch, str) else prefetch)
 
     # -- weight gradients on a side stream: nothing downstream in backward depends on them, so they fill the
     # ramp / tail bubbles of the dgrad chain.  dy lives in scratch that later layers overwrite: every writer of such a
@@ -563,7 +570,7 @@ class MAEEngine:
         tile = int(os.environ.get("SKYEMB_WGRAD_TILE_DEC" if prefix.startswith("decoder") else "SKYEMB_WGRAD_TILE_ENC", "0"))
         # (the launch sits between the data-gradient chains of two blocks: its first problem touches the weights the next chain starts
         # with -- the block below's fc2 -- and this block's qkv data gradient, right in front of it, names nothing: _block_bwd)
-        hint = self._pf("bwd", f"{prefix}.attn.qkv.weight")
+        hint = self._pf("bwd", f"{prefix}.attn.qkv.weight", M)
         args = [ops.gemm_args(dy, x_in, M=n_out, N=k_in, K=M, a_layout=RC, b_layout=RC, lda=n_out, ldb=k_in,
                               colsum_a=st.grad(f"{name}.bias"), prefetch=hint if j == 0 else None, **dst(name, n_out, k_in))
                 for j, (dy, x_in, name, n_out, k_in) in enumerate(layers)]

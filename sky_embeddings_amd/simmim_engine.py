@@ -168,7 +168,7 @@ class SimMIMEngine(MAEEngine):
         pos = st.frozen["pos_embed"].view(-1, D)
         ops.gemm(w["patches"], st.lp("patch_embed.proj.weight"), M=B * L, N=D, K=pv, bias=st.param("patch_embed.proj.bias"),
                  table=pos[E:], tab_row=w["pe_tab"], ldt=D, dst_row=w["pe_dst"], out_f32=x0, ldo32=D,
-                 prefetch=self._pf("fwd", "patch_embed.proj.weight"))
+                 prefetch=self._pf("fwd", "patch_embed.proj.weight", B * L))
         x0.view(B, Ne, D)[:, 0, :] = st.param("cls_token").view(D) + pos[0]        # utils/mim_vit.py:417-419 (host glue)
         if cfg.ra_dec:
             P = st.param
