@@ -103,10 +103,13 @@ typedef struct skyemb_gemm_args {
                                    the epilogue.  One workspace per stream. */
     int64_t ws_bytes;
     int32_t split_k;            /* 0 = auto (1 when ws == NULL), 1 = off, n = force n-way */
+    int32_t prefetch_wgs;       /* resolved by the library (callers leave 0): workgroups behind the tiles that carry the prefetch hint */
     const void *prefetch;       /* optional hint, no effect on results: `prefetch_bytes` bytes (a multiple of 4, 4-byte aligned) that a LATER
                                    launch will read -- the next layer's weight matrix -- are touched once by this launch's workgroups
                                    (one 4-byte LDS-DMA read per 128-byte line, ahead of their first operand loads), so that they sit in
                                    the memory-side cache when that launch starts instead of coming from HBM inside its k-loops.
+                                   Where the launch leaves workgroup slots of the device free, extra workgroups behind its tiles do the
+                                   touching (the tiles' own request queues stay clear); else the tiles' waves do, ahead of their first loads.
                                    Honoured by the pipelined bf16 kernels (gemm_pipe.hip); ignored elsewhere. */
     int64_t prefetch_bytes;
 } skyemb_gemm_args;

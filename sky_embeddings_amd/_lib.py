@@ -41,7 +41,7 @@ class GemmArgs(ctypes.Structure):
         ("bias", c_vp), ("table", c_vp), ("tab_row", c_vp), ("ldt", c_i64), ("dst_row", c_vp),
         ("resid", c_vp), ("ldr", c_i64), ("aux", c_vp), ("ldaux", c_i64), ("act", c_i32),
         ("out_f32", c_vp), ("ldo32", c_i64), ("out", c_vp), ("ldo", c_i64), ("out2", c_vp), ("ldo2", c_i64),
-        ("tile", c_i32), ("colsum_a", c_vp), ("ws", c_vp), ("ws_bytes", c_i64), ("split_k", c_i32),
+        ("tile", c_i32), ("colsum_a", c_vp), ("ws", c_vp), ("ws_bytes", c_i64), ("split_k", c_i32), ("prefetch_wgs", c_i32),
         ("prefetch", c_vp), ("prefetch_bytes", c_i64),
     ]
 

@@ -342,7 +342,7 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
     // The prefetch hint (skyemb.h): this workgroup's share of the lines a later launch will read, requested BEFORE its own first
     // operand loads -- the oldest requests of every wave, so the counted waits below cover them and they cost no wait of their own:
     // they return with the first stage (both are HBM / memory-side-cache misses issued at the same moment).
-    if (g.prefetch != nullptr && split == 0 && KT > 0) {
+    if (g.prefetch != nullptr && g.prefetch_wgs == 0 && split == 0 && KT > 0) {
         constexpr int PA = issue_per_wave<BM, NW>();
         const int piece = wave * PA < BM / 8 ? wave * PA : BM / 8 - 1;          // the wave's first A piece of stage 0, k-group 0
         const unsigned int nchunk = (unsigned int)((g.prefetch_bytes + 8191) >> 13);
@@ -647,13 +647,34 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
 constexpr int tile_stride_m(int bm, int bn) { return bm == 144 ? (bn == 256 ? 130 : 136) : bm; }
 constexpr bool pow2_rows(int r) { return r == 64 || r == 128 || r == 256; }
 
+// The prefetch hint carried by WORKGROUPS OF ITS OWN (skyemb_gemm_args.prefetch_wgs of them, behind the launch's tiles: launch_n
+// adds them where the tiles leave workgroup slots of the device free).  Carried by the tiles' own waves -- gemm_pipe_body -- the
+// hint's lines, which come from HBM, sit in front of the wave's first operand stage in its in-order request queue: 0.8-1.7 us per
+// launch once the operands themselves are cache hits (tools/ubench/hint_cost_probe.py).  Here nobody waits for them but the wave that
+// asked: chunk c of 8 KiB = one instruction (a 4-byte LDS-DMA read per 128-byte line into the wave's 256 bytes of scratch LDS).
+template <int NW>
+__device__ __forceinline__ void prefetch_job(const skyemb_gemm_args &g, const unsigned int wg, const unsigned int nwg, char *smem) {
+    const int lane = threadIdx.x & 63;
+    const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned int nchunk = (unsigned int)((g.prefetch_bytes + 8191) >> 13);
+    for (unsigned int c = wg * NW + wave; c < nchunk; c += nwg * NW) {
+        const long long left = g.prefetch_bytes - ((long long)c << 13);
+        const unsigned int last = (unsigned int)(left < 8192 ? left : 8192) - 4u;
+        const unsigned int off = (unsigned int)lane * 128u;
+        glds4_sbase((const char *)g.prefetch + ((size_t)c << 13), off < last ? off : last, smem + wave * 256);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the LDS must not be handed to another workgroup with requests in flight)
+}
+
 template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int WM, int WN, int WK = 1>
 __global__ __launch_bounds__(WM * WN * WK * 64) void gemm_pipe_kernel(const skyemb_gemm_args g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int S = g.split_k > 1 ? g.split_k : 1;           // split-K factor (host-resolved)
-    unsigned int ntiles = gridDim.x, split = 0;
+    const unsigned int tile_wgs = gridDim.x - (unsigned int)g.prefetch_wgs;
+    if (blockIdx.x >= tile_wgs) return prefetch_job<WM * WN * WK>(g, blockIdx.x - tile_wgs, (unsigned int)g.prefetch_wgs, smem);
+    unsigned int ntiles = tile_wgs, split = 0;
     if (S > 1) {
-        ntiles = gridDim.x / (unsigned int)S;
+        ntiles = tile_wgs / (unsigned int)S;
         split = blockIdx.x / ntiles;
     }
     gemm_pipe_body<BM, BN, A_KC, B_KC, NSTAGE, WM, WN, WK, false, tile_stride_m(BM, BN)>(g, (int)(blockIdx.x - split * ntiles), (int)ntiles,
@@ -879,7 +900,29 @@ int launch_n(const skyemb_gemm_args &g, hipStream_t st) {
     }
     const int64_t tiles = ceil_div64(g.M, tile_stride_m(BM, BN)) * ceil_div64(g.N, BN);
     const int S = g.split_k > 1 ? g.split_k : 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * S)), dim3(WM * WN * WK * 64), smem, st, g);
+    // the prefetch hint goes to workgroups of its own where the tiles leave slots of the device free (prefetch_job), else it stays
+    // with the tiles' waves (gemm_pipe_body): slots = resident workgroups per CU of this instance x CUs
+    skyemb_gemm_args gl = g;
+    gl.prefetch_wgs = 0;
+    if (g.prefetch != nullptr && g.prefetch_bytes >= 4) {
+        static int slots[64] = {};
+        static const bool hint_wgs_on = []() { const char *e = getenv("SKYEMB_PREFETCH_WGS"); return !(e && e[0] == '0'); }();
+        {
+            std::lock_guard<std::mutex> lock(attr_mutex);
+            if (slots[dev & 63] == 0) {
+                int per_cu = 0, cus = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, WM * WN * WK * 64, smem) != hipSuccess) per_cu = 1;
+                if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+                slots[dev & 63] = (per_cu > 0 ? per_cu : 1) * cus;
+            }
+        }
+        const int64_t free_slots = slots[dev & 63] - tiles * S;
+        if (hint_wgs_on && free_slots >= 8) gl.prefetch_wgs = (int)(free_slots < 32 ? free_slots : 32);
+    } else {
+        gl.prefetch = nullptr;
+        gl.prefetch_bytes = 0;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * S + gl.prefetch_wgs)), dim3(WM * WN * WK * 64), smem, st, gl);
     skyemb_count_gemm(SKYEMB_GEMM_COUNT_PIPE);
     if (S > 1) {
         int64_t blocks = ceil_div64((int64_t)g.M * g.N / 4, 256);
@@ -1085,6 +1128,8 @@ int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
             if (St < 1 || !g.ws) St = 1;
             gt.tile = 64064;
             gt.split_k = St;
+            gt.prefetch = nullptr;                          // (the main launch carries the hint)
+            gt.prefetch_bytes = 0;
             // short k-loops: the tail as ONE launch of the two-k-group tile (at most one workgroup per CU, no slabs, no reduce
             // launch -- mim_19 spent 145 reduce launches per step on its row tails)
             if (wk2_on && (g.K / BK) % 2 == 0 && g.K <= 2048 && t64 <= 256) {
@@ -1177,6 +1222,7 @@ extern "C" int skyemb_gemm_group_plan(const skyemb_gemm_args *args, int n, int t
         }
         g.split_k = 1;
         g.tile = tile;
+        g.prefetch_wgs = 0;                                // (a grouped launch's hint stays with its tiles' waves)
         out[i] = g;
         mask |= class_bit(g);
         hdr[8 + i] = start;

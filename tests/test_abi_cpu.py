@@ -40,7 +40,7 @@ def test_loader_and_error_channel():
 def test_gemm_args_struct_layout_matches_header():
     # offsets a C compiler gives the struct (natural alignment) -- guards against ctypes drift
     assert ctypes.sizeof(_lib.GemmArgs) == 248 and _lib.GemmArgs.split_k.offset == 224
-    assert _lib.GemmArgs.prefetch.offset == 232 and _lib.GemmArgs.prefetch_bytes.offset == 240
+    assert _lib.GemmArgs.prefetch_wgs.offset == 228 and _lib.GemmArgs.prefetch.offset == 232 and _lib.GemmArgs.prefetch_bytes.offset == 240
     assert _lib.GemmArgs.tile.offset == 192 and _lib.GemmArgs.out_f32.offset == 144 and _lib.GemmArgs.colsum_a.offset == 200
 
 

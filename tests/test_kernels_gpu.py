@@ -230,6 +230,29 @@ def test_gemm_prefetch_hint_changes_no_result(ops, tile, layouts):
     out = torch.full((M, N), float("nan"), device=DEV)
     ops.gemm(Ad, Bd, out_f32=out, bias=bias, prefetch=tail, **kw)
     assert torch.equal(out, ref)
+    # (these launches leave most workgroup slots of the device free, so the hint rode in workgroups of its own behind the tiles:
+    # prefetch_job; the next test fills the device, which leaves the hint with the tiles' waves)
+
+
+@pytest.mark.parametrize("b_l", [0, 1])
+def test_gemm_prefetch_hint_carried_by_the_tiles_own_waves(ops, b_l):
+    """A launch with more tiles than the device has workgroup slots (1536 tiles of 64 x 64, 768 slots): no workgroups of its own for the
+    hint, every wave requests its share ahead of its first operand loads (gemm_pipe_body).  Same bits as without the hint, for a range
+    that gives every wave two requests, one, or none."""
+    M, N, K = 2048, 3072, 192
+    g = torch.Generator().manual_seed(91 + b_l)
+    T = torch.bfloat16
+    Ad = dev(torch.randn(M, K, generator=g), T)
+    B = torch.randn(N, K, generator=g) * 0.2
+    Bd = dev(B.T.contiguous() if b_l else B, T)
+    kw = dict(M=M, N=N, K=K, a_layout=0, b_layout=b_l, tile=64064)
+    ref = torch.empty(M, N, device=DEV, dtype=T)
+    ops.gemm(Ad, Bd, out=ref, **kw)
+    pool = torch.randn(32 * 1024 * 1024, device=DEV)         # 128 MB
+    for nbytes in (128 * 1024 * 1024, 40 * 1024 * 1024 + 4, 8192 * 5):
+        out = torch.zeros(M, N, device=DEV, dtype=T)
+        ops.gemm(Ad, Bd, out=out, prefetch=pool[: nbytes // 4], **kw)
+        assert torch.equal(out, ref), nbytes
 
 
 def test_gemm_group_equals_single_launches(ops):
