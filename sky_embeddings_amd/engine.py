@@ -323,7 +323,8 @@ class MAEEngine:
     def _pf(self, direction, wname, rows=0):
         """The bf16 weights the GEMM after the one reading `wname` will read (forward chain / backward's data-gradient chain), or None.
         rows: token rows of the naming launch."""
-        if rows >= self.PF_MAX_ROWS:
+        import os
+        if rows >= int(os.environ.get("SKYEMB_PF_MAX_ROWS", self.PF_MAX_ROWS)):
             return None
         maps = getattr(self, "_pf_maps", None)
         if maps is None:
