@@ -13,9 +13,9 @@
  *     synchronisation, safe under stream capture (hipGraph);
  *   - return 0 on success, non-zero on error with the text in skyemb_last_error()
  *     (thread-local);
- *   - `dtype` selects the ACTIVATION element type of the call: SKYEMB_BF16 (throughput
- *     mode: bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulate) or SKYEMB_F32
- *     (parity mode: exact-fp32 v_mfma_f32_16x16x4_f32).  Statistics, losses, the
+ *   - `dtype` selects the ACTIVATION element type of the call: SKYEMB_BF16 / SKYEMB_F16
+ *     (throughput modes: 16-bit operands on v_mfma_f32_16x16x32_{bf16,f16}, fp32 accumulate)
+ *     or SKYEMB_F32 (parity mode: exact-fp32 v_mfma_f32_16x16x4_f32).  Statistics, losses, the
  *     residual stream, gradients of parameters and optimiser state are always fp32.
  */
 #ifndef SKYEMB_H
@@ -29,6 +29,11 @@ extern "C" {
 
 #define SKYEMB_BF16 0
 #define SKYEMB_F32 1
+#define SKYEMB_F16 2 /* IEEE half operands on v_mfma_f32_16x16x32_f16 (same rate as bf16, 11-bit significand): the throughput mode
+                        that holds loss and reconstructed pixels within 1e-3 of the fp32 reference.  Every
+                        `dtype` argument below that accepts SKYEMB_BF16 accepts SKYEMB_F16 with the same layouts and constraints.
+                        fp16 underflows where bf16 does not: the caller scales d loss / d pred (`dscale` of the loss entry points)
+                        and removes the factor in skyemb_adamw's / skyemb_adamw_desc's grad_scale. */
 
 /* operand layouts of skyemb_gemm (logical A[M,K], B[N,K]; C = A * B^T) */
 #define SKYEMB_KC 0 /* k contiguous:   X(r,k) at X[r*ld + k] */
@@ -116,7 +121,7 @@ typedef struct skyemb_gemm_args {
 
 int skyemb_gemm(const skyemb_gemm_args *args, void *stream);
 
-/* Grouped launch: n <= 32 independent bf16 problems run as ONE grid (the four weight-gradient GEMMs of a transformer
+/* Grouped launch: n <= 32 independent 16-bit problems (all bf16 or all f16) run as ONE grid (the four weight-gradient GEMMs of a transformer
  * block fill the chip together: no split-K, no reduce launch).
  * skyemb_gemm_group_plan validates the problems and fills a HOST blob of skyemb_gemm_group_blob_bytes(n) bytes; the
  * caller copies it to device memory once (pointers inside are fixed) and replays skyemb_gemm_group_launch.
@@ -125,7 +130,8 @@ typedef struct skyemb_gemm_group_info {
     int32_t total_blocks; /* grid size of the launch                                                          */
     int32_t tile;         /* tile code the plan chose (BM * 1000 + BN): 64064, 128064, 128128 or 256256        */
     int32_t class_mask;   /* operand-layout classes present: 1 KC.KC, 2 KC.RC (dgrad), 4 RC.RC (wgrad)        */
-    int32_t reserved;     /* bit 0: the tiles' epilogue is the AdamW step (plan_adamw); bit 1: side optimiser job (plan_side_adamw) */
+    int32_t reserved;     /* bit 0: the tiles' epilogue is the AdamW step (plan_adamw); bit 1: side jobs (plan_side_adamw, attach_ln_bwd);
+                             bit 2: the problems are SKYEMB_F16 */
 } skyemb_gemm_group_info;
 int64_t skyemb_gemm_group_blob_bytes(int n);
 /* tile = 0: chosen from the total tile count.  The problems share ONE tile shape and may mix the data-gradient
@@ -145,7 +151,7 @@ int skyemb_gemm_group_launch(const void *blob_dev, const skyemb_gemm_group_info 
  * RC.RC problems only; plan it with skyemb_gemm_group_plan_adamw, launch it with skyemb_gemm_group_launch. */
 typedef struct skyemb_adamw_desc {
     float *g_base, *p, *m, *v;
-    void *p_lp;            /* bf16 shadow of p */
+    void *p_lp;            /* 16-bit shadow of p, in the format of the group's problems (bf16 / f16) */
     const float *hyper;
     int64_t n_decay;
     float beta1, beta2, eps, weight_decay, grad_scale;
@@ -284,11 +290,14 @@ int skyemb_rowsum_select(const float *src, int64_t ld, const float *sel, int row
  * variance normalisation + masked MSE (loss_l1 == 0) or L1 + NaN exclusion.
  * pred fp32 [B, Nd, pv] with the first `extra` rows of each sample ignored (cls / ra_dec).
  * Outputs: loss (fp32 scalar, device), dpred dtype/fp32 [B, Nd, pv] (extra + unmasked rows
- * zero) = d loss / d pred.  NaN target elements contribute zero gradient (DESIGN.md deviation).
+ * zero) = dscale * d loss / d pred.  NaN target elements contribute zero gradient (DESIGN.md deviation).
+ * dscale: static loss scale of the backward pass (1 = none; a power of two for SKYEMB_F16, whose data gradients would
+ * underflow otherwise -- every later step of backward is linear in dpred, so the caller divides it out again through
+ * grad_scale of skyemb_adamw / skyemb_adamw_desc); `loss` itself is never scaled.
  * `ws` fp32 workspace of 4*B*L + 4 floats. */
 int skyemb_masked_patch_loss(const float *imgs, const float *pred, const float *mask, float *loss, void *dpred,
                              float *dpred32, int dtype, float *ws, int B, int C, int H, int W, int p, int extra,
-                             float pixel_mean, float pixel_std, int norm_pix, int loss_l1, void *stream);
+                             float pixel_mean, float pixel_std, int norm_pix, int loss_l1, float dscale, void *stream);
 
 /* SimMIM mode (utils/mim_vit.py:469, 480-493, 497-521): pixel-wise loss on the head GEMM's token rows
  * pred_tok fp32 [B*(L+extra), C*p*p] (column c*p*p + py*p + px == PixelShuffle(p) of the Conv1x1 output) with
@@ -296,10 +305,11 @@ int skyemb_masked_patch_loss(const float *imgs, const float *pred, const float *
  * normalisation of the target.  Outputs: loss, dpred_tok (dtype, same layout; extra rows zero; may be NULL),
  * pred_img fp32 [B,C,H,W] (the reference's `pred`; may be NULL).  ws: 4*B*L + 4 floats.
  * pooled != 0 (attention-pooled models, utils/mim_vit.py:250): pred_tok / dpred_tok are [B, C*H*W], one row per image laid
- * out like the image (PixelShuffle(img_size) of the head's output); p stays the patch size of the normalisation; extra = 0. */
+ * out like the image (PixelShuffle(img_size) of the head's output); p stays the patch size of the normalisation; extra = 0.
+ * dscale: as in skyemb_masked_patch_loss (dpred_tok = dscale * d loss / d pred_tok). */
 int skyemb_simmim_pixel_loss(const float *imgs, const float *pred_tok, const float *pixel_mask, float *loss, void *dpred_tok,
                              int dtype, float *pred_img, float *ws, int B, int C, int H, int W, int p, int extra,
-                             float pixel_mean, float pixel_std, int norm_pix, int loss_l1, int pooled, void *stream);
+                             float pixel_mean, float pixel_std, int norm_pix, int loss_l1, int pooled, float dscale, void *stream);
 
 /* dst[0..3] = {a, b, c, d} by a kernel launch (the values travel as kernel arguments): how the scalars of optimiser step t --
  * lr, 1 - beta1^t, 1 - beta2^t -- reach the device buffer `hyper` of skyemb_adamw / skyemb_adamw_desc in front of a replayed HIP
@@ -311,9 +321,9 @@ int skyemb_set_scalars(float *dst, float a, float b, float c, float d, void *str
  * elements [0, n_decay) use weight decay `wd`, the rest 0.  Step scalars {lr, 1-beta1^t, 1-beta2^t}
  * come from `hyper` (device fp32[4], for launches captured in a HIP graph) when non-NULL, else
  * from the lr/bc1/bc2 arguments.  Also refreshes the dtype shadow copy `p_lp` used by the GEMMs
- * (NULL to skip), scales gradients by grad_scale (DDP averaging) and optionally zeroes g.  `g` holds `grad_dtype`
- * elements: SKYEMB_F32 (the flat gradient buffer the kernels write), or SKYEMB_BF16 (the copy a bf16 gradient
- * all-reduce worked on: half the xGMI bytes per step). */
+ * (NULL to skip), scales gradients by grad_scale (DDP averaging, and the inverse of the backward pass's loss scale)
+ * and optionally zeroes g.  `g` holds `grad_dtype` elements: SKYEMB_F32 (the flat gradient buffer the kernels write), or
+ * SKYEMB_BF16 / SKYEMB_F16 (the copy a 16-bit gradient all-reduce worked on: half the xGMI bytes per step). */
 int skyemb_adamw(float *p, void *g, float *m, float *v, void *p_lp, int dtype, int64_t n, int64_t n_decay,
                  const float *hyper, float lr, float bc1, float bc2, float beta1, float beta2, float eps, float wd,
                  float grad_scale, int zero_grad, int grad_dtype, void *stream);

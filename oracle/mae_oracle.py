@@ -332,6 +332,25 @@ def layer_norm(x, w, b, eps):
     return F.layer_norm(x, (x.shape[-1],), w, b, eps)
 
 
+# TEST-ONLY operand-rounding hook (tools/operand_rounding_study.py, tests/test_oracle_golden.py): when set, every
+# contraction of the path -- the linear layers, the patch-embedding conv (as the GEMM the HIP path runs), the two attention
+# products -- goes through ``OPERAND_HOOK(a, b, kind)`` = a @ b with kind in {"aw", "aa"} (activation x weight-transposed /
+# activation x activation), so that the effect of a GEMM operand format (bf16, fp16, split hi + lo) on loss / pred / gradients
+# can be measured against the unrounded fp32 restatement.  None (the default) leaves every line below as the plain torch op.
+OPERAND_HOOK = None
+
+
+def linear(x, w, b=None):
+    if OPERAND_HOOK is None:
+        return F.linear(x, w, b)
+    y = OPERAND_HOOK(x, w.t(), "aw")
+    return y if b is None else y + b
+
+
+def _amm(a, b):
+    return a @ b if OPERAND_HOOK is None else OPERAND_HOOK(a, b, "aa")
+
+
 def block(x, st, prefix, num_heads, eps):
     """timm ``Block`` as the reference instantiates it (mim_vit.py:231-233):
     pre-LN, qkv bias, softmax(q k^T * hd^-0.5) v, exact-erf GELU MLP, no
@@ -341,16 +360,16 @@ def block(x, st, prefix, num_heads, eps):
     B, N, D = x.shape
     hd = D // num_heads
     h = layer_norm(x, st[f"{prefix}.norm1.weight"], st[f"{prefix}.norm1.bias"], eps)
-    qkv = F.linear(h, st[f"{prefix}.attn.qkv.weight"], st[f"{prefix}.attn.qkv.bias"])
+    qkv = linear(h, st[f"{prefix}.attn.qkv.weight"], st[f"{prefix}.attn.qkv.bias"])
     qkv = qkv.reshape(B, N, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
-    att = (q * hd ** -0.5) @ k.transpose(-2, -1)
+    att = _amm(q * hd ** -0.5, k.transpose(-2, -1))
     att = att.softmax(dim=-1)
-    o = (att @ v).transpose(1, 2).reshape(B, N, D)
-    x = x + F.linear(o, st[f"{prefix}.attn.proj.weight"], st[f"{prefix}.attn.proj.bias"])
+    o = _amm(att, v).transpose(1, 2).reshape(B, N, D)
+    x = x + linear(o, st[f"{prefix}.attn.proj.weight"], st[f"{prefix}.attn.proj.bias"])
     h = layer_norm(x, st[f"{prefix}.norm2.weight"], st[f"{prefix}.norm2.bias"], eps)
-    h = F.gelu(F.linear(h, st[f"{prefix}.mlp.fc1.weight"], st[f"{prefix}.mlp.fc1.bias"]))
-    x = x + F.linear(h, st[f"{prefix}.mlp.fc2.weight"], st[f"{prefix}.mlp.fc2.bias"])
+    h = F.gelu(linear(h, st[f"{prefix}.mlp.fc1.weight"], st[f"{prefix}.mlp.fc1.bias"]))
+    x = x + linear(h, st[f"{prefix}.mlp.fc2.weight"], st[f"{prefix}.mlp.fc2.bias"])
     return x
 
 
@@ -384,8 +403,13 @@ def forward_features(st, x, cfg: MAEConfig, mask_ratio=0.0, noise=None, mask=Non
     if cfg.simmim and mask is not None:
         x = x * (1 - mask) + pmv * mask
     # timm PatchEmbed == Conv2d(k=s=p) -> flatten(2).transpose(1,2)  (mim_vit.py:206,402)
-    x = F.conv2d(x, st["patch_embed.proj.weight"], st["patch_embed.proj.bias"], stride=cfg.patch_size)
-    x = x.flatten(2).transpose(1, 2)
+    if OPERAND_HOOK is None:
+        x = F.conv2d(x, st["patch_embed.proj.weight"], st["patch_embed.proj.bias"], stride=cfg.patch_size)
+        x = x.flatten(2).transpose(1, 2)
+    else:   # the same contraction as the [B L, C p p] x [C p p, D] GEMM the HIP path runs
+        p_, g_ = cfg.patch_size, cfg.grid
+        rows = x.reshape(B, cfg.in_chans, g_, p_, g_, p_).permute(0, 2, 4, 1, 3, 5).reshape(B, g_ * g_, -1)
+        x = linear(rows, st["patch_embed.proj.weight"].reshape(cfg.embed_dim, -1), st["patch_embed.proj.bias"])
     x = x + st["pos_embed"][:, E:, :]
     if not cfg.simmim:
         if noise is None:
@@ -417,7 +441,7 @@ def forward_decoder(st, x, ids_restore, cfg: MAEConfig):
         x = F.conv2d(x, st["decoder.0.weight"], st["decoder.0.bias"])
         # reference: tile_size (== patch_size when H == p*p), img_size behind an attention pool (mim_vit.py:250)
         return F.pixel_shuffle(x, cfg.img_size if cfg.attn_pool else cfg.patch_size)
-    x = F.linear(x, st["decoder_embed.weight"], st["decoder_embed.bias"])
+    x = linear(x, st["decoder_embed.weight"], st["decoder_embed.bias"])
     n_mask = ids_restore.shape[1] + E - x.shape[1]
     mask_tokens = st["mask_token"].repeat(x.shape[0], n_mask, 1)
     x_ = torch.cat([x[:, E:, :], mask_tokens], dim=1)
@@ -427,7 +451,7 @@ def forward_decoder(st, x, ids_restore, cfg: MAEConfig):
     for i in range(cfg.decoder_depth):
         x = block(x, st, f"decoder_blocks.{i}", cfg.decoder_num_heads, cfg.ln_eps)
     x = layer_norm(x, st["decoder_norm.weight"], st["decoder_norm.bias"], cfg.ln_eps)
-    x = F.linear(x, st["decoder_pred.weight"], st["decoder_pred.bias"])
+    x = linear(x, st["decoder_pred.weight"], st["decoder_pred.bias"])
     return x[:, E:, :]
 
 

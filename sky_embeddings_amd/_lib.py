@@ -18,7 +18,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("SKYEMB_LIB") or os.path.join(_HERE, "libskyemb.so")   # SKYEMB_LIB: experiment builds
 CSRC = os.path.join(_HERE, "csrc")
 
-BF16, F32 = 0, 1
+BF16, F32, F16 = 0, 1, 2
+ABI_VERSION = 110          # skyemb_version() of the library this binding was written against (csrc/api.cpp)
 KC, RC = 0, 1
 ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
 
@@ -91,7 +92,7 @@ PROTOTYPES = {
     "skyemb_radec_token_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "skyemb_radec_token_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "skyemb_simmim_pixel_loss": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
-                                         c_f32, c_f32, c_i32, c_i32, c_i32, c_vp]),
+                                         c_f32, c_f32, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "skyemb_gather_rows_host": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i32]),
     "skyemb_h5_unchunk_host": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32]),
     "skyemb_augment": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
@@ -111,7 +112,7 @@ PROTOTYPES = {
     "skyemb_gather_rows": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "skyemb_rowsum_select": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "skyemb_masked_patch_loss": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32,
-                                         c_i32, c_i32, c_f32, c_f32, c_i32, c_i32, c_vp]),
+                                         c_i32, c_i32, c_f32, c_f32, c_i32, c_i32, c_f32, c_vp]),
     "skyemb_adamw": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_vp, c_f32, c_f32, c_f32, c_f32,
                              c_f32, c_f32, c_f32, c_f32, c_i32, c_i32, c_vp]),
     "skyemb_cast": (c_i32, [c_vp, c_vp, c_i32, c_i64, c_vp]),
@@ -163,6 +164,9 @@ def lib():
             except AttributeError as e:
                 raise SkyembLibraryError(f"{SO_PATH} does not export {name}") from e
             fn.restype, fn.argtypes = res, args
+        if L.skyemb_version() != ABI_VERSION:    # struct layouts / argument lists changed between versions: never call across them
+            raise SkyembLibraryError(f"{SO_PATH} reports ABI version {L.skyemb_version()}, this binding is written against "
+                                     f"{ABI_VERSION}: rebuild the library (make -C sky_embeddings_amd/csrc)")
         _LIB = L
     return _LIB
 

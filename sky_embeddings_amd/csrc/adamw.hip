@@ -75,7 +75,9 @@ extern "C" int skyemb_adamw(float *p, void *g, float *m, float *v, void *p_lp, i
                             float wd, float grad_scale, int zero_grad, int grad_dtype, void *stream) {
     SKY_CHECK_ARG(n > 0 && n % 4 == 0 && n_decay >= 0 && n_decay <= n, "skyemb_adamw: n must be a positive multiple of 4");
     SKY_CHECK_ARG(aligned16(p) && aligned16(m) && aligned16(v) && (((uintptr_t)g) & 7) == 0, "skyemb_adamw: unaligned buffers");
-    SKY_CHECK_ARG(grad_dtype == SKYEMB_F32 || grad_dtype == SKYEMB_BF16, "skyemb_adamw: bad grad_dtype %d", grad_dtype);
+    SKY_CHECK_ARG(grad_dtype == SKYEMB_F32 || sky_is_lp(grad_dtype), "skyemb_adamw: bad grad_dtype %d", grad_dtype);
+    SKY_CHECK_ARG(!sky_is_lp(grad_dtype) || !p_lp || grad_dtype == dtype || dtype == SKYEMB_F32,
+                  "skyemb_adamw: a 16-bit gradient buffer and a 16-bit shadow must share their format");
     int64_t blocks = ceil_div64(n / 4, 256);
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipStream_t st = (hipStream_t)stream;
@@ -83,15 +85,20 @@ extern "C" int skyemb_adamw(float *p, void *g, float *m, float *v, void *p_lp, i
 #define ADAMW_LAUNCH(T, LP, GT, lp_ptr)                                                                                        \
     hipLaunchKernelGGL((adamw_kernel<T, LP, GT>), grid, block, 0, st, p, (GT *)g, m, v, lp_ptr, n / 4, n_decay, hyper, lr, bc1, \
                        bc2, beta1, beta2, eps, wd, grad_scale, zero_grad)
-    const bool g16 = grad_dtype == SKYEMB_BF16;
+    const bool g16 = grad_dtype == SKYEMB_BF16, gh = grad_dtype == SKYEMB_F16;
     if (!p_lp) {
         if (g16) ADAMW_LAUNCH(float, false, bf16_t, (float *)nullptr);
+        else if (gh) ADAMW_LAUNCH(float, false, f16_t, (float *)nullptr);
         else ADAMW_LAUNCH(float, false, float, (float *)nullptr);
     } else if (dtype == SKYEMB_BF16) {
         if (g16) ADAMW_LAUNCH(bf16_t, true, bf16_t, (bf16_t *)p_lp);
         else ADAMW_LAUNCH(bf16_t, true, float, (bf16_t *)p_lp);
+    } else if (dtype == SKYEMB_F16) {
+        if (gh) ADAMW_LAUNCH(f16_t, true, f16_t, (f16_t *)p_lp);
+        else ADAMW_LAUNCH(f16_t, true, float, (f16_t *)p_lp);
     } else {
         if (g16) ADAMW_LAUNCH(float, true, bf16_t, (float *)p_lp);
+        else if (gh) ADAMW_LAUNCH(float, true, f16_t, (float *)p_lp);
         else ADAMW_LAUNCH(float, true, float, (float *)p_lp);
     }
 #undef ADAMW_LAUNCH

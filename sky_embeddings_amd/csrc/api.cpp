@@ -16,7 +16,10 @@ void skyemb_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *skyemb_last_error(void) { return g_err; }
-extern "C" int skyemb_version(void) { return 100; }
+// 100: rounds 1-4.  110 (round 6): skyemb_gemm_args lost colsum_parts and gained prefetch / prefetch_bytes / prefetch_wgs in round 5
+// (sizeof 240 -> 248, group blob + 128 B, skyemb_gemm_group_ws_bytes removed) without a bump; round 6 adds SKYEMB_F16 and the
+// `dscale` argument of the two loss entry points.  Callers built against an older header must be rebuilt (_lib.py asserts it).
+extern "C" int skyemb_version(void) { return 110; }
 
 // Measurement aid (bench.py): kernels of the families in `mask` are not launched (their entry points return 0), so that
 // a timed region with and without them gives that family's in-step time.  bit 0: MFMA GEMM launches (single, grouped,

@@ -179,12 +179,12 @@ int set_lds(K kern, size_t smem, const char *name) {
 }  // namespace
 
 // attention_mfma.hip: bf16, N <= 32, head dim 32 / 64 (the shapes of the MAE path); -1 = not handled
-int skyemb_mha_mfma_try(bool bwd, const void *qkv, const void *dout, void *out, int B, int N, int H, int hd, hipStream_t st);
+int skyemb_mha_mfma_try(bool bwd, const void *qkv, const void *dout, void *out, int dtype, int B, int N, int H, int hd, hipStream_t st);
 
 extern "C" int skyemb_mha_fwd(const void *qkv, void *out, int dtype, int B, int N, int H, int hd, void *stream) {
     SKY_CHECK_ARG(B > 0 && N > 0 && H > 0 && hd > 0 && hd % 8 == 0, "skyemb_mha_fwd: bad shape (head dim must be a multiple of 8)");
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == SKYEMB_BF16 && skyemb_mha_mfma_try(false, qkv, nullptr, out, B, N, H, hd, st) == 0) {
+    if (sky_is_lp(dtype) && skyemb_mha_mfma_try(false, qkv, nullptr, out, dtype, B, N, H, hd, st) == 0) {
         SKY_LAUNCH_CHECK("skyemb_mha_fwd");
         return 0;
     }
@@ -194,6 +194,10 @@ extern "C" int skyemb_mha_fwd(const void *qkv, void *out, int dtype, int B, int 
     if (dtype == SKYEMB_BF16) {
         if ((rc = set_lds(mha_fwd_kernel<bf16_t>, p.smem, "skyemb_mha_fwd"))) return rc;
         hipLaunchKernelGGL(mha_fwd_kernel<bf16_t>, grid, block, p.smem, st, (const bf16_t *)qkv, (bf16_t *)out, B, N, H, hd,
+                           p.waves, p.per_wave_floats);
+        } else if (dtype == SKYEMB_F16) {
+        if ((rc = set_lds(mha_fwd_kernel<f16_t>, p.smem, "skyemb_mha_fwd"))) return rc;
+        hipLaunchKernelGGL(mha_fwd_kernel<f16_t>, grid, block, p.smem, st, (const f16_t *)qkv, (f16_t *)out, B, N, H, hd,
                            p.waves, p.per_wave_floats);
     } else {
         if ((rc = set_lds(mha_fwd_kernel<float>, p.smem, "skyemb_mha_fwd"))) return rc;
@@ -208,7 +212,7 @@ extern "C" int skyemb_mha_bwd(const void *qkv, const void *dout, void *dqkv, int
                               void *stream) {
     SKY_CHECK_ARG(B > 0 && N > 0 && H > 0 && hd > 0 && hd % 8 == 0, "skyemb_mha_bwd: bad shape (head dim must be a multiple of 8)");
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == SKYEMB_BF16 && skyemb_mha_mfma_try(true, qkv, dout, dqkv, B, N, H, hd, st) == 0) {
+    if (sky_is_lp(dtype) && skyemb_mha_mfma_try(true, qkv, dout, dqkv, dtype, B, N, H, hd, st) == 0) {
         SKY_LAUNCH_CHECK("skyemb_mha_bwd");
         return 0;
     }
@@ -219,6 +223,10 @@ extern "C" int skyemb_mha_bwd(const void *qkv, const void *dout, void *dqkv, int
         if ((rc = set_lds(mha_bwd_kernel<bf16_t>, p.smem, "skyemb_mha_bwd"))) return rc;
         hipLaunchKernelGGL(mha_bwd_kernel<bf16_t>, grid, block, p.smem, st, (const bf16_t *)qkv, (const bf16_t *)dout,
                            (bf16_t *)dqkv, B, N, H, hd, p.waves, p.per_wave_floats);
+        } else if (dtype == SKYEMB_F16) {
+        if ((rc = set_lds(mha_bwd_kernel<f16_t>, p.smem, "skyemb_mha_bwd"))) return rc;
+        hipLaunchKernelGGL(mha_bwd_kernel<f16_t>, grid, block, p.smem, st, (const f16_t *)qkv, (const f16_t *)dout,
+                           (f16_t *)dqkv, B, N, H, hd, p.waves, p.per_wave_floats);
     } else {
         if ((rc = set_lds(mha_bwd_kernel<float>, p.smem, "skyemb_mha_bwd"))) return rc;
         hipLaunchKernelGGL(mha_bwd_kernel<float>, grid, block, p.smem, st, (const float *)qkv, (const float *)dout,

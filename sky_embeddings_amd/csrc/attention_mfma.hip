@@ -13,65 +13,65 @@
 // qkv layout is the reference's [B, N, 3, H, hd] (timm Attention: qkv(x).reshape(B,N,3,H,hd)); softmax statistics,
 // probabilities and dS are fp32, rounded to bf16 only as MFMA operands.
 #include <mutex>
-#include "common.h"
+#include "lp_twin.h"
 #include <stdlib.h>
 
 namespace {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+__device__ __forceinline__ f32x16 mfma32(lp8 a, lp8 b, f32x16 c) {
+    return sky_mfma_32x32x16(a, b, c);
 }
 __device__ __forceinline__ int pi_row(int s, int g, int e) { return 16 * s + 8 * (e >> 2) + 4 * g + (e & 3); }
 __device__ __forceinline__ int acc_row(int reg, int g) { return (reg & 3) + 8 * (reg >> 2) + 4 * g; }
 
-__device__ __forceinline__ bf16x8 zero8() {
-    bf16x8 z;
+__device__ __forceinline__ lp8 zero8() {
+    lp8 z;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) z[e] = (bf16_t)0.0f;
+    for (int e = 0; e < 8; ++e) z[e] = (lp_t)0.0f;
     return z;
 }
 // row fragment: lane (r, g) holds X[row r][16 s + 8 g + 0..7]  (the A and the B operand maps coincide)
-__device__ __forceinline__ bf16x8 row_frag(const bf16_t *base, int64_t row_stride, int r, int g, int s, int N) {
-    return r < N ? *(const bf16x8 *)(base + (int64_t)r * row_stride + 16 * s + 8 * g) : zero8();
+__device__ __forceinline__ lp8 row_frag(const lp_t *base, int64_t row_stride, int r, int g, int s, int N) {
+    return r < N ? *(const lp8 *)(base + (int64_t)r * row_stride + 16 * s + 8 * g) : zero8();
 }
-__device__ __forceinline__ bf16x8 pack_regs(const f32x16 &x, int s) {
-    bf16x8 f;
+__device__ __forceinline__ lp8 pack_regs(const f32x16 &x, int s) {
+    lp8 f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = (bf16_t)x[8 * s + e];
+    for (int e = 0; e < 8; ++e) f[e] = (lp_t)x[8 * s + e];
     return f;
 }
 
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
+typedef __attribute__((address_space(3))) lp4 lds_lp4_t;
 // a wave's [32 tokens][HD] operand parked in LDS, rows PITCH = HD + 8 elements apart (16 bytes of padding spread the four
 // token rows of a transposing read over the banks)
 template <int HD>
-__device__ __forceinline__ void park_rows(bf16_t *tile, const bf16x8 (&f)[HD / 16], int r, int g) {
+__device__ __forceinline__ void park_rows(lp_t *tile, const lp8 (&f)[HD / 16], int r, int g) {
 #pragma unroll
-    for (int s = 0; s < HD / 16; ++s) *(bf16x8 *)(tile + r * (HD + 8) + 16 * s + 8 * g) = f[s];
+    for (int s = 0; s < HD / 16; ++s) *(lp8 *)(tile + r * (HD + 8) + 16 * s + 8 * g) = f[s];
 }
 // transposed fragment out of a parked operand: lane (r, g) gets X[token pi(s, g, e)][32 blk + r], e = 0..7 -- two runs of four
 // consecutive tokens, each one ds_read_b64_tr_b16 (16 lanes x 8 bytes = 4 token rows x 16 columns, transposed in flight)
 template <int HD>
-__device__ __forceinline__ bf16x8 tok_frag_lds(const bf16_t *tile, int blk, int r, int g, int s) {
+__device__ __forceinline__ lp8 tok_frag_lds(const lp_t *tile, int blk, int r, int g, int s) {
     const int i = r & 15, q = i >> 2, p = i & 3;
     const int col0 = 32 * blk + (r & 16) + 4 * p;
     const int t0 = 16 * s + 4 * g;
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)(tile + (t0 + q) * (HD + 8) + col0));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)(tile + (t0 + 8 + q) * (HD + 8) + col0));
-    bf16x8 f;
+    const lp4 lo = sky_ds_read_tr16_b64((lds_lp4_t *)(tile + (t0 + q) * (HD + 8) + col0));
+    const lp4 hi = sky_ds_read_tr16_b64((lds_lp4_t *)(tile + (t0 + 8 + q) * (HD + 8) + col0));
+    lp8 f;
     f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
     f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
     return f;
 }
 // store the [d][token] result tile: lane (token r, g) owns d = 8 q + 4 g + 0..3 for q = 0..3
 template <int HD>
-__device__ __forceinline__ void store_tile(bf16_t *dst_row, const f32x16 &t, int blk, int g, float scale) {
+__device__ __forceinline__ void store_tile(lp_t *dst_row, const f32x16 &t, int blk, int g, float scale) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int d0 = 32 * blk + 8 * q + 4 * g;
-        if (d0 < HD) store4<bf16_t>(dst_row + d0, t[4 * q] * scale, t[4 * q + 1] * scale, t[4 * q + 2] * scale, t[4 * q + 3] * scale);
+        if (d0 < HD) store4<lp_t>(dst_row + d0, t[4 * q] * scale, t[4 * q + 1] * scale, t[4 * q + 2] * scale, t[4 * q + 3] * scale);
     }
 }
 
@@ -95,11 +95,11 @@ __device__ __forceinline__ PackInfo pack_of(int head, int B, int N, int H) {
 __device__ __forceinline__ int seq_of(int row, const PackInfo &pi) { return (row * pi.inv_n) >> 16; }   // row / N, exact for row < 32
 
 template <int HD>
-__global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out, int B,
+__global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const lp_t *__restrict__ qkv, lp_t *__restrict__ out, int B,
                                                            int N, int H, int nheads) {
     constexpr int KS = HD / 16, NB = (HD + 31) / 32;
     // transposed operands through LDS (see the file header)
-    __shared__ __attribute__((aligned(16))) bf16_t park[4][32 * (HD + 8)];
+    __shared__ __attribute__((aligned(16))) lp_t park[4][32 * (HD + 8)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int head = blockIdx.x * 4 + wave;
     if (head >= nheads) return;
@@ -108,18 +108,18 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t *__restr
     const int D = H * HD;
     const int64_t rs = 3 * (int64_t)D;
     const int r = lane & 31, g = lane >> 5;
-    const bf16_t *qb = qkv + (int64_t)pk.b0 * N * rs + h * HD, *kb = qb + D, *vb = qb + 2 * D;
+    const lp_t *qb = qkv + (int64_t)pk.b0 * N * rs + h * HD, *kb = qb + D, *vb = qb + 2 * D;
     const int NS = NR > 16 ? 2 : 1;       // k-steps over the token index
     const int my_seq = r < NR ? seq_of(r, pk) : 0;
 
-    bf16x8 qf[KS], kf[KS], vt[2][NB];
+    lp8 qf[KS], kf[KS], vt[2][NB];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         qf[s] = row_frag(qb, rs, r, g, s, NR);
         kf[s] = row_frag(kb, rs, r, g, s, NR);
     }
     {
-        bf16x8 vf[KS];
+        lp8 vf[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) vf[s] = row_frag(vb, rs, r, g, s, NR);
         park_rows<HD>(park[wave], vf, r, g);
@@ -156,8 +156,8 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t *__restr
 #pragma unroll
     for (int e = 0; e < 16; ++e) st[e] *= inv;
 
-    bf16x8 pf[2] = {pack_regs(st, 0), pack_regs(st, 1)};
-    bf16_t *orow = out + ((int64_t)pk.b0 * N + r) * D + h * HD;
+    lp8 pf[2] = {pack_regs(st, 0), pack_regs(st, 1)};
+    lp_t *orow = out + ((int64_t)pk.b0 * N + r) * D + h * HD;
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) {
         f32x16 ot;
@@ -170,11 +170,11 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t *__restr
 }
 
 template <int HD>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 32 ? 4 : 2))) void mha_bwd_mfma_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
-                                                           bf16_t *__restrict__ dqkv, int B, int N, int H, int nheads) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 32 ? 4 : 2))) void mha_bwd_mfma_kernel(const lp_t *__restrict__ qkv, const lp_t *__restrict__ dout,
+                                                           lp_t *__restrict__ dqkv, int B, int N, int H, int nheads) {
     constexpr int KS = HD / 16, NB = (HD + 31) / 32;
     __shared__ float stats[4][3][32];
-    __shared__ __attribute__((aligned(16))) bf16_t park[4][3][32 * (HD + 8)];      // K, Q, dO of each wave
+    __shared__ __attribute__((aligned(16))) lp_t park[4][3][32 * (HD + 8)];      // K, Q, dO of each wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int head = blockIdx.x * 4 + wave;
     if (head >= nheads) return;
@@ -183,13 +183,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 32 ? 
     const int D = H * HD;
     const int64_t rs = 3 * (int64_t)D;
     const int r = lane & 31, g = lane >> 5;
-    const bf16_t *qb = qkv + (int64_t)pk.b0 * N * rs + h * HD, *kb = qb + D, *vb = qb + 2 * D;
-    const bf16_t *ob = dout + (int64_t)pk.b0 * N * D + h * HD;
+    const lp_t *qb = qkv + (int64_t)pk.b0 * N * rs + h * HD, *kb = qb + D, *vb = qb + 2 * D;
+    const lp_t *ob = dout + (int64_t)pk.b0 * N * D + h * HD;
     const int NS = NR > 16 ? 2 : 1;
     const float scale = rsqrtf((float)HD);
     const int my_seq = r < NR ? seq_of(r, pk) : 0;
 
-    bf16x8 qf[KS], kf[KS], vf[KS], of[KS];
+    lp8 qf[KS], kf[KS], vf[KS], of[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         qf[s] = row_frag(qb, rs, r, g, s, NR);
@@ -254,10 +254,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 32 ? 
         sn[e] = p * (dpn[e] - stats[wave][2][i]);                     // dS[i][j]
     }
 
-    bf16_t *dq = dqkv + ((int64_t)pk.b0 * N + r) * rs + h * HD, *dk = dq + D, *dv = dq + 2 * D;
-    bf16x8 dst_f[2] = {pack_regs(st, 0), pack_regs(st, 1)};           // dS^T, k = j
-    bf16x8 dsn_f[2] = {pack_regs(sn, 0), pack_regs(sn, 1)};           // dS,   k = i
-    bf16x8 pn_f[2] = {pack_regs(pn, 0), pack_regs(pn, 1)};            // P,    k = i
+    lp_t *dq = dqkv + ((int64_t)pk.b0 * N + r) * rs + h * HD, *dk = dq + D, *dv = dq + 2 * D;
+    lp8 dst_f[2] = {pack_regs(st, 0), pack_regs(st, 1)};           // dS^T, k = j
+    lp8 dsn_f[2] = {pack_regs(sn, 0), pack_regs(sn, 1)};           // dS,   k = i
+    lp8 pn_f[2] = {pack_regs(pn, 0), pack_regs(pn, 1)};            // P,    k = i
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) {
         f32x16 tq, tk, tv;
@@ -266,9 +266,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 32 ? 
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             if (s < NS) {
-                const bf16x8 kt = tok_frag_lds<HD>(park[wave][0], blk, r, g, s);
-                const bf16x8 qt = tok_frag_lds<HD>(park[wave][1], blk, r, g, s);
-                const bf16x8 ot = tok_frag_lds<HD>(park[wave][2], blk, r, g, s);
+                const lp8 kt = tok_frag_lds<HD>(park[wave][0], blk, r, g, s);
+                const lp8 qt = tok_frag_lds<HD>(park[wave][1], blk, r, g, s);
+                const lp8 ot = tok_frag_lds<HD>(park[wave][2], blk, r, g, s);
                 tq = mfma32(kt, dst_f[s], tq);   // dQ^T[d][i] = sum_j K[j][d] dS[i][j]
                 tk = mfma32(qt, dsn_f[s], tk);   // dK^T[d][j] = sum_i Q[i][d] dS[i][j]
                 tv = mfma32(ot, pn_f[s], tv);    // dV^T[d][j] = sum_i dO[i][d] P[i][j]
@@ -294,8 +294,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 32 ? 
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int MAX_NT = 4;
 
-__device__ __forceinline__ bf16x8 row_frag_at(const bf16_t *base, int64_t row_stride, int row, int g, int s, int N) {
-    return row < N ? *(const bf16x8 *)(base + (int64_t)row * row_stride + 16 * s + 8 * g) : zero8();
+__device__ __forceinline__ lp8 row_frag_at(const lp_t *base, int64_t row_stride, int row, int g, int s, int N) {
+    return row < N ? *(const lp8 *)(base + (int64_t)row * row_stride + 16 * s + 8 * g) : zero8();
 }
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
@@ -305,36 +305,36 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 // [rows][HD] of one head -> LDS tile with pitch HD + 8; rows >= N become zeros
 template <int HD>
-__device__ __forceinline__ void stage_rows(bf16_t *tile, const bf16_t *base, int64_t row_stride, int N, int rows, int tid, int nthreads) {
+__device__ __forceinline__ void stage_rows(lp_t *tile, const lp_t *base, int64_t row_stride, int N, int rows, int tid, int nthreads) {
     constexpr int PR = HD / 8;                            // 16-byte pieces per row
     for (int p = tid; p < rows * PR; p += nthreads) {
         const int row = p / PR, c = p - row * PR;
-        *(bf16x8 *)(tile + row * (HD + 8) + 8 * c) = row < N ? *(const bf16x8 *)(base + (int64_t)row * row_stride + 8 * c) : zero8();
+        *(lp8 *)(tile + row * (HD + 8) + 8 * c) = row < N ? *(const lp8 *)(base + (int64_t)row * row_stride + 8 * c) : zero8();
     }
 }
 // NTILES operands of one head at once: every 16-byte piece of every tile is REQUESTED before the first one is written to LDS.
 // (stage_rows tile after tile, a loop of load -> write per piece, was 13 dependent global round trips per thread in the backward
 // kernel: most of a workgroup's 20 us at mim_19's 65 tokens, whose matrix work is ~3 k cycles per wave.)
 template <int HD, int NT, int NTILES>
-__device__ __forceinline__ void stage_tiles(bf16_t *const (&tiles)[NTILES], const bf16_t *const (&bases)[NTILES],
+__device__ __forceinline__ void stage_tiles(lp_t *const (&tiles)[NTILES], const lp_t *const (&bases)[NTILES],
                                             const int64_t (&strides)[NTILES], int N, int rows, int tid) {
     constexpr int PR = HD / 8, THREADS = 64 * NT;
     constexpr int MAXP = ((32 * NT + 4) * PR + THREADS - 1) / THREADS;       // pieces per thread and tile at the longest sequence
-    bf16x8 v[NTILES][MAXP];
+    lp8 v[NTILES][MAXP];
 #pragma unroll
     for (int t = 0; t < NTILES; ++t)
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
             const int p = tid + i * THREADS, row = p / PR, c = p - row * PR;
             const int rc = row < N ? row : N - 1;                                // clamped: the request is unconditional
-            v[t][i] = *(const bf16x8 *)(bases[t] + (int64_t)rc * strides[t] + 8 * c);
+            v[t][i] = *(const lp8 *)(bases[t] + (int64_t)rc * strides[t] + 8 * c);
         }
 #pragma unroll
     for (int t = 0; t < NTILES; ++t)
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
             const int p = tid + i * THREADS, row = p / PR, c = p - row * PR;
-            if (p < rows * PR) *(bf16x8 *)(tiles[t] + row * (HD + 8) + 8 * c) = row < N ? v[t][i] : zero8();
+            if (p < rows * PR) *(lp8 *)(tiles[t] + row * (HD + 8) + 8 * c) = row < N ? v[t][i] : zero8();
         }
 }
 // The LDS tiles hold round_up(N, 4) + 4 rows: the data rows, zero-filled up to the 4-row group, and one all-zero group
@@ -344,50 +344,50 @@ struct StripRows {
     int n4, zrow;      // round_up(N, 4); first row of the zero group
 };
 template <int HD>
-__device__ __forceinline__ bf16x8 row_frag_lds(const bf16_t *tile, int row, int g, int s, const StripRows &sr) {
+__device__ __forceinline__ lp8 row_frag_lds(const lp_t *tile, int row, int g, int s, const StripRows &sr) {
     row = row < sr.n4 ? row : sr.zrow;
-    return *(const bf16x8 *)(tile + row * (HD + 8) + 16 * s + 8 * g);
+    return *(const lp8 *)(tile + row * (HD + 8) + 16 * s + 8 * g);
 }
 // tok_frag_lds for tokens row0 + pi(s, g, e): the two 4-row groups it reads are redirected as wholes
 template <int HD>
-__device__ __forceinline__ bf16x8 tok_frag_strip(const bf16_t *tile, int row0, int blk, int r, int g, int s, const StripRows &sr) {
+__device__ __forceinline__ lp8 tok_frag_strip(const lp_t *tile, int row0, int blk, int r, int g, int s, const StripRows &sr) {
     const int i = r & 15, q = i >> 2, p = i & 3;
     const int col0 = 32 * blk + (r & 16) + 4 * p;
     int g0 = row0 + 16 * s + 4 * g, g1 = g0 + 8;
     g0 = g0 < sr.n4 ? g0 : sr.zrow;
     g1 = g1 < sr.n4 ? g1 : sr.zrow;
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)(tile + (g0 + q) * (HD + 8) + col0));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)(tile + (g1 + q) * (HD + 8) + col0));
-    bf16x8 f;
+    const lp4 lo = sky_ds_read_tr16_b64((lds_lp4_t *)(tile + (g0 + q) * (HD + 8) + col0));
+    const lp4 hi = sky_ds_read_tr16_b64((lds_lp4_t *)(tile + (g1 + q) * (HD + 8) + col0));
+    lp8 f;
     f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
     f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
     return f;
 }
 
-extern __shared__ __attribute__((aligned(16))) bf16_t strip_lds[];
+extern __shared__ __attribute__((aligned(16))) lp_t strip_lds[];
 
 template <int HD, int NT>
-__global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(NT <= 3 ? 5 : 3))) void mha_fwd_strip_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out, int B,
+__global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(NT <= 3 ? 5 : 3))) void mha_fwd_strip_kernel(const lp_t *__restrict__ qkv, lp_t *__restrict__ out, int B,
                                                                 int N, int H) {
     constexpr int KS = HD / 16, NB = (HD + 31) / 32, PITCH = HD + 8;
     const StripRows sr = {(N + 3) & ~3, (N + 3) & ~3};
     const int ROWS = sr.n4 + 4;
-    bf16_t *kt = strip_lds, *vt = strip_lds + ROWS * PITCH;
+    lp_t *kt = strip_lds, *vt = strip_lds + ROWS * PITCH;
     const int lane = threadIdx.x & 63, strip = threadIdx.x >> 6;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     const int D = H * HD;
     const int64_t rs = 3 * (int64_t)D;
     const int r = lane & 31, g = lane >> 5;
-    const bf16_t *qb = qkv + (int64_t)b * N * rs + h * HD, *kb = qb + D, *vb = qb + 2 * D;
+    const lp_t *qb = qkv + (int64_t)b * N * rs + h * HD, *kb = qb + D, *vb = qb + 2 * D;
     const int my = 32 * strip + r;                        // this lane's query token
     const float scale = rsqrtf((float)HD);
 
-    bf16x8 qf[KS];
+    lp8 qf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) qf[s] = row_frag_at(qb, rs, my, g, s, N);
     {
-        bf16_t *const tiles[2] = {kt, vt};
-        const bf16_t *const bases[2] = {kb, vb};
+        lp_t *const tiles[2] = {kt, vt};
+        const lp_t *const bases[2] = {kb, vb};
         const int64_t strides[2] = {rs, rs};
         stage_tiles<HD, NT, 2>(tiles, bases, strides, N, ROWS, threadIdx.x);
     }
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(NT <= 3
         }
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
-    bf16_t *orow = out + ((int64_t)b * N + my) * D + h * HD;
+    lp_t *orow = out + ((int64_t)b * N + my) * D + h * HD;
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) {
         f32x16 ot = zero16();
@@ -427,9 +427,9 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(NT <= 3
 #pragma unroll
             for (int s = 0; s < 2; ++s)
                 if (32 * t + 16 * s < N) {
-                    bf16x8 pf;
+                    lp8 pf;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)(st[t][8 * s + e] * inv);
+                    for (int e = 0; e < 8; ++e) pf[e] = (lp_t)(st[t][8 * s + e] * inv);
                     ot = mfma32(tok_frag_strip<HD>(vt, 32 * t, blk, r, g, s, sr), pf, ot);   // O^T[d][i] += V[j][d] P[i][j]
                 }
         if (my < N) store_tile<HD>(orow, ot, blk, g, 1.0f);
@@ -437,27 +437,27 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(NT <= 3
 }
 
 template <int HD, int NT>
-__global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(NT <= 3 ? 3 : 2))) void mha_bwd_strip_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
-                                                                bf16_t *__restrict__ dqkv, int B, int N, int H) {
+__global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(NT <= 3 ? 3 : 2))) void mha_bwd_strip_kernel(const lp_t *__restrict__ qkv, const lp_t *__restrict__ dout,
+                                                                lp_t *__restrict__ dqkv, int B, int N, int H) {
     constexpr int KS = HD / 16, NB = (HD + 31) / 32, PITCH = HD + 8;
     __shared__ float stats[3][32 * MAX_NT];               // per query token: softmax max, 1 / sum, rowsum(P dP)
     const StripRows sr = {(N + 3) & ~3, (N + 3) & ~3};
     const int ROWS = sr.n4 + 4;
-    bf16_t *qt = strip_lds, *kt = qt + ROWS * PITCH, *vt = kt + ROWS * PITCH, *dot = vt + ROWS * PITCH;
+    lp_t *qt = strip_lds, *kt = qt + ROWS * PITCH, *vt = kt + ROWS * PITCH, *dot = vt + ROWS * PITCH;
     const int lane = threadIdx.x & 63, strip = threadIdx.x >> 6;
     const int b = blockIdx.x / H, h = blockIdx.x - b * H;
     const int D = H * HD;
     const int64_t rs = 3 * (int64_t)D;
     const int r = lane & 31, g = lane >> 5;
-    const bf16_t *qb = qkv + (int64_t)b * N * rs + h * HD, *kb = qb + D, *vb = qb + 2 * D;
-    const bf16_t *ob = dout + (int64_t)b * N * D + h * HD;
+    const lp_t *qb = qkv + (int64_t)b * N * rs + h * HD, *kb = qb + D, *vb = qb + 2 * D;
+    const lp_t *ob = dout + (int64_t)b * N * D + h * HD;
     const int my = 32 * strip + r;
     const float scale = rsqrtf((float)HD);
-    bf16_t *dq = dqkv + ((int64_t)b * N + my) * rs + h * HD, *dk = dq + D, *dv = dq + 2 * D;
+    lp_t *dq = dqkv + ((int64_t)b * N + my) * rs + h * HD, *dk = dq + D, *dv = dq + 2 * D;
 
     {
-        bf16_t *const tiles[4] = {qt, kt, vt, dot};
-        const bf16_t *const bases[4] = {qb, kb, vb, ob};
+        lp_t *const tiles[4] = {qt, kt, vt, dot};
+        const lp_t *const bases[4] = {qb, kb, vb, ob};
         const int64_t strides[4] = {rs, rs, rs, (int64_t)D};
         stage_tiles<HD, NT, 4>(tiles, bases, strides, N, ROWS, threadIdx.x);
     }
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(NT <= 3
 
     // ---- phase A: my query strip against every key tile: statistics, dS^T, dQ
     {
-        bf16x8 qf[KS], of[KS];
+        lp8 qf[KS], of[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             qf[s] = row_frag_lds<HD>(qt, my, g, s, sr);
@@ -523,9 +523,9 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(NT <= 3
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
                     if (32 * t + 16 * s < N) {
-                        bf16x8 df;
+                        lp8 df;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) df[e] = (bf16_t)(st[t][8 * s + e] * (dpt[t][8 * s + e] - rsum));   // dS^T[j][i]
+                        for (int e = 0; e < 8; ++e) df[e] = (lp_t)(st[t][8 * s + e] * (dpt[t][8 * s + e] - rsum));   // dS^T[j][i]
                         tq = mfma32(tok_frag_strip<HD>(kt, 32 * t, blk, r, g, s, sr), df, tq);   // dQ^T[d][i] += K[j][d] dS[i][j]
                     }
             if (my < N) store_tile<HD>(dq, tq, blk, g, scale);
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(NT <= 3
     __syncthreads();
     // ---- phase B: my key strip against every query tile: P, dS (tokens i in the registers), dK, dV
     {
-        bf16x8 kf[KS], vf[KS];
+        lp8 kf[KS], vf[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             kf[s] = row_frag_lds<HD>(kt, my, g, s, sr);
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(NT <= 3
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 if (32 * t + 16 * s >= N) break;
-                const bf16x8 pf = pack_regs(sn, s), df = pack_regs(dpn, s);
+                const lp8 pf = pack_regs(sn, s), df = pack_regs(dpn, s);
 #pragma unroll
                 for (int blk = 0; blk < NB; ++blk) {
                     tk[blk] = mfma32(tok_frag_strip<HD>(qt, 32 * t, blk, r, g, s, sr), df, tk[blk]);    // dK^T[d][j] += Q[i][d] dS[i][j]
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(64 * NT) __attribute__((amdgpu_waves_per_eu(NT <= 3
 }
 
 template <int HD, int NT>
-int launch_strip(bool bwd, const bf16_t *x, const bf16_t *dout, bf16_t *out, int B, int N, int H, hipStream_t st) {
+int launch_strip(bool bwd, const lp_t *x, const lp_t *dout, lp_t *out, int B, int N, int H, hipStream_t st) {
     const dim3 grid(B * H), block(64 * NT);
     const int smem = (bwd ? 4 : 2) * (((N + 3) & ~3) + 4) * (HD + 8) * 2;
     if (smem > 65536) {
@@ -613,14 +613,21 @@ int launch_strip(bool bwd, const bf16_t *x, const bf16_t *dout, bf16_t *out, int
 }  // namespace
 
 // returns -1 when the shape is outside this kernel's subset (caller falls back to the LDS kernel of attention.hip)
-int skyemb_mha_mfma_try(bool bwd, const void *qkv, const void *dout, void *out, int B, int N, int H, int hd, hipStream_t st) {
+#ifndef SKY_F16
+int skyemb_mha_mfma_try_f16(bool bwd, const void *qkv, const void *dout, void *out, int dtype, int B, int N, int H, int hd, hipStream_t st);
+#endif
+int SKY_TWIN(skyemb_mha_mfma_try)(bool bwd, const void *qkv, const void *dout, void *out, int dtype, int B, int N, int H, int hd, hipStream_t st) {
+#ifndef SKY_F16
+    if (dtype == SKYEMB_F16) return skyemb_mha_mfma_try_f16(bwd, qkv, dout, out, dtype, B, N, H, hd, st);
+#endif
+    if (dtype != SKY_LP_DTYPE) return -1;
     if (N > 32 * MAX_NT || (hd != 32 && hd != 64)) return -1;
     static const bool off = []() { const char *e = getenv("SKYEMB_MHA_MFMA"); return e && e[0] == '0'; }();
     if (off) return -1;
-    const bf16_t *x = (const bf16_t *)qkv;
+    const lp_t *x = (const lp_t *)qkv;
     if (N > 32) {
         const int nt = (N + 31) / 32;
-#define STRIP(HD_, NT_) launch_strip<HD_, NT_>(bwd, x, (const bf16_t *)dout, (bf16_t *)out, B, N, H, st)
+#define STRIP(HD_, NT_) launch_strip<HD_, NT_>(bwd, x, (const lp_t *)dout, (lp_t *)out, B, N, H, st)
         int rc;
         if (hd == 32) rc = nt == 2 ? STRIP(32, 2) : nt == 3 ? STRIP(32, 3) : STRIP(32, 4);
         else rc = nt == 2 ? STRIP(64, 2) : nt == 3 ? STRIP(64, 3) : STRIP(64, 4);
@@ -631,11 +638,11 @@ int skyemb_mha_mfma_try(bool bwd, const void *qkv, const void *dout, void *out, 
     const int nheads = ((B + P - 1) / P) * H;
     const dim3 grid((nheads + 3) / 4), block(256);
     if (!bwd) {
-        if (hd == 32) hipLaunchKernelGGL(mha_fwd_mfma_kernel<32>, grid, block, 0, st, x, (bf16_t *)out, B, N, H, nheads);
-        else hipLaunchKernelGGL(mha_fwd_mfma_kernel<64>, grid, block, 0, st, x, (bf16_t *)out, B, N, H, nheads);
+        if (hd == 32) hipLaunchKernelGGL(mha_fwd_mfma_kernel<32>, grid, block, 0, st, x, (lp_t *)out, B, N, H, nheads);
+        else hipLaunchKernelGGL(mha_fwd_mfma_kernel<64>, grid, block, 0, st, x, (lp_t *)out, B, N, H, nheads);
     } else {
-        if (hd == 32) hipLaunchKernelGGL(mha_bwd_mfma_kernel<32>, grid, block, 0, st, x, (const bf16_t *)dout, (bf16_t *)out, B, N, H, nheads);
-        else hipLaunchKernelGGL(mha_bwd_mfma_kernel<64>, grid, block, 0, st, x, (const bf16_t *)dout, (bf16_t *)out, B, N, H, nheads);
+        if (hd == 32) hipLaunchKernelGGL(mha_bwd_mfma_kernel<32>, grid, block, 0, st, x, (const lp_t *)dout, (lp_t *)out, B, N, H, nheads);
+        else hipLaunchKernelGGL(mha_bwd_mfma_kernel<64>, grid, block, 0, st, x, (const lp_t *)dout, (lp_t *)out, B, N, H, nheads);
     }
     return 0;
 }

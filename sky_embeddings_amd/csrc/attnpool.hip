@@ -165,6 +165,8 @@ extern "C" int skyemb_attnpool_fwd(const float *q, const void *kv, int dtype, vo
     const dim3 grid((B * H + 3) / 4), block(256);
     if (dtype == SKYEMB_BF16)
         hipLaunchKernelGGL(attnpool_fwd_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, q, (const bf16_t *)kv, (bf16_t *)out, prob, B, N, H, hd);
+    else if (dtype == SKYEMB_F16)
+        hipLaunchKernelGGL(attnpool_fwd_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, q, (const f16_t *)kv, (f16_t *)out, prob, B, N, H, hd);
     else
         hipLaunchKernelGGL(attnpool_fwd_kernel<float>, grid, block, 0, (hipStream_t)stream, q, (const float *)kv, (float *)out, prob, B, N, H, hd);
     SKY_LAUNCH_CHECK("skyemb_attnpool_fwd");
@@ -179,6 +181,9 @@ extern "C" int skyemb_attnpool_bwd(const float *q, const void *kv, int dtype, co
     if (dtype == SKYEMB_BF16)
         hipLaunchKernelGGL(attnpool_bwd_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, q, (const bf16_t *)kv, (const bf16_t *)dout, prob,
                            (bf16_t *)dkv, dq_part, B, N, H, hd);
+    else if (dtype == SKYEMB_F16)
+        hipLaunchKernelGGL(attnpool_bwd_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, q, (const f16_t *)kv, (const f16_t *)dout, prob,
+                           (f16_t *)dkv, dq_part, B, N, H, hd);
     else
         hipLaunchKernelGGL(attnpool_bwd_kernel<float>, grid, block, 0, (hipStream_t)stream, q, (const float *)kv, (const float *)dout, prob,
                            (float *)dkv, dq_part, B, N, H, hd);

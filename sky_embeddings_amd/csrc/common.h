@@ -10,6 +10,9 @@
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef _Float16 f16_t;     // SKYEMB_F16: the second 16-bit operand format (11-bit significand, same MFMA rate as bf16)
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
@@ -47,12 +50,18 @@ __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <>
 __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
 
+template <>
+__device__ __forceinline__ float to_f32<f16_t>(f16_t v) { return (float)v; }
+
 template <typename T>
 __device__ __forceinline__ T from_f32(float v);
 template <>
 __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <>
 __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+
+template <>
+__device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return (f16_t)v; }  // v_cvt_f16_f32: RNE, overflow -> inf
 
 template <typename T>
 __device__ __forceinline__ void store4(T *p, float a, float b, float c, float d);
@@ -66,6 +75,12 @@ __device__ __forceinline__ void store4<bf16_t>(bf16_t *p, float a, float b, floa
     v[0] = (bf16_t)a; v[1] = (bf16_t)b; v[2] = (bf16_t)c; v[3] = (bf16_t)d;
     *(bf16x4 *)p = v;
 }
+template <>
+__device__ __forceinline__ void store4<f16_t>(f16_t *p, float a, float b, float c, float d) {
+    f16x4 v;
+    v[0] = (f16_t)a; v[1] = (f16_t)b; v[2] = (f16_t)c; v[3] = (f16_t)d;
+    *(f16x4 *)p = v;
+}
 template <typename T>
 __device__ __forceinline__ float4 load4(const T *p);
 template <>
@@ -75,6 +90,14 @@ __device__ __forceinline__ float4 load4<bf16_t>(const bf16_t *p) {
     bf16x4 v = *(const bf16x4 *)p;
     return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
 }
+
+template <>
+__device__ __forceinline__ float4 load4<f16_t>(const f16_t *p) {
+    f16x4 v = *(const f16x4 *)p;
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+// is `dtype` one of the two 16-bit operand formats?
+static inline bool sky_is_lp(int dtype) { return dtype == SKYEMB_BF16 || dtype == SKYEMB_F16; }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -321,6 +321,9 @@ static int patch_gather_launch(const float *imgs, const float *pmv, const int32_
     if (dtype == SKYEMB_BF16)
         hipLaunchKernelGGL(patch_gather_kernel<bf16_t>, dim3(B * keep), dim3(256), 0, st, imgs, pmv, ids_keep, (bf16_t *)out,
                            C, H, W, p, keep, pixel_mean, pixel_std, pixel_mask);
+    else if (dtype == SKYEMB_F16)
+        hipLaunchKernelGGL(patch_gather_kernel<f16_t>, dim3(B * keep), dim3(256), 0, st, imgs, pmv, ids_keep, (f16_t *)out,
+                           C, H, W, p, keep, pixel_mean, pixel_std, pixel_mask);
     else
         hipLaunchKernelGGL(patch_gather_kernel<float>, dim3(B * keep), dim3(256), 0, st, imgs, pmv, ids_keep, (float *)out, C,
                            H, W, p, keep, pixel_mean, pixel_std, pixel_mask);
@@ -345,6 +348,8 @@ extern "C" int skyemb_colsum(const void *X, int dtype, int64_t ldx, int M, int N
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SKYEMB_BF16)
         hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((N + 63) / 64), dim3(256), 0, st, (const bf16_t *)X, ldx, M, N, out);
+    else if (dtype == SKYEMB_F16)
+        hipLaunchKernelGGL(colsum_kernel<f16_t>, dim3((N + 63) / 64), dim3(256), 0, st, (const f16_t *)X, ldx, M, N, out);
     else
         hipLaunchKernelGGL(colsum_kernel<float>, dim3((N + 63) / 64), dim3(256), 0, st, (const float *)X, ldx, M, N, out);
     SKY_LAUNCH_CHECK("skyemb_colsum");
@@ -381,6 +386,8 @@ extern "C" int skyemb_gather_rows(const float *src, const int32_t *idx, float *o
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SKYEMB_BF16)
         hipLaunchKernelGGL(gather_rows_kernel<bf16_t>, dim3(n_rows), dim3(256), 0, st, src, idx, out, (bf16_t *)out_lp, D);
+    else if (dtype == SKYEMB_F16)
+        hipLaunchKernelGGL(gather_rows_kernel<f16_t>, dim3(n_rows), dim3(256), 0, st, src, idx, out, (f16_t *)out_lp, D);
     else
         hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(n_rows), dim3(256), 0, st, src, idx, out, (float *)out_lp, D);
     SKY_LAUNCH_CHECK("skyemb_gather_rows");
@@ -404,6 +411,8 @@ extern "C" int skyemb_cast(const float *src, void *dst, int dtype, int64_t n, vo
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SKYEMB_BF16)
         hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, src, (bf16_t *)dst, n / 4);
+    else if (dtype == SKYEMB_F16)
+        hipLaunchKernelGGL(cast_kernel<f16_t>, dim3((unsigned)blocks), dim3(256), 0, st, src, (f16_t *)dst, n / 4);
     else
         hipLaunchKernelGGL(cast_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, src, (float *)dst, n / 4);
     SKY_LAUNCH_CHECK("skyemb_cast");

@@ -13,7 +13,7 @@
 // Block = 256 threads = 4 waves (2x2), tile BM x BN in {128x128, 64x64}, BK = 64 (bf16) / 16 (f32),
 // register-staged global->LDS double buffer (one barrier per k-tile).
 #include <mutex>
-#include "common.h"
+#include "lp_twin.h"
 #include <stdlib.h>
 
 namespace {
@@ -21,9 +21,9 @@ namespace {
 template <typename T>
 struct Cfg;
 template <>
-struct Cfg<bf16_t> {
+struct Cfg<lp_t> {
     static constexpr int BK = 64, VEC = 8, KSTEP = 32, PAD_KC = 8, PAD_RC = 16;
-    typedef bf16x8 Frag;
+    typedef lp8 Frag;
 };
 template <>
 struct Cfg<float> {
@@ -38,7 +38,7 @@ struct TileShape {
     static constexpr int NVEC = R * Cfg<T>::BK / Cfg<T>::VEC / 256;  // 16-byte vectors per thread
 };
 
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+typedef __attribute__((address_space(3))) lp4 lds_lp4_t;
 
 // ---- fragment reads ------------------------------------------------------------------
 // rbase: first tile row of this 16-row MFMA operand block (multiple of 16); lane supplies row lane&15
@@ -46,36 +46,36 @@ template <typename T, bool KC, int R>
 __device__ __forceinline__ typename Cfg<T>::Frag read_frag(const T *s, int rbase, int kk, int lane);
 
 template <>
-__device__ __forceinline__ bf16x8 read_frag<bf16_t, true, 128>(const bf16_t *s, int rbase, int kk, int lane) {
-    return *(const bf16x8 *)&s[(rbase + (lane & 15)) * TileShape<bf16_t, true, 128>::PITCH + kk * 32 + 8 * (lane >> 4)];
+__device__ __forceinline__ lp8 read_frag<lp_t, true, 128>(const lp_t *s, int rbase, int kk, int lane) {
+    return *(const lp8 *)&s[(rbase + (lane & 15)) * TileShape<lp_t, true, 128>::PITCH + kk * 32 + 8 * (lane >> 4)];
 }
 template <>
-__device__ __forceinline__ bf16x8 read_frag<bf16_t, true, 64>(const bf16_t *s, int rbase, int kk, int lane) {
-    return *(const bf16x8 *)&s[(rbase + (lane & 15)) * TileShape<bf16_t, true, 64>::PITCH + kk * 32 + 8 * (lane >> 4)];
+__device__ __forceinline__ lp8 read_frag<lp_t, true, 64>(const lp_t *s, int rbase, int kk, int lane) {
+    return *(const lp8 *)&s[(rbase + (lane & 15)) * TileShape<lp_t, true, 64>::PITCH + kk * 32 + 8 * (lane >> 4)];
 }
 template <int R>
-__device__ __forceinline__ bf16x8 read_frag_rc_bf16(const bf16_t *s, int rbase, int kk, int lane) {
-    constexpr int P = TileShape<bf16_t, false, R>::PITCH;
+__device__ __forceinline__ lp8 read_frag_rc_lp(const lp_t *s, int rbase, int kk, int lane) {
+    constexpr int P = TileShape<lp_t, false, R>::PITCH;
     const int i = lane & 15, q = i >> 2, p = i & 3;
     const int kb = kk * 32 + 8 * (lane >> 4);
     // block = 4 k-rows x 16 matrix rows; lane 4q+p supplies &[kb+q][rbase + 4p]; lane i receives
     // matrix row rbase+i for k = kb..kb+3 (cdna_hip_programming.md T10)
-    const bf16_t *a0 = &s[(kb + q) * P + rbase + 4 * p];
-    const bf16_t *a1 = a0 + 4 * P;
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)a0);
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)a1);
-    bf16x8 r;
+    const lp_t *a0 = &s[(kb + q) * P + rbase + 4 * p];
+    const lp_t *a1 = a0 + 4 * P;
+    lp4 lo = sky_ds_read_tr16_b64((lds_lp4_t *)a0);
+    lp4 hi = sky_ds_read_tr16_b64((lds_lp4_t *)a1);
+    lp8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
 }
 template <>
-__device__ __forceinline__ bf16x8 read_frag<bf16_t, false, 128>(const bf16_t *s, int rbase, int kk, int lane) {
-    return read_frag_rc_bf16<128>(s, rbase, kk, lane);
+__device__ __forceinline__ lp8 read_frag<lp_t, false, 128>(const lp_t *s, int rbase, int kk, int lane) {
+    return read_frag_rc_lp<128>(s, rbase, kk, lane);
 }
 template <>
-__device__ __forceinline__ bf16x8 read_frag<bf16_t, false, 64>(const bf16_t *s, int rbase, int kk, int lane) {
-    return read_frag_rc_bf16<64>(s, rbase, kk, lane);
+__device__ __forceinline__ lp8 read_frag<lp_t, false, 64>(const lp_t *s, int rbase, int kk, int lane) {
+    return read_frag_rc_lp<64>(s, rbase, kk, lane);
 }
 template <>
 __device__ __forceinline__ float read_frag<float, true, 128>(const float *s, int rbase, int kk, int lane) {
@@ -94,8 +94,8 @@ __device__ __forceinline__ float read_frag<float, false, 64>(const float *s, int
     return s[(kk * 4 + (lane >> 4)) * TileShape<float, false, 64>::PITCH + rbase + (lane & 15)];
 }
 
-__device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+__device__ __forceinline__ f32x4 mfma(lp8 a, lp8 b, f32x4 c) {
+    return sky_mfma_16x16x32(a, b, c);
 }
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -301,14 +301,20 @@ int dispatch_layout(const skyemb_gemm_args &g, hipStream_t st) {
 
 }  // namespace
 
-int skyemb_gemm_pipe_try(const skyemb_gemm_args &g, hipStream_t st);  // gemm_pipe.hip (-1: not applicable)
+int SKY_TWIN(skyemb_gemm_pipe_try)(const skyemb_gemm_args &g, hipStream_t st);  // gemm_pipe.hip (-1: not applicable)
+#ifndef SKY_F16
+extern "C" __attribute__((visibility("hidden"))) int skyemb_gemm_f16(const skyemb_gemm_args *args, void *stream);   // this file, compiled with -DSKY_F16 (lp_twin.h)
+#endif
 
-extern "C" int skyemb_gemm(const skyemb_gemm_args *args, void *stream) {
+extern "C" SKY_TWIN_VIS int SKY_TWIN(skyemb_gemm)(const skyemb_gemm_args *args, void *stream) {
     SKY_CHECK_ARG(args != nullptr, "skyemb_gemm: null args");
     const skyemb_gemm_args &g = *args;
+#ifndef SKY_F16
+    if (g.dtype == SKYEMB_F16) return skyemb_gemm_f16(args, stream);
+#endif
     SKY_CHECK_ARG(g.M > 0 && g.N > 0 && g.K > 0, "skyemb_gemm: empty problem M=%d N=%d K=%d", g.M, g.N, g.K);
-    SKY_CHECK_ARG(g.dtype == SKYEMB_BF16 || g.dtype == SKYEMB_F32, "skyemb_gemm: bad dtype %d", g.dtype);
-    const int vec = g.dtype == SKYEMB_BF16 ? 8 : 4;
+    SKY_CHECK_ARG(g.dtype == SKY_LP_DTYPE || g.dtype == SKYEMB_F32, "skyemb_gemm: bad dtype %d", g.dtype);
+    const int vec = g.dtype == SKY_LP_DTYPE ? 8 : 4;
     const int a_cont = g.a_layout == SKYEMB_KC ? g.K : g.M;
     const int b_cont = g.b_layout == SKYEMB_KC ? g.K : g.N;
     SKY_CHECK_ARG(a_cont % vec == 0 && b_cont % vec == 0 && g.lda % vec == 0 && g.ldb % vec == 0,
@@ -323,13 +329,13 @@ extern "C" int skyemb_gemm(const skyemb_gemm_args *args, void *stream) {
     if (skyemb_skip_mask() & 1) return 0;
     static const bool use_pipe = []() { const char *e = getenv("SKYEMB_GEMM_PIPE"); return !(e && e[0] == '0'); }();
     if (use_pipe) {
-        const int rc = skyemb_gemm_pipe_try(g, st);
+        const int rc = SKY_TWIN(skyemb_gemm_pipe_try)(g, st);
         if (rc >= 0) return rc;
     }
     int tile = g.tile;
     if (tile == 0) tile = (ceil_div64(g.M, 128) * ceil_div64(g.N, 128) >= 200) ? 128 : 64;
-    if (g.dtype == SKYEMB_BF16) {
-        return tile == 128 ? dispatch_layout<bf16_t, 128>(g, st) : dispatch_layout<bf16_t, 64>(g, st);
+    if (g.dtype == SKY_LP_DTYPE) {
+        return tile == 128 ? dispatch_layout<lp_t, 128>(g, st) : dispatch_layout<lp_t, 64>(g, st);
     }
     return tile == 128 ? dispatch_layout<float, 128>(g, st) : dispatch_layout<float, 64>(g, st);
 }

@@ -11,7 +11,7 @@
 //                               ch ^ rc_swz(k); fragments by ds_read_b64_tr_b16 (transposed read).
 // The MFMA is issued with operands swapped (D = B_frag x A_frag) so that every lane owns 4
 // consecutive output COLUMNS of one row: 16-byte fp32 / 8-byte bf16 stores, float4 bias loads.
-#include "common.h"
+#include "lp_twin.h"
 #include "adamw_math.h"
 #include "ln_bwd_body.h"
 #include <stdlib.h>
@@ -23,7 +23,7 @@ namespace {
 
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
+typedef __attribute__((address_space(3))) lp4 lds_lp4_t;
 
 constexpr int BK = 64;
 
@@ -46,13 +46,13 @@ __device__ __forceinline__ void glds16(const void *src, char *lds_wave_base) {
 // loads through an explicitly GLOBAL pointer: a struct member like `const float *bias` is a generic pointer to the compiler, which
 // then emits flat_load -- out of order with respect to global loads, so every wait behind one is a full `vmcnt(0) lgkmcnt(0)`
 typedef __attribute__((address_space(1))) const f32x4 gf32x4_t;
-typedef __attribute__((address_space(1))) const bf16x8 gbf16x8_t;
+typedef __attribute__((address_space(1))) const lp8 gbf16x8_t;
 typedef __attribute__((address_space(1))) const int gint_t;
 __device__ __forceinline__ float4 gload4(const float *p) {
     const f32x4 v = *(gf32x4_t *)p;
     return make_float4(v[0], v[1], v[2], v[3]);
 }
-__device__ __forceinline__ bf16x8 gload8h(const bf16_t *p) { return *(gbf16x8_t *)p; }
+__device__ __forceinline__ lp8 gload8h(const lp_t *p) { return *(gbf16x8_t *)p; }
 __device__ __forceinline__ int gloadi(const int *p) { return *(gint_t *)p; }
 
 template <int N>
@@ -86,11 +86,11 @@ __device__ __forceinline__ float dgelu_f(float x) {
     return fmaf(x * 0.39894228040143267794f, gauss, cdf);
 }
 
-__device__ __forceinline__ void store8(bf16_t *p, const float (&v)[8]) {
-    bf16x8 o;
+__device__ __forceinline__ void store8(lp_t *p, const float (&v)[8]) {
+    lp8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-    *(bf16x8 *)p = o;
+    for (int e = 0; e < 8; ++e) o[e] = (lp_t)v[e];
+    *(lp8 *)p = o;
 }
 
 // One 4-byte LDS-DMA read per lane from a workgroup-uniform base + a 32-bit lane offset into the 256 bytes at `lds_wave_base`: the
@@ -112,7 +112,7 @@ __device__ __forceinline__ void glds4_sbase(const void *base_uniform, unsigned i
 template <int R, int NW>
 constexpr int issue_per_wave() { return (R / 8 + NW - 1) / NW; }
 template <int R, int NW>
-__device__ __forceinline__ void issue_kc(const bf16_t *__restrict__ X, int64_t ld, int r0, int rows, int k0, char *sbase,
+__device__ __forceinline__ void issue_kc(const lp_t *__restrict__ X, int64_t ld, int r0, int rows, int k0, char *sbase,
                                          int wave, int lane) {
     constexpr int PER_WAVE = issue_per_wave<R, NW>();
     constexpr bool EXACT = (R / 8) % NW == 0;
@@ -137,7 +137,7 @@ __device__ __forceinline__ int rc_swz(int k) {
 }
 // RC operand: 64 k-rows x R rows (R*2 bytes per k-row).  One wave-instruction = 1 KiB = 512/R k-rows.
 template <int R, int NW>
-__device__ __forceinline__ void issue_rc(const bf16_t *__restrict__ X, int64_t ld, int r0, int rows, int k0, char *sbase,
+__device__ __forceinline__ void issue_rc(const lp_t *__restrict__ X, int64_t ld, int r0, int rows, int k0, char *sbase,
                                          int wave, int lane) {
     constexpr int CH = R / 8;                 // 16-byte chunks per k-row
     constexpr int KROWS = 64 / CH;            // k-rows per wave-instruction (4 for R=128, 8 for R=64)
@@ -165,21 +165,21 @@ __device__ __forceinline__ int rc_off(int k, int ch) {
 }
 
 // ---- fragment reads --------------------------------------------------------------------------
-__device__ __forceinline__ bf16x8 frag_kc(const char *sbase, int rbase, int kk, int lane) {
+__device__ __forceinline__ lp8 frag_kc(const char *sbase, int rbase, int kk, int lane) {
     const int r = rbase + (lane & 15);
     const int c = (4 * kk + (lane >> 4)) ^ (lane & 7);
-    return *(const bf16x8 *)(sbase + r * 128 + (c << 4));
+    return *(const lp8 *)(sbase + r * 128 + (c << 4));
 }
 template <int R>
-__device__ __forceinline__ bf16x8 frag_rc(const char *sbase, int rbase, int kk, int lane) {
+__device__ __forceinline__ lp8 frag_rc(const char *sbase, int rbase, int kk, int lane) {
     const int i = lane & 15, q = i >> 2, p = i & 3;
     const int kb = kk * 32 + 8 * (lane >> 4);
     const int ch = (rbase >> 3) + (p >> 1);
     const char *a0 = sbase + rc_off<R>(kb + q, ch) + 8 * (p & 1);
     const char *a1 = sbase + rc_off<R>(kb + 4 + q, ch) + 8 * (p & 1);
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)a0);
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t *)a1);
-    bf16x8 r;
+    lp4 lo = sky_ds_read_tr16_b64((lds_lp4_t *)a0);
+    lp4 hi = sky_ds_read_tr16_b64((lds_lp4_t *)a1);
+    lp8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
@@ -192,19 +192,19 @@ __device__ __forceinline__ bf16x8 frag_rc(const char *sbase, int rbase, int kk, 
 // weight-gradient launch).  As asm the reads are invisible to that pass; the LDS counter is then waited on by hand
 // (lds_wait), with every read of a k-step in asm so that the count is exact.
 __device__ __forceinline__ uint32_t lds_addr(const char *p) { return (uint32_t)(uintptr_t)(lvoid_t *)p; }
-__device__ __forceinline__ bf16x8 frag_kc_asm(const char *sbase, int rbase, int kk, int lane) {
+__device__ __forceinline__ lp8 frag_kc_asm(const char *sbase, int rbase, int kk, int lane) {
     const int r = rbase + (lane & 15);
     const int c = (4 * kk + (lane >> 4)) ^ (lane & 7);
-    bf16x8 v;
+    lp8 v;
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(lds_addr(sbase + r * 128 + (c << 4))) : "memory");
     return v;
 }
 template <int R>
-__device__ __forceinline__ bf16x8 frag_rc_asm(const char *sbase, int rbase, int kk, int lane) {
+__device__ __forceinline__ lp8 frag_rc_asm(const char *sbase, int rbase, int kk, int lane) {
     const int i = lane & 15, q = i >> 2, p = i & 3;
     const int kb = kk * 32 + 8 * (lane >> 4);
     const int ch = (rbase >> 3) + (p >> 1);
-    bf16x4 lo, hi;
+    lp4 lo, hi;
 #ifdef SKY_RC_AS_B64      // experiment build (wrong products): plain 8-byte reads at the same addresses -- same k-step time
     asm volatile("ds_read_b64 %0, %1" : "=v"(lo) : "v"(lds_addr(sbase + rc_off<R>(kb + q, ch) + 8 * (p & 1))) : "memory");
     asm volatile("ds_read_b64 %0, %1" : "=v"(hi) : "v"(lds_addr(sbase + rc_off<R>(kb + 4 + q, ch) + 8 * (p & 1))) : "memory");
@@ -212,7 +212,7 @@ __device__ __forceinline__ bf16x8 frag_rc_asm(const char *sbase, int rbase, int 
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(lds_addr(sbase + rc_off<R>(kb + q, ch) + 8 * (p & 1))) : "memory");
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(lds_addr(sbase + rc_off<R>(kb + 4 + q, ch) + 8 * (p & 1))) : "memory");
 #endif
-    bf16x8 r;
+    lp8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
@@ -223,7 +223,7 @@ template <int N>
 __device__ __forceinline__ void lds_wait() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N < 15 ? N : 15) : "memory");
 }
-__device__ __forceinline__ void lds_use(bf16x8 &f) { asm volatile("" : "+v"(f)); }
+__device__ __forceinline__ void lds_use(lp8 &f) { asm volatile("" : "+v"(f)); }
 
 // wait until at most `rem` younger stages (NI LDS-DMA instructions each) are still in flight
 template <int NI, int MAXREM>
@@ -297,8 +297,8 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
     const int tile_m = (int)quo, tile_n = (int)(wg - quo * tiles_n);
 #endif
     const int m0 = tile_m * BMS, n0 = tile_n * BN;
-    const bf16_t *A = (const bf16_t *)g.A;
-    const bf16_t *B = (const bf16_t *)g.B;
+    const lp_t *A = (const lp_t *)g.A;
+    const lp_t *B = (const lp_t *)g.B;
     const int KT_all = g.K / (BK * WK);                 // ring stages (WK k-tiles each; the host checks divisibility)
     int kt_begin = 0, KT = KT_all;
     if (S > 1) {   // K / 64 * 8 < 2^32
@@ -334,9 +334,9 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
     f32x4 cacc[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) cacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8 ones;
+    lp8 ones;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+    for (int e = 0; e < 8; ++e) ones[e] = (lp_t)1.0f;
 
     constexpr int AHEAD = NSTAGE - 1;
     // The prefetch hint (skyemb.h): this workgroup's share of the lines a later launch will read, requested BEFORE its own first
@@ -381,7 +381,7 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
         if constexpr (A_KC && B_KC) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 fa[TM], fb[TN];
+                lp8 fa[TM], fb[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) fa[i] = frag_kc(sa, wm * SM + i * 16, kk, lane);
 #pragma unroll
@@ -390,12 +390,12 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D[n][m]
+                        acc[i][j] = sky_mfma_16x16x32(fb[j], fa[i], acc[i][j]);  // D[n][m]
             }
         } else {
             // both halves of the k-step are requested up front; the first half's MFMAs run while the second half lands
             constexpr int READS = TM * (A_KC ? 1 : 2) + TN * (B_KC ? 1 : 2);     // asm LDS reads per half
-            bf16x8 fa[2][TM], fb[2][TN];
+            lp8 fa[2][TM], fb[2][TN];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
@@ -422,12 +422,12 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);  // D[n][m]
+                        acc[i][j] = sky_mfma_16x16x32(fb[kk][j], fa[kk][i], acc[i][j]);  // D[n][m]
 #endif
                 if (!A_KC && do_colsum) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
-                        cacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[kk][i], cacc[i], 0, 0, 0);
+                        cacc[i] = sky_mfma_16x16x32(ones, fa[kk][i], cacc[i]);
                 }
             }
         }
@@ -458,10 +458,10 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
     const bool fused = S == 1;                           // split-K: raw partial tiles, splitk_reduce_kernel applies the epilogue
     int orow[CH], trow[CH];
     float4 e_bias[CH][2], e_tab[CH][2], e_res[CH][2];
-    bf16x8 e_aux[CH];
+    lp8 e_aux[CH];
     float4 e_p[CH][2], e_m[CH][2], e_v[CH][2];           // (ADAM) the parameters and moments the piece updates
     const int64_t ad_off = ADAM ? (int64_t)(g.out_f32 - ad->g_base) : 0;   // element offset of this problem in the flat buffers
-    const bf16_t *aux = (const bf16_t *)g.aux;
+    const lp_t *aux = (const lp_t *)g.aux;
     // (two copies of the request block: without row maps -- every launch of a transformer block -- no load feeds an address,
     // so nothing is waited for before the tile is staged; with them the residual / table rows wait for the maps only)
     auto request_inputs = [&](int j0, auto with_maps) {
@@ -556,8 +556,8 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
     }
     __syncthreads();
     GSTAMP(st_staged);
-    bf16_t *out = (bf16_t *)g.out;
-    bf16_t *out2 = (bf16_t *)g.out2;
+    lp_t *out = (lp_t *)g.out;
+    lp_t *out2 = (lp_t *)g.out2;
     float *slab = S > 1 ? (float *)g.ws + (int64_t)split * g.M * g.N : nullptr;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
@@ -615,7 +615,7 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
                 *(float4 *)(ad->m + o + 4) = make_float4(mm[4], mm[5], mm[6], mm[7]);
                 *(float4 *)(ad->v + o) = make_float4(vv[0], vv[1], vv[2], vv[3]);
                 *(float4 *)(ad->v + o + 4) = make_float4(vv[4], vv[5], vv[6], vv[7]);
-                store8((bf16_t *)ad->p_lp + o, pp);
+                store8((lp_t *)ad->p_lp + o, pp);
                 continue;
             }
             if (g.out_f32) {
@@ -709,7 +709,7 @@ __device__ __forceinline__ void side_adamw_job(const char *__restrict__ blob, co
     const int64_t n8 = (hi - lo) >> 3, stride = (int64_t)nwg * THREADS, n_decay = ad->n_decay;
     float *__restrict__ P = ad->p, *__restrict__ M = ad->m, *__restrict__ V = ad->v;
     const float *__restrict__ G = ad->g_base;
-    bf16_t *__restrict__ PL = (bf16_t *)ad->p_lp;
+    lp_t *__restrict__ PL = (lp_t *)ad->p_lp;
     for (int64_t i0 = (int64_t)wg * THREADS + threadIdx.x; i0 < n8; i0 += U * stride) {
         float4 p4[U][2], g4[U][2], m4[U][2], v4[U][2];
 #pragma unroll
@@ -770,15 +770,15 @@ __device__ __forceinline__ void side_ln_bwd_job(const char *__restrict__ blob, c
     float *gam_lds = (float *)smem + (THREADS / 256) * 1024;
     for (int c = (int)threadIdx.x; c < ln.D; c += THREADS) gam_lds[c] = ln.gamma[c];
     __syncthreads();
-    const bf16_t *dy = (const bf16_t *)ln.dy;
-    bf16_t *g_lp = (bf16_t *)ln.g_lp;
+    const lp_t *dy = (const lp_t *)ln.dy;
+    lp_t *g_lp = (lp_t *)ln.g_lp;
     switch ((ln.D + 255) / 256) {                           // (workgroup-uniform)
-        case 1: return sky_ln_bwd_rows<bf16_t, bf16_t, 1, true>(dy, ln.x, ln.gamma, ln.mean, ln.rstd, ln.g_in, ln.g_out, g_lp, ln.part, ln.M, ln.D, nblk, blk, wave & 3, lane, red, gam_lds);
-        case 2: return sky_ln_bwd_rows<bf16_t, bf16_t, 2, true>(dy, ln.x, ln.gamma, ln.mean, ln.rstd, ln.g_in, ln.g_out, g_lp, ln.part, ln.M, ln.D, nblk, blk, wave & 3, lane, red, gam_lds);
-        case 3: return sky_ln_bwd_rows<bf16_t, bf16_t, 3, true>(dy, ln.x, ln.gamma, ln.mean, ln.rstd, ln.g_in, ln.g_out, g_lp, ln.part, ln.M, ln.D, nblk, blk, wave & 3, lane, red, gam_lds);
+        case 1: return sky_ln_bwd_rows<lp_t, lp_t, 1, true>(dy, ln.x, ln.gamma, ln.mean, ln.rstd, ln.g_in, ln.g_out, g_lp, ln.part, ln.M, ln.D, nblk, blk, wave & 3, lane, red, gam_lds);
+        case 2: return sky_ln_bwd_rows<lp_t, lp_t, 2, true>(dy, ln.x, ln.gamma, ln.mean, ln.rstd, ln.g_in, ln.g_out, g_lp, ln.part, ln.M, ln.D, nblk, blk, wave & 3, lane, red, gam_lds);
+        case 3: return sky_ln_bwd_rows<lp_t, lp_t, 3, true>(dy, ln.x, ln.gamma, ln.mean, ln.rstd, ln.g_in, ln.g_out, g_lp, ln.part, ln.M, ln.D, nblk, blk, wave & 3, lane, red, gam_lds);
         default:
             if constexpr (MAXNV >= 4)
-                return sky_ln_bwd_rows<bf16_t, bf16_t, 4, true>(dy, ln.x, ln.gamma, ln.mean, ln.rstd, ln.g_in, ln.g_out, g_lp, ln.part, ln.M, ln.D, nblk, blk, wave & 3, lane, red, gam_lds);
+                return sky_ln_bwd_rows<lp_t, lp_t, 4, true>(dy, ln.x, ln.gamma, ln.mean, ln.rstd, ln.g_in, ln.g_out, g_lp, ln.part, ln.M, ln.D, nblk, blk, wave & 3, lane, red, gam_lds);
     }
 }
 // which side job a workgroup behind the tiles runs: LayerNorm rows first, then the optimiser's slice
@@ -832,9 +832,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const skyemb_gemm_ar
     const float *ws = (const float *)g.ws;
     const int M = g.M, N = g.N;
     const int64_t mn4 = (int64_t)M * N / 4;
-    bf16_t *out = (bf16_t *)g.out;
-    bf16_t *out2 = (bf16_t *)g.out2;
-    const bf16_t *aux = (const bf16_t *)g.aux;
+    lp_t *out = (lp_t *)g.out;
+    lp_t *out2 = (lp_t *)g.out2;
+    const lp_t *aux = (const lp_t *)g.aux;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < mn4; i += (int64_t)gridDim.x * 256) {
         float4 a = *(const float4 *)(ws + 4 * i);
         for (int s = 1; s < S; ++s) {
@@ -858,14 +858,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const skyemb_gemm_ar
             v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
         }
         if (g.act == SKYEMB_ACT_GELU) {
-            if (out2) store4<bf16_t>(out2 + (int64_t)orow * g.ldo2 + n, v[0], v[1], v[2], v[3]);
+            if (out2) store4<lp_t>(out2 + (int64_t)orow * g.ldo2 + n, v[0], v[1], v[2], v[3]);
             v[0] = gelu_f(v[0]); v[1] = gelu_f(v[1]); v[2] = gelu_f(v[2]); v[3] = gelu_f(v[3]);
         } else if (g.act == SKYEMB_ACT_DGELU) {
-            const float4 t = load4<bf16_t>(aux + (int64_t)m * g.ldaux + n);
+            const float4 t = load4<lp_t>(aux + (int64_t)m * g.ldaux + n);
             v[0] *= dgelu_f(t.x); v[1] *= dgelu_f(t.y); v[2] *= dgelu_f(t.z); v[3] *= dgelu_f(t.w);
         }
         if (g.out_f32) *(float4 *)(g.out_f32 + (int64_t)orow * g.ldo32 + n) = make_float4(v[0], v[1], v[2], v[3]);
-        if (out) store4<bf16_t>(out + (int64_t)orow * g.ldo + n, v[0], v[1], v[2], v[3]);
+        if (out) store4<lp_t>(out + (int64_t)orow * g.ldo + n, v[0], v[1], v[2], v[3]);
     }
     if (g.colsum_a && g.a_layout == SKYEMB_RC && blockIdx.x == 0) {
         const float *cs = ws + (int64_t)S * M * N;
@@ -1010,9 +1010,9 @@ const TunedGemm kTuned[] = {
 }  // namespace
 
 // returns -1 when the problem is outside the fast-path subset (caller falls back to gemm.hip)
-int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
+int SKY_TWIN(skyemb_gemm_pipe_try)(const skyemb_gemm_args &g_in, hipStream_t st) {
     skyemb_gemm_args g = g_in;
-    if (g.dtype != SKYEMB_BF16 || g.K % BK != 0 || g.N % 8 != 0) return -1;
+    if (g.dtype != SKY_LP_DTYPE || g.K % BK != 0 || g.N % 8 != 0) return -1;
     // alignment of the vectorised epilogue operands
     if ((g.ldo32 % 4) || (g.ldo % 8) || (g.ldo2 % 8) || (g.ldr % 4) || (g.ldt % 4) || (g.ldaux % 8)) return -1;
     if (!aligned16(g.out) || !aligned16(g.out2) || !aligned16(g.aux) || !aligned16(g.out_f32) || !aligned16(g.resid) ||
@@ -1138,7 +1138,7 @@ int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
             }
             const int rc = tile == 256256 ? gemm256_launch(gm, st) : dispatch_code(tile, gm, st);
             if (rc != 0) return rc;
-            return skyemb_gemm_pipe_try(gt, st);
+            return SKY_TWIN(skyemb_gemm_pipe_try)(gt, st);
         }
     }
     if (tile == 256256) return gemm256_launch(g, st);
@@ -1149,6 +1149,9 @@ int skyemb_gemm_pipe_try(const skyemb_gemm_args &g_in, hipStream_t st) {
 // [header 256 B][n problems][skyemb_ln_bwd_side, 128 B reserved]
 constexpr int GROUP_TAIL_BYTES = 128;
 static_assert(sizeof(skyemb_ln_bwd_side) <= GROUP_TAIL_BYTES, "the blob's tail holds the LayerNorm side job's record");
+// (the plans are host logic common to both 16-bit formats: built once, in the bf16 object; only the launch has a twin)
+#ifndef SKY_F16
+extern "C" __attribute__((visibility("hidden"))) int skyemb_gemm_group_launch_f16(const void *blob_dev, const skyemb_gemm_group_info *info, void *stream);
 extern "C" int64_t skyemb_gemm_group_blob_bytes(int n) { return GROUP_HEADER_BYTES + (int64_t)n * sizeof(skyemb_gemm_args) + GROUP_TAIL_BYTES; }
 
 static int class_bit(const skyemb_gemm_args &g) {
@@ -1210,14 +1213,14 @@ extern "C" int skyemb_gemm_group_plan(const skyemb_gemm_args *args, int n, int t
     int start = 0, mask = 0;
     for (int i = 0; i < n; ++i) {
         skyemb_gemm_args g = args[i];
-        const bool ok = g.dtype == SKYEMB_BF16 && g.K % BK == 0 && g.K >= BK && g.N % 8 == 0 && !(g.ldo32 % 4) && !(g.ldo % 8) &&
+        const bool ok = sky_is_lp(g.dtype) && g.dtype == args[0].dtype && g.K % BK == 0 && g.K >= BK && g.N % 8 == 0 && !(g.ldo32 % 4) && !(g.ldo % 8) &&
                         !(g.ldo2 % 8) && !(g.ldr % 4) && !(g.ldt % 4) && !(g.ldaux % 8) &&
                         (g.a_layout == SKYEMB_KC ? g.M >= 1 : (g.M % 8 == 0 && g.M >= 8)) &&
                         (g.b_layout == SKYEMB_KC ? g.N >= 1 : (g.N % 8 == 0 && g.N >= 8)) && aligned16(g.A) && aligned16(g.B) &&
                         aligned16(g.out) && aligned16(g.out2) && aligned16(g.aux) && aligned16(g.out_f32) && aligned16(g.resid) &&
                         aligned16(g.bias) && aligned16(g.table) && (g.out || g.out_f32);
         if (!ok) {
-            skyemb_set_error("skyemb_gemm_group_plan: problem %d is outside the pipelined bf16 subset", i);
+            skyemb_set_error("skyemb_gemm_group_plan: problem %d is outside the pipelined 16-bit subset (or mixes formats)", i);
             return -1;
         }
         g.split_k = 1;
@@ -1246,7 +1249,7 @@ extern "C" int skyemb_gemm_group_plan(const skyemb_gemm_args *args, int n, int t
     info->total_blocks = start;
     info->tile = tile;
     info->class_mask = mask;
-    info->reserved = 0;
+    info->reserved = args[0].dtype == SKYEMB_F16 ? 4 : 0;     // bit 2: the problems are SKYEMB_F16 (the launch takes the _f16 twin)
     return 0;
 }
 
@@ -1272,7 +1275,7 @@ extern "C" int skyemb_gemm_group_plan_adamw(const skyemb_gemm_args *args, int n,
     skyemb_adamw_desc d = *adamw;
     d.enabled = 1;
     memcpy((char *)blob_host + GROUP_ADAMW_OFFSET, &d, sizeof d);
-    info->reserved = 1;
+    info->reserved = (info->reserved & 4) | 1;
     return 0;
 }
 
@@ -1302,7 +1305,7 @@ extern "C" int skyemb_gemm_group_plan_side_adamw(const skyemb_gemm_args *args, i
     memcpy(hdr + 4, range, sizeof range);
     info->total_blocks += side_blocks;
     hdr[1] = (hdr[1] & (1 << 30)) | info->total_blocks;
-    info->reserved = (own_step ? 1 : 0) | 2;
+    info->reserved = (info->reserved & 4) | (own_step ? 1 : 0) | 2;
     return 0;
 }
 
@@ -1339,6 +1342,7 @@ extern "C" int skyemb_gemm_group_attach_ln_bwd(void *blob_host, int64_t blob_byt
     info->reserved |= 2;
     return 0;
 }
+#endif   // !SKY_F16
 
 template <int BM, int BN, int NSTAGE, int WM, int WN, int CLASSES, int WK = 1, bool ADAM = false, bool SIDE = false>
 static int group_launch_n(const void *blob_dev, int total_blocks, hipStream_t st) {
@@ -1377,12 +1381,16 @@ static int group_launch_classes(const void *blob_dev, int total_blocks, int mask
     return 1;
 }
 
-extern "C" int skyemb_gemm_group_launch(const void *blob_dev, const skyemb_gemm_group_info *info, void *stream) {
+extern "C" SKY_TWIN_VIS int SKY_TWIN(skyemb_gemm_group_launch)(const void *blob_dev, const skyemb_gemm_group_info *info, void *stream) {
     SKY_CHECK_ARG(blob_dev && info && info->total_blocks > 0, "skyemb_gemm_group_launch: bad arguments");
+#ifndef SKY_F16
+    if (info->reserved & 4) return skyemb_gemm_group_launch_f16(blob_dev, info, stream);
+#endif
     if (skyemb_skip_mask() & 1) return 0;
     hipStream_t st = (hipStream_t)stream;
-    if (info->reserved == 2 || info->reserved == 3) {          // side optimiser job (plan_side_adamw), own tiles stored (2) or stepped (3)
-        const bool own = info->reserved == 3;
+    const int mode = info->reserved & 3;
+    if (mode == 2 || mode == 3) {          // side optimiser job (plan_side_adamw), own tiles stored (2) or stepped (3)
+        const bool own = mode == 3;
         switch (info->tile) {
             case 64064: return own ? group_launch_n<64, 64, 3, 2, 2, 4, 1, true, true>(blob_dev, info->total_blocks, st)
                                    : group_launch_n<64, 64, 3, 2, 2, 4, 1, false, true>(blob_dev, info->total_blocks, st);
@@ -1396,7 +1404,7 @@ extern "C" int skyemb_gemm_group_launch(const void *blob_dev, const skyemb_gemm_
         skyemb_set_error("skyemb_gemm_group_launch: tile %d not built with a side optimiser job", info->tile);
         return 1;
     }
-    if (info->reserved == 1) {                                 // optimiser step fused into the epilogue (plan_adamw: class 4 only)
+    if (mode == 1) {                                 // optimiser step fused into the epilogue (plan_adamw: class 4 only)
         switch (info->tile) {
             case 64064: return group_launch_n<64, 64, 3, 2, 2, 4, 1, true>(blob_dev, info->total_blocks, st);
             case 128064: return group_launch_n<128, 64, 3, 4, 2, 4, 1, true>(blob_dev, info->total_blocks, st);

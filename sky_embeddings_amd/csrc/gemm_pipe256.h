@@ -63,8 +63,8 @@ __device__ __forceinline__ void gemm256_tile(const skyemb_gemm_args &g, const un
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const unsigned int tiles_n = ((unsigned int)g.N + 255u) / 256u, tiles_m = ((unsigned int)g.M + 255u) / 256u;
-    const bf16_t *A = (const bf16_t *)g.A + 0;
-    const bf16_t *B = (const bf16_t *)g.B + 0;
+    const lp_t *A = (const lp_t *)g.A + 0;
+    const lp_t *B = (const lp_t *)g.B + 0;
     const int KT = g.K / BK, H = 4 * KT;
     const bool colmajor = g.N > g.M;
   {
@@ -154,7 +154,7 @@ __device__ __forceinline__ void gemm256_tile(const skyemb_gemm_args &g, const un
 #else
 #define G256_STAMP(w)
 #endif
-    bf16x8 fa[4][2], fb[2][2][2];                         // A: one 64-row half of the wave's block; B: both 32-column halves
+    lp8 fa[4][2], fb[2][2][2];                         // A: one 64-row half of the wave's block; B: both 32-column halves
     int rs = 0;                                           // slot of half-tile 4 t
     const int a_rows = 0, b_rows = (wc & 1) * 64;         // first row of the wave's block inside its A / B half-tile
     (void)a_rows;
@@ -195,7 +195,7 @@ __device__ __forceinline__ void gemm256_tile(const skyemb_gemm_args &g, const un
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[ih * 4 + ii][j] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j >> 1][j & 1][kk], fa[ii][kk], acc[ih * 4 + ii][j], 0, 0, 0);  // D[n][m]
+                        sky_mfma_16x16x32(fb[j >> 1][j & 1][kk], fa[ii][kk], acc[ih * 4 + ii][j]);  // D[n][m]
 #ifndef G256_NOPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -261,11 +261,11 @@ __device__ __forceinline__ void gemm256_tile(const skyemb_gemm_args &g, const un
                 const int row = lane_fresh() & 15;
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
-                    bf16x8 sel;
+                    lp8 sel;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) sel[e] = row == q * 4 + ii ? (bf16_t)1.0f : (bf16_t)0.0f;
+                    for (int e = 0; e < 8; ++e) sel[e] = row == q * 4 + ii ? (lp_t)1.0f : (lp_t)0.0f;
 #pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) cacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel, fa[ii][kk], cacc, 0, 0, 0);
+                    for (int kk = 0; kk < 2; ++kk) cacc = sky_mfma_16x16x32(sel, fa[ii][kk], cacc);
                 }
             }
         }
@@ -296,9 +296,9 @@ __device__ __forceinline__ void gemm256_tile(const skyemb_gemm_args &g, const un
         }
     }
     const int64_t ad_off = ADAM ? (int64_t)(g.out_f32 - ad->g_base) : 0;
-    bf16_t *out = (bf16_t *)g.out;
-    bf16_t *out2 = (bf16_t *)g.out2;
-    const bf16_t *aux = (const bf16_t *)g.aux;
+    lp_t *out = (lp_t *)g.out;
+    lp_t *out2 = (lp_t *)g.out2;
+    const lp_t *aux = (const lp_t *)g.aux;
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
         if (wr == half) {
@@ -314,7 +314,7 @@ __device__ __forceinline__ void gemm256_tile(const skyemb_gemm_args &g, const un
 #pragma unroll 1
         for (int jj = 0; jj < 8; jj += 2) {               // 128 rows x 32 pieces over 512 threads: 8 each, two at a time
             float4 e_bias[2][2], e_res[2][2];
-            bf16x8 e_aux[2];
+            lp8 e_aux[2];
             float4 e_p[2][2], e_m[2][2], e_v[2][2];       // (ADAM) the parameters and moments the piece updates
 #pragma unroll
             for (int u = 0; u < 2; ++u) {                 // every fused input of the two pieces requested up front, clamped
@@ -354,7 +354,7 @@ __device__ __forceinline__ void gemm256_tile(const skyemb_gemm_args &g, const un
                     *(float4 *)(ad->m + o + 4) = make_float4(mm[4], mm[5], mm[6], mm[7]);
                     *(float4 *)(ad->v + o) = make_float4(vv[0], vv[1], vv[2], vv[3]);
                     *(float4 *)(ad->v + o + 4) = make_float4(vv[4], vv[5], vv[6], vv[7]);
-                    store8((bf16_t *)ad->p_lp + o, pp);
+                    store8((lp_t *)ad->p_lp + o, pp);
                     continue;
                 }
                 auto add8 = [&](const float4 &a, const float4 &b) {

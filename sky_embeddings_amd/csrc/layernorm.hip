@@ -139,6 +139,9 @@ extern "C" int skyemb_layernorm_fwd(const float *x, const float *gamma, const fl
     if (dtype == SKYEMB_BF16)                                                                                        \
         hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, NV>), grid, block, 0, st, x, gamma, beta, (bf16_t *)y, y32, mean,   \
                            rstd, M, D, eps);                                                                         \
+    else if (dtype == SKYEMB_F16)                                                                                    \
+        hipLaunchKernelGGL((ln_fwd_kernel<f16_t, NV>), grid, block, 0, st, x, gamma, beta, (f16_t *)y, y32, mean,     \
+                           rstd, M, D, eps);                                                                         \
     else                                                                                                             \
         hipLaunchKernelGGL((ln_fwd_kernel<float, NV>), grid, block, 0, st, x, gamma, beta, (float *)y, y32, mean,     \
                            rstd, M, D, eps);
@@ -181,6 +184,13 @@ extern "C" int skyemb_layernorm_bwd(const void *dy, int dy_is_f32, int dtype, co
         else                                                                                                         \
             hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, bf16_t, NV>), grid, block, 0, st, (const bf16_t *)dy, x, gamma, \
                                mean, rstd, g_in, g_out, (bf16_t *)g_lp, part, M, D, nblk);                           \
+    } else if (dtype == SKYEMB_F16) {                                                                                \
+        if (dy_is_f32)                                                                                               \
+            hipLaunchKernelGGL((ln_bwd_kernel<float, f16_t, NV>), grid, block, 0, st, (const float *)dy, x, gamma,    \
+                               mean, rstd, g_in, g_out, (f16_t *)g_lp, part, M, D, nblk);                            \
+        else                                                                                                         \
+            hipLaunchKernelGGL((ln_bwd_kernel<f16_t, f16_t, NV>), grid, block, 0, st, (const f16_t *)dy, x, gamma,    \
+                               mean, rstd, g_in, g_out, (f16_t *)g_lp, part, M, D, nblk);                            \
     } else {                                                                                                         \
         hipLaunchKernelGGL((ln_bwd_kernel<float, float, NV>), grid, block, 0, st, (const float *)dy, x, gamma, mean,  \
                            rstd, g_in, g_out, (float *)g_lp, part, M, D, nblk);                                      \

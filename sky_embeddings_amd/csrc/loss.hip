@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void loss_pass1(const float *__restrict__ imgs
     if (threadIdx.x == 0) { o[0] = s; o[1] = n; o[2] = mu; o[3] = istd; }
 }
 
-__global__ __launch_bounds__(256) void loss_finalize(float *__restrict__ ws, float *__restrict__ loss, int BL, float numel) {
+__global__ __launch_bounds__(256) void loss_finalize(float *__restrict__ ws, float *__restrict__ loss, int BL, float numel, float dscale) {
     __shared__ float red[4];
     float s = 0.f, n = 0.f;
     for (int i = threadIdx.x; i < BL; i += 256) { s += ws[4 * (int64_t)i]; n += ws[4 * (int64_t)i + 1]; }
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void loss_finalize(float *__restrict__ ws, flo
         const float inv = 1.0f / (scale + 1e-5f);
         loss[0] = s / (scale + 1e-5f);
         ws[4 * (int64_t)BL] = loss[0];
-        ws[4 * (int64_t)BL + 1] = inv;
+        ws[4 * (int64_t)BL + 1] = inv * dscale;   // dscale: the caller's static loss scale (a power of two; 1 = none)
     }
 }
 
@@ -250,17 +250,21 @@ __global__ __launch_bounds__(256) void simmim_pass2(const float *__restrict__ im
 extern "C" int skyemb_masked_patch_loss(const float *imgs, const float *pred, const float *mask, float *loss, void *dpred,
                                         float *dpred32, int dtype, float *ws, int B, int C, int H, int W, int p,
                                         int extra, float pixel_mean, float pixel_std, int norm_pix, int loss_l1,
-                                        void *stream) {
+                                        float dscale, void *stream) {
     SKY_CHECK_ARG(B > 0 && C > 0 && p > 0 && H % p == 0 && W % p == 0 && extra >= 0, "skyemb_masked_patch_loss: bad geometry");
+    SKY_CHECK_ARG(dscale > 0.f, "skyemb_masked_patch_loss: dscale must be positive (1 = no loss scale)");
     hipStream_t st = (hipStream_t)stream;
     const int L = (H / p) * (W / p), BL = B * L;
     const float numel = (float)((double)BL * C * p * p);
     hipLaunchKernelGGL(loss_pass1, dim3(BL), dim3(256), 0, st, imgs, pred, mask, ws, C, H, W, p, L, extra, pixel_mean,
                        pixel_std, norm_pix, loss_l1);
-    hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(256), 0, st, ws, loss, BL, numel);
+    hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(256), 0, st, ws, loss, BL, numel, dscale);
     if (dpred || dpred32) {
         if (dtype == SKYEMB_BF16)
             hipLaunchKernelGGL(loss_pass2<bf16_t>, dim3(B * (L + extra)), dim3(256), 0, st, imgs, pred, mask, ws, (bf16_t *)dpred,
+                               dpred32, C, H, W, p, L, extra, pixel_mean, pixel_std, norm_pix, loss_l1, BL);
+        else if (dtype == SKYEMB_F16)
+            hipLaunchKernelGGL(loss_pass2<f16_t>, dim3(B * (L + extra)), dim3(256), 0, st, imgs, pred, mask, ws, (f16_t *)dpred,
                                dpred32, C, H, W, p, L, extra, pixel_mean, pixel_std, norm_pix, loss_l1, BL);
         else
             hipLaunchKernelGGL(loss_pass2<float>, dim3(B * (L + extra)), dim3(256), 0, st, imgs, pred, mask, ws, (float *)dpred,
@@ -273,18 +277,22 @@ extern "C" int skyemb_masked_patch_loss(const float *imgs, const float *pred, co
 extern "C" int skyemb_simmim_pixel_loss(const float *imgs, const float *pred_tok, const float *pixel_mask, float *loss,
                                         void *dpred_tok, int dtype, float *pred_img, float *ws, int B, int C, int H, int W,
                                         int p, int extra, float pixel_mean, float pixel_std, int norm_pix, int loss_l1,
-                                        int pooled, void *stream) {
+                                        int pooled, float dscale, void *stream) {
     SKY_CHECK_ARG(B > 0 && C > 0 && p > 0 && H % p == 0 && W % p == 0 && extra >= 0 && pixel_mask, "skyemb_simmim_pixel_loss: bad arguments");
+    SKY_CHECK_ARG(dscale > 0.f, "skyemb_simmim_pixel_loss: dscale must be positive (1 = no loss scale)");
     SKY_CHECK_ARG(!pooled || extra == 0, "skyemb_simmim_pixel_loss: a pooled prediction has one row per image (extra = 0)");
     hipStream_t st = (hipStream_t)stream;
     const int L = (H / p) * (W / p), BL = B * L;
     hipLaunchKernelGGL(simmim_pass1, dim3(BL), dim3(256), 0, st, imgs, pred_tok, pixel_mask, ws, C, H, W, p, L, extra, pixel_mean,
                        pixel_std, norm_pix, loss_l1, pooled);
-    hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(256), 0, st, ws, loss, BL, 1.0f);   // scale = sum(w) (n/numel*numel)
+    hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(256), 0, st, ws, loss, BL, 1.0f, dscale);   // scale = sum(w) (n/numel*numel)
     if (dpred_tok || pred_img) {
         if (dtype == SKYEMB_BF16)
             hipLaunchKernelGGL(simmim_pass2<bf16_t>, dim3(B * (L + extra)), dim3(256), 0, st, imgs, pred_tok, pixel_mask, ws,
                                (bf16_t *)dpred_tok, pred_img, C, H, W, p, L, extra, pixel_mean, pixel_std, norm_pix, loss_l1, BL, pooled);
+        else if (dtype == SKYEMB_F16)
+            hipLaunchKernelGGL(simmim_pass2<f16_t>, dim3(B * (L + extra)), dim3(256), 0, st, imgs, pred_tok, pixel_mask, ws,
+                               (f16_t *)dpred_tok, pred_img, C, H, W, p, L, extra, pixel_mean, pixel_std, norm_pix, loss_l1, BL, pooled);
         else
             hipLaunchKernelGGL(simmim_pass2<float>, dim3(B * (L + extra)), dim3(256), 0, st, imgs, pred_tok, pixel_mask, ws,
                                (float *)dpred_tok, pred_img, C, H, W, p, L, extra, pixel_mean, pixel_std, norm_pix, loss_l1, BL, pooled);

@@ -111,6 +111,17 @@ class MAEEngine:
         self.device = torch.device(device)
         self.dtype = compute_dtype
         self.code = ops.dtype_code(compute_dtype)
+        # Static loss scale of the backward pass (a power of two; 1 outside the fp16 mode).  fp16 data gradients underflow without
+        # one (d loss / d pred ~ 2 / masked elements ~ 5e-7 at B = 256: below fp16's normal range); every step of backward is linear
+        # in d loss / d pred, so the loss kernel multiplies that by `loss_scale` (dscale of skyemb_masked_patch_loss) and the
+        # optimiser divides it out (FusedAdamW.grad_scale, skyemb_adamw_desc.grad_scale): the flat gradient buffer holds
+        # loss_scale x the gradients -- `grad(name)` of this class returns them unscaled.  2^16 puts d loss / d pred at ~0.03 for
+        # B = 256 (profiles/r06_operand_rounding.json: with it fp16 gradients are at the format's rounding floor, 1e-3; without,
+        # 2.6e-2) and leaves four decades below the format's maximum for anything backward multiplies it by.
+        import os
+        self.loss_scale = float(os.environ.get("SKYEMB_LOSS_SCALE", 65536.0)) if compute_dtype == torch.float16 else 1.0
+        assert self.loss_scale > 0 and math.log2(self.loss_scale).is_integer(), "loss_scale must be a power of two"
+        self.fold_decoder_wgrads = True      # utils.vit's predictor turns it off: it never runs backward_decoder (_extra_wgrad_layers)
         self.store = ParamStore(cfg, self.device, compute_dtype)
         self._ws = {}
         self._last = None
@@ -159,6 +170,11 @@ class MAEEngine:
             else:
                 st.frozen[k].copy_(torch.randn(st.shapes[k], generator=gen) * 0.02)   # SimMIM's unused mask_token
         st.refresh_lp()
+
+    def grad(self, name):
+        """d loss / d parameter `name` of the last backward(): the flat gradient buffer's view without the loss scale."""
+        g = self.store.grad(name)
+        return g if self.loss_scale == 1.0 else g / self.loss_scale
 
     def state_dict(self):
         out = OrderedDict()
@@ -250,7 +266,7 @@ class MAEEngine:
             # (the block's norm1 backward rides in the same launch as a side job: _make_wgrad_group)
             w["splitk_ws"] = self._splitk_ws
             w["wgrad_groups"] = {}
-            if self.dtype == torch.bfloat16:
+            if self.dtype in ops.LP_DTYPES:
                 for tag, blocks, M_, dim in (("blocks", w["enc"], Me, D), ("decoder_blocks", w["dec"], Md, Dd)):
                     for i, bufs in enumerate(blocks):
                         w["wgrad_groups"][f"{tag}.{i}"] = self._make_wgrad_group(f"{tag}.{i}", bufs, M_, dim, w)
@@ -330,9 +346,8 @@ class MAEEngine:
         if maps is None:
             chain = self._weight_chain()
             maps = self._pf_maps = {"fwd": dict(zip(chain[:-1], chain[1:])), "bwd": dict(zip(chain[1:], chain[:-1]))}
-        if self.dtype != torch.bfloat16:
+        if self.dtype not in ops.LP_DTYPES:
             return None
-        import os
         only = os.environ.get("SKYEMB_PF_ONLY", "")        # (bench.py's A/B: hints in one direction only)
         if only and only != direction:
             return None
@@ -460,7 +475,8 @@ class MAEEngine:
                  out_f32=w["pred"])
         # ---- loss + d loss / d pred (utils/mim_vit.py:473-521)
         ops.masked_patch_loss(imgs, w["pred"], w["mask"], w["loss"], w["dpred"], None, self.code, w["loss_ws"],
-                              cfg.patch_size, E, cfg.pixel_mean, cfg.pixel_std, cfg.norm_pix_loss, cfg.loss_fn != "mse")
+                              cfg.patch_size, E, cfg.pixel_mean, cfg.pixel_std, cfg.norm_pix_loss, cfg.loss_fn != "mse",
+                              dscale=self.loss_scale)
         self._last = (imgs, B, keep)
         return w["loss"], w["pred"][:, E:, :], w["mask"]
 
@@ -588,7 +604,10 @@ class MAEEngine:
         into the first encoder block's.  As launches of their own (a split-K GEMM + its reduce each) they were 25 and 14 us of the
         step's dependent chain.  -> [(dy, x_in, layer name, n_out, k_in)]; the names are recorded in w['folded_wgrads']."""
         import os
-        if os.environ.get("SKYEMB_FOLD_WGRADS", "1") == "0" or self._side is not None or "dpred" not in w:
+        if (os.environ.get("SKYEMB_FOLD_WGRADS", "1") == "0" or self._side is not None or "dpred" not in w
+                or not self.fold_decoder_wgrads):
+            # (fold_decoder_wgrads = False: a caller that runs backward_encoder / backward_embed WITHOUT backward_decoder -- the
+            # downstream predictor, whose token count makes Me == Md -- would otherwise multiply an uninitialised dE every step)
             return []
         cfg = self.cfg
         out = []
@@ -640,7 +659,7 @@ class MAEEngine:
         self._adamw_side = os.environ.get("SKYEMB_ADAMW_SIDE", "auto") if side is None else ("1" if side is True else "0" if side is False else str(side))
         assert self._adamw_side in ("auto", "0", "1", "dec", "enc"), self._adamw_side
         self._adamw_side_blocks = int(os.environ.get("SKYEMB_SIDE_BLOCKS", "256"))
-        assert self.dtype == torch.bfloat16, "the fused optimiser step exists on the bf16 path (grouped weight gradients)"
+        assert self.dtype in ops.LP_DTYPES, "the fused optimiser step exists on the 16-bit paths (grouped weight gradients)"
         from ._lib import AdamwDesc
         st = self.store
         b1, b2 = optimizer.defaults["betas"]

@@ -11,9 +11,10 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ACT_DGELU, ACT_GELU, ACT_NONE, BF16, F32, KC, RC, AdamwDesc, GemmArgs, GemmGroupInfo, LnBwdSide, check, lib
+from ._lib import ACT_DGELU, ACT_GELU, ACT_NONE, BF16, F16, F32, KC, RC, AdamwDesc, GemmArgs, GemmGroupInfo, LnBwdSide, check, lib
 
-TORCH_DTYPE = {BF16: torch.bfloat16, F32: torch.float32}
+TORCH_DTYPE = {BF16: torch.bfloat16, F32: torch.float32, F16: torch.float16}
+LP_DTYPES = (torch.bfloat16, torch.float16)     # the two 16-bit operand formats of the MFMA kernels (SKYEMB_BF16 / SKYEMB_F16)
 
 
 def dtype_code(t: torch.dtype) -> int:
@@ -21,6 +22,8 @@ def dtype_code(t: torch.dtype) -> int:
         return BF16
     if t == torch.float32:
         return F32
+    if t == torch.float16:
+        return F16
     raise TypeError(f"unsupported activation dtype {t}")
 
 
@@ -106,7 +109,7 @@ class GemmGroup:
         # workgroups that compute TILES (the grid also holds the side jobs' workgroups)
         self.tile_blocks = self.info.total_blocks - (int(side[3]) if side is not None else 0)
         self.ln_side = False
-        if self.ok and ln_bwd is not None and ln_bwd["dy"].dtype == torch.bfloat16:
+        if self.ok and ln_bwd is not None and ln_bwd["dy"].dtype in LP_DTYPES:
             rec = LnBwdSide()
             for k in ("dy", "x", "gamma", "mean", "rstd", "g_in", "g_out", "g_lp", "part"):
                 setattr(rec, k, _p(ln_bwd[k]))
@@ -133,7 +136,7 @@ def gemm_launch_counts(reset=False):
 
 
 def colsum(X, M, N, out, ldx=None):
-    code = F32 if X.dtype == torch.float32 else BF16
+    code = dtype_code(X.dtype)
     check(lib().skyemb_colsum(_p(X), code, ldx if ldx is not None else N, M, N, _p(out), _stream()), "skyemb_colsum")
 
 
@@ -221,11 +224,11 @@ def radec_token_bwd(g_rows, row_stride, W1, sh, z, dz_ws, dW0, db0, dW1, db1, B,
 
 
 def simmim_pixel_loss(imgs, pred_tok, pixel_mask, loss, dpred_tok, dtype, pred_img, ws, p, extra, pixel_mean, pixel_std,
-                      norm_pix, loss_l1, pooled=False):
+                      norm_pix, loss_l1, pooled=False, dscale=1.0):
     B, C, H, W = imgs.shape
     check(lib().skyemb_simmim_pixel_loss(_p(imgs), _p(pred_tok), _p(pixel_mask), _p(loss), _p(dpred_tok), dtype, _p(pred_img),
                                          _p(ws), B, C, H, W, p, extra, pixel_mean, pixel_std, int(norm_pix), int(loss_l1),
-                                         int(pooled), _stream()), "skyemb_simmim_pixel_loss")
+                                         int(pooled), float(dscale), _stream()), "skyemb_simmim_pixel_loss")
 
 
 def layernorm_fwd(x, gamma, beta, y, mean, rstd, M, D, eps, y32=None, dtype=None):
@@ -239,7 +242,7 @@ def layernorm_bwd_blocks(M):
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, g_in, g_out, g_lp, part, dgamma, dbeta, M, D, dtype):
-    dy_f32 = 1 if (dy.dtype == torch.float32 and dtype == BF16) else 0
+    dy_f32 = 1 if (dy.dtype == torch.float32 and dtype in (BF16, F16)) else 0
     check(lib().skyemb_layernorm_bwd(_p(dy), dy_f32, dtype, _p(x), _p(gamma), _p(mean), _p(rstd), _p(g_in), _p(g_out),
                                      _p(g_lp), _p(part), _p(dgamma), _p(dbeta), M, D, _stream()), "skyemb_layernorm_bwd")
 
@@ -292,11 +295,11 @@ def rowsum_select(src, ld, sel, row0, inner, outer_stride, n_rows, D, partial, o
 
 
 def masked_patch_loss(imgs, pred, mask, loss, dpred, dpred32, dtype, ws, p, extra, pixel_mean, pixel_std, norm_pix,
-                      loss_l1):
+                      loss_l1, dscale=1.0):
     B, C, H, W = imgs.shape
     check(lib().skyemb_masked_patch_loss(_p(imgs), _p(pred), _p(mask), _p(loss), _p(dpred), _p(dpred32), dtype, _p(ws),
                                          B, C, H, W, p, extra, pixel_mean, pixel_std, int(norm_pix), int(loss_l1),
-                                         _stream()), "skyemb_masked_patch_loss")
+                                         float(dscale), _stream()), "skyemb_masked_patch_loss")
 
 
 def adamw(p, g, m, v, p_lp, n, n_decay, hyper, beta1, beta2, eps, wd, grad_scale=1.0, zero_grad=False, lr=0.0, bc1=1.0,

@@ -25,7 +25,7 @@ class FusedAdamW:
         self.param_groups = [dict(lr=lr, initial_lr=lr, betas=tuple(betas), eps=eps, weight_decay=0.0),
                              dict(lr=lr, initial_lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)]
         self.step_count = 0
-        self.grad_scale = 1.0
+        self.grad_scale = 1.0 / getattr(engine, "loss_scale", 1.0)   # (fp16 mode: the flat gradient buffer holds loss_scale x the gradients)
         # graph mode: step scalars live in device memory (kernel arguments are frozen in a HIP graph)
         self.hyper_device = None
         self.process_group = process_group

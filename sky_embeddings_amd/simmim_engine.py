@@ -130,7 +130,7 @@ class SimMIMEngine(MAEEngine):
                 order.append(("block", f"blocks.{i}", w["enc"][i], M, D))
             self._build_reduce_table(w, order)
             w["wgrad_groups"] = {}            # (built after the reduce table: every group carries its block's norm1 backward)
-            if self.dtype == torch.bfloat16:
+            if self.dtype in ops.LP_DTYPES:
                 for i, bufs in enumerate(w["enc"]):
                     w["wgrad_groups"][f"blocks.{i}"] = self._make_wgrad_group(f"blocks.{i}", bufs, M, D, w)
         if train and getattr(self, "_fused_adamw", None) is not None and w.get("wgrad_groups"):
@@ -236,7 +236,7 @@ class SimMIMEngine(MAEEngine):
                  out_f32=w["pred_tok"])
         ops.simmim_pixel_loss(imgs, w["pred_tok"], mask, w["loss"], w["dpred"], self.code, w["pred_img"], w["loss_ws"],
                               cfg.patch_size, 0 if pool else E, cfg.pixel_mean, cfg.pixel_std, cfg.norm_pix_loss, cfg.loss_fn != "mse",
-                              pooled=pool)
+                              pooled=pool, dscale=self.loss_scale)
         self._last = (imgs, B, L, mask)
         return w["loss"], w["pred_img"], mask
 

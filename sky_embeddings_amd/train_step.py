@@ -85,7 +85,9 @@ class TrainStep:
         self.grad_comm = grad_comm if (world_size > 1 or (staged and explicit_comm)) else "f32"
         self.g16 = None
         if self.grad_comm == "bf16":
-            self.g16 = torch.zeros(engine.store.n, device=dev, dtype=torch.bfloat16)
+            # (the mirror holds the compute dtype's 16-bit format: the weight-gradient launches write it in their epilogue.  In the
+            # fp16 mode the sums carry the loss scale: world_size x 2^16 x a gradient element stays far inside fp16's range)
+            self.g16 = torch.zeros(engine.store.n, device=dev, dtype=engine.dtype if engine.dtype in ops.LP_DTYPES else torch.bfloat16)
         if staged is None:
             env = os.environ.get("SKYEMB_STAGED")
             staged = (world_size > 1) if env is None else env == "1"
@@ -95,8 +97,8 @@ class TrainStep:
             # bubbles they fill), so off unless asked for
             wgrad_overlap = os.environ.get("SKYEMB_WGRAD_OVERLAP", "0") == "1"
         engine.enable_wgrad_overlap(wgrad_overlap)   # weight-gradient GEMMs on a side stream (a parallel graph branch)
-        if world_size > 1:
-            optimizer.grad_scale = 1.0 / world_size  # DDP mean of per-rank gradients
+        # DDP mean of per-rank gradients, and the backward pass's static loss scale divided out again (fp16 mode)
+        optimizer.grad_scale = 1.0 / (world_size * getattr(engine, "loss_scale", 1.0))
         # stage list: [(callable, [(start, end) slices of the flat gradient buffer final after it])]
         if n_encoder_groups is None:
             # finer stages with N GPUs: the all-reduce of the LAST encoder group has only the short embedding stage to hide
@@ -152,7 +154,7 @@ class TrainStep:
         if fused_adamw is None:
             fused_adamw = os.environ.get("SKYEMB_FUSED_ADAMW", "1") == "1"
         self.fused_adamw = bool(fused_adamw and world_size == 1 and not self.staged and not self.optimizer_overlap
-                                and engine.dtype == torch.bfloat16 and hasattr(engine, "enable_fused_adamw"))
+                                and engine.dtype in ops.LP_DTYPES and hasattr(engine, "enable_fused_adamw"))
         self._rest_ranges = None
         snap = None
         if self.fused_adamw:

@@ -9,7 +9,8 @@ Build extensions (all optional, defaults reproduce the reference):
     configs lack (``attn_pool``, ``ra_dec``);
   * ``noise=`` keyword on ``forward`` / ``forward_features`` to supply the masking noise
     (reference draws ``torch.rand`` internally, utils/mim_vit.py:363);
-  * ``[TRAINING] compute_dtype = bf16|f32`` (default bf16; f32 = exact-fp32 MFMA parity mode).
+  * ``[TRAINING] compute_dtype = bf16|f16|f32`` (default bf16; f16 = IEEE-half MFMA operands with a static loss scale: the throughput mode
+    that holds loss / reconstructed pixels within 1e-3 of the fp32 reference; f32 = exact-fp32 MFMA parity mode).
 Deviation: NaN target pixels contribute a ZERO gradient (the reference's MSE backward is NaN
 there).  SimMIM configurations (``model_type`` simmim / mimlarge / mimhuge, with or without the RA/Dec
 token) run on ``sky_embeddings_amd.simmim_engine.SimMIMEngine``.
@@ -201,9 +202,11 @@ def _compute_dtype(config):
     name = name.lower()
     if name in ("bf16", "bfloat16"):
         return torch.bfloat16
+    if name in ("f16", "fp16", "float16", "half"):
+        return torch.float16
     if name in ("f32", "fp32", "float32"):
         return torch.float32
-    raise ValueError(f"compute_dtype must be bf16 or f32, got {name!r}")
+    raise ValueError(f"compute_dtype must be bf16, f16 or f32, got {name!r}")
 
 
 def build_model(config, model_filename, device, build_optimizer=False):

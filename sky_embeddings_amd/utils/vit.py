@@ -60,7 +60,12 @@ class VisionTransformer:
         if global_pool not in ('', 'avg', 'token', 'map'):
             raise ValueError(f"global_pool = {global_pool!r}")
         self.cfg = cfg
+        if compute_dtype == torch.float16:
+            # the predictor's loss lives in the caller's torch code: its backward enters the engine unscaled, and fp16 data gradients
+            # need the static loss scale the MIM engines apply in their own loss kernels
+            raise NotImplementedError("the downstream predictor runs in bf16 or f32 (compute_dtype = f16 is a pretraining mode)")
         self.engine = MAEEngine(cfg, device=device, compute_dtype=compute_dtype, seed=seed)
+        self.engine.fold_decoder_wgrads = False      # backward_decoder never runs here: its folded weight gradients would read garbage
         dev = self.engine.device
         self.patch_embed = _PatchEmbedInfo(cfg)
         self.num_extra_tokens, self.attn_pool, self.simmim = cfg.num_extra_tokens, None, False

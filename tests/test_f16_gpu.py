@@ -1,0 +1,289 @@
+"""SKYEMB_F16: the IEEE-half operand format of the MFMA kernels (round 6; the throughput mode that meets north_star's 1e-3).
+
+The 16-bit kernels are compiled twice from one source (csrc/lp_twin.h: bf16 and, under -DSKY_F16, fp16); everything but the MFMA
+opcode and the fp32 <-> 16-bit conversion is shared.  Hence two kinds of test:
+
+* TWIN tests: on operands exactly representable in BOTH formats (multiples of 1/16 up to +-6) the fp16 kernels must return the
+  bf16 kernels' fp32 outputs BIT FOR BIT -- every tile, operand class, epilogue, grouped launch, attention shape: same layouts,
+  same accumulation order, products exact in either format;
+* accuracy tests of the mode itself: kernels against fp64 on fp16-rounded operands; the engine against the CPU oracle with the
+  bar north_star states -- loss and reconstructed pixels within 1e-3 relative (oracle/mae_oracle.py restates
+  utils/mim_vit.py:381-521 of the reference) -- on the tiny goldens' geometry and at config A, B = 256, the batch bench.py times.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mae_oracle as mo
+from tests.helpers import record_parity
+
+DEV = "cuda"
+BF, FH = torch.bfloat16, torch.float16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    from sky_embeddings_amd import ops as _ops
+    _ops.lib()
+    return _ops
+
+
+def grid16(shape, g, lim=6.0):
+    """Values k / 16, |k / 16| <= lim: 8 significant bits at most, exponents inside fp16's normal range -> exact in bf16 AND fp16."""
+    return (torch.randn(shape, generator=g) * 2).clamp_(-lim, lim).mul_(16).round_().div_(16)
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+# ------------------------------------------------------------------------------------ twin tests
+@pytest.mark.parametrize("tile", [0, 64064, 128064, 6128064, 128128, 9064064, 9144064, 13144256, 2256128, 256256])
+@pytest.mark.parametrize("layouts", [(0, 0), (0, 1), (1, 1)])
+def test_f16_gemm_equals_bf16_gemm_on_common_operands(ops, tile, layouts):
+    a_l, b_l = layouts
+    if a_l == 1 and tile in (9144064, 13144256, 2256128, 9064064):
+        pytest.skip("k-contiguous A only")
+    M, N, K = (512, 768, 256) if tile == 256256 else (407, 520, 256)
+    if a_l:
+        M = 512 if tile == 256256 else 400
+    g = torch.Generator().manual_seed(tile % 1000 + 7 * a_l + b_l)
+    A, B = grid16((M, K), g), grid16((N, K), g, 2.0)
+    bias, resid = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    aux = grid16((M, N), g)
+    outs = {}
+    for T in (BF, FH):
+        Ad = (A.T.contiguous() if a_l else A).to(DEV, T)
+        Bd = (B.T.contiguous() if b_l else B).to(DEV, T)
+        kw = dict(M=M, N=N, K=K, a_layout=a_l, b_layout=b_l, tile=tile, lda=M if a_l else K, ldb=N if b_l else K)
+        o32 = torch.full((M, N), float("nan"), device=DEV)
+        cs = torch.full((M,), float("nan"), device=DEV) if a_l else None
+        try:
+            ops.gemm(Ad, Bd, out_f32=o32, bias=bias.to(DEV), resid=resid.to(DEV), ldr=N, colsum_a=cs, **kw)
+        except Exception as e:                                   # (a tile that refuses the shape refuses it in both formats)
+            outs[T] = ("refused", str(e)[:40])
+            continue
+        res = [o32, cs]
+        if a_l == 0:
+            act, pre = torch.zeros(M, N, device=DEV, dtype=T), torch.zeros(M, N, device=DEV, dtype=T)
+            ops.gemm(Ad, Bd, bias=bias.to(DEV), act=ops.ACT_GELU, out=act, out2=pre, **kw)
+            dg = torch.zeros(M, N, device=DEV, dtype=T)
+            ops.gemm(Ad, Bd, aux=aux.to(DEV, T), ldaux=N, act=ops.ACT_DGELU, out=dg, **kw)
+            res += [act.float(), pre.float(), dg.float()]
+        outs[T] = res
+    if isinstance(outs[BF], tuple) or isinstance(outs[FH], tuple):
+        assert isinstance(outs[BF], tuple) and isinstance(outs[FH], tuple), outs
+        pytest.skip(f"tile {tile} refuses this shape in both formats")
+    assert torch.equal(outs[BF][0], outs[FH][0]), (tile, layouts)                 # fp32 accumulators: bit for bit
+    exact = torch.from_numpy(A.double().numpy() @ B.double().numpy().T) + bias.double() + resid.double()
+    assert float((outs[FH][0].cpu().double() - exact).abs().max()) <= 1e-4 * float(exact.abs().max())
+    if a_l:
+        assert torch.equal(outs[BF][1], outs[FH][1])
+    for x, y in zip(outs[BF][2:], outs[FH][2:]):
+        # 16-bit outputs: fp16 keeps three more bits of the same fp32 value
+        assert float((x.double() - y.double()).abs().max()) <= 2.0 ** -8 * float(y.abs().max())
+
+
+def test_f16_grouped_weight_gradients_equal_bf16(ops):
+    g = torch.Generator().manual_seed(3)
+    tokens = 320
+    shapes = [(192, 768), (768, 192), (192, 192), (576, 200)]
+    res = {}
+    for T in (BF, FH):
+        g.manual_seed(3)
+        args, outs, keep = [], [], []
+        for n_out, k_in in shapes:
+            dy, x = grid16((tokens, n_out), g).to(DEV, T), grid16((tokens, k_in), g).to(DEV, T)
+            dw, db = torch.full((n_out, k_in), float("nan"), device=DEV), torch.full((n_out,), float("nan"), device=DEV)
+            args.append(ops.gemm_args(dy, x, out_f32=dw, colsum_a=db, M=n_out, N=k_in, K=tokens, a_layout=ops.RC, b_layout=ops.RC, lda=n_out,
+                                      ldb=k_in))
+            keep.append((dy, x))
+            outs += [dw, db]
+        grp = ops.GemmGroup(args, DEV)
+        assert grp.ok and bool(grp.info.reserved & 4) == (T == FH)
+        grp.launch()
+        torch.cuda.synchronize()
+        res[T] = outs
+    for a, b in zip(res[BF], res[FH]):
+        assert torch.equal(a, b)
+    # formats must not be mixed inside one launch
+    mixed = [ops.gemm_args(grid16((tokens, 192), g).to(DEV, T), grid16((tokens, 192), g).to(DEV, T), out_f32=torch.empty(192, 192, device=DEV),
+                           M=192, N=192, K=tokens, a_layout=ops.RC, b_layout=ops.RC, lda=192, ldb=192) for T in (BF, FH)]
+    assert not ops.GemmGroup(mixed, DEV).ok
+
+
+@pytest.mark.parametrize("cfg", [(3, 5, 12, 64), (2, 17, 16, 32), (2, 65, 4, 32), (8, 5, 3, 64), (2, 128, 2, 64), (3, 66, 2, 32)])
+def test_f16_attention_against_fp64(ops, cfg):
+    """Both formats of the MFMA attention against fp64 on the format's own rounding of the inputs; fp16 must be the tighter one."""
+    B, N, H, hd = cfg
+    D = H * hd
+    g = torch.Generator().manual_seed(N * 100 + hd)
+    qkv, dout = torch.randn(B, N, 3 * D, generator=g), torch.randn(B, N, D, generator=g)
+    err = {}
+    for T in (BF, FH):
+        q_r = qkv.to(T).double().requires_grad_(True)
+        t = q_r.reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+        att = ((t[0] * hd ** -0.5) @ t[1].transpose(-2, -1)).softmax(-1)
+        o = (att @ t[2]).transpose(1, 2).reshape(B, N, D)
+        o.backward(dout.to(T).double())
+        out = torch.empty(B, N, D, device=DEV, dtype=T)
+        dqkv = torch.empty(B, N, 3 * D, device=DEV, dtype=T)
+        ops.mha_fwd(qkv.to(DEV, T), out, B, N, H, hd)
+        ops.mha_bwd(qkv.to(DEV, T), dout.to(DEV, T), dqkv, B, N, H, hd)
+        err[T] = (rel(out.float(), o.detach()), rel(dqkv.float(), q_r.grad))
+    assert err[FH][0] < 1e-3 and err[FH][1] < 1e-3, err
+    assert err[FH][0] < err[BF][0] and err[FH][1] < err[BF][1], err
+
+
+def test_f16_adamw_shadow_and_16_bit_gradients(ops):
+    n, n_decay = 4096 + 8, 1000
+    g = torch.Generator().manual_seed(5)
+    p, gr = torch.randn(n, generator=g), grid16((n,), g)
+    m, v = torch.randn(n, generator=g) * 0.01, torch.rand(n, generator=g) * 0.01
+    outs = []
+    for gt in (torch.float32, FH):                  # fp32 gradients, or the fp16 sums a 16-bit all-reduce left (same values here)
+        pd, gd, md, vd = p.to(DEV).clone(), gr.to(DEV, gt), m.to(DEV).clone(), v.to(DEV).clone()
+        plp = torch.empty(n, device=DEV, dtype=FH)
+        ops.adamw(pd, gd, md, vd, plp, n, n_decay, None, 0.9, 0.95, 1e-8, 0.05, grad_scale=2.0 ** -16, lr=1e-3, bc1=0.271, bc2=0.1426)
+        assert torch.equal(plp.cpu(), pd.cpu().to(FH))
+        outs.append((pd, md, vd))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    with pytest.raises(Exception):                  # a bf16 gradient buffer beside an fp16 shadow: refused
+        ops.adamw(p.to(DEV), gr.to(DEV, BF), m.to(DEV), v.to(DEV), torch.empty(n, device=DEV, dtype=FH), n, n_decay, None, 0.9, 0.95, 1e-8,
+                  0.05, lr=1e-3)
+
+
+# ------------------------------------------------------------------------------------ the mode against the oracle
+TINY = dict(img_size=64, patch_size=16, in_chans=5, embed_dim=64, depth=2, num_heads=4, decoder_embed_dim=32, decoder_depth=1,
+            decoder_num_heads=4, norm_pix_loss=True, loss_fn="mse")
+
+
+def _engine(kw_or_cfg, dtype, st):
+    from sky_embeddings_amd.engine import MAEEngine
+    from sky_embeddings_amd.model_config import MAEConfig
+    cfg = MAEConfig(**kw_or_cfg) if isinstance(kw_or_cfg, dict) else kw_or_cfg
+    eng = MAEEngine(cfg, device=DEV, compute_dtype=dtype, seed=0)
+    eng.load_state_dict(st)
+    return eng
+
+
+def test_f16_loss_scale_is_divided_out_exactly():
+    """The flat gradient buffer holds loss_scale x the gradients; a power of two changes no bit of them (no overflow, values far
+    above fp16's subnormals at either scale) and the optimiser's grad_scale removes it: parameters after a step are identical
+    for two different scales."""
+    from sky_embeddings_amd.optim import CosineLR, FusedAdamW
+    cfg_o = mo.MAEConfig(**TINY)
+    st = mo.init_state(cfg_o, seed=0)
+    g = torch.Generator().manual_seed(0)
+    imgs = torch.randn(8, 5, 64, 64, generator=g).clamp_(min=-3.0).to(DEV)
+    noise = torch.rand(8, 16, generator=g).to(DEV)
+    after = []
+    for scale in (2.0 ** 12, 2.0 ** 16):
+        eng = _engine(TINY, FH, st)
+        eng.loss_scale = scale
+        opt = FusedAdamW(eng, lr=1e-3, weight_decay=0.05)
+        assert opt.grad_scale == 1.0 / scale
+        eng.forward_train(imgs, 0.75, noise)
+        eng.backward()
+        gq = eng.grad("blocks.0.attn.qkv.weight").clone()
+        assert torch.equal(eng.store.grad("blocks.0.attn.qkv.weight") / scale, gq)
+        opt.step()
+        torch.cuda.synchronize()
+        after.append((gq, eng.store.p.clone()))
+    assert rel(after[0][0], after[1][0]) < 2e-3            # (data gradients are rounded to fp16 at different binades: not bit-equal)
+    # (Adam's first step is lr * g / (|g| + eps'): the few gradient elements whose fp16 roundings differ in sign move by 2 lr)
+    assert rel(after[0][1], after[1][1]) < 2e-4
+
+
+@pytest.mark.parametrize("B", [8, 256])
+def test_f16_mode_meets_the_reference_tolerance_at_config_a(B):
+    """north_star: 'MAE loss and reconstructed pixels within 1e-3 relative fp32'.  Config A (MAE ViT-B/16, 5 x 64 x 64, mask 0.75)
+    at B = 256 -- the batch bench.py times -- and B = 8, fp16 engine against oracle/mae_oracle.py (fp32, CPU) on the same weights,
+    inputs and noise.  The bars ARE the stated tolerance (1e-3 on loss and pixels), not a multiple of what was measured; bf16 on the
+    same inputs is recorded beside it (6e-3)."""
+    cfg_o = mo.config_for("base", patch_size=16, in_chans=5, img_size=64, embed_dim=768)
+    st = mo.init_state(cfg_o, seed=0)
+    g = torch.Generator().manual_seed(1234)
+    imgs = torch.randn(B, 5, 64, 64, generator=g).clamp_(min=-3.0)
+    noise = torch.rand(B, 16, generator=g)
+    loss_o, pred_o, mask_o, _, _, grads_o = mo.loss_and_grads(st, imgs, cfg_o, 0.75, noise)
+    from sky_embeddings_amd.model_config import config_for
+    out = {}
+    for name, T in (("f16", FH), ("bf16", BF)):
+        eng = _engine(config_for("base", patch_size=16, in_chans=5, img_size=64, embed_dim=768), T, st)
+        loss, pred, mask = eng.forward_train(imgs.to(DEV), 0.75, noise.to(DEV))
+        eng.backward()
+        torch.cuda.synchronize()
+        assert torch.equal(mask.cpu(), mask_o)
+        gerr = {k: rel(eng.grad(k).cpu().reshape(grads_o[k].shape), grads_o[k]) for k in eng.store.order}
+        out[name] = dict(loss_rel=abs(float(loss) - float(loss_o)) / float(loss_o), pred_rel_l2=rel(pred.cpu(), pred_o),
+                         pred_max_abs_over_rms=float((pred.cpu() - pred_o).abs().max() / pred_o.pow(2).mean().sqrt()),
+                         grad_rel_l2_max=max(gerr.values()), grad_rel_l2_median=float(np.median(list(gerr.values()))),
+                         finite=bool(torch.isfinite(eng.store.g).all()))
+        del eng
+        torch.cuda.empty_cache()
+    record_parity(f"config_A_B{B}_f16_vs_oracle", out)
+    f = out["f16"]
+    assert f["finite"]
+    assert f["loss_rel"] <= 1e-3 and f["pred_rel_l2"] <= 1e-3, out          # the reference tolerance itself
+    assert f["loss_rel"] <= 1e-4, out                                       # (loss_rel <= 1e-4)
+    assert f["grad_rel_l2_max"] <= 4e-3, out                                # gradients: 2 x the CPU study's 1.4e-3 .. 2e-3
+    assert f["pred_rel_l2"] < 0.25 * out["bf16"]["pred_rel_l2"], out        # and ~8x inside bf16's
+
+
+def test_f16_train_step_with_the_fused_optimiser_equals_the_separate_launch():
+    """TrainStep in the fp16 mode: HIP graph + the AdamW step inside the grouped weight-gradient launches (the loss scale is part of
+    the grad_scale baked into their descriptors) against the schedule with the separate optimiser launch: parameters, moments and
+    the fp16 shadow bit for bit after ten steps, and the loss goes down."""
+    from sky_embeddings_amd.engine import MAEEngine
+    from sky_embeddings_amd.model_config import config_for
+    from sky_embeddings_amd.optim import CosineLR, FusedAdamW
+    from sky_embeddings_amd.train_step import TrainStep
+    cfg = config_for("tiny", img_size=64, patch_size=16, in_chans=5, embed_dim=192)
+    g = torch.Generator().manual_seed(0)
+    imgs = torch.randn(64, 5, 64, 64, generator=g).cuda()
+    out = []
+    for fused in (False, True):
+        eng = MAEEngine(cfg, compute_dtype=FH, seed=1)
+        opt = FusedAdamW(eng, lr=1e-3, weight_decay=0.05)
+        step = TrainStep(eng, opt, CosineLR(opt, 100), 64, fused_adamw=fused)
+        assert step.fused_adamw == fused and opt.grad_scale == 1.0 / eng.loss_scale == 2.0 ** -16
+        torch.manual_seed(123)
+        dev_losses = [step(imgs).clone() for _ in range(10)]
+        torch.cuda.synchronize()
+        st = eng.store
+        out.append(([float(l) for l in dev_losses], st.p.clone(), st.m.clone(), st.v.clone(), st.p_lp.clone()))
+        assert st.p_lp.dtype == FH and bool(torch.isfinite(st.p).all())
+    a, b = out
+    assert a[0] == b[0] and a[0][-1] < a[0][0]
+    for x, y in zip(a[1:], b[1:]):
+        assert torch.equal(x, y)
+
+
+def test_f16_simmim_engine_against_oracle():
+    """SimMIM mode (pixel loss with dscale, per-channel masks, L1) in fp16 against the oracle: 64 / 8 geometry at a narrow width."""
+    from sky_embeddings_amd.model_config import MAEConfig
+    from sky_embeddings_amd.simmim_engine import SimMIMEngine
+    kw = dict(img_size=64, patch_size=8, in_chans=5, embed_dim=128, depth=2, num_heads=4, norm_pix_loss=True, loss_fn="L1", simmim=True)
+    cfg_o = mo.MAEConfig(**kw)
+    st = mo.init_state(cfg_o, seed=2)
+    g = torch.Generator().manual_seed(5)
+    B = 16
+    imgs = torch.randn(B, 5, 64, 64, generator=g).clamp_(min=-3.0)
+    mask = mo.simmim_mask_from_noise(torch.rand(B, 5, 64, generator=g), torch.rand(B, generator=g), 0.9, 8)
+    loss_o, pred_o, _, _, _, grads_o = mo.loss_and_grads(st, imgs, cfg_o, mask=mask, nan_safe=True)
+    eng = SimMIMEngine(MAEConfig(**kw), device=DEV, compute_dtype=FH, seed=0)
+    eng.load_state_dict(st)
+    loss, pred, _ = eng.forward_train(imgs.to(DEV), mask.to(DEV))
+    eng.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(loss_o)) <= 1e-4 * float(loss_o)
+    assert rel(pred.cpu(), pred_o) <= 1e-3
+    k = "blocks.0.mlp.fc1.weight"
+    assert rel(eng.grad(k).cpu(), grads_o[k]) <= 2e-2     # L1: sign flips of a few near-zero differences
+    assert torch.isfinite(eng.store.g).all()

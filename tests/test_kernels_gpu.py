@@ -40,7 +40,7 @@ def relerr(a, b):
 
 
 # ------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("layouts", [(0, 0), (0, 1), (1, 1), (1, 0)])
 @pytest.mark.parametrize("tile", [64, 128])
 @pytest.mark.parametrize("shape", [(20, 72, 40), (68, 96, 256), (200, 136, 72), (128, 128, 64), (257, 520, 264)])
@@ -156,7 +156,7 @@ def test_gemm_two_k_group_weight_gradients(ops, tile):
             assert torch.equal(dw, dw1) and torch.equal(db, db1)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_gemm_epilogues(ops, dtype):
     M, N, K = 70, 136, 96
     g = torch.Generator().manual_seed(11)
@@ -168,7 +168,7 @@ def test_gemm_epilogues(ops, dtype):
     resid = torch.randn(M + 5, N, generator=g)
     Ar, Br = A.to(dtype).float(), B.to(dtype).float()
     base = Ar @ Br.T * 0.5 + bias + table[tab_row.long()]
-    tol = 3e-2 if dtype == torch.bfloat16 else 1e-4
+    tol = 3e-2 if dtype != torch.float32 else 1e-4
     # scatter + table + resid, fp32 out and low-precision out
     out32 = torch.zeros(M + 5, N, device=DEV)
     outlp = torch.zeros(M + 5, N, device=DEV, dtype=dtype)
@@ -296,7 +296,7 @@ def test_gemm_group_equals_single_launches(ops):
 
 
 # ------------------------------------------------------------------------------------ LayerNorm
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("shape", [(20, 64), (1280, 768), (37, 512), (9, 1280), (5, 192), (8320, 1024), (8197, 256), (4352, 512)])
 def test_layernorm(ops, dtype, shape):
     M, D = shape
@@ -314,7 +314,7 @@ def test_layernorm(ops, dtype, shape):
     mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
     ops.layernorm_fwd(dev(x), dev(gamma), dev(beta), yd, mean, rstd, M, D, 1e-6, y32=y32)
     assert relerr(y32, y.detach()) < 2e-6
-    assert relerr(yd.float(), y.detach()) < (5e-3 if dtype == torch.bfloat16 else 2e-6)
+    assert relerr(yd.float(), y.detach()) < (5e-3 if dtype != torch.float32 else 2e-6)
     nblk = ops.layernorm_bwd_blocks(M)
     part = torch.empty(2, nblk, D, device=DEV)
     g_in = torch.randn(M, D, generator=g)
@@ -324,7 +324,7 @@ def test_layernorm(ops, dtype, shape):
     dgam, dbet = torch.empty(D, device=DEV), torch.empty(D, device=DEV)
     ops.layernorm_bwd(dev(dy, dtype), dev(x), dev(gamma), mean, rstd, g_out, g_out, g_lp, part, dgam, dbet, M, D, code)
     assert relerr(g_out, g_in + xr.grad) < 5e-6
-    assert relerr(g_lp.float(), g_in + xr.grad) < (5e-3 if dtype == torch.bfloat16 else 5e-6)
+    assert relerr(g_lp.float(), g_in + xr.grad) < (5e-3 if dtype != torch.float32 else 5e-6)
     assert relerr(dgam, gr.grad) < 1e-5 and relerr(dbet, br.grad) < 1e-5
 
 
@@ -494,7 +494,7 @@ def test_vit_l_weight_gradient_group_takes_the_256_tile(ops):
 
 
 # ------------------------------------------------------------------------------------ attention
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("cfg", [(3, 5, 12, 64), (2, 17, 16, 32), (2, 66, 2, 64), (4, 5, 4, 16), (1, 65, 3, 8),
                                  (2, 32, 3, 32), (5, 16, 2, 64), (3, 1, 2, 32), (7, 31, 5, 64),
                                  (2, 65, 4, 32), (1, 100, 2, 32), (3, 33, 2, 32), (2, 97, 3, 32), (2, 64, 2, 64),
@@ -514,7 +514,7 @@ def test_attention(ops, dtype, cfg):
     dqkv = torch.empty(B, N, 3 * D, device=DEV, dtype=dtype)
     ops.mha_fwd(dev(qkv, dtype), out, B, N, H, hd)
     ops.mha_bwd(dev(qkv, dtype), dev(dout, dtype), dqkv, B, N, H, hd)
-    tol = 6e-3 if dtype == torch.bfloat16 else 3e-6
+    tol = 6e-3 if dtype != torch.float32 else 3e-6
     assert relerr(out.float(), o.detach()) < tol
     assert relerr(dqkv.float(), q_r.grad) < tol
 
@@ -560,7 +560,7 @@ def test_random_mask_from_noise(ops, L, ratio):
     assert torch.equal(dd.cpu().long(), dt.cpu().long() + torch.arange(B)[:, None] * (L + 1))
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("geom", [(5, 64, 16), (9, 64, 8), (3, 32, 4)])
 def test_patch_gather_and_pmv_grad(ops, dtype, geom):
     C, H, p = geom
@@ -660,7 +660,7 @@ def test_masked_patch_loss(ops, norm_pix, loss_fn, geom):
 
 
 # ------------------------------------------------------------------------------------ optimiser
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_adamw(ops, dtype):
     n, n_decay = 4096 + 8, 1000
     g = torch.Generator().manual_seed(5)
