@@ -441,6 +441,7 @@ def staged_schedule_price(eng, opt, sched, B, pool, dev, args):
     st = eng.store
     snap = [t.clone() for t in (st.p, st.m, st.v, st.p_lp)]
     counters = (opt.step_count, sched.last_epoch)
+    grad_scale = opt.grad_scale
     res = {}
     try:
         # the monolithic step with the separate AdamW launch (what every rank of a data-parallel run executes per stage set)
@@ -491,14 +492,33 @@ def staged_schedule_price(eng, opt, sched, B, pool, dev, args):
             res[comm] = dict(ms_per_step=e0.elapsed_time(e1) / 50, stages=len(s2.stages),
                              bytes_per_stage=[sum(e - s for s, e in ranges) * elem for _, ranges in s2.stages])
             del s2
+        # the N > 1 default since round 6: the optimiser sharded over the ranks (reduce-scatter -> AdamW on this rank's eighth of
+        # every block-weight range -> all-gather of the 16-bit shadow).  Priced here as rank 0 of 8, collectives left out: the
+        # compute one rank of an 8-GPU job executes per step (the parameters of this leg are wrong by design and restored below)
+        s3 = TrainStep(eng, opt, sched, B, mask_ratio=0.75, use_graph=not args.no_graph, world_size=1, staged=True, n_encoder_groups=6,
+                       grad_comm="bf16", shard_optimizer=True, shard_emulate=(0, 8))
+        assert s3.shard_optimizer
+        for i in range(5):
+            s3(pool[i % 2])
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for i in range(50):
+            s3(pool[i % 2])
+        e1.record()
+        e1.synchronize()
+        res["sharded_optimizer_rank0_of_8"] = dict(ms_per_step=e0.elapsed_time(e1) / 50,
+                                                   optimizer_elements_per_rank=sum(max(c.numel(), 0) for c in s3._own.values()) +
+                                                   sum(e - s for s, e in s3.stages[-1][1]), optimizer_elements_total=st.n)
+        del s3
     finally:
         for dst, src in zip((st.p, st.m, st.v, st.p_lp), snap):
             dst.copy_(src)
         opt.step_count, sched.last_epoch = counters
         sched._apply()
-        opt.grad_scale = 1.0
+        opt.grad_scale = grad_scale
     res["note"] = ("TrainStep(staged=True, n_encoder_groups=6) at world 1: stage graphs + skyemb_cast launches, no collectives; the "
-                   "8-GPU step = this + the exposed part of the last stages' all-reduce (DESIGN.md §2)")
+                   "8-GPU step = sharded_optimizer_rank0_of_8 + the exposed part of the last stages' reduce-scatter / all-gather "
+                   "(DESIGN.md section 2; bf16 / f32 = the replicated schedule of rounds 2-5: every rank steps every parameter)")
     return res
 
 

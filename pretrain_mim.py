@@ -11,6 +11,7 @@ validation loss every ``verbose_iters``, checkpoints ``models/<model_name>.pth.t
 The linear-probe validation hook (``lp_class_data_file`` / ``lp_regress_data_file`` / ``lp_combine``) runs on rank 0; plots are
 out of scope.
 """
+import ast
 import configparser
 import os
 import time
@@ -86,7 +87,7 @@ def main(args):
         # survey tiles (FITS): every item is one sky patch cut into cutouts_per_tile windows on the GPU
         # (utils/dataloaders.py:538-654); ranks take every world-th patch, the same number each
         from utils.misc import str2bool
-        tile_loader = build_fits_dataloader(eval(config['DATA']['train_data_paths']), bands=eval(config['DATA']['bands']),
+        tile_loader = build_fits_dataloader(ast.literal_eval(config['DATA']['train_data_paths']), bands=ast.literal_eval(config['DATA']['bands']),
                                             min_bands=int(config['DATA']['min_bands']), batch_size=common['batch_size'],
                                             num_workers=num_workers, patch_size=common['patch_size'], max_mask_ratio=None,
                                             img_size=common['img_size'], cutouts_per_tile=int(config['DATA']['cutouts_per_tile']),
@@ -115,6 +116,7 @@ def main(args):
         # SimMIM mode: the per-channel patch masks are drawn on the device inside the step (max_mask_ratio)
         train_step = TrainStep(model.module.engine, optimizer, lr_scheduler, common['batch_size'], mask_ratio=mask_ratio,
                                world_size=world, max_mask_ratio=max_mask_ratio)
+    sharded = train_step is not None and getattr(train_step, "shard_optimizer", False)
     dataloader_val = build_h5_dataloader(os.path.join(data_dir, config['DATA']['val_data_file']), shuffle=True, **common)
     if rank == 0:
         if from_tiles:
@@ -208,12 +210,21 @@ def main(args):
                                   (losses['train_lp_r2'][-1], losses['val_lp_r2'][-1]))
                 losses_cp = defaultdict(list)
             cur_iter += 1
-            if (time.time() - cp_start_time) >= args.cp_time * 60:
+            due = (time.time() - cp_start_time) >= args.cp_time * 60
+            if sharded:
+                # the optimiser is sharded over the ranks (TrainStep): a checkpoint starts with a collective gather of the fp32 state,
+                # so the ranks take the wall-clock decision together -- rank 0's, looked at every 50 iterations
+                due = cur_iter % 50 == 0 and sdist.agree(due)
+            if due:
+                if sharded:
+                    train_step.gather_full_state()
                 if rank == 0:
                     print('Saving network...')
                     save_checkpoint(model_filename, cur_iter, losses, optimizer, lr_scheduler, model)
                 cp_start_time = time.time()
             if cur_iter > total_batch_iters:
+                if sharded:
+                    train_step.gather_full_state()
                 if rank == 0:
                     print('Saving network...')
                     save_checkpoint(model_filename, cur_iter, losses, optimizer, lr_scheduler, model)
@@ -225,6 +236,8 @@ def main(args):
                                % (common['batch_size'], world))
     if os.environ.get('SKYEMB_SAVE_RANK_PARAMS'):
         # test hook: every rank's flat fp32 master weights, to check that the replicas stayed identical
+        if sharded:
+            train_step.gather_full_state()
         torch.cuda.synchronize(device)
         torch.save(model.module.engine.store.p.cpu(), os.path.join(os.environ['SKYEMB_SAVE_RANK_PARAMS'], f'rank{rank}.pt'))
     if world > 1:

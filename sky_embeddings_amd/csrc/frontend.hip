@@ -2,6 +2,7 @@
 // normalise + NaN-fill + patch gather (im2row of the kept patches only), decoder mask-token fill,
 // row gathers, small deterministic reductions.  All HBM-bound, coalesced 16-byte accesses.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -108,6 +109,14 @@ __global__ __launch_bounds__(256) void patch_gather_kernel(const float *__restri
             o.y = o.y * (1.0f - k.y) + m.y * k.y;
             o.z = o.z * (1.0f - k.z) + m.z * k.z;
             o.w = o.w * (1.0f - k.w) + m.w * k.w;
+        }
+        if constexpr (std::is_same<T, f16_t>::value) {
+            // the one place an INPUT of any size enters the fp16 path: a saturated star of > 65504 normalised units stays the
+            // largest finite half instead of becoming inf (NaNs were replaced above; fminf / fmaxf would pass the other operand)
+            o.x = fminf(fmaxf(o.x, -65504.f), 65504.f);
+            o.y = fminf(fmaxf(o.y, -65504.f), 65504.f);
+            o.z = fminf(fmaxf(o.z, -65504.f), 65504.f);
+            o.w = fminf(fmaxf(o.w, -65504.f), 65504.f);
         }
         store4<T>(out + (int64_t)row * (C * p * p) + 4 * e, o.x, o.y, o.z, o.w);
     }

@@ -72,6 +72,25 @@ def host_barrier(timeout_s: float = 6 * 3600.0, poll_s: float = 0.05):
         arrived = store.add(key, 0)
 
 
+_AGREEMENTS = 0
+
+
+def agree(flag: bool) -> bool:
+    """Rank 0's `flag` on every rank, through the rendezvous store (host side, no collective, no device sync): decisions that depend
+    on a rank's wall clock -- the time-based checkpoint -- must be taken together once a collective hangs on them (the sharded
+    optimiser's state gather).  Every rank must call it the same number of times.  Single process: the flag itself."""
+    global _AGREEMENTS
+    if not dist.is_initialized() or dist.get_world_size() <= 1:
+        return bool(flag)
+    store = dist.distributed_c10d._get_default_store()
+    key = f"skyemb/agree/{_AGREEMENTS}"
+    _AGREEMENTS += 1
+    if dist.get_rank() == 0:
+        store.set(key, b"1" if flag else b"0")
+        return bool(flag)
+    return store.get(key) == b"1"
+
+
 def bucket_bounds(n: int, bucket_elems: int):
     """Contiguous [start, end) slices of a flat buffer, each a multiple of 8 elements except the last."""
     bucket_elems = max(8, bucket_elems // 8 * 8)
@@ -91,6 +110,56 @@ def allreduce_flat_gradients(g: torch.Tensor, world: int, bucket_elems: int = 16
         if async_op:
             works.append(w)
     return works
+
+
+def shard_chunk(length: int, world: int) -> int:
+    """Elements per rank of a flat range cut into `world` equal owner chunks (multiples of 8: the kernels' piece size); the
+    < 8 * world elements behind world * chunk are the range's TAIL, which stays replicated."""
+    return (length // world) // 8 * 8
+
+
+def reduce_scatter_range(g: torch.Tensor, s: int, e: int, rank: int, world: int, own: torch.Tensor, group=None):
+    """Sum over the ranks of g[s:e], every rank receiving only ITS chunk: own[:c] <- sum_r g_r[s + rank c : s + (rank + 1) c]
+    (c = shard_chunk(e - s, world)); the tail g[s + world c : e] is all-reduced in place.  Same bytes over xGMI as the all-reduce
+    it replaces (a ring all-reduce IS this reduce-scatter followed by an all-gather).  -> async work handles.
+    gloo (the rehearsal backend; several ranks on one GPU, collectives staged through the host) has no reduce-scatter for device
+    tensors: there the whole range is all-reduced and `finish()` of the returned handle copies this rank's chunk out."""
+    c = shard_chunk(e - s, world)
+    works = []
+    if dist.get_backend(group) == "gloo":
+        w = dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, group=group, async_op=True)
+        works.append(_Then(w, (lambda: own[:c].copy_(g[s + rank * c:s + (rank + 1) * c])) if c > 0 else None))
+        return works
+    if c > 0:
+        works.append(dist.reduce_scatter_tensor(own[:c], g[s:s + world * c], op=dist.ReduceOp.SUM, group=group, async_op=True))
+    if s + world * c < e:
+        works.append(dist.all_reduce(g[s + world * c:e], op=dist.ReduceOp.SUM, group=group, async_op=True))
+    return works
+
+
+class _Then:
+    """An async work handle with a follow-up on the waiting stream (wait() keeps torch.distributed's meaning)."""
+
+    def __init__(self, work, then=None):
+        self.work, self.then = work, then
+
+    def wait(self):
+        self.work.wait()
+        if self.then is not None:
+            self.then()
+            self.then = None
+
+
+def all_gather_range(buf: torch.Tensor, s: int, e: int, rank: int, world: int, group=None):
+    """buf[s : s + world c] <- every rank's chunk buf[s + r c : s + (r + 1) c] (in place: each rank's input is its own slot of the
+    output, as NCCL / RCCL define the in-place all-gather).  -> async work handle, or None for an empty chunk."""
+    c = shard_chunk(e - s, world)
+    if c == 0:
+        return None
+    if dist.get_backend(group) == "gloo":
+        outs = [buf[s + r * c:s + (r + 1) * c] for r in range(world)]
+        return dist.all_gather(outs, buf[s + rank * c:s + (rank + 1) * c].clone(), group=group, async_op=True)
+    return dist.all_gather_into_tensor(buf[s:s + world * c], buf[s + rank * c:s + (rank + 1) * c], group=group, async_op=True)
 
 
 def shard_rows(n_rows: int, rank: int, world: int):

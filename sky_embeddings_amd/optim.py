@@ -72,16 +72,24 @@ class FusedAdamW:
             # or an eager optimizer.step() after graph-mode steps would read the scalars of an older step
             self.write_scalars(self.step_count)
 
-    def apply_range(self, start, end):
-        """AdamW update of flat elements [start, end) on the current stream (start, end multiples of 8: tensor bounds)."""
+    def apply_range(self, start, end, grad=None):
+        """AdamW update of flat elements [start, end) on the current stream (start, end multiples of 8: tensor bounds).
+        grad: the gradients of exactly these elements in a buffer of their own (a reduce-scatter's output: TrainStep with the
+        optimiser sharded over the ranks); default: the same slice of the flat gradient buffer / its 16-bit mirror."""
         b1, b2 = self.defaults["betas"]
         t = self.step_count
         st = self.store
         n = end - start
+        if n <= 0:
+            return
         n_decay = min(max(st.n_decay - start, 0), n)     # layout is [decayed | not decayed]
         sl = slice(start, end)
         g = st.g if self.grad_buffer is None else self.grad_buffer
-        ops.adamw(st.p[sl], g[sl], st.m[sl], st.v[sl], st.p_lp[sl], n, n_decay, self.hyper_device, b1, b2,
+        if grad is not None:
+            g, sl_g = grad, slice(0, n)
+        else:
+            sl_g = sl
+        ops.adamw(st.p[sl], g[sl_g], st.m[sl], st.v[sl], st.p_lp[sl], n, n_decay, self.hyper_device, b1, b2,
                   self.defaults["eps"], self.param_groups[1]["weight_decay"], grad_scale=self.grad_scale, zero_grad=False,
                   lr=self.lr, bc1=1.0 - b1 ** t, bc2=1.0 - b2 ** t)
 

@@ -17,6 +17,8 @@ incoming gradient), ``''``.
 """
 from __future__ import annotations
 
+import ast
+
 import math
 import os
 from collections import OrderedDict, defaultdict
@@ -447,18 +449,21 @@ def build_model(config, mae_config, model_filename, mae_filename, device, build_
     if 'num_classes' in data:
         num_labels = int(data['num_classes'])
     elif 'label_keys' in data:
-        num_labels = len(eval(data['label_keys']))
+        num_labels = len(ast.literal_eval(data['label_keys']))
         if 'TRAINING' in config and str2bool(config['TRAINING'].get('use_label_errs', 'False')):
             num_labels = num_labels // 2
     else:
         num_labels = 0                           # similarity_search.py routes through forward_features only
-    model = VisionTransformer(cfg, device, _compute_dtype(mae_config), num_classes=num_labels,
+    dt = _compute_dtype(mae_config, default='bf16')
+    if dt == torch.float16:      # (a pretraining ini that names f16: the predictor's loss is the caller's torch code -- no loss scale -- so bf16)
+        dt = torch.bfloat16
+    model = VisionTransformer(cfg, device, dt, num_classes=num_labels,
                               global_pool=config['ARCHITECTURE'].get('global_pool', 'token'),
                               # utils/vit.py:38-39 as written: the LENGTHS of the configured lists -- 1 for every shipped ini, so
                               # labels are normalised as (y - 1) / 1 whatever the ini says (label_stds = [0] in all cls_*.ini)
-                              label_means=len(eval(data['label_means'])) if 'label_means' in data else 1,
-                              label_stds=len(eval(data['label_stds'])) if 'label_stds' in data else 1,
-                              drop_rate=float(eval(config['ARCHITECTURE'].get('dropout', '0.0'))))
+                              label_means=len(ast.literal_eval(data['label_means'])) if 'label_means' in data else 1,
+                              label_stds=len(ast.literal_eval(data['label_stds'])) if 'label_stds' in data else 1,
+                              drop_rate=float(ast.literal_eval(config['ARCHITECTURE'].get('dropout', '0.0'))))
     model = _DataParallelShim(model)
     if not build_optimizer:
         return load_model(model, model_filename, mae_filename)

@@ -83,7 +83,7 @@ def main():
                                             patch_size=int(mae_config['ARCHITECTURE']['patch_size']),
                                             num_channels=int(mae_config['ARCHITECTURE']['num_channels']), max_mask_ratio=None,
                                             shuffle=False, indices=target_indices)
-    test_dataloader = build_fits_dataloader(args.test_dirs, bands=eval(config['DATA']['bands']), min_bands=int(config['DATA']['min_bands']),
+    test_dataloader = build_fits_dataloader(args.test_dirs, bands=ast.literal_eval(config['DATA']['bands']), min_bands=int(config['DATA']['min_bands']),
                                             batch_size=args.batch_size, num_workers=2, patch_size=int(config['ARCHITECTURE']['patch_size']),
                                             max_mask_ratio=None, img_size=int(config['ARCHITECTURE']['img_size']),
                                             cutouts_per_tile=int(config['DATA']['cutouts_per_tile']),

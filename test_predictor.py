@@ -9,6 +9,7 @@ regressions by the photo-z metrics of the whole set and per redshift / S/N bin, 
 reference saves figures into ``figures/``, the numbers those figures show are saved as ``figures/<same name>.npz``
 (``utils.plotting_fns``; rendering is out of scope).  The encoder runs in the HIP engine.
 """
+import ast
 import configparser
 import os
 
@@ -50,7 +51,7 @@ def load_predictor(model_name, config_dir, model_dir, device):
 
 def validation_loader(config, mae_config, model, data_dir):
     return build_h5_dataloader(os.path.join(data_dir, config['DATA']['val_data_file']), batch_size=int(config['TRAINING']['batch_size']),
-                               num_workers=max(1, min(os.cpu_count(), 12) - 1), label_keys=eval(config['DATA']['label_keys']),
+                               num_workers=max(1, min(os.cpu_count(), 12) - 1), label_keys=ast.literal_eval(config['DATA']['label_keys']),
                                img_size=int(config['ARCHITECTURE']['img_size']), patch_size=int(mae_config['ARCHITECTURE']['patch_size']),
                                num_channels=int(mae_config['ARCHITECTURE']['num_channels']), num_patches=model.module.patch_embed.num_patches,
                                shuffle=False)

@@ -33,7 +33,7 @@ def _make(dev, B, world, **kw):
     return eng, step
 
 
-def _rank_main(rank, port, out_dir, grad_comm, use_nccl, world=WORLD):
+def _rank_main(rank, port, out_dir, grad_comm, use_nccl, world=WORLD, shard=None):
     import torch.distributed as dist
     dev = torch.device("cuda", rank if use_nccl else 0)
     torch.cuda.set_device(dev)
@@ -43,30 +43,41 @@ def _rank_main(rank, port, out_dir, grad_comm, use_nccl, world=WORLD):
         dist.init_process_group("gloo", rank=rank, world_size=world, init_method=f"tcp://127.0.0.1:{port}")
     imgs, noise = _data(world)
     rows = slice(rank * B_RANK, (rank + 1) * B_RANK)
-    eng, step = _make(dev, B_RANK, world, grad_comm=grad_comm)
+    eng, step = _make(dev, B_RANK, world, grad_comm=grad_comm, shard_optimizer=shard)
     assert step.staged and len(step.stages) >= 4          # decoder | encoder groups | embedding: comm overlaps backward
+    # (default with N > 1: the optimiser sharded over the ranks -- reduce-scatter, AdamW on the owned chunks, all-gather of the shadow)
+    assert step.shard_optimizer == (shard is not False) and step.shard_world == world and step.shard_rank == rank
     losses = []
     for it in range(STEPS):
         step.noise.copy_(noise[it][rows])
         losses.append(float(step(imgs[rows].to(dev))))
+    if step.shard_optimizer:
+        # a chunk's fp32 master weights are current on its owner only (the other ranks hold the gathered 16-bit shadow)
+        own_s, own_e = next(iter(step._own))
+        stale = not torch.equal(eng.store.p_lp[own_s:own_e].float(), eng.store.p[own_s:own_e].to(eng.store.p_lp.dtype).float())
+        assert stale, "no non-owned chunk went stale: the optimiser was not sharded"
+        step.gather_full_state()
     torch.cuda.synchronize(dev)
-    torch.save({"losses": losses, "p": eng.store.p.cpu()}, os.path.join(out_dir, f"rank{rank}.pt"))
+    assert torch.equal(eng.store.p_lp.float(), eng.store.p.to(eng.store.p_lp.dtype).float())       # shadow == rounded master, everywhere
+    torch.save({"losses": losses, "p": eng.store.p.cpu(), "m": eng.store.m.cpu()}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
 # world 4 = the most ranks a one-GPU box lets a test start next to the test process itself (six GPU processes per card)
-@pytest.mark.parametrize("grad_comm,world", [("f32", 2), ("bf16", 2), ("bf16", 4)])
-def test_n_rank_training_step_matches_one_rank_on_the_concatenated_batch(tmp_path, grad_comm, world):
+@pytest.mark.parametrize("grad_comm,world,shard", [("f32", 2, None), ("bf16", 2, None), ("bf16", 4, None), ("bf16", 2, False), ("f32", 4, None)])
+def test_n_rank_training_step_matches_one_rank_on_the_concatenated_batch(tmp_path, grad_comm, world, shard):
+    """shard = None: the default of an N > 1 job, the optimiser sharded over the ranks; False: the replicated schedule (all-reduce,
+    every rank steps everything).  Both against ONE rank on the concatenated batch, to the same bars."""
     import torch.multiprocessing as mp
     use_nccl = torch.cuda.device_count() >= world
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    mp.spawn(_rank_main, args=(port, str(tmp_path), grad_comm, use_nccl, world), nprocs=world, join=True)
+    mp.spawn(_rank_main, args=(port, str(tmp_path), grad_comm, use_nccl, world, shard), nprocs=world, join=True)
     r = [torch.load(tmp_path / f"rank{k}.pt") for k in range(world)]
-    # the replicas stay identical, bit for bit
-    assert all(torch.equal(r[0]["p"], rk["p"]) for rk in r[1:])
+    # the replicas stay identical, bit for bit (sharded: after the gather of the owners' fp32 state)
+    assert all(torch.equal(r[0]["p"], rk["p"]) and torch.equal(r[0]["m"], rk["m"]) for rk in r[1:])
     # one process, the whole batch, fp32 gradients
     imgs, noise = _data(world)
     eng, step = _make(torch.device("cuda", 0), world * B_RANK, 1)
@@ -89,7 +100,7 @@ def test_n_rank_training_step_matches_one_rank_on_the_concatenated_batch(tmp_pat
     # move of an element whose gradient is rounding noise, but not the bulk
     frac_close = float((err <= (0.05 if grad_comm == "f32" else 0.25) * LR * STEPS).float().mean())
     from tests.helpers import record_parity
-    record_parity(f"ddp_{world}_ranks_vs_one_{grad_comm}",
+    record_parity(f"ddp_{world}_ranks_vs_one_{grad_comm}" + ("_replicated" if shard is False else "_sharded_optimizer"),
                   dict(loss_rel_max=float(np.max(np.abs(mean_losses - np.asarray(ref_losses)) / np.abs(ref_losses))),
                        frac_within_band=frac_close, band_in_lr_steps=0.05 if grad_comm == "f32" else 0.25,
                        err_max_in_lr_steps=float(err.max()) / (LR * STEPS), err_mean_in_lr_steps=float(err.mean()) / (LR * STEPS),

@@ -634,6 +634,36 @@ def _worker8(rank, world, port, tmp):
     counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
     dist.all_gather(counts, torch.tensor([batches_per_epoch(1001, 16, rank, world)]))
     assert len({int(c) for c in counts}) == 1 and int(counts[0]) == 1001 // world // 16
+    # (5) the sharded optimiser's collectives (TrainStep(shard_optimizer=True)): every stage range cut into 8 owner chunks --
+    # reduce-scatter of the gradients (+ the replicated tail of < 64 elements), an "optimiser step" on the owned chunk only, the
+    # in-place all-gather of the result -- equals all-reduce + the step on everything, for ragged range lengths and both dtypes
+    for dt, tol in ((torch.float32, 1e-5), (torch.bfloat16, 8 * 2.0 ** -8)):
+        ranges = [(0, 4096), (4096, 4096 + 8 * 1237), (4096 + 8 * 1237, n)]      # chunk 512 / 1232 (+ tail 40) / the rest
+        gr = grads[rank].clone().to(dt)
+        param = torch.arange(n, dtype=torch.float32) * 1e-3
+        for (s_, e_) in ranges:
+            c = sdist.shard_chunk(e_ - s_, world)
+            own = torch.zeros(max(c, 8), dtype=dt)
+            for wk in sdist.reduce_scatter_range(gr, s_, e_, rank, world, own):
+                wk.wait()
+            ref_chunk = want[s_ + rank * c:s_ + (rank + 1) * c]
+            scale = torch.stack(grads).abs().double().sum(0)[s_ + rank * c:s_ + (rank + 1) * c] + 1e-30
+            assert float(((own[:c].double() - ref_chunk).abs() / scale).max()) < tol
+            tail = slice(s_ + world * c, e_)
+            if tail.start < tail.stop:
+                assert float(((gr[tail].double() - want[tail]).abs() / (torch.stack(grads).abs().double().sum(0)[tail] + 1e-30)).max()) < tol
+            # "step": p -= g on the owned chunk and on the tail, then gather
+            param[s_ + rank * c:s_ + (rank + 1) * c] -= own[:c].float()
+            param[tail] -= gr[tail].float()
+            wk = sdist.all_gather_range(param, s_, e_, rank, world)
+            if wk is not None:
+                wk.wait()
+        every = [torch.zeros_like(param) for _ in range(world)]
+        dist.all_gather(every, param)
+        assert all(torch.equal(every[0], e) for e in every)                   # every rank holds the same parameters afterwards
+        assert float((param.double() - (torch.arange(n, dtype=torch.float64) * 1e-3 - want)).abs().max()) < (1e-4 if dt == torch.float32 else 0.2)
+    # (6) a wall-clock decision taken together: every rank gets rank 0's flag
+    assert sdist.agree(rank == 0) is True and sdist.agree(rank != 0) is False
     sdist.host_barrier(timeout_s=60.0)
     dist.barrier()
     dist.destroy_process_group()
@@ -642,7 +672,8 @@ def _worker8(rank, world, port, tmp):
 
 def test_eight_process_gloo_paths(tmp_path):
     """World size 8 -- the split BASELINE.json names -- over gloo on CPU: all-reduce (fp32 / bf16), sharded search with ties in three
-    shards, index shards with a remainder, the feeder's batch count, the store barrier."""
+    shards, index shards with a remainder, the feeder's batch count, the sharded optimiser's reduce-scatter / all-gather over ragged
+    ranges, the store barrier and the store agreement."""
     port = _free_port()
     mp.spawn(_worker8, args=(8, port, str(tmp_path)), nprocs=8, join=True)
     assert all(os.path.exists(tmp_path / f"ok{k}") for k in range(8))

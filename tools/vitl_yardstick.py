@@ -1,9 +1,16 @@
 #!/usr/bin/env python3
-"""Yardstick only (not a product path): the GEMM shapes of one mim_19 block (ViT-L/16, 8320 token rows) -- this library's launches
-as the step issues them (forward with bias / GELU / residual epilogues, data gradients against the row-contiguous weight) beside
-the vendor BLAS (torch.matmul -> hipBLASLt, plain GEMMs), each 20x in one HIP graph.  Also: the fc2 data gradient with a
-k-contiguous (pre-transposed) copy of the weight, the question DESIGN.md section 7 left open.
-usage: vitl_yardstick.py  (one MI355X)"""
+"""Yardstick only (not a product path): the GEMM shapes of one mim_19 block (ViT-L/16, 8320 token rows) beside the vendor BLAS
+(torch.matmul -> hipBLASLt), each 20x in one HIP graph, us per launch.
+
+Round 6: like for like.  The step's launches carry their layer's elementwise work in the epilogue -- bias, exact-erf GELU with the
+pre-activation as a second output, the fp32 residual stream (read + written), the dGELU factor -- which a plain BLAS GEMM does
+not do; rounds 4-5 compared the two anyway.  Columns per shape and direction:
+  step      this library as the engine launches it (tuned tile, fused epilogue)
+  plain     the same kernel with a bare epilogue (16-bit output only): the k-loops, like for like with ...
+  blas      ... hipBLASLt's plain GEMM
+  blas+ew   hipBLASLt + the elementwise torch kernels that produce what `step` produces (bias / GELU + pre-activation / residual add
+            in fp32 / dGELU multiply): what the layer costs without the fusion
+usage: vitl_yardstick.py [bf16|f16]  (one MI355X)"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,6 +18,7 @@ from sky_embeddings_amd import ops
 from sky_embeddings_amd.ops import ACT_DGELU, ACT_GELU, KC, RC
 M, D = 8320, 1024
 dev = "cuda"
+T = torch.float16 if (len(sys.argv) > 1 and sys.argv[1] == "f16") else torch.bfloat16
 
 
 def timeit(f):
@@ -33,49 +41,53 @@ def timeit(f):
 
 
 ws = torch.zeros(8 * 1024 * 1024, device=dev)
-rows = []
+print(f"# operand format {T}; us per launch, 20 launches per HIP graph")
+tot = dict(step=0.0, plain=0.0, blas=0.0, blas_ew=0.0)
 for name, N, K, epi in (("qkv", 3 * D, D, "bias"), ("proj", D, D, "resid"), ("fc1", 4 * D, D, "gelu"), ("fc2", D, 4 * D, "resid")):
-    x = torch.randn(M, K, device=dev).bfloat16()
-    w = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
-    wt = w.t().contiguous()                       # [K, N]: the weight as a k-contiguous B operand of the data gradient
-    dy = torch.randn(M, N, device=dev).bfloat16()
+    x = torch.randn(M, K, device=dev).to(T)
+    w = (torch.randn(N, K, device=dev) * 0.05).to(T)
+    dy = torch.randn(M, N, device=dev).to(T)
     bias = torch.zeros(N, device=dev)
-    y, y2 = torch.empty(M, N, device=dev, dtype=torch.bfloat16), torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    y, y2 = torch.empty(M, N, device=dev, dtype=T), torch.empty(M, N, device=dev, dtype=T)
     y32, res = torch.empty(M, N, device=dev), torch.randn(M, N, device=dev)
-    dx, aux = torch.empty(M, K, device=dev, dtype=torch.bfloat16), torch.randn(M, K, device=dev).bfloat16()
-    dw = torch.empty(N, K, device=dev, dtype=torch.bfloat16)
+    dx, aux = torch.empty(M, K, device=dev, dtype=T), torch.randn(M, K, device=dev).to(T)
     if epi == "gelu":
         fwd = lambda: ops.gemm(x, w, M=M, N=N, K=K, bias=bias, act=ACT_GELU, out=y, out2=y2)
+
+        def blas_ew():
+            torch.matmul(x, w.t(), out=y2)
+            y2.add_(bias.to(T))                                  # pre-activation (second output)
+            torch.nn.functional.gelu(y2, approximate="none")     # activation (allocating: torch has no out= form)
     elif epi == "resid":
         fwd = lambda: ops.gemm(x, w, M=M, N=N, K=K, bias=bias, resid=res, ldr=N, out_f32=y32, ws=ws)
+
+        def blas_ew():
+            torch.matmul(x, w.t(), out=y)
+            torch.add(res, y, out=y32)                           # fp32 residual stream: read + write (bias folded in would be a third op)
     else:
         fwd = lambda: ops.gemm(x, w, M=M, N=N, K=K, bias=bias, out=y)
+
+        def blas_ew():
+            torch.matmul(x, w.t(), out=y)
+            y.add_(bias.to(T))
+    plain = lambda: ops.gemm(x, w, M=M, N=N, K=K, out=y)
+    blas = lambda: torch.matmul(x, w.t(), out=y)
     kw = dict(act=ACT_DGELU, aux=aux, ldaux=K) if name == "fc2" else {}
     dgrad = lambda: ops.gemm(dy, w, M=M, N=K, K=N, a_layout=KC, b_layout=RC, lda=N, ldb=K, out=dx, ws=ws, **kw)
-    dgrad_kc = lambda: ops.gemm(dy, wt, M=M, N=K, K=N, a_layout=KC, b_layout=KC, lda=N, ldb=N, out=dx, ws=ws, **kw)
-    fl = 2.0 * M * N * K
-    # the 144-row image stepping by 130 rows x 256 columns (8320 = 64 x 130: whole rounds of 256 tiles, no row tail): explicit tile code
-    T130 = 13144256
-    if epi == "gelu":
-        fwd130 = lambda: ops.gemm(x, w, M=M, N=N, K=K, bias=bias, act=ACT_GELU, out=y, out2=y2, tile=T130)
-    elif epi == "resid":
-        fwd130 = lambda: ops.gemm(x, w, M=M, N=N, K=K, bias=bias, resid=res, ldr=N, out_f32=y32, tile=T130)
-    else:
-        fwd130 = lambda: ops.gemm(x, w, M=M, N=N, K=K, bias=bias, out=y, tile=T130)
-    dgrad130 = lambda: ops.gemm(dy, w, M=M, N=K, K=N, a_layout=KC, b_layout=RC, lda=N, ldb=K, out=dx, tile=T130, **kw)
-    # numerics of the new tile against fp32 matmuls of the same bf16 operands
-    fwd130()
-    ref = x.float() @ w.float().t() + bias
-    got = (y32 - res) if epi == "resid" else (y2.float() if epi == "gelu" else y.float())
-    e_f = float((got - ref).norm() / ref.norm())
-    dgrad130()
-    refd = dy.float() @ w.float()
+    dplain = lambda: ops.gemm(dy, w, M=M, N=K, K=N, a_layout=KC, b_layout=RC, lda=N, ldb=K, out=dx, ws=ws)
+    dblas = lambda: torch.matmul(dy, w, out=dx)
     if name == "fc2":
-        z = aux.float()
-        refd = refd * (0.5 * (1 + torch.erf(z / 2 ** 0.5)) + z * torch.exp(-0.5 * z * z) / (2 * 3.141592653589793) ** 0.5)
-    e_d = float((dx.float() - refd).norm() / refd.norm())
-    print(f"      tile 130x256 rel-L2 error: fwd {e_f:.2e} dgrad {e_d:.2e}")
-    t = dict(fwd=timeit(fwd), fwd130=timeit(fwd130), dgrad=timeit(dgrad), dgrad130=timeit(dgrad130), dgrad_kcB=timeit(dgrad_kc),
-             blas_fwd=timeit(lambda: torch.matmul(x, w.t(), out=y)), blas_dgrad=timeit(lambda: torch.matmul(dy, w, out=dx)),
-             blas_wgrad=timeit(lambda: torch.matmul(dy.t(), x, out=dw)))
-    print(f"{name:5s} [{M} x {N} x {K}] " + " | ".join(f"{k} {v:6.1f} us {fl / v / 1e6:5.0f} TF" for k, v in t.items()), flush=True)
+        def dblas_ew():
+            torch.matmul(dy, w, out=dx)
+            z = aux.float()
+            dx.mul_((0.5 * (1 + torch.erf(z * 0.7071067811865476)) + z * torch.exp(-0.5 * z * z) * 0.3989422804014327).to(T))
+    else:
+        dblas_ew = dblas
+    fl = 2.0 * M * N * K
+    for tag, fs in (("fwd", (fwd, plain, blas, blas_ew)), ("dgrad", (dgrad, dplain, dblas, dblas_ew))):
+        t = [timeit(f) for f in fs]
+        for k_, v in zip(tot, t):
+            tot[k_] += v
+        print(f"{name:5s} {tag:5s} [{M} x {(N if tag == 'fwd' else K)} x {(K if tag == 'fwd' else N)}]  step {t[0]:6.1f} us {fl / t[0] / 1e6:5.0f} TF | plain {t[1]:6.1f} us "
+              f"{fl / t[1] / 1e6:5.0f} TF | blas {t[2]:6.1f} us {fl / t[2] / 1e6:5.0f} TF | blas+ew {t[3]:6.1f} us", flush=True)
+print("sum of the eight launches (one block, forward + data gradients): " + " | ".join(f"{k} {v:6.1f} us" for k, v in tot.items()))

@@ -10,6 +10,7 @@ evaluates the validation set every ``verbose_iters``, keeps ``models/<name>_best
 stops after 50 evaluations without improvement) and checkpoints ``models/<name>.pth.tar`` every ``cp_time`` minutes, in the
 reference's format.  The encoder runs forward and backward in the HIP engine; progress plots are out of scope.
 """
+import ast
 import configparser
 import os
 import time
@@ -78,7 +79,7 @@ def main(args):
         train_indices = select_training_indices(train_file, num_train, balanced=False) if 'crossentropy' in loss_fn.lower() else range(num_train)
     else:
         train_indices = None
-    common = dict(batch_size=int(tr['batch_size']), num_workers=num_workers, label_keys=eval(config['DATA']['label_keys']),
+    common = dict(batch_size=int(tr['batch_size']), num_workers=num_workers, label_keys=ast.literal_eval(config['DATA']['label_keys']),
                   img_size=int(config['ARCHITECTURE']['img_size']), patch_size=int(mae_config['ARCHITECTURE']['patch_size']),
                   num_channels=int(mae_config['ARCHITECTURE']['num_channels']), num_patches=model.module.patch_embed.num_patches, shuffle=True)
     dataloader_train = build_h5_dataloader(train_file, augment=str2bool(tr.get('augment', 'False')), brightness=float(tr.get('brightness', '0.8')),
