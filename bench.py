@@ -250,7 +250,8 @@ def bench_pretrain(args, rank, world, dev):
             if step.fused_adamw and not args.no_graph:
                 out["optimizer_placement"] = placement_ab(lambda: MAEEngine(cfg, device=dev, compute_dtype=dtype, seed=0), B, pool, dev, step,
                                                           ["1", "0", "ln_separate=SKYEMB_LN_SIDE=0"] if os.environ.get("SKYEMB_BENCH_PLACEMENT_ALL")
-                                                          else ["0", "ln_separate=SKYEMB_LN_SIDE=0", "no_fold=SKYEMB_FOLD_WGRADS=0", "no_prefetch=SKYEMB_PREFETCH=0"] + os.environ.get("SKYEMB_BENCH_EXTRA_VARIANTS", "").split())
+                                                          else ["0", "ln_separate=SKYEMB_LN_SIDE=0", "no_fold=SKYEMB_FOLD_WGRADS=0", "no_prefetch=SKYEMB_PREFETCH=0",
+                                                                "tiles_per_problem=SKYEMB_GROUP_XCD_ORDER=0"] + os.environ.get("SKYEMB_BENCH_EXTRA_VARIANTS", "").split())
         if world == 1 and not args.skip_feeder:
             out["feeder"] = bench_feeder(args, dev, step, B)
     return out, eng

@@ -94,14 +94,16 @@ __device__ __forceinline__ PackInfo pack_of(int head, int B, int N, int H) {
 }
 __device__ __forceinline__ int seq_of(int row, const PackInfo &pi) { return (row * pi.inv_n) >> 16; }   // row / N, exact for row < 32
 
-template <int HD>
-__global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const lp_t *__restrict__ qkv, lp_t *__restrict__ out, int B,
+// WPB = waves (independent head tiles) per workgroup: 4 when there are enough tiles for every CU, 1 when there are not (the
+// encoder's packed 5-token sequences at B = 256: 516 tiles -- 129 four-wave workgroups left half of the 256 CUs without work)
+template <int HD, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void mha_fwd_mfma_kernel(const lp_t *__restrict__ qkv, lp_t *__restrict__ out, int B,
                                                            int N, int H, int nheads) {
     constexpr int KS = HD / 16, NB = (HD + 31) / 32;
     // transposed operands through LDS (see the file header)
-    __shared__ __attribute__((aligned(16))) lp_t park[4][32 * (HD + 8)];
+    __shared__ __attribute__((aligned(16))) lp_t park[WPB][32 * (HD + 8)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int head = blockIdx.x * 4 + wave;
+    const int head = blockIdx.x * WPB + wave;
     if (head >= nheads) return;
     const PackInfo pk = pack_of(head, B, N, H);
     const int h = pk.h, NR = pk.nrows;
@@ -169,14 +171,14 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const lp_t *__restric
     }
 }
 
-template <int HD>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 32 ? 4 : 2))) void mha_bwd_mfma_kernel(const lp_t *__restrict__ qkv, const lp_t *__restrict__ dout,
+template <int HD, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(HD == 32 ? 4 : 2))) void mha_bwd_mfma_kernel(const lp_t *__restrict__ qkv, const lp_t *__restrict__ dout,
                                                            lp_t *__restrict__ dqkv, int B, int N, int H, int nheads) {
     constexpr int KS = HD / 16, NB = (HD + 31) / 32;
-    __shared__ float stats[4][3][32];
-    __shared__ __attribute__((aligned(16))) lp_t park[4][3][32 * (HD + 8)];      // K, Q, dO of each wave
+    __shared__ float stats[WPB][3][32];
+    __shared__ __attribute__((aligned(16))) lp_t park[WPB][3][32 * (HD + 8)];      // K, Q, dO of each wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int head = blockIdx.x * 4 + wave;
+    const int head = blockIdx.x * WPB + wave;
     if (head >= nheads) return;
     const PackInfo pk = pack_of(head, B, N, H);        // packed short sequences: see mha_fwd_mfma_kernel
     const int h = pk.h, NR = pk.nrows;
@@ -636,13 +638,22 @@ int SKY_TWIN(skyemb_mha_mfma_try)(bool bwd, const void *qkv, const void *dout, v
     }
     const int P = N <= 16 ? 32 / N : 1;                   // samples packed into one wave's 32-row tile
     const int nheads = ((B + P - 1) / P) * H;
-    const dim3 grid((nheads + 3) / 4), block(256);
+    // fewer four-wave workgroups than twice the compute units: one tile per workgroup, so that the tiles spread over every CU
+    static const int wpb_env = []() { const char *e = getenv("SKYEMB_MHA_WPB"); return e ? atoi(e) : 0; }();
+    const bool one = wpb_env ? wpb_env == 1 : (nheads + 3) / 4 < 512;
+    const dim3 grid(one ? nheads : (nheads + 3) / 4), block(one ? 64 : 256);
+#define MHA_GO(KERN, HD_, ...)                                                                         \
+    do {                                                                                               \
+        if (one) hipLaunchKernelGGL((KERN<HD_, 1>), grid, block, 0, st, __VA_ARGS__);                  \
+        else hipLaunchKernelGGL((KERN<HD_, 4>), grid, block, 0, st, __VA_ARGS__);                      \
+    } while (0)
     if (!bwd) {
-        if (hd == 32) hipLaunchKernelGGL(mha_fwd_mfma_kernel<32>, grid, block, 0, st, x, (lp_t *)out, B, N, H, nheads);
-        else hipLaunchKernelGGL(mha_fwd_mfma_kernel<64>, grid, block, 0, st, x, (lp_t *)out, B, N, H, nheads);
+        if (hd == 32) MHA_GO(mha_fwd_mfma_kernel, 32, x, (lp_t *)out, B, N, H, nheads);
+        else MHA_GO(mha_fwd_mfma_kernel, 64, x, (lp_t *)out, B, N, H, nheads);
     } else {
-        if (hd == 32) hipLaunchKernelGGL(mha_bwd_mfma_kernel<32>, grid, block, 0, st, x, (const lp_t *)dout, (lp_t *)out, B, N, H, nheads);
-        else hipLaunchKernelGGL(mha_bwd_mfma_kernel<64>, grid, block, 0, st, x, (const lp_t *)dout, (lp_t *)out, B, N, H, nheads);
+        if (hd == 32) MHA_GO(mha_bwd_mfma_kernel, 32, x, (const lp_t *)dout, (lp_t *)out, B, N, H, nheads);
+        else MHA_GO(mha_bwd_mfma_kernel, 64, x, (const lp_t *)dout, (lp_t *)out, B, N, H, nheads);
     }
+#undef MHA_GO
     return 0;
 }

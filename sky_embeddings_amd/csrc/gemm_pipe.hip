@@ -255,7 +255,7 @@ __device__ __forceinline__ void wait_stages(int rem) {
 // 64-row tiles gave 544 (three on 32 CUs, two on the rest: the launch ran at the pace of the CUs with three).
 template <int BM, int BN, bool A_KC, bool B_KC, int NSTAGE, int WM, int WN, int WK = 1, bool ADAM = false, int BMS = BM>
 __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const int tb, const int ntiles, const int split,
-                                               const int S, char *smem, const skyemb_adamw_desc *ad = nullptr) {
+                                               const int S, char *smem, const skyemb_adamw_desc *ad = nullptr, const bool linear = false) {
     constexpr int NWG = WM * WN, NW = NWG * WK;         // waves per k-group / per workgroup
     constexpr int SM = BM / WM, SN = BN / WN;           // rows / columns of the tile owned by one wave
     constexpr int TM = SM / 16, TN = SN / 16;
@@ -282,6 +282,7 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
         const unsigned int nwg = (unsigned int)ntiles, xcd = (unsigned int)tb & 7u, local = (unsigned int)tb >> 3;
         const unsigned int q = nwg >> 3, r = nwg & 7u;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+        if (linear) wg = (unsigned int)tb;               // (grouped launches: the group kernel has laid the tiles out per XCD)
     }
     // An XCD's chunk of consecutive tiles walks ONE operand in full and a slice of the other (the 8 L2s are not coherent:
     // each fetches what its tiles touch).  Row-major tile order makes that full operand B, column-major A: let the SMALLER
@@ -792,6 +793,8 @@ __device__ __forceinline__ void side_job(const char *__restrict__ blob, char *sm
     return side_adamw_job<THREADS, U>(blob, s - n_ln, hdr[3]);
 }
 
+__device__ __forceinline__ int starts_total(const int *hdr, int n) { return hdr[8 + n]; }   // padded tile count of the whole group
+
 template <int BM, int BN, int NSTAGE, int WM, int WN, int CLASSES, int WK = 1, bool ADAM = false, bool SIDE = false>
 __global__ __launch_bounds__(WM * WN * WK * 64) void gemm_pipe_group_kernel(const char *__restrict__ blob) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -805,25 +808,32 @@ __global__ __launch_bounds__(WM * WN * WK * 64) void gemm_pipe_group_kernel(cons
     int starts[GROUP_MAX + 1];
 #pragma unroll
     for (int i = 0; i <= GROUP_MAX; ++i) starts[i] = hdr[8 + i];
+    // Tile order across the GROUP (round 6, as the 256 x 256 group since round 5; header word 1 bit 30 = on): workgroup b runs on XCD
+    // b & 7, and XCD x takes the x-th EIGHTH of the concatenated tile list -- consecutive tiles of mostly ONE problem -- instead of an
+    // eighth of EVERY problem.  Config A encoder block (456 tiles of 128 x 128, five problems): an XCD's 57 tiles touch 16 operand
+    // panels of 327 KB instead of 36, i.e. 42 instead of 94 MB enter the eight L2s per launch.
+    const bool by_xcd = (hdr[1] >> 30) & 1;
+    int gt = blockIdx.x;
+    if (by_xcd) gt = (gt & 7) * (starts_total(hdr, n) >> 3) + (gt >> 3);
     int p = 0, first = 0;
 #pragma unroll
     for (int i = 1; i < GROUP_MAX; ++i)
-        if (i < n && (int)blockIdx.x >= starts[i]) { p = i; first = starts[i]; }
+        if (i < n && gt >= starts[i]) { p = i; first = starts[i]; }
     const skyemb_gemm_args g = ((const skyemb_gemm_args *)(blob + GROUP_HEADER_BYTES))[p];
-    const int tb = blockIdx.x - first;
+    const int tb = gt - first;
     const int ntiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     if (tb >= ntiles) return;                             // padding up to the next multiple of 8 (keeps tb & 7 == XCD)
     const bool a = g.a_layout == SKYEMB_KC, b = g.b_layout == SKYEMB_KC;   // workgroup-uniform
-    if constexpr (CLASSES & 1) if (a && b) return gemm_pipe_body<BM, BN, true, true, NSTAGE, WM, WN, WK>(g, tb, ntiles, 0, 1, smem);
-    if constexpr (CLASSES & 2) if (a && !b) return gemm_pipe_body<BM, BN, true, false, NSTAGE, WM, WN, WK>(g, tb, ntiles, 0, 1, smem);
+    if constexpr (CLASSES & 1) if (a && b) return gemm_pipe_body<BM, BN, true, true, NSTAGE, WM, WN, WK>(g, tb, ntiles, 0, 1, smem, nullptr, by_xcd);
+    if constexpr (CLASSES & 2) if (a && !b) return gemm_pipe_body<BM, BN, true, false, NSTAGE, WM, WN, WK>(g, tb, ntiles, 0, 1, smem, nullptr, by_xcd);
     if constexpr (SIDE) static_assert(CLASSES == 4, "side optimiser jobs ride in weight-gradient (RC.RC) groups only");
     if constexpr (ADAM) {
         static_assert(CLASSES == 4, "the fused optimiser step exists for weight-gradient (RC.RC) groups only");
         return gemm_pipe_body<BM, BN, false, false, NSTAGE, WM, WN, WK, true>(g, tb, ntiles, 0, 1, smem,
-                                                                            (const skyemb_adamw_desc *)(blob + GROUP_ADAMW_OFFSET));
+                                                                            (const skyemb_adamw_desc *)(blob + GROUP_ADAMW_OFFSET), by_xcd);
     }
-    if constexpr (CLASSES & 4) if (!a && !b) return gemm_pipe_body<BM, BN, false, false, NSTAGE, WM, WN, WK>(g, tb, ntiles, 0, 1, smem);
-    if constexpr (CLASSES & 8) if (!a && b) return gemm_pipe_body<BM, BN, false, true, NSTAGE, WM, WN, WK>(g, tb, ntiles, 0, 1, smem);
+    if constexpr (CLASSES & 4) if (!a && !b) return gemm_pipe_body<BM, BN, false, false, NSTAGE, WM, WN, WK>(g, tb, ntiles, 0, 1, smem, nullptr, by_xcd);
+    if constexpr (CLASSES & 8) if (!a && b) return gemm_pipe_body<BM, BN, false, true, NSTAGE, WM, WN, WK>(g, tb, ntiles, 0, 1, smem, nullptr, by_xcd);
 }
 
 // second launch of a split-K GEMM: v = sum_s slab[s][m][n] (fixed order, alpha already applied), then
@@ -1240,11 +1250,13 @@ extern "C" int skyemb_gemm_group_plan(const skyemb_gemm_args *args, int n, int t
     hdr[8 + n] = start;
     hdr[0] = n;
     hdr[1] = start;
-    if (tile == 256256) {
-        // tile order across the group (gemm256_group_kernel): an XCD takes consecutive tiles of the concatenated list
-        // (read per plan, not once per process: bench.py builds both orders in one process for its interleaved A/B)
+    {
+        // tile order across the group (gemm256_group_kernel since round 5, gemm_pipe_group_kernel since round 6): an XCD takes
+        // consecutive tiles of the concatenated list (read per plan, not once per process: bench.py builds both orders in one
+        // process for its interleaved A/B).  SKYEMB_GROUP_XCD_ORDER=0: an eighth of every problem per XCD; =256: 256 x 256 tiles only
         const char *e = getenv("SKYEMB_GROUP_XCD_ORDER");
-        if (!(e && e[0] == '0')) hdr[1] |= 1 << 30;
+        const bool off = e && e[0] == '0', only256 = e && atoi(e) == 256;
+        if (!off && (tile == 256256 || !only256)) hdr[1] |= 1 << 30;
     }
     info->total_blocks = start;
     info->tile = tile;

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
                                                        int cap, int *__restrict__ cnt, int *__restrict__ cand_i, float *__restrict__ cand_d,
                                                        uint4 *__restrict__ wg_list, int *__restrict__ wg_count, int capw,
                                                        int *__restrict__ overflow
-#ifdef PF_STAMP
+#if defined(PF_STAMP) || defined(PF_CLOCK)
                                                        , unsigned long long *__restrict__ dbg
 #endif
                                                        ) {
@@ -601,6 +601,11 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
         kt_s = kt_s + 1 < KT ? kt_s + 1 : 0;
     };
     STAMP(-1);
+#ifdef PF_CLOCK
+    // -DPF_CLOCK (a diagnostic build of its own, no per-segment stamps): the clock the chip holds inside THIS kernel's loop =
+    // delta s_memtime / delta s_memrealtime x 100 MHz, stamped once around the whole pass (MI355X_MICROARCH.md, DVFS item 6)
+    const unsigned long long pfc_t0 = __builtin_amdgcn_s_memtime(), pfc_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (!late) {
         for (int s = 0; s < steps; ++s) {
             const bool issue = s + AHEAD < steps;
@@ -650,6 +655,17 @@ __global__ __launch_bounds__(NT) void prefilter_kernel(const half_t *__restrict_
         flush_item(qt_done, t_done);
         if (tid == 0) wg_count[blockIdx.x] = wpos;
     }
+#ifdef PF_CLOCK
+    {
+        const unsigned long long pfc_t1 = __builtin_amdgcn_s_memtime(), pfc_r1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            atomicAdd(dbg + 20, pfc_t1 - pfc_t0);
+            atomicAdd(dbg + 21, pfc_r1 - pfc_r0);
+            atomicAdd(dbg + 22, (unsigned long long)steps);
+            atomicAdd(dbg + 23, 1ull);
+        }
+    }
+#endif
 #ifdef PF_STAMP
     if (lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(dbg + (late ? 8 : 0) + i, (unsigned long long)seg[i]);
@@ -1054,7 +1070,7 @@ extern "C" int skyemb_cosine_topk_prefiltered(const float *tw, const float *qn, 
         if (p == 0 && thr0) continue;                          // a valid floor is as good as the first slice
         if (t1 <= t0) continue;
         if (t1 > T) t1 = T;
-#ifdef PF_STAMP
+#if defined(PF_STAMP) || defined(PF_CLOCK)
         static unsigned long long *dbg = nullptr;
         if (!dbg) { hipMalloc(&dbg, 32 * 8); }
         hipMemsetAsync(dbg, 0, 32 * 8, st);
@@ -1081,6 +1097,18 @@ extern "C" int skyemb_cosine_topk_prefiltered(const float *tw, const float *qn, 
         }
 #undef PF_LAUNCH
 #undef PF_ARGS
+#ifdef PF_CLOCK
+        {
+            unsigned long long h[32];
+            hipStreamSynchronize(st);
+            hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+            if (h[23])
+                fprintf(stderr, "[clock] phase %d (%s): in-kernel clock %.3f GHz over %.2f ms, %.0f shader cycles per k-step (256 MFMAs = 64 per SIMD x 16 cycles = 1024 at the "
+                                "matrix pipe's rate), steps/wg %.0f\n",
+                        p, p == 0 ? "take-all" : p == 1 ? "direct append" : "staged", (double)h[20] / (double)h[21] * 0.1, (double)h[21] / h[23] * 1e-5,
+                        (double)h[20] / (double)h[22], (double)h[22] / h[23]);
+        }
+#endif
 #ifdef PF_STAMP
         {
             unsigned long long h[32];
