@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--skip-feeder", action="store_true")
     ap.add_argument("--skip-f32", action="store_true", help="skip the timing of the fp32 parity mode (extra.f32_mode)")
     ap.add_argument("--skip-mim19", action="store_true", help="skip the BASELINE configs[4] leg (SimMIM ViT-L/16, 5x128x128)")
+    ap.add_argument("--skip-leg", action="store_true", help=argparse.SUPPRESS)   # internal: the GEMM-skip measurement (run_skip_leg)
     ap.add_argument("--probe", action="store_true", help="also time every GEMM shape of the step alone (HIP-graph probe)")
     ap.add_argument("--bank-rows", type=int, default=1_000_000)
     ap.add_argument("--queries", type=int, default=10_000)
@@ -155,6 +156,74 @@ def gemm_flops_per_step(cfg, B, mask_ratio=0.75):
     return 3.0 * fwd * B
 
 
+MEASURE_SO = os.path.join(ROOT, "sky_embeddings_amd", "libskyemb_measure.so")
+
+
+def run_skip_leg(args):
+    """The GEMM family's in-step time by difference: the step with and without its MFMA GEMM launches (skyemb_debug_skip).  That
+    switch is compiled into libskyemb_measure.so only, so the leg runs in a child process that loads that library (SKYEMB_LIB); both
+    halves of each difference come from that one process.  Fails loudly when the measurement library has not been built."""
+    import subprocess
+    if not os.path.exists(MEASURE_SO):
+        raise RuntimeError(f"{MEASURE_SO} is missing (make -C sky_embeddings_amd/csrc builds it beside libskyemb.so)")
+    env = dict(os.environ, SKYEMB_LIB=MEASURE_SO)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--skip-leg", "--batch", str(args.batch), "--dtype", args.dtype, "--steps", str(max(args.steps, 20))]
+    if args.no_graph:
+        cmd.append("--no-graph")
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    if res.returncode != 0:
+        raise RuntimeError("bench.py --skip-leg failed:\n" + res.stderr[-2000:])
+    return json.loads(res.stdout.strip().splitlines()[-1])
+
+
+def skip_leg(args):
+    """Child of run_skip_leg (measurement library loaded): config A step, fused-optimiser schedule and separate-AdamW schedule, each
+    with and without the GEMM launches; HIP events over `steps` steps.  Prints one JSON object."""
+    from sky_embeddings_amd import _lib
+    from sky_embeddings_amd.engine import MAEEngine
+    from sky_embeddings_amd.model_config import config_for
+    from sky_embeddings_amd.optim import CosineLR, FusedAdamW
+    from sky_embeddings_amd.train_step import TrainStep
+    assert os.path.realpath(_lib.SO_PATH) == os.path.realpath(MEASURE_SO), _lib.SO_PATH
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    cfg = config_for("base", img_size=64, patch_size=16, in_chans=5, embed_dim=768, norm_pix_loss=True, loss_fn="mse")
+    eng = MAEEngine(cfg, device=dev, compute_dtype=DTYPES[args.dtype], seed=0)
+    torch.manual_seed(1234)
+    opt = FusedAdamW(eng, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
+    sched = CosineLR(opt, 1_000_000, eta_min=1e-4 / 1e7)
+    B = args.batch
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    pool = [torch.randn(B, 5, 64, 64, generator=g).clamp_(min=-3.0).to(dev) for _ in range(2)]
+
+    def time_step(fused, skip):
+        # (a new TrainStep per leg: the switch acts when the launches are CAPTURED, a captured graph replays what it recorded)
+        assert _lib.lib().skyemb_debug_skip(1 if skip else 0) >= 0
+        try:
+            s_ = TrainStep(eng, opt, sched, B, mask_ratio=0.75, use_graph=not args.no_graph, world_size=1, fused_adamw=fused)
+            for i in range(5):
+                s_(pool[i % 2])
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(args.steps):
+                s_(pool[i % 2])
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / args.steps, s_.fused_adamw
+        finally:
+            _lib.lib().skyemb_debug_skip(0)
+
+    out = {"library": "libskyemb_measure.so", "steps": args.steps}
+    for name, fused in (("fused", True), ("separate", False)):
+        with_ms, was_fused = time_step(fused, False)
+        bare_ms, _ = time_step(fused, True)
+        out[name] = dict(with_gemm_ms=with_ms, without_gemm_ms=bare_ms) if (was_fused == fused) else None
+    print(json.dumps(out))
+
+
 def bench_pretrain(args, rank, world, dev):
     from sky_embeddings_amd import _lib
     from sky_embeddings_amd.engine import MAEEngine
@@ -203,31 +272,12 @@ def bench_pretrain(args, rank, world, dev):
         # In-step time of the dominant kernel family: the same step with the MFMA GEMM launches left out (the C ABI's
         # measurement switch), HIP events over the same number of steps; the difference is what the GEMM launches take
         # INSIDE the step (cold weights, launch gaps and all) -- the figure rocprofv3's kernel_stats must agree with.
-        st = eng.store
-        snap = [t.clone() for t in (st.p, st.m, st.v, st.p_lp)]
-        counters = (opt.step_count, sched.last_epoch)
-        _lib.lib().skyemb_debug_skip(1)
-        try:
-            bare = TrainStep(eng, opt, sched, B, mask_ratio=0.75, use_graph=not args.no_graph, world_size=1)
-            for i in range(3):
-                bare(pool[i % 2])
-            torch.cuda.synchronize(dev)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for i in range(args.steps):
-                bare(pool[i % 2])
-            e1.record()
-            e1.synchronize()
-            bare_ms = e0.elapsed_time(e1) / args.steps
-        finally:
-            _lib.lib().skyemb_debug_skip(0)
-            for dst, src in zip((st.p, st.m, st.v, st.p_lp), snap):
-                dst.copy_(src)
-            opt.step_count, sched.last_epoch = counters
-            sched._apply()
-        del bare, snap
+        skip = run_skip_leg(args)          # (a process of its own on libskyemb_measure.so: the product library has no such switch)
+        out["skip_leg"] = skip
+        bare_ms = skip["fused"]["without_gemm_ms"] if skip["fused"] else skip["separate"]["without_gemm_ms"]
+        with_ms = skip["fused"]["with_gemm_ms"] if skip["fused"] else skip["separate"]["with_gemm_ms"]
         gf = gemm_flops_per_step(cfg, B)
-        gemm_ms = gpu_ms - bare_ms
+        gemm_ms = with_ms - bare_ms        # both legs on the measurement build, same process, same box state
         # forward, dgrad singles; 20 grouped weight-gradient launches + the single ones (patch_embed; decoder_pred / decoder_embed unless
         # they ride in a grouped launch as further problems: engine._extra_wgrad_layers)
         folded = max((len(w_.get("folded_wgrads", ())) for k_, w_ in eng._ws.items() if k_[-1] is True), default=0)
@@ -242,7 +292,7 @@ def bench_pretrain(args, rank, world, dev):
             n_long = max(100, args.steps)
             _, long_ms, _ = timed(step, n_long)
             out["long_run"] = dict(steps=n_long, ms_per_step=long_ms, images_per_sec=B / long_ms * 1e3)
-            out["staged"] = staged_schedule_price(eng, opt, sched, B, pool, dev, args)
+            out["staged"] = staged_schedule_price(eng, opt, sched, B, pool, dev, args, skip)
             if B == 256 and not args.no_graph:
                 out["batch_sweep"] = batch_sweep(eng, opt, sched, dev, rank, long_ms)
             if args.dtype in ("f16", "bf16") and not args.no_graph:
@@ -433,7 +483,7 @@ def f32_mode_timing(dev, rank, B=256):
     return res
 
 
-def staged_schedule_price(eng, opt, sched, B, pool, dev, args):
+def staged_schedule_price(eng, opt, sched, B, pool, dev, args, skip):
     """What the N > 1 schedule costs in COMPUTE on one GPU (no 8-GPU node is guaranteed to the driver): the step as 8 stage
     graphs (decoder, six encoder groups, embedding) with the per-stage gradient casts into the bf16 communication mirror --
     everything the data-parallel step does except the collectives -- beside the monolithic graph; also with fp32 communication
@@ -458,24 +508,11 @@ def staged_schedule_price(eng, opt, sched, B, pool, dev, args):
         e1.synchronize()
         sep_ms = e0.elapsed_time(e1) / 50
         # ... and the same step with the GEMM launches left out: the GEMM family's in-step time without optimiser work in it
-        from sky_embeddings_amd import _lib
-        _lib.lib().skyemb_debug_skip(1)
-        try:
-            # (a new TrainStep: the switch acts when the launches are CAPTURED, a captured graph replays what it recorded)
-            s1b = TrainStep(eng, opt, sched, B, mask_ratio=0.75, use_graph=not args.no_graph, world_size=1, fused_adamw=False)
-            for i in range(3):
-                s1b(pool[i % 2])
-            torch.cuda.synchronize(dev)
-            e0.record()
-            for i in range(50):
-                s1b(pool[i % 2])
-            e1.record()
-            e1.synchronize()
-            sep_bare = e0.elapsed_time(e1) / 50
-            del s1b
-        finally:
-            _lib.lib().skyemb_debug_skip(0)
-        res["monolithic_separate_adamw"] = dict(ms_per_step=sep_ms, step_without_gemm_ms=sep_bare, gemm_ms_per_step=sep_ms - sep_bare)
+        # (measured by run_skip_leg on the measurement build; handed in through `skip`)
+        sep_bare = skip["separate"]["without_gemm_ms"]
+        sep_with = skip["separate"]["with_gemm_ms"]
+        res["monolithic_separate_adamw"] = dict(ms_per_step=sep_ms, step_without_gemm_ms=sep_bare, gemm_ms_per_step=sep_with - sep_bare,
+                                                measurement_build_ms_per_step=sep_with)
         del s1
         for comm in ("bf16", "f32"):
             s2 = TrainStep(eng, opt, sched, B, mask_ratio=0.75, use_graph=not args.no_graph, world_size=1, staged=True,
@@ -802,6 +839,8 @@ def spawn_ranks(args):
 
 def main():
     args = parse()
+    if args.skip_leg:
+        return skip_leg(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))

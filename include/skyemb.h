@@ -48,10 +48,9 @@ const char *skyemb_last_error(void);
 int skyemb_version(void);
 /* Measurement aid for bench.py: entry points of the kernel families in `mask` return 0 without launching (bit 0: the MFMA
  * GEMM launches), so a timed region with and without them gives the family's in-step time.  Returns the previous mask.
- * Not part of the drop-in surface; results are garbage while a bit is set. */
-int skyemb_debug_skip(int mask); /* MEASUREMENT ONLY: process-global, not thread-safe -- a second thread calling into the library
-                                  * while a bit is set gets no-op launches too.  bench.py sets it around one captured replay and
-                                  * clears it in a `finally`; nothing else may. */
+ * MEASUREMENT BUILD ONLY: libskyemb_measure.so (-DSKYEMB_MEASURE).  In the product library (libskyemb.so) the switch is not
+ * compiled in: the call returns -1 with skyemb_last_error set and no launch can ever be skipped. */
+int skyemb_debug_skip(int mask);
 /* Diagnostic: launches issued so far by each GEMM kernel family of this process (out[i] for the slots below; reset != 0 zeroes
  * them after reading).  Tests use it to assert that a shape ran on the kernel it is meant to exercise (e.g. the 256 x 256 tile
  * at ViT-L width); no product path reads it. */

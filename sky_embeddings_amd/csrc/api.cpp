@@ -23,7 +23,9 @@ extern "C" int skyemb_version(void) { return 110; }
 
 // Measurement aid (bench.py): kernels of the families in `mask` are not launched (their entry points return 0), so that
 // a timed region with and without them gives that family's in-step time.  bit 0: MFMA GEMM launches (single, grouped,
-// split-K reduce).  Never set by the product path; results are garbage while a bit is set.
+// split-K reduce).  Exists in libskyemb_measure.so only (-DSKYEMB_MEASURE: csrc/Makefile builds it beside the product library,
+// bench.py runs its skip leg on it in a process of its own); in the product library the call fails and nothing is ever skipped.
+#ifdef SKYEMB_MEASURE
 static int g_skip_mask = 0;
 extern "C" int skyemb_debug_skip(int mask) {
     const int old = g_skip_mask;
@@ -31,6 +33,13 @@ extern "C" int skyemb_debug_skip(int mask) {
     return old;
 }
 int skyemb_skip_mask(void) { return g_skip_mask; }
+#else
+extern "C" int skyemb_debug_skip(int mask) {
+    (void)mask;
+    skyemb_set_error("skyemb_debug_skip: this is the product build; the measurement switch exists in libskyemb_measure.so only");
+    return -1;
+}
+#endif
 
 // Diagnostic: how many launches each GEMM kernel family has issued in this process (relaxed counters; tests assert through
 // them that a configuration really ran on the kernels it is meant to exercise).  Slots: SKYEMB_GEMM_COUNT_* of skyemb.h.

@@ -19,7 +19,13 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 #define SKYEMB_WAVE 64
 
 void skyemb_set_error(const char *fmt, ...);
-int skyemb_skip_mask(void);   // api.cpp: measurement aid, see skyemb_debug_skip
+// measurement aid (skyemb_debug_skip): compiled into libskyemb_measure.so only (-DSKYEMB_MEASURE, csrc/Makefile); the product
+// library has no switch that turns launches into no-ops
+#ifdef SKYEMB_MEASURE
+int skyemb_skip_mask(void);   // api.cpp
+#else
+static inline int skyemb_skip_mask(void) { return 0; }
+#endif
 void skyemb_count_gemm(int slot);   // api.cpp: diagnostic launch counters, see skyemb_gemm_launch_counts
 
 // Also drops any stale sticky HIP error left by other code in this thread (e.g. a device probe),

@@ -76,3 +76,25 @@ def test_integration_md_bindings_match_the_prototypes():
                 i += 1
             if text[start:i - 1].strip():
                 assert n_args == len(want), f"INTEGRATION.md: a call of {name} passes {n_args} values, the header takes {len(want)}"
+
+
+def test_the_product_library_has_no_launch_skipping_switch():
+    """skyemb_debug_skip (bench.py's measurement aid: GEMM launches become no-ops) is compiled into libskyemb_measure.so only; in the
+    product library the call fails and leaves nothing set.  No compute call: loads and calls two host functions."""
+    import ctypes
+    import os
+    from sky_embeddings_amd import _lib
+    here = os.path.dirname(_lib.SO_PATH)
+    prod = ctypes.CDLL(os.path.join(here, "libskyemb.so"))
+    prod.skyemb_last_error.restype = ctypes.c_char_p
+    assert prod.skyemb_debug_skip(1) == -1 and b"product build" in prod.skyemb_last_error()
+    assert prod.skyemb_debug_skip(0) == -1
+    meas_path = os.path.join(here, "libskyemb_measure.so")
+    assert os.path.exists(meas_path), "make -C sky_embeddings_amd/csrc builds the measurement library beside the product one"
+    meas = ctypes.CDLL(meas_path)
+    assert meas.skyemb_debug_skip(1) == 0 and meas.skyemb_debug_skip(0) == 1
+    # same exported surface
+    import subprocess
+    syms = [set(l.split()[-1] for l in subprocess.check_output(["nm", "-D", "--defined-only", p], text=True).splitlines() if " T skyemb_" in l)
+            for p in (os.path.join(here, "libskyemb.so"), meas_path)]
+    assert syms[0] == syms[1]

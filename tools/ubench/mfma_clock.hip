@@ -31,7 +31,8 @@ __global__ __launch_bounds__(64 * WAVES) void loop_kernel(const h8 *__restrict__
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j)   // (inline asm: through the builtin the compiler shuffled accumulators between VGPRs and AGPRs inside the loop)
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(a[i]), "v"(b[j]));
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0.f;
