@@ -574,7 +574,8 @@ def bench_mim19(args, dev):
     cfg = config_for(a["model_type"], img_size=int(a["img_size"]), patch_size=int(a["patch_size"]), in_chans=int(a["num_channels"]),
                      embed_dim=int(a["embed_dim"]), norm_pix_loss=t.getboolean("norm_pix_loss"), loss_fn=t["loss_fn"])
     B = int(t["batch_size"])
-    lp = DTYPES[args.dtype] if args.dtype in ("f16", "bf16") else torch.bfloat16      # (the headline's 16-bit operand format)
+    name = getattr(args, "dtype", None) or os.environ.get("SKYEMB_DTYPE", "f16")       # (args = None: tools/mim19_bench.py)
+    lp = DTYPES[name] if name in ("f16", "bf16") else torch.bfloat16                   # (the headline's 16-bit operand format)
     eng = SimMIMEngine(cfg, device=dev, compute_dtype=lp, seed=0)
     opt = FusedAdamW(eng, lr=float(t["init_lr"]), betas=(0.9, 0.95), weight_decay=float(t["weight_decay"]))
     step = TrainStep(eng, opt, CosineLR(opt, 1_000_000), B)

@@ -293,7 +293,7 @@ int skyemb_rowsum_select(const float *src, int64_t ld, const float *sel, int row
  * dscale: static loss scale of the backward pass (1 = none; a power of two for SKYEMB_F16, whose data gradients would
  * underflow otherwise -- every later step of backward is linear in dpred, so the caller divides it out again through
  * grad_scale of skyemb_adamw / skyemb_adamw_desc); `loss` itself is never scaled.
- * `ws` fp32 workspace of 4*B*L + 4 floats. */
+ * `ws` fp32 workspace of 4*B*L + 4 floats.  p % 4 == 0, W % 4 == 0, 16-byte aligned buffers. */
 int skyemb_masked_patch_loss(const float *imgs, const float *pred, const float *mask, float *loss, void *dpred,
                              float *dpred32, int dtype, float *ws, int B, int C, int H, int W, int p, int extra,
                              float pixel_mean, float pixel_std, int norm_pix, int loss_l1, float dscale, void *stream);

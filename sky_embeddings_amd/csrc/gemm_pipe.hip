@@ -343,6 +343,12 @@ __device__ __forceinline__ void gemm_pipe_body(const skyemb_gemm_args &g, const 
     // The prefetch hint (skyemb.h): this workgroup's share of the lines a later launch will read, requested BEFORE its own first
     // operand loads -- the oldest requests of every wave, so the counted waits below cover them and they cost no wait of their own:
     // they return with the first stage (both are HBM / memory-side-cache misses issued at the same moment).
+    // Where the 4 bytes per lane land: in the LDS piece THIS wave writes its own first operand piece of stage 0 to, right after.  A
+    // wave's vector-memory loads return in issue order (that order is what the counted vmcnt waits of this loop are built on: vmcnt
+    // retires loads oldest first), so the wave's operand piece overwrites its hint; where several waves share a piece (tiles whose
+    // piece count does not divide over the waves: the surplus waves repeat the LAST piece), each of them writes that piece's correct
+    // bytes after its own hint, and nobody reads the stage before every wave's waits and the barrier: whichever write lands last, it
+    // is the operand.  (test_gemm_prefetch_hint_changes_no_result: every ring tile, both the exact and the surplus-wave cases.)
     if (g.prefetch != nullptr && g.prefetch_wgs == 0 && split == 0 && KT > 0) {
         constexpr int PA = issue_per_wave<BM, NW>();
         const int piece = wave * PA < BM / 8 ? wave * PA : BM / 8 - 1;          // the wave's first A piece of stage 0, k-group 0

@@ -27,11 +27,50 @@ __device__ __forceinline__ float target_elem(const float *__restrict__ imgs, int
     return (imgs[(((int64_t)b * C + c) * H + y) * W + x] - mean) / stdv;
 }
 
+// The patch's pv = C p p target elements into LDS in patchify order e = (py p + px) C + c, READ in image order (rows of p
+// consecutive pixels: float4 loads of whole 64-byte rows instead of one 4-byte request per element with the channel -- 16 KB
+// apart -- as the fastest index: round 6, loss_pass1 26.7 -> ~10 us at config A).  Same values as target_elem, so every sum below
+// keeps its bits.  pv <= STAGE_MAX, p % 4 == 0.
+constexpr int STAGE_MAX = 12 * 256;
+__device__ __forceinline__ void stage_patch(const float *__restrict__ imgs, int b, int l, int C, int H, int W, int p, float mean,
+                                            float stdv, float *__restrict__ lds) {
+    const int gw = W / p, p4 = p >> 2, n4 = C * p * p4;
+    const int y0 = (l / gw) * p, x0 = (l % gw) * p;
+    for (int j = threadIdx.x; j < n4; j += 256) {
+        const int px4 = j % p4, py = (j / p4) % p, c = j / (p4 * p);
+        const float4 v = *(const float4 *)(imgs + (((int64_t)b * C + c) * H + y0 + py) * W + x0 + 4 * px4);
+        float *d = lds + ((py * p + 4 * px4) * C + c);
+        d[0] = (v.x - mean) / stdv;
+        d[C] = (v.y - mean) / stdv;
+        d[2 * C] = (v.z - mean) / stdv;
+        d[3 * C] = (v.w - mean) / stdv;
+    }
+    __syncthreads();
+}
+
+// the scalar reduction of the loss (loss_finalize).  (Round 6 tried it inside pass 1, run by the last workgroup to arrive at a
+// counter: 4096 returning atomic adds on one word serialise at ~90 per us -- pass 1 went from 27 to 55 us -- and a release fence per
+// workgroup writes back the XCD's whole L2, 0.35 ms in all; one more 1.5 us launch boundary is the cheaper form.)
+__device__ __forceinline__ void finalize_body(float *__restrict__ ws, float *__restrict__ loss, int BL, float numel, float dscale, float *red) {
+    float s = 0.f, n = 0.f;
+    for (int i = threadIdx.x; i < BL; i += 256) { s += ws[4 * (int64_t)i]; n += ws[4 * (int64_t)i + 1]; }
+    s = block_sum(s, red);
+    n = block_sum(n, red);
+    if (threadIdx.x == 0) {
+        // avg_scale_factor = mask.sum() / mask.numel() * loss.numel()   (mim_vit.py:518)
+        const float scale = n / numel * numel;
+        const float inv = 1.0f / (scale + 1e-5f);
+        loss[0] = s / (scale + 1e-5f);
+        ws[4 * (int64_t)BL] = loss[0];
+        ws[4 * (int64_t)BL + 1] = inv * dscale;   // dscale: the caller's static loss scale (a power of two; 1 = none)
+    }
+}
 __global__ __launch_bounds__(256) void loss_pass1(const float *__restrict__ imgs, const float *__restrict__ pred,
                                                   const float *__restrict__ mask, float *__restrict__ ws, int C, int H,
                                                   int W, int p, int L, int extra, float mean, float stdv, int norm_pix,
                                                   int loss_l1) {
     __shared__ float red[4];
+    __shared__ __attribute__((aligned(16))) float patch[STAGE_MAX];
     const int b = blockIdx.x / L, l = blockIdx.x % L;
     const int pv = C * p * p;
     float *o = ws + (int64_t)blockIdx.x * 4;
@@ -45,10 +84,11 @@ __global__ __launch_bounds__(256) void loss_pass1(const float *__restrict__ imgs
     const bool cached = pv <= MAXE * 256;
     float tv[MAXE];
     if (cached) {
+        stage_patch(imgs, b, l, C, H, W, p, mean, stdv, patch);
 #pragma unroll
         for (int u = 0; u < MAXE; ++u) {
             const int e = threadIdx.x + u * 256;
-            tv[u] = e < pv ? target_elem(imgs, b, l, e, C, H, W, p, mean, stdv) : 0.f;
+            tv[u] = e < pv ? patch[e] : 0.f;
         }
     }
     float mu = 0.f, istd = 1.f;
@@ -109,18 +149,13 @@ __global__ __launch_bounds__(256) void loss_pass1(const float *__restrict__ imgs
 
 __global__ __launch_bounds__(256) void loss_finalize(float *__restrict__ ws, float *__restrict__ loss, int BL, float numel, float dscale) {
     __shared__ float red[4];
-    float s = 0.f, n = 0.f;
-    for (int i = threadIdx.x; i < BL; i += 256) { s += ws[4 * (int64_t)i]; n += ws[4 * (int64_t)i + 1]; }
-    s = block_sum(s, red);
-    n = block_sum(n, red);
-    if (threadIdx.x == 0) {
-        // avg_scale_factor = mask.sum() / mask.numel() * loss.numel()   (mim_vit.py:518)
-        const float scale = n / numel * numel;
-        const float inv = 1.0f / (scale + 1e-5f);
-        loss[0] = s / (scale + 1e-5f);
-        ws[4 * (int64_t)BL] = loss[0];
-        ws[4 * (int64_t)BL + 1] = inv * dscale;   // dscale: the caller's static loss scale (a power of two; 1 = none)
-    }
+    finalize_body(ws, loss, BL, numel, dscale, red);
+}
+
+template <typename T>
+__device__ __forceinline__ void store8t(T *p, const float (&v)[8]) {
+    store4<T>(p, v[0], v[1], v[2], v[3]);
+    store4<T>(p + 4, v[4], v[5], v[6], v[7]);
 }
 
 template <typename T>
@@ -129,29 +164,39 @@ __global__ __launch_bounds__(256) void loss_pass2(const float *__restrict__ imgs
                                                   T *__restrict__ dpred, float *__restrict__ dpred32, int C, int H, int W,
                                                   int p, int L, int extra, float mean, float stdv, int norm_pix,
                                                   int loss_l1, int BL) {
+    __shared__ __attribute__((aligned(16))) float patch[STAGE_MAX];
     const int Nd = L + extra;
     const int b = blockIdx.x / Nd, r = blockIdx.x % Nd;
-    const int pv = C * p * p;
+    const int pv = C * p * p;                              // a multiple of 16 (p % 4 == 0)
     const int64_t off = (int64_t)blockIdx.x * pv;
     const int l = r - extra;
     const bool live = l >= 0 && mask[(int64_t)b * L + l] != 0.0f;
     if (!live) {
-        for (int e = threadIdx.x; e < pv; e += 256) {
-            if (dpred) dpred[off + e] = from_f32<T>(0.f);
-            if (dpred32) dpred32[off + e] = 0.f;
+        const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int e = 8 * threadIdx.x; e < pv; e += 8 * 256) {
+            if (dpred) store8t<T>(dpred + off + e, z);
+            if (dpred32) { *(float4 *)(dpred32 + off + e) = make_float4(0.f, 0.f, 0.f, 0.f); *(float4 *)(dpred32 + off + e + 4) = make_float4(0.f, 0.f, 0.f, 0.f); }
         }
         return;
     }
     const float inv = ws[4 * (int64_t)BL + 1];
     const float mu = ws[((int64_t)b * L + l) * 4 + 2], istd = ws[((int64_t)b * L + l) * 4 + 3];
-    for (int e = threadIdx.x; e < pv; e += 256) {
-        float t = target_elem(imgs, b, l, e, C, H, W, p, mean, stdv);
-        if (norm_pix) t = (t - mu) * istd;
-        const float d = pred[off + e] - t;  // d loss_e / d pred = 2 d (mse) | sign(d) (l1)
-        float g = 0.f;
-        if (d == d) g = (loss_l1 ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : 2.f * d) * inv;
-        if (dpred) dpred[off + e] = from_f32<T>(g);
-        if (dpred32) dpred32[off + e] = g;
+    const bool cached = pv <= STAGE_MAX;
+    if (cached) stage_patch(imgs, b, l, C, H, W, p, mean, stdv, patch);
+    for (int e0 = 8 * threadIdx.x; e0 < pv; e0 += 8 * 256) {  // 8 consecutive elements per thread: 32-byte loads, 16 / 32-byte stores
+        const float4 p0 = *(const float4 *)(pred + off + e0), p1 = *(const float4 *)(pred + off + e0 + 4);
+        const float pr[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+        float g[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float t = cached ? patch[e0 + k] : target_elem(imgs, b, l, e0 + k, C, H, W, p, mean, stdv);
+            if (norm_pix) t = (t - mu) * istd;
+            const float d = pr[k] - t;  // d loss_e / d pred = 2 d (mse) | sign(d) (l1)
+            g[k] = 0.f;
+            if (d == d) g[k] = (loss_l1 ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : 2.f * d) * inv;
+        }
+        if (dpred) store8t<T>(dpred + off + e0, g);
+        if (dpred32) { *(float4 *)(dpred32 + off + e0) = make_float4(g[0], g[1], g[2], g[3]); *(float4 *)(dpred32 + off + e0 + 4) = make_float4(g[4], g[5], g[6], g[7]); }
     }
 }
 
@@ -253,6 +298,8 @@ extern "C" int skyemb_masked_patch_loss(const float *imgs, const float *pred, co
                                         float dscale, void *stream) {
     SKY_CHECK_ARG(B > 0 && C > 0 && p > 0 && H % p == 0 && W % p == 0 && extra >= 0, "skyemb_masked_patch_loss: bad geometry");
     SKY_CHECK_ARG(dscale > 0.f, "skyemb_masked_patch_loss: dscale must be positive (1 = no loss scale)");
+    SKY_CHECK_ARG(p % 4 == 0 && aligned16(imgs) && aligned16(pred) && (!dpred || aligned16(dpred)) && (!dpred32 || aligned16(dpred32)) && W % 4 == 0,
+                  "skyemb_masked_patch_loss: patch size and image width must be multiples of 4, buffers 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const int L = (H / p) * (W / p), BL = B * L;
     const float numel = (float)((double)BL * C * p * p);

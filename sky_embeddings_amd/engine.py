@@ -500,6 +500,11 @@ class MAEEngine:
         if bool(on) != (self._side is not None):
             # workspaces are planned for one of the two schedules (side workgroups and folded problems of the grouped launches exist
             # only without the side stream: _norm1_side_record, _extra_wgrad_layers): rebuild them on the next forward
+            if self._ws and getattr(self, "_graph_captures", 0):
+                # HIP graphs captured by an earlier TrainStep hold raw pointers into those workspaces (group blobs, scratch):
+                # dropping them would leave that step replaying freed memory
+                raise RuntimeError("enable_wgrad_overlap: the weight-gradient schedule cannot change while HIP graphs captured on this "
+                                   "engine's workspaces exist (build a new engine, or construct every TrainStep with the same wgrad_overlap)")
             self._ws, self._last = {}, None
         if on and self._side is None:
             self._side = torch.cuda.Stream(device=self.device)

@@ -227,6 +227,7 @@ class TrainStep:
                     fn()
                 pool = g.pool()
                 self.graphs.append(g)
+            engine._graph_captures = getattr(engine, "_graph_captures", 0) + 1     # (engine.enable_wgrad_overlap refuses to re-plan under them)
         if snap is not None:
             if not use_graph:                                  # (graph mode ran the warm-up above: the workspace exists)
                 self.stages[0][0]()

@@ -21,19 +21,19 @@ def _data(world=WORLD):
     return imgs, noise
 
 
-def _make(dev, B, world, **kw):
+def _make(dev, B, world, dtype=torch.bfloat16, **kw):
     from sky_embeddings_amd.engine import MAEEngine
     from sky_embeddings_amd.model_config import config_for
     from sky_embeddings_amd.optim import CosineLR, FusedAdamW
     from sky_embeddings_amd.train_step import TrainStep
     cfg = config_for("tiny", img_size=64, patch_size=16, in_chans=5, embed_dim=192)
-    eng = MAEEngine(cfg, device=dev, compute_dtype=torch.bfloat16, seed=1)
+    eng = MAEEngine(cfg, device=dev, compute_dtype=dtype, seed=1)
     opt = FusedAdamW(eng, lr=LR, betas=(0.9, 0.95), weight_decay=0.05)
     step = TrainStep(eng, opt, CosineLR(opt, 100), B, world_size=world, external_noise=True, **kw)        # default staging: 6 encoder groups with N > 1, 3 with one rank
     return eng, step
 
 
-def _rank_main(rank, port, out_dir, grad_comm, use_nccl, world=WORLD, shard=None):
+def _rank_main(rank, port, out_dir, grad_comm, use_nccl, world=WORLD, shard=None, dtype=torch.bfloat16):
     import torch.distributed as dist
     dev = torch.device("cuda", rank if use_nccl else 0)
     torch.cuda.set_device(dev)
@@ -43,7 +43,10 @@ def _rank_main(rank, port, out_dir, grad_comm, use_nccl, world=WORLD, shard=None
         dist.init_process_group("gloo", rank=rank, world_size=world, init_method=f"tcp://127.0.0.1:{port}")
     imgs, noise = _data(world)
     rows = slice(rank * B_RANK, (rank + 1) * B_RANK)
-    eng, step = _make(dev, B_RANK, world, grad_comm=grad_comm, shard_optimizer=shard)
+    eng, step = _make(dev, B_RANK, world, dtype=dtype, grad_comm=grad_comm, shard_optimizer=shard)
+    if dtype == torch.float16:       # fp16 mode: 16-bit mirror in fp16, sums of world x 2^16 x gradients, the optimiser divides both out
+        assert step.g16 is None or step.g16.dtype == torch.float16
+        assert step.optimizer.grad_scale == 1.0 / (world * eng.loss_scale) and eng.loss_scale == 65536.0
     assert step.staged and len(step.stages) >= 4          # decoder | encoder groups | embedding: comm overlaps backward
     # (default with N > 1: the optimiser sharded over the ranks -- reduce-scatter, AdamW on the owned chunks, all-gather of the shadow)
     assert step.shard_optimizer == (shard is not False) and step.shard_world == world and step.shard_rank == rank
@@ -65,8 +68,9 @@ def _rank_main(rank, port, out_dir, grad_comm, use_nccl, world=WORLD, shard=None
 
 
 # world 4 = the most ranks a one-GPU box lets a test start next to the test process itself (six GPU processes per card)
-@pytest.mark.parametrize("grad_comm,world,shard", [("f32", 2, None), ("bf16", 2, None), ("bf16", 4, None), ("bf16", 2, False), ("f32", 4, None)])
-def test_n_rank_training_step_matches_one_rank_on_the_concatenated_batch(tmp_path, grad_comm, world, shard):
+@pytest.mark.parametrize("grad_comm,world,shard,dtype", [("f32", 2, None, "bf16"), ("bf16", 2, None, "bf16"), ("bf16", 4, None, "bf16"),
+                                                         ("bf16", 2, False, "bf16"), ("f32", 4, None, "bf16"), ("bf16", 2, None, "f16")])
+def test_n_rank_training_step_matches_one_rank_on_the_concatenated_batch(tmp_path, grad_comm, world, shard, dtype):
     """shard = None: the default of an N > 1 job, the optimiser sharded over the ranks; False: the replicated schedule (all-reduce,
     every rank steps everything).  Both against ONE rank on the concatenated batch, to the same bars."""
     import torch.multiprocessing as mp
@@ -74,13 +78,14 @@ def test_n_rank_training_step_matches_one_rank_on_the_concatenated_batch(tmp_pat
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    mp.spawn(_rank_main, args=(port, str(tmp_path), grad_comm, use_nccl, world, shard), nprocs=world, join=True)
+    dtype = torch.float16 if dtype == "f16" else torch.bfloat16      # ("bf16" grad_comm = the 16-bit mirror in the compute dtype's format)
+    mp.spawn(_rank_main, args=(port, str(tmp_path), grad_comm, use_nccl, world, shard, dtype), nprocs=world, join=True)
     r = [torch.load(tmp_path / f"rank{k}.pt") for k in range(world)]
     # the replicas stay identical, bit for bit (sharded: after the gather of the owners' fp32 state)
     assert all(torch.equal(r[0]["p"], rk["p"]) and torch.equal(r[0]["m"], rk["m"]) for rk in r[1:])
     # one process, the whole batch, fp32 gradients
     imgs, noise = _data(world)
-    eng, step = _make(torch.device("cuda", 0), world * B_RANK, 1)
+    eng, step = _make(torch.device("cuda", 0), world * B_RANK, 1, dtype=dtype)
     p0 = eng.store.p.cpu().clone()
     ref_losses = []
     for it in range(STEPS):
@@ -100,7 +105,7 @@ def test_n_rank_training_step_matches_one_rank_on_the_concatenated_batch(tmp_pat
     # move of an element whose gradient is rounding noise, but not the bulk
     frac_close = float((err <= (0.05 if grad_comm == "f32" else 0.25) * LR * STEPS).float().mean())
     from tests.helpers import record_parity
-    record_parity(f"ddp_{world}_ranks_vs_one_{grad_comm}" + ("_replicated" if shard is False else "_sharded_optimizer"),
+    record_parity(f"ddp_{world}_ranks_vs_one_{grad_comm}" + ("_replicated" if shard is False else "_sharded_optimizer") + ("_f16" if dtype == torch.float16 else ""),
                   dict(loss_rel_max=float(np.max(np.abs(mean_losses - np.asarray(ref_losses)) / np.abs(ref_losses))),
                        frac_within_band=frac_close, band_in_lr_steps=0.05 if grad_comm == "f32" else 0.25,
                        err_max_in_lr_steps=float(err.max()) / (LR * STEPS), err_mean_in_lr_steps=float(err.mean()) / (LR * STEPS),
