@@ -17,6 +17,11 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 #define SKYEMB_WAVE 64
+// most four-wave blocks of a LayerNorm backward launch (skyemb_layernorm_bwd_blocks / sky_ln_bwd_blocks: every block the same
+// number of rows); -DSKY_LN_BWD_CAP=... builds the experiment variants (tools/build_variant.sh)
+#ifndef SKY_LN_BWD_CAP
+#define SKY_LN_BWD_CAP 576
+#endif
 
 void skyemb_set_error(const char *fmt, ...);
 // measurement aid (skyemb_debug_skip): compiled into libskyemb_measure.so only (-DSKYEMB_MEASURE, csrc/Makefile); the product

@@ -759,7 +759,7 @@ constexpr int GROUP_LN_COUNT_WORD = 41, GROUP_LN_OFFSET_WORD = 42;
 __host__ __device__ inline int sky_ln_bwd_blocks(int M) {   // == skyemb_layernorm_bwd_blocks (layernorm.hip)
     int nb = (M + 3) / 4;
     if (nb < 1) nb = 1;
-    const int rounds = (nb + 575) / 576;
+    const int rounds = (nb + SKY_LN_BWD_CAP - 1) / SKY_LN_BWD_CAP;
     return (nb + rounds - 1) / rounds;
 }
 // MAXNV = widest row in 256-column units the instance carries: 4 (D <= 1024) in the 256 x 256 kernel, whose waves own 236 registers

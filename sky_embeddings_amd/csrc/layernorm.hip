@@ -165,7 +165,7 @@ extern "C" int skyemb_layernorm_bwd_blocks(int M) {
     // workgroups left a quarter of the waves with a third row: 544 workgroups x 2 rows; 8320 ViT-L rows: 520 x 4)
     int nb = (M + 3) / 4;
     if (nb < 1) nb = 1;
-    const int rounds = (nb + 575) / 576;
+    const int rounds = (nb + SKY_LN_BWD_CAP - 1) / SKY_LN_BWD_CAP;
     return (nb + rounds - 1) / rounds;
 }
 

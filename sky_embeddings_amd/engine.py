@@ -111,16 +111,20 @@ class MAEEngine:
         self.device = torch.device(device)
         self.dtype = compute_dtype
         self.code = ops.dtype_code(compute_dtype)
-        # Static loss scale of the backward pass (a power of two; 1 outside the fp16 mode).  fp16 data gradients underflow without
-        # one (d loss / d pred ~ 2 / masked elements ~ 5e-7 at B = 256: below fp16's normal range); every step of backward is linear
-        # in d loss / d pred, so the loss kernel multiplies that by `loss_scale` (dscale of skyemb_masked_patch_loss) and the
-        # optimiser divides it out (FusedAdamW.grad_scale, skyemb_adamw_desc.grad_scale): the flat gradient buffer holds
-        # loss_scale x the gradients -- `grad(name)` of this class returns them unscaled.  2^16 puts d loss / d pred at ~0.03 for
-        # B = 256 (profiles/r06_operand_rounding.json: with it fp16 gradients are at the format's rounding floor, 1e-3; without,
-        # 2.6e-2) and leaves four decades below the format's maximum for anything backward multiplies it by.
+        # Loss scale of the backward pass (a power of two; 1 outside the fp16 mode).  fp16 data gradients underflow without one
+        # (d loss / d pred ~ 2 / masked elements ~ 5e-7 at B = 256: below fp16's normal range); every step of backward is linear in
+        # d loss / d pred, so the loss kernel multiplies that by `loss_scale` (dscale of skyemb_masked_patch_loss) and the optimiser
+        # divides it out (FusedAdamW.grad_scale, skyemb_adamw_desc.grad_scale): the flat gradient buffer holds loss_scale x the
+        # gradients -- `grad(name)` of this class returns them unscaled.  The scale follows the batch: 2^round(log2(expected masked
+        # elements / 64)), at most 2^16, so that d loss / d pred enters backward at ~0.03 whatever the batch (2^16 at B = 256 and at
+        # mim_19's B = 128 -- profiles/r06_operand_rounding.json: with it fp16 gradients sit at the format's rounding floor, 1e-3;
+        # without, 2.6e-2 -- 2^11 at B = 8: a fixed 2^16 would put d loss / d pred of a four-image batch at ~10 and the products
+        # behind it past fp16's 65504).  SKYEMB_LOSS_SCALE or assigning `engine.loss_scale` fixes it by hand.
         import os
-        self.loss_scale = float(os.environ.get("SKYEMB_LOSS_SCALE", 65536.0)) if compute_dtype == torch.float16 else 1.0
-        assert self.loss_scale > 0 and math.log2(self.loss_scale).is_integer(), "loss_scale must be a power of two"
+        env = os.environ.get("SKYEMB_LOSS_SCALE")
+        self._loss_scale_auto = compute_dtype == torch.float16 and env is None
+        self._loss_scale = float(env) if (env is not None and compute_dtype == torch.float16) else (65536.0 if compute_dtype == torch.float16 else 1.0)
+        assert self._loss_scale > 0 and math.log2(self._loss_scale).is_integer(), "loss_scale must be a power of two"
         self.fold_decoder_wgrads = True      # utils.vit's predictor turns it off: it never runs backward_decoder (_extra_wgrad_layers)
         self.store = ParamStore(cfg, self.device, compute_dtype)
         self._ws = {}
@@ -170,6 +174,28 @@ class MAEEngine:
             else:
                 st.frozen[k].copy_(torch.randn(st.shapes[k], generator=gen) * 0.02)   # SimMIM's unused mask_token
         st.refresh_lp()
+
+    @property
+    def loss_scale(self):
+        return self._loss_scale
+
+    @loss_scale.setter
+    def loss_scale(self, v):
+        assert v > 0 and math.log2(v).is_integer(), "loss_scale must be a power of two"
+        self._loss_scale, self._loss_scale_auto = float(v), False
+
+    def plan_loss_scale(self, masked_elements):
+        """fp16 mode: the scale for a batch whose loss averages over ~`masked_elements` pixels (see __init__); called by forward_train
+        with the batch's expected count, and by TrainStep before it bakes the scale into the fused optimiser launches."""
+        if self._loss_scale_auto:
+            e = round(math.log2(max(float(masked_elements), 64.0) / 64.0))
+            self._loss_scale = float(2 ** min(max(e, 0), 16))
+        return self._loss_scale
+
+    def expected_masked_elements(self, B, mask_ratio):
+        """Pixels the loss of a B-image batch averages over (MAE: the masked patches)."""
+        cfg = self.cfg
+        return B * (cfg.num_patches - int(cfg.num_patches * (1 - mask_ratio))) * cfg.patch_dim
 
     def grad(self, name):
         """d loss / d parameter `name` of the last backward(): the flat gradient buffer's view without the loss scale."""
@@ -459,6 +485,7 @@ class MAEEngine:
         Ne, Nd = E + keep, E + L
         Me, Md = B * Ne, B * Nd
         w = self._workspace(B, keep, True)
+        self.plan_loss_scale(B * (L - keep) * pv)
         self._encoder_fwd(imgs, noise, keep, w, True, ra_dec)
         # ---- decoder (utils/mim_vit.py:440-467)
         xd = w["xd"]

@@ -25,13 +25,23 @@ class FusedAdamW:
         self.param_groups = [dict(lr=lr, initial_lr=lr, betas=tuple(betas), eps=eps, weight_decay=0.0),
                              dict(lr=lr, initial_lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)]
         self.step_count = 0
-        self.grad_scale = 1.0 / getattr(engine, "loss_scale", 1.0)   # (fp16 mode: the flat gradient buffer holds loss_scale x the gradients)
+        # gradients are multiplied by grad_scale on their way into the update: base_grad_scale (1 / world size: the DDP mean) over the
+        # engine's loss scale (fp16 mode: the flat gradient buffer holds loss_scale x the gradients; the scale follows the batch)
+        self.base_grad_scale = 1.0
         # graph mode: step scalars live in device memory (kernel arguments are frozen in a HIP graph)
         self.hyper_device = None
         self.process_group = process_group
         # gradient source of the update: the engine's flat fp32 buffer, or (set by TrainStep for bf16 gradient
         # communication) a flat bf16 copy of it that the all-reduce summed over the ranks
         self.grad_buffer = None
+
+    @property
+    def grad_scale(self):
+        return self.base_grad_scale / getattr(self.engine, "loss_scale", 1.0)
+
+    @grad_scale.setter
+    def grad_scale(self, v):          # (callers that set the whole factor: kept for the predictor / tests; the loss scale is divided back in)
+        self.base_grad_scale = float(v) * getattr(self.engine, "loss_scale", 1.0)
 
     @property
     def lr(self):

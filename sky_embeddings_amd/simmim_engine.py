@@ -229,6 +229,7 @@ class SimMIMEngine(MAEEngine):
         L, D, pv, E = cfg.num_patches, cfg.embed_dim, cfg.patch_dim, cfg.num_extra_tokens
         M = B * (E + L)
         w = self._workspace(B, L, True)
+        self.plan_loss_scale(self.expected_masked_elements(B, None))
         self._encoder_fwd_simmim(imgs, mask, ra_dec, w, True)
         # head: Conv1x1 D -> p*p*C per token; PixelShuffle(p) is the loss kernel's index map (utils/mim_vit.py:254-261,469)
         pool = cfg.attn_pool         # one row per image, laid out like the image (PixelShuffle(img_size), utils/mim_vit.py:250)
@@ -239,6 +240,12 @@ class SimMIMEngine(MAEEngine):
                               pooled=pool, dscale=self.loss_scale)
         self._last = (imgs, B, L, mask)
         return w["loss"], w["pred_img"], mask
+
+    def expected_masked_elements(self, B, mask_ratio):
+        """SimMIM: the ratio is drawn per sample, U(0, max_mask_ratio) -- the scale is planned for a quarter of the pixels (any
+        power of two within a few binades serves: see MAEEngine.__init__)."""
+        cfg = self.cfg
+        return B * cfg.in_chans * cfg.img_size * cfg.img_size // 4
 
     # ------------------------------------------------------------------ backward
     def _ctx(self):

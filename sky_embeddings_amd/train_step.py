@@ -98,7 +98,9 @@ class TrainStep:
             wgrad_overlap = os.environ.get("SKYEMB_WGRAD_OVERLAP", "0") == "1"
         engine.enable_wgrad_overlap(wgrad_overlap)   # weight-gradient GEMMs on a side stream (a parallel graph branch)
         # DDP mean of per-rank gradients, and the backward pass's static loss scale divided out again (fp16 mode)
-        optimizer.grad_scale = 1.0 / (world_size * getattr(engine, "loss_scale", 1.0))
+        if hasattr(engine, "plan_loss_scale"):     # fp16 mode: the scale of THIS batch size, before anything bakes it into a launch
+            engine.plan_loss_scale(engine.expected_masked_elements(batch_size, mask_ratio))
+        optimizer.base_grad_scale = 1.0 / world_size
         # stage list: [(callable, [(start, end) slices of the flat gradient buffer final after it])]
         if n_encoder_groups is None:
             # finer stages with N GPUs: the all-reduce of the LAST encoder group has only the short embedding stage to hide

@@ -46,7 +46,7 @@ def _rank_main(rank, port, out_dir, grad_comm, use_nccl, world=WORLD, shard=None
     eng, step = _make(dev, B_RANK, world, dtype=dtype, grad_comm=grad_comm, shard_optimizer=shard)
     if dtype == torch.float16:       # fp16 mode: 16-bit mirror in fp16, sums of world x 2^16 x gradients, the optimiser divides both out
         assert step.g16 is None or step.g16.dtype == torch.float16
-        assert step.optimizer.grad_scale == 1.0 / (world * eng.loss_scale) and eng.loss_scale == 65536.0
+        assert step.optimizer.grad_scale == 1.0 / (world * eng.loss_scale) and eng.loss_scale == 1024.0     # 4 images: 61 k masked pixels / 64
     assert step.staged and len(step.stages) >= 4          # decoder | encoder groups | embedding: comm overlaps backward
     # (default with N > 1: the optimiser sharded over the ranks -- reduce-scatter, AdamW on the owned chunks, all-gather of the shadow)
     assert step.shard_optimizer == (shard is not False) and step.shard_world == world and step.shard_rank == rank

@@ -252,7 +252,7 @@ def test_f16_train_step_with_the_fused_optimiser_equals_the_separate_launch():
         eng = MAEEngine(cfg, compute_dtype=FH, seed=1)
         opt = FusedAdamW(eng, lr=1e-3, weight_decay=0.05)
         step = TrainStep(eng, opt, CosineLR(opt, 100), 64, fused_adamw=fused)
-        assert step.fused_adamw == fused and opt.grad_scale == 1.0 / eng.loss_scale == 2.0 ** -16
+        assert step.fused_adamw == fused and opt.grad_scale == 1.0 / eng.loss_scale == 2.0 ** -14       # 64 images: 983 k masked pixels / 64
         torch.manual_seed(123)
         dev_losses = [step(imgs).clone() for _ in range(10)]
         torch.cuda.synchronize()

@@ -19,6 +19,6 @@ for src in "$@"; do
   fi
 done
 rest=""
-for o in *.o; do case " $skip " in *" $o "*) ;; *) rest="$rest $o";; esac; done
+for o in *.o; do case "$o" in *_m.o) continue;; esac; case " $skip " in *" $o "*) ;; *) rest="$rest $o";; esac; done   # (*_m.o: the measurement build's objects)
 /opt/rocm/bin/hipcc -shared -fPIC -pthread --offload-arch=gfx950 -o "../libskyemb_${name}.so" $objs $rest
 echo "../libskyemb_${name}.so"
