@@ -744,7 +744,7 @@ def pmc_traffic(args):
     """HBM-side bytes per Q = 16 bank-pass launch from the newest committed PMC summary (profiles/rNN_topk_stream_pmc.json), or None."""
     if args.bank_rows != 1_000_000 or args.topk != 100 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
         return None                                        # (counters cannot be read from inside the timed process: the profiles/ figure of the same workload)
-    rec, _, _ = _pmc_load(("r05_topk_stream_pmc.json", "r04_topk_stream_pmc.json", "r03_topk_stream_pmc.json"))
+    rec, _, _ = _pmc_load(("r06_topk_stream_pmc.json", "r05_topk_stream_pmc.json", "r04_topk_stream_pmc.json", "r03_topk_stream_pmc.json"))
     try:
         return rec["kernels"]["cosine_topk_stream_kernel<8>"]["traffic_bytes_per_launch"]
     except (TypeError, KeyError):
@@ -1013,7 +1013,7 @@ def mim19_pmc_record():
     """Matrix-pipe utilisation of the mim_19 step's GEMM kernels by hardware counters (profiles/r04_mim19_pmc.json: cycle-weighted
     SQ_VALU_MFMA_BUSY_CYCLES over the launches' SIMD-cycles, a separate --pmc pass over two eager steps), or {}."""
     try:
-        rec, src, cur = _pmc_load(("r05_mim19_pmc.json", "r04_mim19_pmc.json"))
+        rec, src, cur = _pmc_load(("r06_mim19_pmc.json", "r05_mim19_pmc.json", "r04_mim19_pmc.json"))
         ks = {n: v for n, v in rec["kernels"].items() if n.startswith("gemm")}
         cyc = {n: v["gpu_cycles_per_launch"] * v["launches"] for n, v in ks.items()}
         tot = sum(cyc.values())
@@ -1027,7 +1027,7 @@ def search_pmc_record():
     """Matrix-pipe utilisation of the many-query pass by hardware counters (profiles/r04_search_pmc.json: SQ_VALU_MFMA_BUSY_CYCLES over
     the launch's SIMD-cycles, a separate --pmc pass), or {}."""
     try:
-        rec, src, cur = _pmc_load(("r05_search_pmc.json", "r04_search_pmc.json"))
+        rec, src, cur = _pmc_load(("r06_search_pmc.json", "r05_search_pmc.json", "r04_search_pmc.json"))
         ks = rec["kernels"]
         k = next(v for n, v in ks.items() if n.startswith("prefilter_kernelILi2ELb0"))
         return {"mfma_busy_pmc": k["mfma_util"], "l2_hit_rate_pmc": k["l2_hit_rate"], "pmc_source": src, "pmc_current": cur,
@@ -1040,7 +1040,7 @@ def search_pmc_record():
 def gemm_pmc_record():
     """The GEMM family's record of the newest committed PMC summary (profiles/rNN_mfma_pmc.json: FETCH_SIZE doubled per the
     gfx950 correction + WRITE_SIZE, separate --pmc passes), or None."""
-    rec, src, cur = _pmc_load(("r05_mfma_pmc.json", "r04_mfma_pmc.json", "r03_mfma_pmc.json"))
+    rec, src, cur = _pmc_load(("r06_mfma_pmc.json", "r05_mfma_pmc.json", "r04_mfma_pmc.json", "r03_mfma_pmc.json"))
     try:
         rec = dict(rec["gemm_family_total"])
     except (TypeError, KeyError):

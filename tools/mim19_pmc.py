@@ -4,6 +4,7 @@ passes, which serialise every dispatch.  Prints a progress line per step."""
 import configparser, os, sys
 import numpy as np
 import torch
+LP = torch.bfloat16 if os.environ.get("SKYEMB_DTYPE", "f16") == "bf16" else torch.float16   # the headline's operand format (f16) unless SKYEMB_DTYPE=bf16
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from sky_embeddings_amd.model_config import config_for
@@ -16,7 +17,7 @@ a, t = ini["ARCHITECTURE"], ini["TRAINING"]
 cfg = config_for(a["model_type"], img_size=int(a["img_size"]), patch_size=int(a["patch_size"]), in_chans=int(a["num_channels"]),
                  embed_dim=int(a["embed_dim"]), norm_pix_loss=t.getboolean("norm_pix_loss"), loss_fn=t["loss_fn"])
 B, dev = int(t["batch_size"]), torch.device("cuda", 0)
-eng = SimMIMEngine(cfg, device=dev, compute_dtype=torch.bfloat16, seed=0)
+eng = SimMIMEngine(cfg, device=dev, compute_dtype=LP, seed=0)
 opt = FusedAdamW(eng, lr=float(t["init_lr"]), betas=(0.9, 0.95), weight_decay=float(t["weight_decay"]))
 step = TrainStep(eng, opt, CosineLR(opt, 1_000_000), B, use_graph=False)
 g = torch.Generator(device=dev).manual_seed(19)
