@@ -301,7 +301,7 @@ def bench_pretrain(args, rank, world, dev):
                 out["optimizer_placement"] = placement_ab(lambda: MAEEngine(cfg, device=dev, compute_dtype=dtype, seed=0), B, pool, dev, step,
                                                           ["1", "0", "ln_separate=SKYEMB_LN_SIDE=0"] if os.environ.get("SKYEMB_BENCH_PLACEMENT_ALL")
                                                           else ["0", "ln_separate=SKYEMB_LN_SIDE=0", "no_fold=SKYEMB_FOLD_WGRADS=0", "no_prefetch=SKYEMB_PREFETCH=0",
-                                                                "tiles_per_problem=SKYEMB_GROUP_XCD_ORDER=0"] + os.environ.get("SKYEMB_BENCH_EXTRA_VARIANTS", "").split())
+                                                                "tiles_per_xcd=SKYEMB_GROUP_XCD_ORDER=1"] + os.environ.get("SKYEMB_BENCH_EXTRA_VARIANTS", "").split())
         if world == 1 and not args.skip_feeder:
             out["feeder"] = bench_feeder(args, dev, step, B)
     return out, eng
@@ -395,7 +395,8 @@ def placement_ab(make_engine, B, pool, dev, step_default, others, load=None, rou
                 note="AdamW of the transformer blocks' weights: 'auto' (shipped) = side job of the NEXT block's grouped weight-gradient launch where "
                      "that launch leaves compute units idle (256 x 256 tiles), else the epilogue of the block's own launch; '0' = epilogue everywhere; "
                      "'1' = side jobs everywhere; 'dec' = carried by the decoder's launches only; 'tiles_per_problem' = the shipped policy with the 256 x 256 "
-                     "groups' tiles laid out per problem instead of per XCD (SKYEMB_GROUP_XCD_ORDER=0); 'ln_separate' = the shipped policy with every block's norm1 "
+                     "groups' tiles laid out per problem instead of per XCD (SKYEMB_GROUP_XCD_ORDER=0); 'tiles_per_xcd' = the shipped policy with the RING-TILE "
+                     "grouped launches' tiles laid out per XCD too (an eighth of the concatenated list per XCD: SKYEMB_GROUP_XCD_ORDER=1; built in round 6, not shipped); 'ln_separate' = the shipped policy with every block's norm1 "
                      "backward as its own launch behind the grouped weight-gradient launch instead of side workgroups inside it (SKYEMB_LN_SIDE=0); 'no_fold' = the "
                      "shipped policy with the single weight gradients outside the blocks (decoder_pred, decoder_embed / the SimMIM head) as their own "
                      "split-K launches instead of fifth problems of a grouped launch (SKYEMB_FOLD_WGRADS=0); 'no_prefetch' = the shipped policy without the "

@@ -1257,12 +1257,15 @@ extern "C" int skyemb_gemm_group_plan(const skyemb_gemm_args *args, int n, int t
     hdr[0] = n;
     hdr[1] = start;
     {
-        // tile order across the group (gemm256_group_kernel since round 5, gemm_pipe_group_kernel since round 6): an XCD takes
-        // consecutive tiles of the concatenated list (read per plan, not once per process: bench.py builds both orders in one
-        // process for its interleaved A/B).  SKYEMB_GROUP_XCD_ORDER=0: an eighth of every problem per XCD; =256: 256 x 256 tiles only
+        // tile order across the group: an XCD takes consecutive tiles of the concatenated list.  Default: the 256 x 256 groups
+        // (round 5: their L2 traffic 2.6x -> 1.35x of the operands).  For the ring-tile groups the same order was built in round 6
+        // and measured (tools/group_dec_time.py, rotating operand sets): config-A decoder group 65.5 -> 66.8 us plain, 78.1 -> 80.8
+        // with the optimiser side job; encoder group 37.8 -> 35.1 us plain but 69.1 -> 70.4 with the optimiser in its epilogue (the
+        // form the step runs); in the step 4.735 -> 4.743 ms: not shipped, SKYEMB_GROUP_XCD_ORDER=1 turns it on, =0 turns both off.
+        // (read per plan, not once per process: bench.py builds both orders in one process for its interleaved A/B)
         const char *e = getenv("SKYEMB_GROUP_XCD_ORDER");
-        const bool off = e && e[0] == '0', only256 = e && atoi(e) == 256;
-        if (!off && (tile == 256256 || !only256)) hdr[1] |= 1 << 30;
+        const bool off = e && e[0] == '0', all = e && e[0] == '1';
+        if (!off && (tile == 256256 || all)) hdr[1] |= 1 << 30;
     }
     info->total_blocks = start;
     info->tile = tile;

@@ -94,6 +94,9 @@ class PredictorHead:
         self.store = HeadStore(shapes, alloc, self.device, compute_dtype)
         self.tensors = OrderedDict((k, self.store.param(k)) for k in shapes)
         self._ws = {}
+        # timm VisionTransformer(drop_rate=...): `head_drop`, an nn.Dropout on the pooled features in front of the classifier
+        # (forward_head: fc_norm -> head_drop -> head), active in training mode.  The caller (utils.vit.VisionTransformer) sets both.
+        self.drop_rate, self.training = 0.0, False
         self._init(gen)
 
     def _init(self, gen):
@@ -176,9 +179,16 @@ class PredictorHead:
             ops.layernorm_fwd(w["feat"], P("fc_norm.weight"), P("fc_norm.bias"), w["z_lp"], w["mean"], w["rstd"], B, D, self.eps, y32=w["z"])
         else:
             w["z"].copy_(feat)
+        w["drop"] = None
+        if self.training and self.drop_rate > 0.0:
+            # inverted dropout as nn.Dropout applies it; the keep mask is drawn with torch's generator on the device (the individual
+            # draws differ from the reference's stream, the distribution does not) and kept for backward.  [B, D] elementwise: glue.
+            keep = 1.0 - self.drop_rate
+            w["drop"] = (torch.rand(B, D, device=self.device) < keep).to(torch.float32).div_(keep)
+            w["z"].mul_(w["drop"])
         if pre_logits or self.C <= 0:
             return w["z"]
-        if self.pool != 'avg':
+        if self.pool != 'avg' or w["drop"] is not None:
             ops.cast(w["z"], w["z_lp"], B * D)
         st = self.store
         ops.gemm(w["z_lp"], st.raw(st.p_lp, "head.weight"), M=B, N=self.Cp, K=D, bias=st.raw(st.p, "head.bias"), out_f32=w["logits"])
@@ -201,6 +211,9 @@ class PredictorHead:
                  out_f32=st.raw(st.g, "head.weight").view(self.Cp, D), colsum_a=st.raw(st.g, "head.bias"))
         ops.gemm(w["dlog"], LP("head.weight"), M=B, N=D, K=self.Cp, a_layout=KC, b_layout=RC, lda=self.Cp, ldb=D,
                  out_f32=w["gz"], out=w["gz_lp"])
+        if w.get("drop") is not None:                                      # d loss / d (features before the dropout)
+            w["gz"].mul_(w["drop"])
+            ops.cast(w["gz"], w["gz_lp"], B * D)
         if self.pool == 'avg':
             ops.layernorm_bwd(w["gz_lp"], w["feat"], P("fc_norm.weight"), w["mean"], w["rstd"], None, w["dfeat"], None, w["part"],
                               G("fc_norm.weight"), G("fc_norm.bias"), B, D, self.code)

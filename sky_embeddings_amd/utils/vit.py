@@ -98,9 +98,11 @@ class VisionTransformer:
         return self.train(False)
 
     def train(self, mode=True):
-        if mode and self.drop_rate != 0.0:
-            raise NotImplementedError("dropout in the downstream predictor (ARCHITECTURE.dropout != 0) is not built")
         self.training = bool(mode)
+        # ARCHITECTURE.dropout (utils/vit.py:40, 55-123 -> timm's `drop_rate`): dropout on the pooled features in front of the classifier
+        # (timm >= 0.9 `head_drop`; the positional / projection / attention dropouts have rates of their own there, which the
+        # reference leaves at 0), active in training mode only
+        self._head_mod.drop_rate, self._head_mod.training = self.drop_rate, self.training
         return self
 
     def no_weight_decay(self):

@@ -143,6 +143,39 @@ def test_predictor_bf16_training_step_runs_and_learns():
     assert np.isfinite(cp["train_loss"]).all() and cp["train_loss"][-1] < 0.5 * cp["train_loss"][0]
 
 
+@pytest.mark.parametrize("case", ["fs_token_mse", "ft_avg_mse", "ft_map_mse"])
+def test_predictor_head_dropout(case):
+    """ARCHITECTURE.dropout (utils/vit.py:40 -> timm's `drop_rate` = dropout on the pooled features in front of the classifier): off in
+    eval mode (same predictions as without it), on in training mode -- the predictions are the classifier applied to the kept, rescaled
+    features and the gradient reaching the features carries the same mask -- for the three pooling modes.  The keep mask comes from
+    torch's device generator: the reference's individual draws cannot be reproduced, the operation can."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "predictor.npz"))
+    _, m = build(z, case, torch.float32)
+    x = torch.from_numpy(z[f"{case}/x"][0]).cuda()
+    m.eval()
+    with torch.no_grad():
+        ref = m(x).clone()
+    m.drop_rate = 0.5
+    m.eval()
+    with torch.no_grad():
+        assert torch.equal(m(x), ref)                                  # eval: no dropout
+    m.train(True)
+    hd = m._head_mod
+    pred = m(x)
+    B = x.shape[0]
+    w = hd._ws[next(k for k in hd._ws if k[0] == B)]
+    mask = w["drop"].clone()
+    assert mask is not None and set(mask.unique().tolist()) <= {0.0, 2.0} and 0.3 < float((mask > 0).float().mean()) < 0.7
+    W, b = hd.tensors["head.weight"], hd.tensors["head.bias"]
+    want = w["z"] @ W.t() + b                                          # w["z"]: the features AFTER the mask
+    assert float((pred.detach() - want).abs().max()) < 1e-4 * max(1.0, float(want.abs().max()))
+    assert bool((w["z"][mask == 0] == 0).all())
+    pred.sum().backward()
+    torch.cuda.synchronize()
+    assert bool((w["gz"][mask == 0] == 0).all()) and bool(torch.isfinite(w["gz"]).all())
+    m.train(False)
+
+
 def test_checkpoint_surgery_matches_reference(tmp_path):
     """interpolate_pos_embed / crop_pos_embed on the reference's inputs, and load_model from an MAE checkpoint of another size."""
     import configparser
