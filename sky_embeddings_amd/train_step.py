@@ -165,7 +165,10 @@ class TrainStep:
         self.shard_rank, self.shard_world = (shard_emulate if shard_emulate is not None else
                                              ((torch.distributed.get_rank(process_group), world_size) if self.collectives and world_size > 1 else (0, 1)))
         self.shard_emulated = shard_emulate is not None
-        self.shard_optimizer = bool(shard_optimizer and self.staged and self.shard_world > 1 and not self.optimizer_overlap)
+        # (one rank with the collectives forced -- SKYEMB_DIST_FORCE=1, the one-GPU RCCL test -- shards over a world of one when asked
+        # to explicitly: reduce_scatter_tensor / all_gather_into_tensor of a single rank are copies, issued for real)
+        forced_one = self.collectives and self.shard_world == 1 and shard_optimizer is True and os.environ.get("SKYEMB_SHARD_OPT", "auto") != "0"
+        self.shard_optimizer = bool(shard_optimizer and self.staged and (self.shard_world > 1 or forced_one) and not self.optimizer_overlap)
         self._own = {}
         if self.shard_optimizer:
             from .distributed import shard_chunk

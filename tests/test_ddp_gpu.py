@@ -130,10 +130,14 @@ def _rccl_one_rank_main(rank, port, out_dir):
     imgs, noise = _data(1)
     res = {}
     # (default schedule of an N > 1 job: waits on the compute stream, one AdamW launch; and the optimiser-stream overlap)
-    for comm, overlap in (("bf16", False), ("bf16", True), ("f32", False)):
+    # ... and (round 6) the sharded optimiser's collectives over the world of one: reduce_scatter_tensor into the owner's buffer,
+    # the in-place all_gather_into_tensor of the 16-bit shadow, the tails' all-reduce -- copies with one rank, issued on RCCL
+    for comm, overlap, shard in (("bf16", False, False), ("bf16", True, False), ("f32", False, False), ("bf16", False, True), ("f32", False, True)):
         for force in ("1", "0"):
             os.environ["SKYEMB_DIST_FORCE"] = force
-            eng, step = _make(dev, B_RANK, 1, staged=True, grad_comm=comm, n_encoder_groups=6, optimizer_overlap=overlap)
+            eng, step = _make(dev, B_RANK, 1, staged=True, grad_comm=comm, n_encoder_groups=6, optimizer_overlap=overlap,
+                              shard_optimizer=bool(shard and force == "1"))
+            assert step.shard_optimizer == bool(shard and force == "1")
             assert step.collectives == (force == "1") and step.staged and len(step.stages) >= 4
             assert (step.g16 is not None) == (comm == "bf16") and step.optimizer_overlap == overlap
             losses = []
@@ -144,7 +148,7 @@ def _rccl_one_rank_main(rank, port, out_dir):
             res[force] = (losses, eng.store.p.clone(), eng.store.m.clone())
             del eng, step
         a, b = res["1"], res["0"]
-        assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), (comm, overlap)
+        assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), (comm, overlap, shard)
     # the search lists: all_gather_into_tensor (the branch gloo never takes), [Q, k] -> [Q, world, k]
     g = torch.Generator().manual_seed(5)
     scores = torch.rand(33, 100, generator=g).to(dev)
