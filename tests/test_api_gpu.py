@@ -281,8 +281,11 @@ def test_downstream_vit_forward_features_matches_reference_goldens(case):
     assert img_like.shape == (imgs.shape[0], cfg.embed_dim, grid, grid)
     assert torch.equal(img_like, tok[:, E:].permute(0, 2, 1).reshape(imgs.shape[0], cfg.embed_dim, grid, grid))
     assert vit.train(True).training and not vit.eval().training            # training is built (tests/test_predictor_gpu.py) ...
-    with pytest.raises(NotImplementedError):                               # ... except with dropout in the head
-        VisionTransformer(c, "cuda", torch.float32, num_classes=2, global_pool="map", drop_rate=0.1).train(True)
+    # ... with dropout in the head too (round 6: tests/test_predictor_gpu.py::test_predictor_head_dropout); fp16 is a pretraining mode
+    vd = VisionTransformer(c, "cuda", torch.float32, num_classes=2, global_pool="map", drop_rate=0.1).train(True)
+    assert vd._head_mod.drop_rate == 0.1 and vd._head_mod.training and not vd.eval()._head_mod.training
+    with pytest.raises(NotImplementedError):
+        VisionTransformer(c, "cuda", torch.float16, num_classes=2, global_pool="map")
 
 
 def test_linear_probe_hook_on_hip_embeddings(tmp_path):

@@ -246,6 +246,50 @@ def test_mim19_vit_large_width_against_oracle():
         torch.cuda.empty_cache()
 
 
+# (bars filled from the first measurement on MI355X, 2x: profiles/r06_parity_errors.json)
+_FULL_DEPTH_CACHE = {}
+FULL_DEPTH_BARS = {torch.float16: dict(loss=None, pred=None, grad=None), torch.bfloat16: dict(loss=None, pred=None, grad=None)}
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_mim19_full_depth_against_oracle(dtype):
+    """BASELINE configs[4] at its real WIDTH AND DEPTH (configs/mim_19.ini: ViT-L/16, 24 blocks, 1024 columns, 16 heads, 5x128x128,
+    L1 + norm-pix) against oracle/mae_oracle.py -- the batch cut to 32 images (2080 token rows) so that the CPU oracle's forward +
+    backward through 24 blocks finishes in a minute: loss, prediction image and the gradients at both ends of the stack.  (The
+    width / batch / kernel selection of the real B = 128 is what test_mim19_vit_large_width_against_oracle checks at depth 2.)"""
+    import configparser
+    import os
+    from oracle import mae_oracle as mo
+    ini = configparser.ConfigParser()
+    ini.read(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "mim_19.ini"))
+    a, t = ini["ARCHITECTURE"], ini["TRAINING"]
+    cfg_o = mo.config_for(a["model_type"], img_size=int(a["img_size"]), patch_size=int(a["patch_size"]), in_chans=int(a["num_channels"]),
+                          embed_dim=int(a["embed_dim"]), norm_pix_loss=t.getboolean("norm_pix_loss"), loss_fn=t["loss_fn"])
+    assert (cfg_o.depth, cfg_o.embed_dim, cfg_o.num_heads, cfg_o.num_patches) == (24, 1024, 16, 64)
+    B = 32
+    if "ref" not in _FULL_DEPTH_CACHE:                     # (one oracle run for both operand formats)
+        st = mo.init_state(cfg_o, seed=11)
+        x, m, _ = _mim19_batch(cfg_o, B, seed=29)
+        _FULL_DEPTH_CACHE["ref"] = (st, x, m, mo.loss_and_grads(st, x, cfg_o, None, None, mask=m, nan_safe=False))
+    st, x, m, (loss_o, pred_o, _, _, _, grads_o) = _FULL_DEPTH_CACHE["ref"]
+    eng = make_engine(cfg_o, st, dtype)
+    loss, pred, _ = eng.forward_train(x.cuda(), mask=m.cuda())
+    eng.backward()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(eng.store.g).all())
+    loss_rel = abs(float(loss) - float(loss_o)) / abs(float(loss_o))
+    pred_rel = rel_err(pred.cpu().numpy(), pred_o.numpy())
+    keys = ["blocks.23.mlp.fc2.weight", "blocks.12.attn.qkv.weight", "blocks.0.attn.qkv.weight", "patch_embed.proj.weight", "norm.weight", "decoder.0.weight"]
+    grel = {k: rel_err(eng.grad(k).cpu().numpy().reshape(grads_o[k].shape), grads_o[k].numpy()) for k in keys}
+    name = "f16" if dtype == torch.float16 else "bf16"
+    record_parity(f"mim19_full_depth_B32_{name}_l1", dict(loss_rel=loss_rel, pred_rel_l2=pred_rel, grad_rel_l2=grel))
+    bars = FULL_DEPTH_BARS[dtype]
+    if bars["loss"] is not None:
+        assert loss_rel <= bars["loss"] and pred_rel <= bars["pred"] and max(grel.values()) <= bars["grad"], (loss_rel, pred_rel, grel)
+    else:
+        assert loss_rel < 1e-3 and pred_rel < 5e-2, (loss_rel, pred_rel, grel)
+
+
 @pytest.mark.parametrize("policy", ["auto", "0"])
 def test_vit_large_width_optimiser_in_the_weight_gradient_launches_equals_the_separate_launch(policy):
     """ViT-L width (1024 columns, B = 128: 8320 token rows, depth 3): three TrainStep steps with the AdamW step of the blocks' weights
