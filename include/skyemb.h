@@ -342,6 +342,23 @@ int skyemb_gather_rows_host(const void *src, int64_t row_bytes, const int64_t *i
 int skyemb_h5_unchunk_host(const void *file_base, int64_t file_bytes, const int64_t *chunk_addr, const int64_t *chunk_off,
                            int64_t nchunks, int rank, const int64_t *chunk_dims, const int64_t *dset_dims, int elem_size, void *dst,
                            int nthreads);
+/* Rice-compressed tiles of a FITS tile-compressed image (ZCMPTYPE = 'RICE_1': what fpack and astropy's CompImageHDU write by
+ * default; the reference reads such survey tiles through astropy, utils/dataloaders.py:418) -> pixels in the host's byte
+ * order, native threads over the tiles; see fits_lite.py, which dequantises floating-point images afterwards.  HOST function.
+ * Tile t: bytes [off[t], off[t] + len[t]) of `base` hold npix[t] pixels of `bytepix` (1, 2 or 4) bytes, coded in blocks of
+ * `blocksize` differences; they are written to dst + dst_off[t] * bytepix (dst holds dst_pixels pixels). */
+int skyemb_fits_rice_tiles_host(const void *base, int64_t base_bytes, const int64_t *off, const int64_t *len, const int64_t *npix,
+                                const int64_t *dst_off, int64_t ntiles, int bytepix, int blocksize, void *dst, int64_t dst_pixels,
+                                int nthreads);
+/* Quantised floating-point tiles of such an image -> float32 pixels placed in the image (FITS 4.0 section 10.2): q * ZSCALE + ZZERO,
+ * or (q - r + 0.5) * ZSCALE + ZZERO with the convention's subtractive dither (method 1 / 2; 2: q == -2147483646 is exactly 0; method 0:
+ * none).  rand: the convention's 10 000 random numbers (fits_lite.dither_sequence), table_row[t]: the tile's 0-based row in the table.
+ * Tile t: q + q_off[t], h[t] x w[t] pixels -> out[(y0[t] + y) * W + x0[t] + x]; has_blank[t] != 0: q == blank[t] -> NaN (both may be
+ * NULL).  big_endian_out != 0: floats stored byte-swapped, the layout of an uncompressed FITS image.  HOST function. */
+int skyemb_fits_dequantise_tiles_host(const int32_t *q, const int64_t *q_off, const int64_t *y0, const int64_t *x0, const int64_t *h,
+                                      const int64_t *w, const int64_t *table_row, int64_t ntiles, const double *zscale, const double *zzero,
+                                      const int32_t *blank, const uint8_t *has_blank, const float *rand, int method, int zdither0,
+                                      float *out, int64_t H, int64_t W, int big_endian_out, int nthreads);
 /* Survey-tile sampler: FitsDataset.__getitem__ (utils/dataloaders.py:589-654) cuts `cutouts_per_tile` windows out of a
  * multi-band FITS tile with a python loop (random_cutouts :449-476 / overlapping_cutouts :507-536) and clips them (:618-621).
  * Here the tile [C, H, W] sits in HBM as the files' own 4-byte words (big_endian[c] != 0: plane c still holds FITS

@@ -12,9 +12,12 @@
 * ``write_image_fits``: writer for the same subset (tests, synthetic tiles).
 
 Tile-compressed images (``ZIMAGE`` binary tables, what ``fpack`` / astropy ``CompImageHDU`` / the LSST stack write; FITS 4.0
-section 10): the lossless gzip codecs (``GZIP_1``, ``GZIP_2`` = byte-shuffled, ``NOCOMPRESS``) without quantisation are
-decoded on the host (zlib) into a native float32 / integer array; ``RICE_1`` / ``HCOMPRESS_1`` / ``PLIO_1`` and quantised
-floating-point tiles (``ZSCALE`` / ``ZZERO`` columns, dithering) raise ``NotImplementedError`` by name: funpack such files.
+section 10) are decoded on the host into a big-endian float32 / integer array: ``RICE_1`` (the default of both writers; native
+threads over the tiles, ``skyemb_fits_rice_tiles_host``), ``GZIP_1``, ``GZIP_2`` (byte-shuffled) and ``NOCOMPRESS``, for integer
+images and for quantised floating-point images (``ZSCALE`` / ``ZZERO`` columns; ``NO_DITHER``, ``SUBTRACTIVE_DITHER_1`` / ``_2`` with
+the convention's random sequence; ``ZBLANK`` -> NaN; tiles the writer left unquantised in ``GZIP_COMPRESSED_DATA``).
+``HCOMPRESS_1`` / ``PLIO_1`` raise ``NotImplementedError`` by name: funpack such files.  Pinned against astropy-written files
+(``tests/golden/io``).
 """
 from __future__ import annotations
 
@@ -138,13 +141,115 @@ def read_image_hdu(path, hdu=1) -> ImageHDU:
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# tile-compressed images (FITS 4.0 section 10), lossless gzip codecs
+# tile-compressed images (FITS 4.0 section 10): RICE_1 and the gzip codecs, integer or quantised floating-point pixels
 # ---------------------------------------------------------------------------------------------------------------
+N_RANDOM = 10000
+_ZERO_VALUE = -2147483646          # SUBTRACTIVE_DITHER_2: this quantised value stands for exactly 0.0 (FITS 4.0 section 10.2.3)
+_rand_cache = []
+
+
+def dither_sequence():
+    """The 10 000 pseudo-random numbers of the tile-compression convention (FITS 4.0 appendix I): the Park-Miller minimal
+    standard generator (a = 16807, m = 2^31 - 1, seed 1) run in double precision, value = seed / m kept in SINGLE precision
+    (what the writers' library holds: the dithered pixels of astropy-written files are reproduced bit for bit only with it)."""
+    if not _rand_cache:
+        a, m, seed = 16807.0, 2147483647.0, 1.0
+        out = np.empty(N_RANDOM, dtype=np.float64)
+        for i in range(N_RANDOM):
+            temp = a * seed
+            seed = temp - m * math.floor(temp / m)
+            out[i] = seed / m
+        _rand_cache.append(out.astype(np.float32))
+    return _rand_cache[0]
+
+
+def _dither_indices(tile_index, zdither0, n):
+    """Indices into dither_sequence() for the n pixels of tile `tile_index` (0-based table row): the walk starts at
+    int(rand[(row + ZDITHER0 - 1) % 10000] * 500) and, on reaching the end of the table, restarts from the NEXT seed entry."""
+    rand = dither_sequence()
+    iseed = (tile_index + zdither0 - 1) % N_RANDOM
+    nxt = int(rand[iseed] * np.float32(500))
+    parts, left = [], n
+    while left > 0:
+        run = min(left, N_RANDOM - nxt)
+        parts.append(np.arange(nxt, nxt + run))
+        left -= run
+        if left > 0 or nxt + run == N_RANDOM:
+            iseed = (iseed + 1) % N_RANDOM
+            nxt = int(rand[iseed] * np.float32(500))
+    return np.concatenate(parts) if len(parts) > 1 else parts[0]
+
+
+def _rice_tiles(buf, offs, lens, npix, bytepix, blocksize):
+    """All Rice tiles of an image -> one flat native-endian unsigned array (tile after tile): skyemb_fits_rice_tiles_host."""
+    import ctypes
+    from ._lib import check, lib
+    offs, lens, npix = (np.ascontiguousarray(a, dtype=np.int64) for a in (offs, lens, npix))
+    dst_off = np.concatenate([[0], np.cumsum(npix)[:-1]]).astype(np.int64) if len(npix) else np.zeros(0, np.int64)
+    total = int(npix.sum())
+    out = np.empty(total, dtype={1: np.uint8, 2: np.uint16, 4: np.uint32}[bytepix])
+    base = np.ascontiguousarray(buf)                      # (a memmap stays a view of the mapping)
+    ptr = lambda a: ctypes.c_void_p(a.ctypes.data)
+    check(lib().skyemb_fits_rice_tiles_host(ptr(base), base.size, ptr(offs), ptr(lens), ptr(npix), ptr(dst_off), len(npix), bytepix,
+                                            blocksize, ptr(out), total, min(16, os.cpu_count() or 1)), "skyemb_fits_rice_tiles_host")
+    return out, dst_off
+
+
+def _dequantise(out, q_parts, tiles, y0, x0, hs, ws, zscale, zzero, zblank_col, zblank_key, method, zdither0):
+    """Quantised tiles -> the big-endian float image `out` (skyemb_fits_dequantise_tiles_host, threads over tiles)."""
+    import ctypes
+    from ._lib import check, lib
+    H, W = out.shape
+    if isinstance(q_parts, tuple) and out.dtype != np.dtype(">f4"):     # (flat array, offsets) -> per-tile views
+        flat, offs = q_parts
+        q_parts = [flat[o:o + int(hs[t]) * int(ws[t])] for o, t in zip(offs, tiles)]
+    if out.dtype != np.dtype(">f4"):                          # ZBITPIX = -64: rare; the same arithmetic in numpy, tile by tile
+        rand = dither_sequence()
+        for part, t in zip(q_parts, tiles):
+            q = part.astype(np.int64)
+            if method.startswith("SUBTRACTIVE"):
+                vals = (q.astype(np.float64) - rand[_dither_indices(int(t), zdither0, q.size)].astype(np.float64) + 0.5) * zscale[t] + zzero[t]
+                if method.endswith("2"):
+                    vals[q == _ZERO_VALUE] = 0.0
+            else:
+                vals = q.astype(np.float64) * zscale[t] + zzero[t]
+            blank = zblank_col[t] if zblank_col is not None else zblank_key
+            if blank is not None:
+                vals[q == int(blank)] = np.nan
+            out[y0[t]:y0[t] + hs[t], x0[t]:x0[t] + ws[t]] = vals.reshape(int(hs[t]), int(ws[t]))
+        return
+    if isinstance(q_parts, tuple):
+        q, q_off = np.ascontiguousarray(q_parts[0], dtype=np.int32), np.ascontiguousarray(q_parts[1], dtype=np.int64)
+    else:
+        sizes = np.array([p.size for p in q_parts], dtype=np.int64)
+        q = np.concatenate([np.asarray(p).astype(np.int32, copy=False) for p in q_parts]) if len(q_parts) > 1 else np.ascontiguousarray(q_parts[0], dtype=np.int32)
+        q_off = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    i64 = lambda a: np.ascontiguousarray(np.asarray(a)[tiles], dtype=np.int64)
+    f64 = lambda a: np.ascontiguousarray(np.asarray(a)[tiles], dtype=np.float64)
+    a_y0, a_x0, a_h, a_w, rows = i64(y0), i64(x0), i64(hs), i64(ws), np.ascontiguousarray(tiles, dtype=np.int64)
+    sc, ze = f64(zscale), f64(zzero)
+    if zblank_col is not None:
+        blank, has = np.ascontiguousarray(zblank_col[tiles], dtype=np.int32), np.ones(len(tiles), np.uint8)
+    elif zblank_key is not None:
+        blank, has = np.full(len(tiles), int(zblank_key), np.int32), np.ones(len(tiles), np.uint8)
+    else:
+        blank = has = None
+    code = {"SUBTRACTIVE_DITHER_1": 1, "SUBTRACTIVE_DITHER_2": 2}.get(method, 0)
+    rand = dither_sequence()
+    ptr = lambda a: ctypes.c_void_p(a.ctypes.data) if a is not None else None
+    assert out.flags.c_contiguous
+    check(lib().skyemb_fits_dequantise_tiles_host(ptr(q), ptr(q_off), ptr(a_y0), ptr(a_x0), ptr(a_h), ptr(a_w), ptr(rows), len(tiles), ptr(sc),
+                                                  ptr(ze), ptr(blank), ptr(has), ptr(rand), code, zdither0, ptr(out), H, W, 1,
+                                                  min(16, os.cpu_count() or 1)), "skyemb_fits_dequantise_tiles_host")
+
+
 def _read_compressed_image(path, hdr, buf, data_pos):
+    import re
     import zlib
     codec = str(hdr.get("ZCMPTYPE", "")).strip()
-    if codec not in ("GZIP_1", "GZIP_2", "NOCOMPRESS"):
-        raise NotImplementedError(f"{path}: tile compression {codec!r} is not supported (lossless GZIP_1 / GZIP_2 only): funpack the file")
+    if codec not in ("RICE_1", "RICE_ONE", "GZIP_1", "GZIP_2", "NOCOMPRESS"):
+        raise NotImplementedError(f"{path}: tile compression {codec!r} is not supported (RICE_1, GZIP_1, GZIP_2, NOCOMPRESS): funpack the file")
+    rice = codec.startswith("RICE")
     zbitpix, znaxis = int(hdr["ZBITPIX"]), int(hdr.get("ZNAXIS", 0))
     if znaxis != 2:
         raise NotImplementedError(f"{path}: compressed image with ZNAXIS = {znaxis} (2-D images only)")
@@ -152,7 +257,6 @@ def _read_compressed_image(path, hdr, buf, data_pos):
     tw, th = int(hdr.get("ZTILE1", W)), int(hdr.get("ZTILE2", 1))
     nfields, row_bytes, nrows = int(hdr["TFIELDS"]), int(hdr["NAXIS1"]), int(hdr["NAXIS2"])
     cols, off = {}, 0
-    import re
     widths = {"L": 1, "B": 1, "I": 2, "J": 4, "K": 8, "E": 4, "D": 8, "A": 1}
     for k in range(1, nfields + 1):
         m = re.match(r"\s*(\d*)([PQ])?([A-Z])", str(hdr[f"TFORM{k}"]))
@@ -161,47 +265,105 @@ def _read_compressed_image(path, hdr, buf, data_pos):
         repeat = int(m.group(1)) if m.group(1) else 1
         name = str(hdr.get(f"TTYPE{k}", "")).strip()
         if m.group(2):                                   # variable-length array: (length, heap offset) descriptor
-            cols[name] = (off, m.group(2))
+            cols[name] = (off, m.group(2), m.group(3))
             off += repeat * (16 if m.group(2) == "Q" else 8)
         else:
-            cols[name] = (off, m.group(3))
+            cols[name] = (off, m.group(3), m.group(3))
             off += repeat * widths[m.group(3)]
-    if zbitpix < 0 and ("ZSCALE" in cols or str(hdr.get("ZQUANTIZ", "NONE")).strip().upper() not in ("NONE", "")):
-        raise NotImplementedError(f"{path}: quantised floating-point tiles ({hdr.get('ZQUANTIZ')}) are not supported: funpack the file")
     if "COMPRESSED_DATA" not in cols and "GZIP_COMPRESSED_DATA" not in cols:
         raise NotImplementedError(f"{path}: compressed image table without a COMPRESSED_DATA column")
+    tiles_x, tiles_y = (W + tw - 1) // tw, (H + th - 1) // th
+    if nrows != tiles_x * tiles_y:
+        raise ValueError(f"{path}: {nrows} table rows for {tiles_x} x {tiles_y} tiles")
+    # algorithm parameters (ZNAMEi / ZVALi) and the quantisation of floating-point pixels
+    params = {str(hdr[f"ZNAME{i}"]).strip().upper(): hdr.get(f"ZVAL{i}") for i in range(1, 10) if f"ZNAME{i}" in hdr}
+    blocksize, bytepix = int(params.get("BLOCKSIZE", 32)), int(params.get("BYTEPIX", 4))
+    quantised = zbitpix < 0 and "ZSCALE" in cols
+    method = str(hdr.get("ZQUANTIZ", "NO_DITHER" if quantised else "NONE")).strip().upper()
+    if zbitpix < 0 and rice and not quantised:
+        raise ValueError(f"{path}: RICE_1 floating-point image without ZSCALE / ZZERO columns")
+    if method not in ("NONE", "", "NO_DITHER", "SUBTRACTIVE_DITHER_1", "SUBTRACTIVE_DITHER_2"):
+        raise NotImplementedError(f"{path}: ZQUANTIZ = {method!r}")
+    zdither0 = int(hdr.get("ZDITHER0", 1))
     heap = data_pos + int(hdr.get("THEAP", row_bytes * nrows))
-    dt = np.dtype(_BITPIX_DTYPE[zbitpix])
-    out = np.empty((H, W), dtype=dt)
-    tiles_x = (W + tw - 1) // tw
     table = np.asarray(buf[data_pos:data_pos + row_bytes * nrows]).reshape(nrows, row_bytes)
 
-    def descriptor(row, col):
-        o, kind = cols[col]
-        n = 16 if kind == "Q" else 8
-        vals = np.frombuffer(table[row, o:o + n].tobytes(), dtype=">i8" if kind == "Q" else ">i4")
-        return int(vals[0]), int(vals[1])
+    def column(name):
+        o, kind, elem = cols[name]
+        if kind in "PQ":                                  # [nrows, 2] = (element count, heap offset)
+            n = 16 if kind == "Q" else 8
+            return np.ascontiguousarray(table[:, o:o + n]).view(">i8" if kind == "Q" else ">i4").astype(np.int64).reshape(nrows, 2)
+        w = widths[kind]
+        return np.ascontiguousarray(table[:, o:o + w]).view({"E": ">f4", "D": ">f8", "J": ">i4", "K": ">i8", "I": ">i2", "B": "u1"}[kind]).reshape(nrows)
 
+    desc = {c: column(c) for c in ("COMPRESSED_DATA", "GZIP_COMPRESSED_DATA", "UNCOMPRESSED_DATA") if c in cols}
+    zscale = column("ZSCALE").astype(np.float64) if "ZSCALE" in cols else None
+    zzero = column("ZZERO").astype(np.float64) if "ZZERO" in cols else None
+    if quantised and zzero is None:
+        raise ValueError(f"{path}: ZSCALE column without ZZERO")
+    zblank_col = column("ZBLANK") if "ZBLANK" in cols else None
+    zblank_key = hdr.get("ZBLANK")
+    # what the main column's bytes decode to: quantised floats and integer images are integers of ZBITPIX (quantised: 32) bits
+    q_dt = np.dtype(">i4") if quantised else np.dtype(_BITPIX_DTYPE[zbitpix])
+    out_dt = np.dtype(_BITPIX_DTYPE[zbitpix])
+    out = np.empty((H, W), dtype=out_dt)
+    ty, tx = np.divmod(np.arange(nrows), tiles_x)
+    hs, ws = np.minimum(th, H - ty * th), np.minimum(tw, W - tx * tw)
+    npix = (hs * ws).astype(np.int64)
+    main = desc.get("COMPRESSED_DATA")
+    in_main = main[:, 0] > 0 if main is not None else np.zeros(nrows, bool)
+    rice_out = rice_off = None
+    if rice and in_main.any():
+        if bytepix not in (1, 2, 4):
+            raise NotImplementedError(f"{path}: RICE_1 with BYTEPIX = {bytepix}")
+        sel = np.nonzero(in_main)[0]
+        rice_out, offs_sel = _rice_tiles(buf, heap + main[sel, 1], main[sel, 0], npix[sel], bytepix, blocksize)
+        rice_off = dict(zip(sel.tolist(), offs_sel.tolist()))
+    signed = {1: np.uint8, 2: np.int16, 4: np.int32}          # (8-bit FITS pixels are unsigned)
+    q_parts, q_tiles = [], []                                 # quantised tiles: dequantised together below
     for t in range(nrows):
-        ty, tx = divmod(t, tiles_x)
-        h, w = min(th, H - ty * th), min(tw, W - tx * tw)
-        nbytes = h * w * dt.itemsize
-        length, ptr, col = 0, 0, None
-        for col in ("COMPRESSED_DATA", "GZIP_COMPRESSED_DATA", "UNCOMPRESSED_DATA"):
-            if col in cols:
-                length, ptr = descriptor(t, col)
-                if length > 0:
-                    break
-        chunk = bytes(buf[heap + ptr:heap + ptr + length * (dt.itemsize if col == "UNCOMPRESSED_DATA" else 1)])
-        if col == "UNCOMPRESSED_DATA" or codec == "NOCOMPRESS":
-            raw = chunk
+        h, w, n = int(hs[t]), int(ws[t]), int(npix[t])
+        dest = out[ty[t] * th:ty[t] * th + h, tx[t] * tw:tx[t] * tw + w]
+        if in_main[t]:
+            if rice and quantised and bytepix == 4:
+                continue                                      # (stay where the decoder put them: dequantised in one call below)
+            if rice:
+                ints = rice_out[rice_off[t]:rice_off[t] + n].view(signed[bytepix])
+            else:
+                length, ptr = int(main[t, 0]), int(main[t, 1])
+                chunk = bytes(buf[heap + ptr:heap + ptr + length])
+                raw = chunk if codec == "NOCOMPRESS" else zlib.decompress(chunk, 15 + 32)      # zlib or gzip wrapper
+                if codec == "GZIP_2":                         # byte planes, most significant first -> pixels
+                    raw = np.frombuffer(raw, dtype=np.uint8).reshape(q_dt.itemsize, n).T.tobytes()
+                if len(raw) != n * q_dt.itemsize:
+                    raise ValueError(f"{path}: tile {t} decompressed to {len(raw)} bytes, expected {n * q_dt.itemsize}")
+                ints = np.frombuffer(raw, dtype=q_dt)
+            if quantised:
+                q_parts.append(ints)
+                q_tiles.append(t)
+            else:
+                dest[...] = ints.reshape(h, w)                # lossless: integers, or floats of the gzip codecs
+            continue
+        # tiles the writer could not quantise (or chose not to compress) stand as gzip-compressed / raw pixels of ZBITPIX
+        for col in ("GZIP_COMPRESSED_DATA", "UNCOMPRESSED_DATA"):
+            if col in desc and desc[col][t, 0] > 0:
+                length, ptr = int(desc[col][t, 0]), int(desc[col][t, 1])
+                if col == "UNCOMPRESSED_DATA":
+                    raw = bytes(buf[heap + ptr:heap + ptr + length * out_dt.itemsize])
+                else:
+                    raw = zlib.decompress(bytes(buf[heap + ptr:heap + ptr + length]), 15 + 32)
+                if len(raw) != n * out_dt.itemsize:
+                    raise ValueError(f"{path}: tile {t} ({col}) holds {len(raw)} bytes, expected {n * out_dt.itemsize}")
+                dest[...] = np.frombuffer(raw, dtype=out_dt).reshape(h, w)
+                break
         else:
-            raw = zlib.decompress(chunk, 15 + 32)              # zlib or gzip wrapper
-            if codec == "GZIP_2" and col == "COMPRESSED_DATA":     # byte planes, most significant first -> pixels
-                raw = np.frombuffer(raw, dtype=np.uint8).reshape(dt.itemsize, h * w).T.tobytes()
-        if len(raw) != nbytes:
-            raise ValueError(f"{path}: tile {t} decompressed to {len(raw)} bytes, expected {nbytes}")
-        out[ty * th:ty * th + h, tx * tw:tx * tw + w] = np.frombuffer(raw, dtype=dt).reshape(h, w)
+            raise ValueError(f"{path}: tile {t} has no data in any column")
+    if rice and quantised and bytepix == 4 and in_main.any():
+        sel = np.nonzero(in_main)[0]
+        flat = (rice_out.view(np.int32), np.array([rice_off[int(t)] for t in sel], dtype=np.int64))
+        _dequantise(out, flat, sel, ty * th, tx * tw, hs, ws, zscale, zzero, zblank_col, zblank_key, method, zdither0)
+    elif q_tiles:
+        _dequantise(out, q_parts, np.asarray(q_tiles), ty * th, tx * tw, hs, ws, zscale, zzero, zblank_col, zblank_key, method, zdither0)
     image_hdr = dict(hdr)
     image_hdr["BITPIX"] = zbitpix
     for key in ("BSCALE", "BZERO"):
@@ -210,31 +372,57 @@ def _read_compressed_image(path, hdr, buf, data_pos):
     return ImageHDU(path, image_hdr, None, decoded=out)
 
 
-def write_compressed_image_fits(path, image, header=None, codec="GZIP_2", tile_rows=1):
+def write_compressed_image_fits(path, image, header=None, codec="GZIP_2", tile_rows=1, quantise=None, blank_column=False):
     """Primary HDU + ONE tile-compressed image extension (BINTABLE, COMPRESSED_DATA as 1PB variable-length arrays, row tiles)
-    with a lossless gzip codec -- the layout read back by ``read_image_hdu`` (tests)."""
+    with a gzip codec -- the layout read back by ``read_image_hdu`` (tests).  Lossless by default; ``quantise=scale`` stores a
+    float32 image as int32 round((x - zero) / scale) with per-tile ZSCALE / ZZERO columns (ZQUANTIZ = 'NO_DITHER'), NaN as
+    ZBLANK (a header keyword, or a column with ``blank_column``)."""
     import zlib
     image = np.asarray(image)
     assert image.ndim == 2 and codec in ("GZIP_1", "GZIP_2")
     bitpix = {np.dtype("float32"): -32, np.dtype("float64"): -64, np.dtype("int16"): 16, np.dtype("int32"): 32}[image.dtype]
     be = image.astype(_BITPIX_DTYPE[bitpix])
     H, W = image.shape
-    chunks = []
+    NULL = -2147483647
+    chunks, scales, zeros = [], [], []
     for y in range(0, H, tile_rows):
-        raw = be[y:y + tile_rows].tobytes()
+        if quantise is not None:
+            assert bitpix == -32
+            tile = image[y:y + tile_rows].astype(np.float64)
+            zero = float(np.nanmin(tile)) if np.isfinite(tile).any() else 0.0
+            q = np.where(np.isnan(tile), NULL, np.rint((np.nan_to_num(tile) - zero) / quantise)).astype(">i4")
+            raw, item = q.tobytes(), 4
+            scales.append(float(quantise))
+            zeros.append(zero)
+        else:
+            raw, item = be[y:y + tile_rows].tobytes(), be.itemsize
         if codec == "GZIP_2":
-            n = len(raw) // be.itemsize
-            raw = np.frombuffer(raw, dtype=np.uint8).reshape(n, be.itemsize).T.tobytes()
+            n = len(raw) // item
+            raw = np.frombuffer(raw, dtype=np.uint8).reshape(n, item).T.tobytes()
         chunks.append(zlib.compress(raw, 6))
     offs = np.cumsum([0] + [len(c) for c in chunks[:-1]])
-    table = b"".join(np.array([len(c), o], dtype=">i4").tobytes() for c, o in zip(chunks, offs))
+    rows = []
+    for i, (c, o) in enumerate(zip(chunks, offs)):
+        row = np.array([len(c), o], dtype=">i4").tobytes()
+        if quantise is not None:
+            row += np.array([scales[i], zeros[i]], dtype=">f8").tobytes()
+            if blank_column:
+                row += np.array([NULL], dtype=">i4").tobytes()
+        rows.append(row)
+    table = b"".join(rows)
     heap = b"".join(chunks)
     primary = [_card("SIMPLE", True), _card("BITPIX", 8), _card("NAXIS", 0), _card("EXTEND", True)]
-    ext = [_card("XTENSION", "BINTABLE"), _card("BITPIX", 8), _card("NAXIS", 2), _card("NAXIS1", 8), _card("NAXIS2", len(chunks)),
-           _card("PCOUNT", len(heap)), _card("GCOUNT", 1), _card("TFIELDS", 1), _card("TTYPE1", "COMPRESSED_DATA"),
-           _card("TFORM1", f"1PB({max(len(c) for c in chunks)})"), _card("ZIMAGE", True), _card("ZCMPTYPE", codec),
-           _card("ZBITPIX", bitpix), _card("ZNAXIS", 2), _card("ZNAXIS1", W), _card("ZNAXIS2", H), _card("ZTILE1", W),
-           _card("ZTILE2", tile_rows), _card("ZQUANTIZ", "NONE")]
+    fields = [("COMPRESSED_DATA", f"1PB({max(len(c) for c in chunks)})")]
+    if quantise is not None:
+        fields += [("ZSCALE", "1D"), ("ZZERO", "1D")] + ([("ZBLANK", "1J")] if blank_column else [])
+    ext = [_card("XTENSION", "BINTABLE"), _card("BITPIX", 8), _card("NAXIS", 2), _card("NAXIS1", len(rows[0])), _card("NAXIS2", len(chunks)),
+           _card("PCOUNT", len(heap)), _card("GCOUNT", 1), _card("TFIELDS", len(fields))]
+    for i, (name, form) in enumerate(fields, 1):
+        ext += [_card(f"TTYPE{i}", name), _card(f"TFORM{i}", form)]
+    ext += [_card("ZIMAGE", True), _card("ZCMPTYPE", codec), _card("ZBITPIX", bitpix), _card("ZNAXIS", 2), _card("ZNAXIS1", W),
+            _card("ZNAXIS2", H), _card("ZTILE1", W), _card("ZTILE2", tile_rows), _card("ZQUANTIZ", "NONE" if quantise is None else "NO_DITHER")]
+    if quantise is not None and not blank_column:
+        ext.append(_card("ZBLANK", NULL))
     for k, v in (header or {}).items():
         ext.append(_card(k, v))
     data = table + heap

@@ -16,6 +16,7 @@ It writes, under tests/golden/io/ (data only; ``--out DIR`` writes elsewhere, ``
 * ``astropy_f4.fits``      -- empty primary HDU + a ``>f4`` IMAGE extension with NaNs and a TAN-SIP header (what HSC
   ``calexp`` patches carry; ``utils/dataloaders.py:418-432`` reads ``hdul[1].data`` and ``WCS(hdul[1].header)``).
 * ``astropy_i2_scaled.fits`` -- an int16 IMAGE extension with BSCALE / BZERO.
+* ``astropy_rice_*.fits``, ``astropy_gzip*_f4_*.fits`` -- tile-compressed images (``CompImageHDU``): see ``write_compressed_fits``.
 * ``io_expected.npz``      -- what h5py / astropy themselves read back from those files: the arrays, ``.data`` of both
   images, and ``WCS.all_pix2world(x, y, 0)`` / ``(x, y, 1)`` at a grid of pixels.
 """
@@ -143,6 +144,59 @@ def write_fits(expected):
         expected["fits_i2/ra_o0"], expected["fits_i2/dec_o0"] = np.asarray(ra), np.asarray(dec)
 
 
+COMPRESSED = (   # name, dtype, (H, W), CompImageHDU keywords
+    ("rice_i2", "int16", (37, 53), dict(compression_type="RICE_1")),
+    ("rice_i4_tiles", "int32", (45, 50), dict(compression_type="RICE_1", tile_size=(16, 20))),
+    ("rice_u1", "uint8", (20, 33), dict(compression_type="RICE_1")),
+    ("rice_f4_nodither", "float32", (40, 64), dict(compression_type="RICE_1", quantize_level=16.0, quantize_method=-1)),
+    # tiles of 100 x 100 pixels: the walk through the 10 000 random numbers restarts inside a tile; dither_seed near the table's end
+    ("rice_f4_dither1", "float32", (120, 110), dict(compression_type="RICE_1", tile_size=(100, 100), quantize_level=16.0,
+                                                    quantize_method=1, dither_seed=9999)),
+    ("rice_f4_dither2", "float32", (48, 70), dict(compression_type="RICE_1", tile_size=(70, 12), quantize_level=8.0,
+                                                  quantize_method=2, dither_seed=42)),
+    ("gzip1_f4_dither1", "float32", (30, 41), dict(compression_type="GZIP_1", quantize_level=16.0, quantize_method=1, dither_seed=7)),
+    ("gzip2_f4_lossless", "float32", (30, 41), dict(compression_type="GZIP_2", quantize_level=0.0)),
+)
+
+
+def write_compressed_fits(expected):
+    """Tile-compressed images as astropy's CompImageHDU (CFITSIO underneath) writes them, and what astropy reads back
+    (``fits.open(fn)[1].data``, utils/dataloaders.py:418-421): Rice on integers of 1 / 2 / 4 bytes, Rice and gzip on
+    quantised floats without dithering and with both subtractive dithers (NaN pixels -> ZBLANK; exact zeros under
+    SUBTRACTIVE_DITHER_2; a constant region, which the writer cannot quantise), 2-D tiles with ragged edges."""
+    rng = np.random.default_rng(20260106)
+    for name, dtype, (h, w), kw in COMPRESSED:
+        if dtype == "float32":
+            yy, xx = np.mgrid[0:h, 0:w]
+            img = (rng.standard_normal((h, w)) * 0.7 + 12.0 * np.exp(-((yy - h / 2) ** 2 + (xx - w / 3) ** 2) / 40.0)).astype(np.float32)
+            img[rng.random(img.shape) < 0.01] = np.nan
+            if kw.get("quantize_method") == 2:
+                img[rng.random(img.shape) < 0.05] = 0.0
+            img[: h // 3, : w // 4] = 3.5                          # constant patch
+        elif dtype == "uint8":
+            img = rng.integers(0, 256, (h, w)).astype(np.uint8)
+            img[5:9] = 17                                          # all-zero difference blocks
+        else:
+            lim = 2000 if dtype == "int16" else 200000
+            img = rng.integers(-lim, lim, (h, w)).astype(dtype)
+            img[3:6] = 7
+            img[10, 5:40] = rng.integers(np.iinfo(dtype).min, np.iinfo(dtype).max, 35).astype(dtype)   # high-entropy blocks
+        hd = fits.ImageHDU(data=img, header=tan_sip_header(h, w)).header       # (astropy 4.3 wants a complete image header)
+        p = os.path.join(OUT, f"astropy_{name}.fits")
+        fits.HDUList([fits.PrimaryHDU(), fits.CompImageHDU(data=img, header=hd, **kw)]).writeto(p, overwrite=True)
+        with fits.open(p, mode="readonly", ignore_missing_simple=True) as hdul:
+            data = np.array(hdul[1].data)
+            assert data.shape == (h, w)
+            expected[f"fits_{name}/data"] = data
+            if dtype != "float32" or kw.get("quantize_level") == 0.0:
+                assert np.array_equal(data, img, equal_nan=True)   # lossless
+        with fits.open(p, mode="readonly", disable_image_compression=True) as hdul:   # the table as it is on disk
+            th = hdul[1].header
+            expected[f"fits_{name}/ztile"] = np.array([th["ZTILE1"], th["ZTILE2"]])
+            expected[f"fits_{name}/zquantiz"] = np.array(str(th.get("ZQUANTIZ", "NONE")))
+            expected[f"fits_{name}/columns"] = np.array([c.name for c in hdul[1].columns])
+
+
 def main():
     global OUT
     full = "--full" in sys.argv          # the reference's real geometry (5 x 64 x 64): ~11 MB, made on the fly by the live test
@@ -152,6 +206,7 @@ def main():
     expected = {}
     write_h5(expected, full)
     write_fits(expected)
+    write_compressed_fits(expected)
     expected["versions"] = np.array([f"h5py {h5py.__version__}", f"hdf5 {h5py.version.hdf5_version}",
                                      f"astropy {__import__('astropy').__version__}", f"numpy {np.__version__}",
                                      f"python {sys.version.split()[0]}"])

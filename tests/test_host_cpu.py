@@ -495,7 +495,8 @@ def test_fits_lite_header_grammar_against_a_third_party_file():
 
 def test_fits_lite_reads_lossless_tile_compressed_images(tmp_path):
     """ZIMAGE binary tables with the lossless gzip codecs (FITS 4.0 section 10; what fpack -g / the LSST stack's GZIP_SHUFFLE
-    write) decode to the same pixels and keep the image header; lossy / other codecs are refused by name."""
+    write) decode to the same pixels and keep the image header; codecs outside the subset are refused by name (Rice and quantised
+    floats: tests/test_io_fixtures_cpu.py, against astropy-written files)."""
     from sky_embeddings_amd import fits_lite
     rng = np.random.default_rng(1)
     img = rng.standard_normal((37, 53)).astype(np.float32)
@@ -511,9 +512,9 @@ def test_fits_lite_reads_lossless_tile_compressed_images(tmp_path):
     assert np.array_equal(fits_lite.read_image_hdu(p, 1).array(), ints)
     raw = bytearray(open(p, "rb").read())
     at = raw.index(b"GZIP_2")
-    raw[at:at + 6] = b"RICE_1"
+    raw[at:at + 6] = b"PLIO_1"
     (tmp_path / "r.fits").write_bytes(bytes(raw))
-    with pytest.raises(NotImplementedError, match="RICE_1"):
+    with pytest.raises(NotImplementedError, match="PLIO_1"):
         fits_lite.read_image_hdu(str(tmp_path / "r.fits"), 1)
 
 
