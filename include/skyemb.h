@@ -342,14 +342,16 @@ int skyemb_gather_rows_host(const void *src, int64_t row_bytes, const int64_t *i
 int skyemb_h5_unchunk_host(const void *file_base, int64_t file_bytes, const int64_t *chunk_addr, const int64_t *chunk_off,
                            int64_t nchunks, int rank, const int64_t *chunk_dims, const int64_t *dset_dims, int elem_size, void *dst,
                            int nthreads);
-/* Rice-compressed tiles of a FITS tile-compressed image (ZCMPTYPE = 'RICE_1': what fpack and astropy's CompImageHDU write by
- * default; the reference reads such survey tiles through astropy, utils/dataloaders.py:418) -> pixels in the host's byte
- * order, native threads over the tiles; see fits_lite.py, which dequantises floating-point images afterwards.  HOST function.
- * Tile t: bytes [off[t], off[t] + len[t]) of `base` hold npix[t] pixels of `bytepix` (1, 2 or 4) bytes, coded in blocks of
- * `blocksize` differences; they are written to dst + dst_off[t] * bytepix (dst holds dst_pixels pixels). */
-int skyemb_fits_rice_tiles_host(const void *base, int64_t base_bytes, const int64_t *off, const int64_t *len, const int64_t *npix,
-                                const int64_t *dst_off, int64_t ntiles, int bytepix, int blocksize, void *dst, int64_t dst_pixels,
-                                int nthreads);
+/* The tiles of a FITS tile-compressed image (FITS 4.0 section 10; the reference reads such survey tiles through astropy / CFITSIO,
+ * utils/dataloaders.py:418) -> integer pixels in the host's byte order, native threads over the tiles; see fits_lite.py, which
+ * dequantises floating-point images afterwards.  HOST function.  codec 1 = RICE_1 (what fpack and astropy's CompImageHDU write by
+ * default; pixels of `bytepix` = 1, 2 or 4 bytes coded in blocks of `blocksize` differences), 2 = PLIO_1 (integer masks), 3 =
+ * HCOMPRESS_1 (both int32 pixels: bytepix = 4; an HCOMPRESS tile's stream carries its own dimensions, whose product must be npix[t]).
+ * Tile t: bytes [off[t], off[t] + len[t]) of `base` hold npix[t] pixels; they are written to dst + dst_off[t] * bytepix (dst holds
+ * dst_pixels pixels). */
+int skyemb_fits_decode_tiles_host(int codec, const void *base, int64_t base_bytes, const int64_t *off, const int64_t *len,
+                                  const int64_t *npix, const int64_t *dst_off, int64_t ntiles, int bytepix, int blocksize, void *dst,
+                                  int64_t dst_pixels, int nthreads);
 /* Quantised floating-point tiles of such an image -> float32 pixels placed in the image (FITS 4.0 section 10.2): q * ZSCALE + ZZERO,
  * or (q - r + 0.5) * ZSCALE + ZZERO with the convention's subtractive dither (method 1 / 2; 2: q == -2147483646 is exactly 0; method 0:
  * none).  rand: the convention's 10 000 random numbers (fits_lite.dither_sequence), table_row[t]: the tile's 0-based row in the table.

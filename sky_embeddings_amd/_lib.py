@@ -95,7 +95,7 @@ PROTOTYPES = {
                                          c_f32, c_f32, c_i32, c_i32, c_i32, c_f32, c_vp]),
     "skyemb_gather_rows_host": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i32]),
     "skyemb_h5_unchunk_host": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32]),
-    "skyemb_fits_rice_tiles_host": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_i32]),
+    "skyemb_fits_decode_tiles_host": (c_i32, [c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_i32]),
     "skyemb_fits_dequantise_tiles_host": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32,
                                                   c_vp, c_i64, c_i64, c_i32, c_i32]),
     "skyemb_augment": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),

@@ -12,11 +12,12 @@
 * ``write_image_fits``: writer for the same subset (tests, synthetic tiles).
 
 Tile-compressed images (``ZIMAGE`` binary tables, what ``fpack`` / astropy ``CompImageHDU`` / the LSST stack write; FITS 4.0
-section 10) are decoded on the host into a big-endian float32 / integer array: ``RICE_1`` (the default of both writers; native
-threads over the tiles, ``skyemb_fits_rice_tiles_host``), ``GZIP_1``, ``GZIP_2`` (byte-shuffled) and ``NOCOMPRESS``, for integer
+section 10) are decoded on the host into a big-endian float32 / integer array: ``RICE_1`` (the default of both writers),
+``PLIO_1`` and ``HCOMPRESS_1`` (native threads over the tiles, ``skyemb_fits_decode_tiles_host``), ``GZIP_1``, ``GZIP_2``
+(byte-shuffled) and ``NOCOMPRESS``, for integer
 images and for quantised floating-point images (``ZSCALE`` / ``ZZERO`` columns; ``NO_DITHER``, ``SUBTRACTIVE_DITHER_1`` / ``_2`` with
 the convention's random sequence; ``ZBLANK`` -> NaN; tiles the writer left unquantised in ``GZIP_COMPRESSED_DATA``).
-``HCOMPRESS_1`` / ``PLIO_1`` raise ``NotImplementedError`` by name: funpack such files.  Pinned against astropy-written files
+(``HCOMPRESS_1`` with the optional smoothing of the decompressed image is refused.)  Pinned against astropy-written files
 (``tests/golden/io``).
 """
 from __future__ import annotations
@@ -180,8 +181,12 @@ def _dither_indices(tile_index, zdither0, n):
     return np.concatenate(parts) if len(parts) > 1 else parts[0]
 
 
-def _rice_tiles(buf, offs, lens, npix, bytepix, blocksize):
-    """All Rice tiles of an image -> one flat native-endian unsigned array (tile after tile): skyemb_fits_rice_tiles_host."""
+_CODEC = {"RICE_1": 1, "RICE_ONE": 1, "PLIO_1": 2, "HCOMPRESS_1": 3}
+
+
+def _decode_tiles(codec, buf, offs, lens, npix, bytepix, blocksize):
+    """All Rice / PLIO / HCOMPRESS tiles of an image -> one flat native-endian unsigned array (tile after tile):
+    skyemb_fits_decode_tiles_host."""
     import ctypes
     from ._lib import check, lib
     offs, lens, npix = (np.ascontiguousarray(a, dtype=np.int64) for a in (offs, lens, npix))
@@ -190,8 +195,9 @@ def _rice_tiles(buf, offs, lens, npix, bytepix, blocksize):
     out = np.empty(total, dtype={1: np.uint8, 2: np.uint16, 4: np.uint32}[bytepix])
     base = np.ascontiguousarray(buf)                      # (a memmap stays a view of the mapping)
     ptr = lambda a: ctypes.c_void_p(a.ctypes.data)
-    check(lib().skyemb_fits_rice_tiles_host(ptr(base), base.size, ptr(offs), ptr(lens), ptr(npix), ptr(dst_off), len(npix), bytepix,
-                                            blocksize, ptr(out), total, min(16, os.cpu_count() or 1)), "skyemb_fits_rice_tiles_host")
+    check(lib().skyemb_fits_decode_tiles_host(_CODEC[codec], ptr(base), base.size, ptr(offs), ptr(lens), ptr(npix), ptr(dst_off), len(npix),
+                                              bytepix, blocksize, ptr(out), total, min(16, os.cpu_count() or 1)),
+          "skyemb_fits_decode_tiles_host")
     return out, dst_off
 
 
@@ -247,9 +253,9 @@ def _read_compressed_image(path, hdr, buf, data_pos):
     import re
     import zlib
     codec = str(hdr.get("ZCMPTYPE", "")).strip()
-    if codec not in ("RICE_1", "RICE_ONE", "GZIP_1", "GZIP_2", "NOCOMPRESS"):
-        raise NotImplementedError(f"{path}: tile compression {codec!r} is not supported (RICE_1, GZIP_1, GZIP_2, NOCOMPRESS): funpack the file")
-    rice = codec.startswith("RICE")
+    if codec not in ("RICE_1", "RICE_ONE", "GZIP_1", "GZIP_2", "NOCOMPRESS", "PLIO_1", "HCOMPRESS_1"):
+        raise NotImplementedError(f"{path}: tile compression {codec!r} is not one of RICE_1, GZIP_1, GZIP_2, PLIO_1, HCOMPRESS_1, NOCOMPRESS")
+    rice = codec in _CODEC                                    # (decoded natively, all tiles in one call)
     zbitpix, znaxis = int(hdr["ZBITPIX"]), int(hdr.get("ZNAXIS", 0))
     if znaxis != 2:
         raise NotImplementedError(f"{path}: compressed image with ZNAXIS = {znaxis} (2-D images only)")
@@ -278,10 +284,14 @@ def _read_compressed_image(path, hdr, buf, data_pos):
     # algorithm parameters (ZNAMEi / ZVALi) and the quantisation of floating-point pixels
     params = {str(hdr[f"ZNAME{i}"]).strip().upper(): hdr.get(f"ZVAL{i}") for i in range(1, 10) if f"ZNAME{i}" in hdr}
     blocksize, bytepix = int(params.get("BLOCKSIZE", 32)), int(params.get("BYTEPIX", 4))
+    if codec in ("PLIO_1", "HCOMPRESS_1"):
+        bytepix = 4                                           # (both decode to 32-bit integers)
+        if codec == "HCOMPRESS_1" and int(params.get("SMOOTH", 0) or 0) != 0:
+            raise NotImplementedError(f"{path}: HCOMPRESS_1 with SMOOTH = {params.get('SMOOTH')} (smoothed decompression)")
     quantised = zbitpix < 0 and "ZSCALE" in cols
     method = str(hdr.get("ZQUANTIZ", "NO_DITHER" if quantised else "NONE")).strip().upper()
     if zbitpix < 0 and rice and not quantised:
-        raise ValueError(f"{path}: RICE_1 floating-point image without ZSCALE / ZZERO columns")
+        raise ValueError(f"{path}: {codec} floating-point image without ZSCALE / ZZERO columns")
     if method not in ("NONE", "", "NO_DITHER", "SUBTRACTIVE_DITHER_1", "SUBTRACTIVE_DITHER_2"):
         raise NotImplementedError(f"{path}: ZQUANTIZ = {method!r}")
     zdither0 = int(hdr.get("ZDITHER0", 1))
@@ -317,7 +327,8 @@ def _read_compressed_image(path, hdr, buf, data_pos):
         if bytepix not in (1, 2, 4):
             raise NotImplementedError(f"{path}: RICE_1 with BYTEPIX = {bytepix}")
         sel = np.nonzero(in_main)[0]
-        rice_out, offs_sel = _rice_tiles(buf, heap + main[sel, 1], main[sel, 0], npix[sel], bytepix, blocksize)
+        words = 2 if cols["COMPRESSED_DATA"][2] == "I" else 1      # PLIO_1: 16-bit words (1PI); the others are byte arrays
+        rice_out, offs_sel = _decode_tiles(codec, buf, heap + main[sel, 1], main[sel, 0] * words, npix[sel], bytepix, blocksize)
         rice_off = dict(zip(sel.tolist(), offs_sel.tolist()))
     signed = {1: np.uint8, 2: np.int16, 4: np.int32}          # (8-bit FITS pixels are unsigned)
     q_parts, q_tiles = [], []                                 # quantised tiles: dequantised together below

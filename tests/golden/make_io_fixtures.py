@@ -156,14 +156,20 @@ COMPRESSED = (   # name, dtype, (H, W), CompImageHDU keywords
                                                   quantize_method=2, dither_seed=42)),
     ("gzip1_f4_dither1", "float32", (30, 41), dict(compression_type="GZIP_1", quantize_level=16.0, quantize_method=1, dither_seed=7)),
     ("gzip2_f4_lossless", "float32", (30, 41), dict(compression_type="GZIP_2", quantize_level=0.0)),
+    ("plio_i4", "mask", (23, 37), dict(compression_type="PLIO_1")),
+    ("hcompress_i2", "int16", (40, 52), dict(compression_type="HCOMPRESS_1", hcomp_scale=0, tile_size=(52, 16))),
+    ("hcompress_i4_odd", "int32", (37, 45), dict(compression_type="HCOMPRESS_1", hcomp_scale=0, tile_size=(45, 13))),
+    ("hcompress_f4_lossy", "float32", (48, 40), dict(compression_type="HCOMPRESS_1", hcomp_scale=2.0, quantize_level=16.0, quantize_method=1,
+                                                     dither_seed=5, tile_size=(40, 16))),
 )
 
 
 def write_compressed_fits(expected):
     """Tile-compressed images as astropy's CompImageHDU (CFITSIO underneath) writes them, and what astropy reads back
     (``fits.open(fn)[1].data``, utils/dataloaders.py:418-421): Rice on integers of 1 / 2 / 4 bytes, Rice and gzip on
-    quantised floats without dithering and with both subtractive dithers (NaN pixels -> ZBLANK; exact zeros under
-    SUBTRACTIVE_DITHER_2; a constant region, which the writer cannot quantise), 2-D tiles with ragged edges."""
+    quantised floats without dithering and with both subtractive dithers (exact zeros under SUBTRACTIVE_DITHER_2; a constant
+    region, which the writer cannot quantise), 2-D tiles with ragged edges; PLIO_1 on a mask-like image; HCOMPRESS_1 lossless on
+    16- and 32-bit integers (odd tile sides) and lossy (scale 2) on dithered quantised floats."""
     rng = np.random.default_rng(20260106)
     for name, dtype, (h, w), kw in COMPRESSED:
         if dtype == "float32":
@@ -173,6 +179,12 @@ def write_compressed_fits(expected):
             if kw.get("quantize_method") == 2:
                 img[rng.random(img.shape) < 0.05] = 0.0
             img[: h // 3, : w // 4] = 3.5                          # constant patch
+        elif dtype == "mask":                                      # PLIO_1: non-negative integers below 2^24, long runs
+            img = rng.integers(0, 50, (h, w)).astype(np.int32)
+            img[5:9] = 0
+            img[10, :20] = 100000
+            img[12, 3:30] = 7
+            img[13] = np.arange(w) * 500
         elif dtype == "uint8":
             img = rng.integers(0, 256, (h, w)).astype(np.uint8)
             img[5:9] = 17                                          # all-zero difference blocks
@@ -189,7 +201,7 @@ def write_compressed_fits(expected):
             assert data.shape == (h, w)
             expected[f"fits_{name}/data"] = data
             if dtype != "float32" or kw.get("quantize_level") == 0.0:
-                assert np.array_equal(data, img, equal_nan=True)   # lossless
+                assert np.array_equal(data, img, equal_nan=True)   # lossless (HCOMPRESS_1 with scale 0 included)
         with fits.open(p, mode="readonly", disable_image_compression=True) as hdul:   # the table as it is on disk
             th = hdul[1].header
             expected[f"fits_{name}/ztile"] = np.array([th["ZTILE1"], th["ZTILE2"]])

@@ -512,9 +512,9 @@ def test_fits_lite_reads_lossless_tile_compressed_images(tmp_path):
     assert np.array_equal(fits_lite.read_image_hdu(p, 1).array(), ints)
     raw = bytearray(open(p, "rb").read())
     at = raw.index(b"GZIP_2")
-    raw[at:at + 6] = b"PLIO_1"
+    raw[at:at + 6] = b"LZMA_1"
     (tmp_path / "r.fits").write_bytes(bytes(raw))
-    with pytest.raises(NotImplementedError, match="PLIO_1"):
+    with pytest.raises(NotImplementedError, match="LZMA_1"):
         fits_lite.read_image_hdu(str(tmp_path / "r.fits"), 1)
 
 

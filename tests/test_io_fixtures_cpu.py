@@ -74,14 +74,15 @@ def check_fits(folder, exp):
 
 
 COMPRESSED = ("rice_i2", "rice_i4_tiles", "rice_u1", "rice_f4_nodither", "rice_f4_dither1", "rice_f4_dither2", "gzip1_f4_dither1",
-              "gzip2_f4_lossless")
+              "gzip2_f4_lossless", "plio_i4", "hcompress_i2", "hcompress_i4_odd", "hcompress_f4_lossy")
 
 
 def check_compressed_fits(folder, exp):
     """Tile-compressed images written by astropy's CompImageHDU: what ``fits_lite`` decodes == what astropy's ``.data`` holds,
     bit for bit (Rice on 1 / 2 / 4-byte integers; Rice and gzip on quantised floats, undithered and with both subtractive
     dithers -- the 100 x 100 tiles of ``rice_f4_dither1`` walk past the end of the random table, its ZDITHER0 = 9999 wraps the
-    seed index; unquantisable tiles in GZIP_COMPRESSED_DATA)."""
+    seed index; unquantisable tiles in GZIP_COMPRESSED_DATA; PLIO_1; HCOMPRESS_1 lossless on integers with odd tile sides and
+    lossy on dithered floats)."""
     for name in COMPRESSED:
         hdu = fits_lite.read_image_hdu(os.path.join(folder, f"astropy_{name}.fits"), hdu=1)
         want = exp[f"fits_{name}/data"]
@@ -122,8 +123,8 @@ def test_tile_compressed_nulls_and_refusals(tmp_path):
     src = os.path.join(IO, "astropy_rice_i2.fits")
     raw = bytearray(open(src, "rb").read())
     p = str(tmp_path / "h.fits")
-    open(p, "wb").write(bytes(raw).replace(b"ZCMPTYPE= 'RICE_1  '", b"ZCMPTYPE= 'PLIO_1  '"))
-    with pytest.raises(NotImplementedError, match="PLIO_1"):
+    open(p, "wb").write(bytes(raw).replace(b"ZCMPTYPE= 'RICE_1  '", b"ZCMPTYPE= 'BZIP2_1 '"))
+    with pytest.raises(NotImplementedError, match="BZIP2_1"):
         fits_lite.read_image_hdu(p, hdu=1)
     hdu = fits_lite.read_image_hdu(src, hdu=1)                          # (sanity: the untouched file reads)
     assert hdu.shape == (37, 53)
@@ -137,6 +138,17 @@ def test_tile_compressed_nulls_and_refusals(tmp_path):
     open(p, "wb").write(bytes(cut))
     with pytest.raises((RuntimeError, ValueError), match="Rice|rice"):
         fits_lite.read_image_hdu(p, hdu=1)
+    for name, what in (("hcompress_i2", "HCOMPRESS"), ("plio_i4", "PLIO")):      # the same damage to the other native codecs
+        raw = bytearray(open(os.path.join(IO, f"astropy_{name}.fits"), "rb").read())
+        buf = np.frombuffer(bytes(raw), dtype=np.uint8)
+        _, pos = fits_lite._read_header(buf, 0)
+        hdr, data_pos = fits_lite._read_header(buf, pos)
+        heap = data_pos + hdr["NAXIS1"] * hdr["NAXIS2"]
+        raw[heap:heap + 64] = b"\x7f" * 64
+        p = str(tmp_path / f"cut_{name}.fits")
+        open(p, "wb").write(bytes(raw))
+        with pytest.raises((RuntimeError, ValueError), match=what):
+            fits_lite.read_image_hdu(p, hdu=1)
 
 
 def test_committed_h5py_files_read_bit_exactly(tmp_path):
