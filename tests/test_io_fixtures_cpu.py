@@ -107,6 +107,22 @@ def test_committed_tile_compressed_files_read_bit_exactly():
     check_compressed_fits(IO, exp)
 
 
+def test_survey_tile_loader_on_compressed_bands():
+    """``load_fits_bands`` (the host mirror of utils/dataloaders.py:381-447) over tile-compressed band files: the planes are what
+    astropy reads, a missing band is a NaN plane, the RA / Dec callback comes from the first band's header."""
+    from sky_embeddings_amd.utils.dataloaders import load_fits_bands
+    exp = np.load(os.path.join(IO, "io_expected.npz"))
+    files = [os.path.join(IO, "astropy_gzip1_f4_dither1.fits"), "None", os.path.join(IO, "astropy_gzip2_f4_lossless.fits")]
+    tile, pix_to_radec = load_fits_bands(files, return_wc=True)
+    assert tile.shape == (3, 30, 41) and np.isnan(tile[1]).all()
+    assert same(tile[0].astype(np.float32), exp["fits_gzip1_f4_dither1/data"].astype(np.float32))
+    assert same(tile[2].astype(np.float32), exp["fits_gzip2_f4_lossless/data"].astype(np.float32))
+    ra, dec = pix_to_radec(np.array([0.0, 40.0]), np.array([0.0, 29.0]))
+    assert np.all(np.isfinite(ra)) and np.all(np.abs(dec - 2.2057) < 0.01)
+    tile, _ = load_fits_bands([os.path.join(IO, "astropy_rice_f4_dither1.fits")])
+    assert same(tile[0].astype(np.float32), exp["fits_rice_f4_dither1/data"].astype(np.float32))
+
+
 def test_tile_compressed_nulls_and_refusals(tmp_path):
     """What no astropy 4.3 file exercises (its writer does no null checking): ZBLANK -> NaN, as keyword and as column, on this
     package's own quantising writer; codecs outside the subset and damaged Rice streams are refused loudly."""
