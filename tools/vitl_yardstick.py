@@ -10,7 +10,8 @@ not do; rounds 4-5 compared the two anyway.  Columns per shape and direction:
   blas      ... hipBLASLt's plain GEMM
   blas+ew   hipBLASLt + the elementwise torch kernels that produce what `step` produces (bias / GELU + pre-activation / residual add
             in fp32 / dGELU multiply): what the layer costs without the fusion
-usage: vitl_yardstick.py [bf16|f16]  (one MI355X)"""
+  t256      (with a third argument "t256") the step's launch forced onto the 256 x 256 persistent kernel, whatever the plan picks
+usage: vitl_yardstick.py [bf16|f16] [t256]  (one MI355X)"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,6 +20,7 @@ from sky_embeddings_amd.ops import ACT_DGELU, ACT_GELU, KC, RC
 M, D = 8320, 1024
 dev = "cuda"
 T = torch.float16 if (len(sys.argv) > 1 and sys.argv[1] == "f16") else torch.bfloat16
+T256 = len(sys.argv) > 2 and sys.argv[2] == "t256"
 
 
 def timeit(f):
@@ -53,6 +55,7 @@ for name, N, K, epi in (("qkv", 3 * D, D, "bias"), ("proj", D, D, "resid"), ("fc
     dx, aux = torch.empty(M, K, device=dev, dtype=T), torch.randn(M, K, device=dev).to(T)
     if epi == "gelu":
         fwd = lambda: ops.gemm(x, w, M=M, N=N, K=K, bias=bias, act=ACT_GELU, out=y, out2=y2)
+        fwd256 = lambda: ops.gemm(x, w, M=M, N=N, K=K, bias=bias, act=ACT_GELU, out=y, out2=y2, tile=256256)
 
         def blas_ew():
             torch.matmul(x, w.t(), out=y2)
@@ -60,12 +63,14 @@ for name, N, K, epi in (("qkv", 3 * D, D, "bias"), ("proj", D, D, "resid"), ("fc
             torch.nn.functional.gelu(y2, approximate="none")     # activation (allocating: torch has no out= form)
     elif epi == "resid":
         fwd = lambda: ops.gemm(x, w, M=M, N=N, K=K, bias=bias, resid=res, ldr=N, out_f32=y32, ws=ws)
+        fwd256 = lambda: ops.gemm(x, w, M=M, N=N, K=K, bias=bias, resid=res, ldr=N, out_f32=y32, ws=ws, tile=256256)
 
         def blas_ew():
             torch.matmul(x, w.t(), out=y)
             torch.add(res, y, out=y32)                           # fp32 residual stream: read + write (bias folded in would be a third op)
     else:
         fwd = lambda: ops.gemm(x, w, M=M, N=N, K=K, bias=bias, out=y)
+        fwd256 = lambda: ops.gemm(x, w, M=M, N=N, K=K, bias=bias, out=y, tile=256256)
 
         def blas_ew():
             torch.matmul(x, w.t(), out=y)
@@ -74,6 +79,7 @@ for name, N, K, epi in (("qkv", 3 * D, D, "bias"), ("proj", D, D, "resid"), ("fc
     blas = lambda: torch.matmul(x, w.t(), out=y)
     kw = dict(act=ACT_DGELU, aux=aux, ldaux=K) if name == "fc2" else {}
     dgrad = lambda: ops.gemm(dy, w, M=M, N=K, K=N, a_layout=KC, b_layout=RC, lda=N, ldb=K, out=dx, ws=ws, **kw)
+    dgrad256 = lambda: ops.gemm(dy, w, M=M, N=K, K=N, a_layout=KC, b_layout=RC, lda=N, ldb=K, out=dx, ws=ws, tile=256256, **kw)
     dplain = lambda: ops.gemm(dy, w, M=M, N=K, K=N, a_layout=KC, b_layout=RC, lda=N, ldb=K, out=dx, ws=ws)
     dblas = lambda: torch.matmul(dy, w, out=dx)
     if name == "fc2":
@@ -84,10 +90,12 @@ for name, N, K, epi in (("qkv", 3 * D, D, "bias"), ("proj", D, D, "resid"), ("fc
     else:
         dblas_ew = dblas
     fl = 2.0 * M * N * K
-    for tag, fs in (("fwd", (fwd, plain, blas, blas_ew)), ("dgrad", (dgrad, dplain, dblas, dblas_ew))):
+    for tag, fs in (("fwd", (fwd, plain, blas, blas_ew, fwd256)), ("dgrad", (dgrad, dplain, dblas, dblas_ew, dgrad256))):
+        t256 = timeit(fs[4]) if T256 else None
+        fs = fs[:4]
         t = [timeit(f) for f in fs]
         for k_, v in zip(tot, t):
             tot[k_] += v
         print(f"{name:5s} {tag:5s} [{M} x {(N if tag == 'fwd' else K)} x {(K if tag == 'fwd' else N)}]  step {t[0]:6.1f} us {fl / t[0] / 1e6:5.0f} TF | plain {t[1]:6.1f} us "
-              f"{fl / t[1] / 1e6:5.0f} TF | blas {t[2]:6.1f} us {fl / t[2] / 1e6:5.0f} TF | blas+ew {t[3]:6.1f} us", flush=True)
+              f"{fl / t[1] / 1e6:5.0f} TF | blas {t[2]:6.1f} us {fl / t[2] / 1e6:5.0f} TF | blas+ew {t[3]:6.1f} us" + (f" | t256 {t256:6.1f} us" if T256 else ""), flush=True)
 print("sum of the eight launches (one block, forward + data gradients): " + " | ".join(f"{k} {v:6.1f} us" for k, v in tot.items()))
