@@ -43,6 +43,12 @@ def timeit(f):
 
 
 ws = torch.zeros(8 * 1024 * 1024, device=dev)
+# (round 6: half a second of matrix work before the first timing -- the first group measured after start-up read 10-15 % slow:
+# qkv fwd 77.4 us first, 65.7 us as the last of its group, same launch)
+_wa, _wb = torch.randn(4096, 4096, device=dev).to(T), torch.randn(4096, 4096, device=dev).to(T)
+for _ in range(400):
+    torch.matmul(_wa, _wb)
+torch.cuda.synchronize()
 print(f"# operand format {T}; us per launch, 20 launches per HIP graph")
 tot = dict(step=0.0, plain=0.0, blas=0.0, blas_ew=0.0)
 for name, N, K, epi in (("qkv", 3 * D, D, "bias"), ("proj", D, D, "resid"), ("fc1", 4 * D, D, "gelu"), ("fc2", D, 4 * D, "resid")):
