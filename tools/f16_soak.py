@@ -52,3 +52,48 @@ for name, dt in (("f16", torch.float16), ("bf16", torch.bfloat16), ("f32", torch
         sys.exit(1)
     del step, opt, eng
     torch.cuda.empty_cache()
+
+
+def soak_mim19(steps):
+    """The same for configs/mim_19.ini (SimMIM ViT-L/16 on 5 x 128 x 128, batch 128, 24 blocks): fp16 beside bf16."""
+    import configparser
+    from sky_embeddings_amd.simmim_engine import SimMIMEngine
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ini = configparser.ConfigParser()
+    ini.read(os.path.join(root, "configs", "mim_19.ini"))
+    a, t = ini["ARCHITECTURE"], ini["TRAINING"]
+    cfg19 = config_for(a["model_type"], img_size=int(a["img_size"]), patch_size=int(a["patch_size"]), in_chans=int(a["num_channels"]),
+                       embed_dim=int(a["embed_dim"]), norm_pix_loss=t.getboolean("norm_pix_loss"), loss_fn=t["loss_fn"])
+    Bm = int(t["batch_size"])
+    L, p = cfg19.num_patches, cfg19.patch_size
+    count = int(np.ceil(L * float(t["max_mask_ratio"])))
+    big = torch.nn.functional.interpolate(data[:1024], size=(cfg19.img_size, cfg19.img_size), mode="bilinear").nan_to_num_(nan=float("nan"))
+    for name, dt in (("f16", torch.float16), ("bf16", torch.bfloat16)):
+        eng = SimMIMEngine(cfg19, device="cuda", compute_dtype=dt, seed=0)
+        opt = FusedAdamW(eng, lr=float(t["init_lr"]), betas=(0.9, 0.95), weight_decay=float(t["weight_decay"]))
+        step = TrainStep(eng, opt, CosineLR(opt, steps), Bm)
+        g = torch.Generator(device="cuda").manual_seed(2)
+        t0, out, acc = time.time(), [], []
+        for it in range(steps):
+            idx = torch.randint(0, big.shape[0], (Bm,), device="cuda", generator=g)
+            order = torch.rand(Bm, cfg19.in_chans, L, device="cuda", generator=g).argsort(dim=2)
+            m = (order < count).float().view(Bm, cfg19.in_chans, cfg19.grid, cfg19.grid).repeat_interleave(p, 2).repeat_interleave(p, 3).contiguous()
+            step.load_batch(big[idx], m)
+            acc.append(step())
+            if (it + 1) % 100 == 0:
+                out.append(float(torch.stack(acc).mean()))
+                acc = []
+                if not np.isfinite(out[-1]):
+                    print("mim_19", name, "NON-FINITE loss at step", it + 1)
+                    sys.exit(1)
+        finite = bool(torch.isfinite(eng.store.p).all())
+        print(f"mim_19 {name:5s} loss scale {getattr(eng, 'loss_scale', 1.0):g}  mean loss per 100 steps: " + " ".join(f"{v:.4f}" for v in out) +
+              f"  | parameters finite: {finite}  ({time.time() - t0:.0f} s)", flush=True)
+        if not finite:
+            sys.exit(1)
+        del step, opt, eng
+        torch.cuda.empty_cache()
+
+
+if os.environ.get("SOAK_MIM19", "1") != "0":
+    soak_mim19(int(os.environ.get("SOAK_MIM19_STEPS", "600")))
