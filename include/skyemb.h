@@ -346,7 +346,8 @@ int skyemb_h5_unchunk_host(const void *file_base, int64_t file_bytes, const int6
  * utils/dataloaders.py:418) -> integer pixels in the host's byte order, native threads over the tiles; see fits_lite.py, which
  * dequantises floating-point images afterwards.  HOST function.  codec 1 = RICE_1 (what fpack and astropy's CompImageHDU write by
  * default; pixels of `bytepix` = 1, 2 or 4 bytes coded in blocks of `blocksize` differences), 2 = PLIO_1 (integer masks), 3 =
- * HCOMPRESS_1 (both int32 pixels: bytepix = 4; an HCOMPRESS tile's stream carries its own dimensions, whose product must be npix[t]).
+ * HCOMPRESS_1 (both int32 pixels: bytepix = 4; an HCOMPRESS tile's stream carries its own dimensions, whose product must be npix[t];
+ * for HCOMPRESS `blocksize` carries the SMOOTH flag of the image, 0 or 1).
  * Tile t: bytes [off[t], off[t] + len[t]) of `base` hold npix[t] pixels; they are written to dst + dst_off[t] * bytepix (dst holds
  * dst_pixels pixels). */
 int skyemb_fits_decode_tiles_host(int codec, const void *base, int64_t base_bytes, const int64_t *off, const int64_t *len,

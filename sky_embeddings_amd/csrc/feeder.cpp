@@ -448,7 +448,73 @@ void unshuffle(int64_t *a, int n, int n2, int64_t *tmp) {
     for (int i = nhalf - 1; i >= 0; --i) a[(int64_t)n2 * 2 * i] = a[(int64_t)n2 * i];
     for (int i = 1, t = 0; i < n; i += 2, ++t) a[(int64_t)n2 * i] = tmp[t];
 }
-void hinv(int64_t *a, int nx, int ny) {
+// The optional smoothing of a lossy image on decompression (ZNAME 'SMOOTH' = 1): between the levels of the inverse transform the
+// differences of a 2 x 2 block are moved towards the slopes and the curvature that the sums of the NEIGHBOURING blocks imply -- by at
+// most scale / 2 (what the division by `scale` may have rounded away) and never past a monotone interpolation.
+void hsmooth(int64_t *a, int nxtop, int nytop, int ny, int scale) {
+    const int64_t smax = scale >> 1;
+    if (smax <= 0) return;
+    auto mn = [](int64_t x, int64_t y) { return x < y ? x : y; };
+    auto mx = [](int64_t x, int64_t y) { return x > y ? x : y; };
+    const int64_t ny2 = (int64_t)ny << 1;
+    for (int i = 2; i < nxtop - 2; i += 2) {              // the x difference hx
+        int64_t s00 = (int64_t)ny * i, s10 = s00 + ny;
+        for (int j = 0; j < nytop; j += 2) {
+            const int64_t hm = a[s00 - ny2], h0 = a[s00], hp = a[s00 + ny2];
+            int64_t diff = hp - hm;
+            const int64_t dmax = mx(mn(hp - h0, h0 - hm), 0) * 4, dmin = mn(mx(hp - h0, h0 - hm), 0) * 4;
+            if (dmin < dmax) {
+                diff = mx(mn(diff, dmax), dmin);
+                int64_t s_ = diff - a[s10] * 8;
+                s_ = s_ >= 0 ? (s_ >> 3) : ((s_ + 7) >> 3);
+                s_ = mx(mn(s_, smax), -smax);
+                a[s10] += s_;
+            }
+            s00 += 2;
+            s10 += 2;
+        }
+    }
+    for (int i = 0; i < nxtop; i += 2) {                  // the y difference hy
+        int64_t s00 = (int64_t)ny * i + 2;
+        for (int j = 2; j < nytop - 2; j += 2) {
+            const int64_t hm = a[s00 - 2], h0 = a[s00], hp = a[s00 + 2];
+            int64_t diff = hp - hm;
+            const int64_t dmax = mx(mn(hp - h0, h0 - hm), 0) * 4, dmin = mn(mx(hp - h0, h0 - hm), 0) * 4;
+            if (dmin < dmax) {
+                diff = mx(mn(diff, dmax), dmin);
+                int64_t s_ = diff - a[s00 + 1] * 8;
+                s_ = s_ >= 0 ? (s_ >> 3) : ((s_ + 7) >> 3);
+                s_ = mx(mn(s_, smax), -smax);
+                a[s00 + 1] += s_;
+            }
+            s00 += 2;
+        }
+    }
+    for (int i = 2; i < nxtop - 2; i += 2) {              // the curvature difference hc
+        int64_t s00 = (int64_t)ny * i + 2, s10 = s00 + ny;
+        for (int j = 2; j < nytop - 2; j += 2) {
+            const int64_t hmm = a[s00 - ny2 - 2], hpm = a[s00 + ny2 - 2], hmp = a[s00 - ny2 + 2], hpp = a[s00 + ny2 + 2], h0 = a[s00];
+            int64_t diff = hpp + hmm - hmp - hpm;
+            const int64_t hx2 = a[s10] * 2, hy2 = a[s00 + 1] * 2;
+            int64_t m1 = mn(mx(hpp - h0, 0) - hx2 - hy2, mx(h0 - hpm, 0) + hx2 - hy2);
+            int64_t m2 = mn(mx(h0 - hmp, 0) - hx2 + hy2, mx(hmm - h0, 0) + hx2 + hy2);
+            const int64_t dmax = mn(m1, m2) * 16;
+            m1 = mx(mn(hpp - h0, 0) - hx2 - hy2, mn(h0 - hpm, 0) + hx2 - hy2);
+            m2 = mx(mn(h0 - hmp, 0) - hx2 + hy2, mn(hmm - h0, 0) + hx2 + hy2);
+            const int64_t dmin = mx(m1, m2) * 16;
+            if (dmin < dmax) {
+                diff = mx(mn(diff, dmax), dmin);
+                int64_t s_ = diff - a[s10 + 1] * 64;
+                s_ = s_ >= 0 ? (s_ >> 6) : ((s_ + 63) >> 6);
+                s_ = mx(mn(s_, smax), -smax);
+                a[s10 + 1] += s_;
+            }
+            s00 += 2;
+            s10 += 2;
+        }
+    }
+}
+void hinv(int64_t *a, int nx, int ny, int smooth, int scale) {
     const int nmax = nx > ny ? nx : ny;
     int log2n = 0;
     while ((1 << log2n) < nmax) ++log2n;
@@ -473,6 +539,7 @@ void hinv(int64_t *a, int nx, int ny) {
         }
         for (int i = 0; i < nxtop; ++i) unshuffle(a + (int64_t)ny * i, nytop, 1, tmp.data());
         for (int j = 0; j < nytop; ++j) unshuffle(a + j, nxtop, ny, tmp.data());
+        if (smooth) hsmooth(a, nxtop, nytop, ny, scale);
         const int oddx = nxtop % 2, oddy = nytop % 2;
         int i;
         for (i = 0; i < nxtop - oddx; i += 2) {
@@ -529,7 +596,7 @@ void hinv(int64_t *a, int nx, int ny) {
         nrnd0 = prnd0 - 1;
     }
 }
-int hcompress_decode_tile(const uint8_t *src, int64_t nbytes, int64_t npix, int32_t *out) {
+int hcompress_decode_tile(const uint8_t *src, int64_t nbytes, int64_t npix, int32_t *out, int smooth) {
     if (nbytes < 2 + 12 + 8 + 3 || src[0] != 0xDD || src[1] != 0x99) return 1;
     auto be32 = [&](const uint8_t *p) { return (int32_t)(((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]); };
     const int nx = be32(src + 2), ny = be32(src + 6), scale = be32(src + 10);
@@ -539,7 +606,7 @@ int hcompress_decode_tile(const uint8_t *src, int64_t nbytes, int64_t npix, int3
     const int nbp[3] = {src[22], src[23], src[24]};
     // (bounds far beyond what 32-bit pixels produce -- coefficients below 2^36, tile sums below 2^56 -- so that a damaged stream
     // cannot overflow the 64-bit arithmetic below)
-    const int64_t sum_cap = ((int64_t)1 << 58) / (scale > 1 ? scale : 1);
+    const int64_t sum_cap = ((int64_t)1 << 56) / (scale > 1 ? scale : 1);      // (x 64 in the smoothing stays below 2^63)
     if (nbp[0] > 36 || nbp[1] > 36 || nbp[2] > 36 || scale < 0 || scale > (1 << 20) || sumall > sum_cap || sumall < -sum_cap) return 1;
     std::vector<int64_t> a((size_t)npix, 0);
     std::vector<uint8_t> scratch;
@@ -558,7 +625,7 @@ int hcompress_decode_tile(const uint8_t *src, int64_t nbytes, int64_t npix, int3
     a[0] = sumall;
     if (scale > 1)
         for (int64_t i = 0; i < npix; ++i) a[i] *= scale;
-    hinv(a.data(), nx, ny);
+    hinv(a.data(), nx, ny, smooth, scale);
     for (int64_t i = 0; i < npix; ++i) out[i] = (int32_t)a[i];
     return 0;
 }
@@ -566,12 +633,12 @@ int hcompress_decode_tile(const uint8_t *src, int64_t nbytes, int64_t npix, int3
 
 // ntiles compressed tile streams -> integer pixels in the host's byte order.  codec 1 = RICE_1 (pixels of `bytepix` = 1, 2 or 4 bytes,
 // blocks of `blocksize` differences), 2 = PLIO_1, 3 = HCOMPRESS_1 (both: int32 pixels, bytepix must be 4; the stream of an
-// HCOMPRESS tile carries its own dimensions, whose product must be npix[t]).  Tile t: bytes [off[t], off[t] + len[t]) of `base`
+// HCOMPRESS tile carries its own dimensions, whose product must be npix[t]; for HCOMPRESS `blocksize` is the SMOOTH flag, 0 or 1).  Tile t: bytes [off[t], off[t] + len[t]) of `base`
 // hold npix[t] pixels, written to dst + dst_off[t] * bytepix.  HOST function (threads over tiles).
 extern "C" int skyemb_fits_decode_tiles_host(int codec, const void *base, int64_t base_bytes, const int64_t *off, const int64_t *len,
                                              const int64_t *npix, const int64_t *dst_off, int64_t ntiles, int bytepix, int blocksize, void *dst,
                                              int64_t dst_pixels, int nthreads) {
-    if (!base || !off || !len || !npix || !dst_off || !dst || ntiles < 0 || codec < 1 || codec > 3 || (codec == 1 && blocksize < 1) ||
+    if (!base || !off || !len || !npix || !dst_off || !dst || ntiles < 0 || codec < 1 || codec > 3 || (codec == 1 && blocksize < 1) || (codec == 3 && (blocksize < 0 || blocksize > 1)) ||
         (bytepix != 1 && bytepix != 2 && bytepix != 4) || (codec != 1 && bytepix != 4)) {
         skyemb_set_error("skyemb_fits_decode_tiles_host: bad arguments (codec %d, bytepix %d, blocksize %d)", codec, bytepix, blocksize);
         return 1;
@@ -591,7 +658,7 @@ extern "C" int skyemb_fits_decode_tiles_host(int codec, const void *base, int64_
             const uint8_t *s = (const uint8_t *)base + off[t];
             int rc;
             if (codec == 2) rc = (len[t] & 1) ? 1 : plio_decode_tile(s, len[t] / 2, npix[t], (int32_t *)dst + dst_off[t]);
-            else if (codec == 3) rc = hcompress_decode_tile(s, len[t], npix[t], (int32_t *)dst + dst_off[t]);
+            else if (codec == 3) rc = hcompress_decode_tile(s, len[t], npix[t], (int32_t *)dst + dst_off[t], blocksize);
             else if (bytepix == 4) rc = rice_decode_tile<uint32_t>(s, len[t], blocksize, npix[t], (uint32_t *)dst + dst_off[t]);
             else if (bytepix == 2) rc = rice_decode_tile<uint16_t>(s, len[t], blocksize, npix[t], (uint16_t *)dst + dst_off[t]);
             else rc = rice_decode_tile<uint8_t>(s, len[t], blocksize, npix[t], (uint8_t *)dst + dst_off[t]);

@@ -17,7 +17,7 @@ section 10) are decoded on the host into a big-endian float32 / integer array: `
 (byte-shuffled) and ``NOCOMPRESS``, for integer
 images and for quantised floating-point images (``ZSCALE`` / ``ZZERO`` columns; ``NO_DITHER``, ``SUBTRACTIVE_DITHER_1`` / ``_2`` with
 the convention's random sequence; ``ZBLANK`` -> NaN; tiles the writer left unquantised in ``GZIP_COMPRESSED_DATA``).
-(``HCOMPRESS_1`` with the optional smoothing of the decompressed image is refused.)  Pinned against astropy-written files
+Pinned against astropy-written files
 (``tests/golden/io``).
 """
 from __future__ import annotations
@@ -286,8 +286,9 @@ def _read_compressed_image(path, hdr, buf, data_pos):
     blocksize, bytepix = int(params.get("BLOCKSIZE", 32)), int(params.get("BYTEPIX", 4))
     if codec in ("PLIO_1", "HCOMPRESS_1"):
         bytepix = 4                                           # (both decode to 32-bit integers)
-        if codec == "HCOMPRESS_1" and int(params.get("SMOOTH", 0) or 0) != 0:
-            raise NotImplementedError(f"{path}: HCOMPRESS_1 with SMOOTH = {params.get('SMOOTH')} (smoothed decompression)")
+        blocksize = 0
+        if codec == "HCOMPRESS_1":
+            blocksize = 1 if int(params.get("SMOOTH", 0) or 0) != 0 else 0      # (the decoder's per-codec parameter: smoothing on / off)
     quantised = zbitpix < 0 and "ZSCALE" in cols
     method = str(hdr.get("ZQUANTIZ", "NO_DITHER" if quantised else "NONE")).strip().upper()
     if zbitpix < 0 and rice and not quantised:

@@ -161,6 +161,10 @@ COMPRESSED = (   # name, dtype, (H, W), CompImageHDU keywords
     ("hcompress_i4_odd", "int32", (37, 45), dict(compression_type="HCOMPRESS_1", hcomp_scale=0, tile_size=(45, 13))),
     ("hcompress_f4_lossy", "float32", (48, 40), dict(compression_type="HCOMPRESS_1", hcomp_scale=2.0, quantize_level=16.0, quantize_method=1,
                                                      dither_seed=5, tile_size=(40, 16))),
+    # the optional smoothing on decompression (ZNAME2 = 'SMOOTH'): lossy integers and dithered floats
+    ("hcompress_i4_smooth", "smooth_int", (70, 90), dict(compression_type="HCOMPRESS_1", hcomp_scale=50, hcomp_smooth=1, tile_size=(45, 35))),
+    ("hcompress_f4_smooth", "float32", (70, 90), dict(compression_type="HCOMPRESS_1", hcomp_scale=4.0, hcomp_smooth=1, quantize_level=16.0,
+                                                      quantize_method=1, dither_seed=9, tile_size=(90, 32))),
 )
 
 
@@ -169,7 +173,8 @@ def write_compressed_fits(expected):
     (``fits.open(fn)[1].data``, utils/dataloaders.py:418-421): Rice on integers of 1 / 2 / 4 bytes, Rice and gzip on
     quantised floats without dithering and with both subtractive dithers (exact zeros under SUBTRACTIVE_DITHER_2; a constant
     region, which the writer cannot quantise), 2-D tiles with ragged edges; PLIO_1 on a mask-like image; HCOMPRESS_1 lossless on
-    16- and 32-bit integers (odd tile sides) and lossy (scale 2) on dithered quantised floats."""
+    16- and 32-bit integers (odd tile sides) and lossy (scale 2) on dithered quantised floats; HCOMPRESS_1 with smoothing on
+    decompression, lossy integers (scale 50) and dithered floats (scale 4)."""
     rng = np.random.default_rng(20260106)
     for name, dtype, (h, w), kw in COMPRESSED:
         if dtype == "float32":
@@ -179,6 +184,9 @@ def write_compressed_fits(expected):
             if kw.get("quantize_method") == 2:
                 img[rng.random(img.shape) < 0.05] = 0.0
             img[: h // 3, : w // 4] = 3.5                          # constant patch
+        elif dtype == "smooth_int":                                # a smooth source on noise, in hundredths
+            yy, xx = np.mgrid[0:h, 0:w]
+            img = np.round((rng.standard_normal((h, w)) * 3 + 10 + 40 * np.exp(-((yy - 30) ** 2 + (xx - 50) ** 2) / 60.0)) * 100).astype(np.int32)
         elif dtype == "mask":                                      # PLIO_1: non-negative integers below 2^24, long runs
             img = rng.integers(0, 50, (h, w)).astype(np.int32)
             img[5:9] = 0
@@ -200,7 +208,7 @@ def write_compressed_fits(expected):
             data = np.array(hdul[1].data)
             assert data.shape == (h, w)
             expected[f"fits_{name}/data"] = data
-            if dtype != "float32" or kw.get("quantize_level") == 0.0:
+            if (dtype != "float32" and not kw.get("hcomp_scale")) or kw.get("quantize_level") == 0.0:
                 assert np.array_equal(data, img, equal_nan=True)   # lossless (HCOMPRESS_1 with scale 0 included)
         with fits.open(p, mode="readonly", disable_image_compression=True) as hdul:   # the table as it is on disk
             th = hdul[1].header

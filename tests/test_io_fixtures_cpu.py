@@ -74,15 +74,16 @@ def check_fits(folder, exp):
 
 
 COMPRESSED = ("rice_i2", "rice_i4_tiles", "rice_u1", "rice_f4_nodither", "rice_f4_dither1", "rice_f4_dither2", "gzip1_f4_dither1",
-              "gzip2_f4_lossless", "plio_i4", "hcompress_i2", "hcompress_i4_odd", "hcompress_f4_lossy")
+              "gzip2_f4_lossless", "plio_i4", "hcompress_i2", "hcompress_i4_odd", "hcompress_f4_lossy", "hcompress_i4_smooth",
+              "hcompress_f4_smooth")
 
 
 def check_compressed_fits(folder, exp):
     """Tile-compressed images written by astropy's CompImageHDU: what ``fits_lite`` decodes == what astropy's ``.data`` holds,
     bit for bit (Rice on 1 / 2 / 4-byte integers; Rice and gzip on quantised floats, undithered and with both subtractive
     dithers -- the 100 x 100 tiles of ``rice_f4_dither1`` walk past the end of the random table, its ZDITHER0 = 9999 wraps the
-    seed index; unquantisable tiles in GZIP_COMPRESSED_DATA; PLIO_1; HCOMPRESS_1 lossless on integers with odd tile sides and
-    lossy on dithered floats)."""
+    seed index; unquantisable tiles in GZIP_COMPRESSED_DATA; PLIO_1; HCOMPRESS_1 lossless on integers with odd tile sides,
+    lossy on dithered floats, and with its smoothing on decompression)."""
     for name in COMPRESSED:
         hdu = fits_lite.read_image_hdu(os.path.join(folder, f"astropy_{name}.fits"), hdu=1)
         want = exp[f"fits_{name}/data"]
@@ -100,6 +101,18 @@ def check_compressed_fits(folder, exp):
     assert str(exp["fits_rice_f4_dither2/zquantiz"]) == "SUBTRACTIVE_DITHER_2" and tuple(exp["fits_rice_i4_tiles/ztile"]) == (16, 20)
     assert "GZIP_COMPRESSED_DATA" in list(exp["fits_rice_f4_nodither/columns"])
     assert int((exp["fits_rice_f4_dither2/data"] == 0).sum()) > 100  # exact zeros survive SUBTRACTIVE_DITHER_2
+    # the smoothing does something: with the file's SMOOTH flag cleared the same tiles decode to other pixels
+    src = os.path.join(folder, "astropy_hcompress_i4_smooth.fits")
+    raw = bytearray(open(src, "rb").read())
+    at = raw.index(b"ZVAL2   =")
+    assert raw[at + 29:at + 30] == b"1"
+    raw[at + 29:at + 30] = b"0"
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "ns.fits")
+        open(p, "wb").write(bytes(raw))
+        plain = fits_lite.read_image_hdu(p, hdu=1).array()
+    assert int((plain != exp["fits_hcompress_i4_smooth/data"]).sum()) > 500
 
 
 def test_committed_tile_compressed_files_read_bit_exactly():

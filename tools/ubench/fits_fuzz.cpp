@@ -1,7 +1,8 @@
 // ASan / UBSan fuzz of the FITS tile decoders of feeder.cpp (Rice, PLIO, HCOMPRESS) on garbage and on damaged real streams -- CPU build only:
 //   g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-sanitize-recover=undefined -pthread -Iinclude tools/ubench/fits_fuzz.cpp -o /tmp/fits_fuzz
-//   /tmp/fits_fuzz tests/golden/io/astropy_hcompress_i2.fits tests/golden/io/astropy_rice_i2.fits tests/golden/io/astropy_plio_i4.fits
-// (round 6: 80 000 cases, no report; the first runs found four shifts of negative values / overflows on damaged input, since bounded)
+//   /tmp/fits_fuzz tests/golden/io/astropy_hcompress_i2.fits tests/golden/io/astropy_rice_i2.fits tests/golden/io/astropy_plio_i4.fits tests/golden/io/astropy_hcompress_i4_smooth.fits \\
+//       tests/golden/io/astropy_hcompress_f4_smooth.fits tests/golden/io/astropy_hcompress_f4_lossy.fits
+// (round 6: 120 000 cases incl. smoothed HCOMPRESS, no report; the first runs found four shifts of negative values / overflows on damaged input, since bounded)
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -36,7 +37,8 @@ int main(int argc, char **argv) {
                 if (len >= 25) { buf[off + 22] %= 40; buf[off + 23] %= 40; buf[off + 24] %= 40; }
             }
             std::vector<uint8_t> dst((size_t)npix * 4 + 16);
-            const int rc = skyemb_fits_decode_tiles_host(codec, buf.data(), n, &off, &len, &npix, &dst_off, 1, bytepix, 32, dst.data(), npix, 1);
+            const int param = codec == 3 ? (int)(rng() & 1) : 32;      // HCOMPRESS: smoothing off / on; Rice: block size
+            const int rc = skyemb_fits_decode_tiles_host(codec, buf.data(), n, &off, &len, &npix, &dst_off, 1, bytepix, param, dst.data(), npix, 1);
             rc ? ++fails : ++oks;
         }
     }
