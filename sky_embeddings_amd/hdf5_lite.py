@@ -11,7 +11,8 @@ This module reads that subset of the HDF5 1.x file format (superblock v0/v1, v1 
 continuation blocks, v1 group B-trees + local heaps, dataspace v1/v2 incl. maximum dimensions,
 fixed-point / IEEE float little-endian datatypes, data layout v3: contiguous, compact and chunked with the
 v1 chunk B-tree) and writes it (the synthetic-data generator; chunked files for round-trip tests).
-Compressed / new-style-group files raise ``NotImplementedError`` naming the feature.
+Chunked datasets may be filtered with what h5py offers without plugins (``compression='gzip'``, ``shuffle``, ``fletcher32``);
+other filters and new-style-group files raise ``NotImplementedError`` naming the feature.
 
 Contiguous datasets are exposed as ``numpy.memmap`` views, so a [N,5,64,64] cutout file is read with plain
 coalesced page-cache I/O instead of the reference's per-item ``h5py.File`` open (utils/dataloaders.py:289).
@@ -40,8 +41,9 @@ class H5LiteError(IOError):
 
 # ------------------------------------------------------------------------------------------ reader
 class Dataset:
-    def __init__(self, name, shape, dtype, offset, fileobj_path, inline=None, chunks=None, btree=None, reader=None):
+    def __init__(self, name, shape, dtype, offset, fileobj_path, inline=None, chunks=None, btree=None, reader=None, filters=None):
         self.name, self.shape, self.dtype = name, tuple(shape), np.dtype(dtype)
+        self.filters = list(filters or [])                 # [(filter id, client data)] in the order the writer applied them
         self._offset, self._path, self._inline = offset, fileobj_path, inline
         self.chunks = tuple(chunks) if chunks is not None else None      # None: contiguous / compact
         self._btree, self._reader = btree, reader
@@ -52,12 +54,55 @@ class Dataset:
     def chunk_table(self):
         """(addresses int64 [n], element offsets int64 [n, rank]) of every stored chunk (v1 B-tree, node type 1)."""
         if self._table is None:
-            addr, off = [], []
+            addr, off, sizes = [], [], []
             if self._btree not in (None, UNDEF):
                 self._reader._walk_chunk_btree(self._btree, len(self.shape), int(np.prod(self.chunks)) * self.dtype.itemsize,
-                                               addr, off)
+                                               addr, off, sizes if self.filters else None)
             self._table = (np.asarray(addr, dtype=np.int64), np.asarray(off, dtype=np.int64).reshape(len(addr), len(self.shape)))
+            self._stored = sizes                                # filtered datasets: (stored bytes, filter mask) per chunk
         return self._table
+
+    def _decode_chunk(self, raw, fmask):
+        """A stored chunk through the dataset's filter pipeline in reverse (HDF5 file format, "Filter Pipeline" message): the
+        filters h5py offers without plugins -- deflate (1, ``compression='gzip'``), shuffle (2), fletcher32 (3; the trailing
+        checksum is dropped, not verified).  Bit i of the chunk's filter mask set = filter i was skipped for this chunk."""
+        import zlib
+        for i in range(len(self.filters) - 1, -1, -1):
+            if (fmask >> i) & 1:
+                continue
+            fid = self.filters[i][0]
+            if fid == 3:
+                raw = raw[:-4]
+            elif fid == 1:
+                raw = zlib.decompress(raw)
+            elif fid == 2:
+                es = self.dtype.itemsize
+                n = len(raw) // es
+                body = np.frombuffer(raw, dtype=np.uint8, count=n * es).reshape(es, n).T.tobytes()
+                raw = body + raw[n * es:]
+        want = int(np.prod(self.chunks)) * self.dtype.itemsize
+        if len(raw) != want:
+            raise H5LiteError(f"{self._path}:{self.name}: a chunk decodes to {len(raw)} bytes, expected {want}")
+        return raw
+
+    def _unchunk_filtered(self, out):
+        """Every stored chunk decoded (threads: zlib releases the interpreter lock) and scattered into the contiguous image."""
+        from concurrent.futures import ThreadPoolExecutor
+        addr, off = self.chunk_table()
+        src = np.memmap(self._path, dtype=np.uint8, mode="r")
+        rank = len(self.shape)
+
+        def one(ci):
+            size, fmask = self._stored[ci]
+            a = int(addr[ci])
+            chunk = np.frombuffer(self._decode_chunk(bytes(src[a:a + size]), fmask), dtype=self.dtype).reshape(self.chunks)
+            o = off[ci]
+            ext = [min(self.chunks[d], self.shape[d] - int(o[d])) for d in range(rank)]
+            out[tuple(slice(int(o[d]), int(o[d]) + ext[d]) for d in range(rank))] = chunk[tuple(slice(0, e) for e in ext)]
+
+        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as pool:
+            for _ in pool.map(one, range(len(addr)), chunksize=64):
+                pass
 
     def _cache_path(self):
         root = os.environ.get("SKYEMB_H5_CACHE")
@@ -114,10 +159,13 @@ class Dataset:
                         src = np.memmap(self._path, dtype=np.uint8, mode="r")
                         cd = np.asarray(self.chunks, dtype=np.int64)
                         dd = np.asarray(self.shape, dtype=np.int64)
-                        check(lib().skyemb_h5_unchunk_host(src.ctypes.data, src.size, addr.ctypes.data,
-                                                           np.ascontiguousarray(off).ctypes.data, len(addr), len(self.shape),
-                                                           cd.ctypes.data, dd.ctypes.data, self.dtype.itemsize, out.ctypes.data,
-                                                           min(16, os.cpu_count() or 1)), "skyemb_h5_unchunk_host")
+                        if self.filters:
+                            self._unchunk_filtered(out)
+                        else:
+                            check(lib().skyemb_h5_unchunk_host(src.ctypes.data, src.size, addr.ctypes.data,
+                                                               np.ascontiguousarray(off).ctypes.data, len(addr), len(self.shape),
+                                                               cd.ctypes.data, dd.ctypes.data, self.dtype.itemsize, out.ctypes.data,
+                                                               min(16, os.cpu_count() or 1)), "skyemb_h5_unchunk_host")
                         out.flush()
                         del out, src
                         if os.path.exists(path):
@@ -158,7 +206,11 @@ class Dataset:
             with open(self._path, "rb") as fh:
                 for ci in sel.tolist():
                     fh.seek(int(addr[ci]))
-                    chunk = np.frombuffer(fh.read(csize), dtype=self.dtype).reshape(self.chunks)
+                    if self.filters:
+                        size, fmask = self._stored[ci]
+                        chunk = np.frombuffer(self._decode_chunk(fh.read(size), fmask), dtype=self.dtype).reshape(self.chunks)
+                    else:
+                        chunk = np.frombuffer(fh.read(csize), dtype=self.dtype).reshape(self.chunks)
                     o = off[ci]
                     ext = [min(self.chunks[d], self.shape[d] - int(o[d])) for d in range(1, len(self.shape))]
                     dst_sl = tuple(slice(int(o[d]), int(o[d]) + ext[d - 1]) for d in range(1, len(self.shape)))
@@ -278,7 +330,7 @@ class File:
                     e = child + 8 + j * 40
                     yield self._u(e, 8), self._u(e + 8, 8)
 
-    def _walk_chunk_btree(self, addr, rank, chunk_bytes, out_addr, out_off):
+    def _walk_chunk_btree(self, addr, rank, chunk_bytes, out_addr, out_off, out_stored=None):
         """v1 B-tree, node type 1 (raw data chunks): key = {chunk size u32, filter mask u32, rank+1 offsets u64}."""
         if self._read(addr, 4) != b"TREE":
             raise H5LiteError("bad chunk B-tree signature")
@@ -293,10 +345,12 @@ class File:
             offs = struct.unpack("<" + "Q" * (rank + 1), node[p + 8:p + ksize])
             child = struct.unpack("<Q", node[p + ksize:p + ksize + 8])[0]
             if level > 0:
-                self._walk_chunk_btree(child + self._base, rank, chunk_bytes, out_addr, out_off)
+                self._walk_chunk_btree(child + self._base, rank, chunk_bytes, out_addr, out_off, out_stored)
             else:
-                if fmask != 0 or size != chunk_bytes:
-                    raise NotImplementedError("filtered (compressed) chunks are not supported")
+                if out_stored is not None:
+                    out_stored.append((size, fmask))
+                elif fmask != 0 or size != chunk_bytes:
+                    raise H5LiteError("a chunk of a dataset without a filter pipeline is stored filtered")
                 out_addr.append(child + self._base)
                 out_off.append(offs[:rank])
 
@@ -321,9 +375,40 @@ class File:
                 p += 8 + msize
         return out
 
+    @staticmethod
+    def _filter_pipeline(name, d):
+        """Filter pipeline message (0x000B), versions 1 and 2 -> [(filter id, client data values)].  What h5py writes without
+        plugins is read: deflate (1), shuffle (2), fletcher32 (3); szip, n-bit, scale-offset and registered third-party filters
+        (LZF 32000, Blosc 32001, ...) are refused by name."""
+        names = {1: "deflate", 2: "shuffle", 3: "fletcher32", 4: "szip", 5: "nbit", 6: "scaleoffset", 32000: "lzf", 32001: "blosc"}
+        ver, nf = d[0], d[1]
+        p = 8 if ver == 1 else 2
+        out = []
+        for _ in range(nf):
+            fid = struct.unpack("<H", d[p:p + 2])[0]
+            if ver == 1 or fid >= 256:
+                nlen = struct.unpack("<H", d[p + 2:p + 4])[0]
+                p += 4
+            else:
+                nlen = 0
+                p += 2
+            _flags, ncd = struct.unpack("<HH", d[p:p + 4])
+            p += 4
+            p += (nlen + 7) // 8 * 8 if ver == 1 else nlen
+            cd = struct.unpack("<" + "I" * ncd, d[p:p + 4 * ncd])
+            p += 4 * ncd
+            if ver == 1 and ncd % 2:
+                p += 4
+            if fid not in (1, 2, 3):
+                raise NotImplementedError(f"dataset {name!r}: filter {names.get(fid, fid)} (id {fid}) is not supported "
+                                          f"(deflate / shuffle / fletcher32 are)")
+            out.append((fid, cd))
+        return out
+
     def _dataset(self, name, addr):
         shape = dtype = None
         layout = None
+        filters = []
         for mtype, d in self._messages(addr):
             if mtype == 0x0001:
                 v, rank, flags = d[0], d[1], d[2]
@@ -359,7 +444,7 @@ class File:
                 else:
                     raise NotImplementedError(f"dataset {name!r}: data layout class {cls} is not supported")
             elif mtype == 0x000B:
-                raise NotImplementedError(f"dataset {name!r} uses a filter pipeline (compression)")
+                filters = self._filter_pipeline(name, d)
         if shape is None or layout is None or dtype is None:
             return None  # a sub-group or an unsupported type: not part of the schema
         if layout[0] == "compact":
@@ -369,7 +454,7 @@ class File:
             if len(dims) != len(shape) + 1 or dims[-1] != np.dtype(dtype).itemsize:
                 raise H5LiteError(f"dataset {name!r}: inconsistent chunk dimensions {dims} for shape {shape}")
             return Dataset(name, shape, dtype, None, self.path, chunks=dims[:-1], btree=bt if bt == UNDEF else bt + self._base,
-                           reader=self)
+                           reader=self, filters=filters)
         a = layout[1]
         return Dataset(name, shape, dtype, a if a == UNDEF else a + self._base, self.path)
 

@@ -13,6 +13,7 @@ It writes, under tests/golden/io/ (data only; ``--out DIR`` writes elsewhere, ``
 * ``h5py_resizable.h5``   -- the layout ``data_processing/combine_h5.py:30-32`` / ``2_create_h5_files.py:72-74`` write:
   ``maxshape=(None, ...)`` datasets, which h5py auto-chunks, grown by ``resize`` and filled in two appends (so the
   chunk B-tree has entries allocated in non-monotonic file order), plus an integer class column.
+* ``h5py_filtered.h5``    -- chunked datasets behind h5py's built-in filters (gzip, shuffle, fletcher32): ``write_h5_filtered``.
 * ``astropy_f4.fits``      -- empty primary HDU + a ``>f4`` IMAGE extension with NaNs and a TAN-SIP header (what HSC
   ``calexp`` patches carry; ``utils/dataloaders.py:418-432`` reads ``hdul[1].data`` and ``WCS(hdul[1].header)``).
 * ``astropy_i2_scaled.fits`` -- an int16 IMAGE extension with BSCALE / BZERO.
@@ -83,6 +84,27 @@ def write_h5(expected, full):
         expected["resizable/chunks"] = np.array(f["cutouts"].chunks)
         for k in f.keys():
             expected["resizable/" + k] = f[k][:]
+
+
+def write_h5_filtered(expected):
+    """Chunked datasets behind h5py's built-in filters: gzip (deflate) with and without byte shuffle, fletcher32 checksums, an
+    explicit chunk shape with ragged edges, a 1-D integer column, and a dataset some of whose chunks were never written."""
+    rng = np.random.default_rng(20260107)
+    p = os.path.join(OUT, "h5py_filtered.h5")
+    cut = cutouts(rng, 37, s=8)
+    cut[:, :, :3] = np.round(cut[:, :, :3], 1)                       # (compressible rows)
+    with h5py.File(p, "w") as f:
+        f.create_dataset("cutouts", data=cut, chunks=(8, 2, 8, 5), compression="gzip", compression_opts=4, shuffle=True)
+        f.create_dataset("gz_only", data=cut[:9], chunks=(4, 5, 8, 8), compression="gzip")
+        f.create_dataset("checked", data=cut[:6], chunks=(3, 5, 8, 8), fletcher32=True)
+        f.create_dataset("all3", data=cut[:10], chunks=(5, 5, 4, 8), compression="gzip", shuffle=True, fletcher32=True)
+        f.create_dataset("class", data=rng.integers(0, 3, 37).astype(np.int64), chunks=(16,), compression="gzip", shuffle=True)
+        d = f.create_dataset("sparse", (20, 5, 8, 8), dtype="f", chunks=(4, 5, 8, 8), compression="gzip")
+        d[8:12] = cut[:4]
+    with h5py.File(p, "r") as f:
+        for k in f.keys():
+            expected["filtered/" + k] = f[k][:]
+        expected["filtered/cutouts_chunks"] = np.array(f["cutouts"].chunks)
 
 
 SIP = {"A_ORDER": 3, "B_ORDER": 3, "A_2_0": 2.1e-7, "A_1_1": -3.4e-7, "A_0_2": 1.2e-7, "A_3_0": 4.0e-11, "A_1_2": -2.5e-11,
@@ -225,6 +247,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     expected = {}
     write_h5(expected, full)
+    write_h5_filtered(expected)
     write_fits(expected)
     write_compressed_fits(expected)
     expected["versions"] = np.array([f"h5py {h5py.__version__}", f"hdf5 {h5py.version.hdf5_version}",

@@ -47,6 +47,27 @@ def check_h5(folder, exp, tmp_path):
         assert same(f["ra"][:], exp["resizable/ra"]) and same(f["dec"][:], exp["resizable/dec"])
 
 
+def check_h5_filtered(folder, exp, tmp_path):
+    """gzip / shuffle / fletcher32 chunks written by h5py: indexed reads and the feeder's one-off contiguous copy, bit for bit."""
+    p = str(tmp_path / "f.h5")
+    shutil.copy(os.path.join(folder, "h5py_filtered.h5"), p)
+    with hdf5_lite.File(p) as f:
+        assert sorted(f.keys()) == ["all3", "checked", "class", "cutouts", "gz_only", "sparse"]
+        assert [fid for fid, _ in f["cutouts"].filters] == [2, 1] and [fid for fid, _ in f["all3"].filters] == [2, 1, 3]
+        assert tuple(f["cutouts"].chunks) == tuple(int(v) for v in exp["filtered/cutouts_chunks"]) == (8, 2, 8, 5)
+        assert same(f["class"][:], exp["filtered/class"]) and same(f["class"][20:30], exp["filtered/class"][20:30])    # per-chunk reads
+        for k in ("cutouts", "gz_only", "checked", "all3", "sparse"):
+            want = exp["filtered/" + k]
+            assert same(f[k][:], want), k                    # through the contiguous cache (Dataset._array)
+            assert same(f[k][want.shape[0] - 1], want[-1]) and same(np.asarray(f[k]), want), k
+        assert not exp["filtered/sparse"][:8].any() and exp["filtered/sparse"][8:12].any()
+    with hdf5_lite.File(p) as f:                             # a fresh handle: the cache file is found and reused
+        assert same(f["cutouts"][5], exp["filtered/cutouts"][5])
+        d = f["cutouts"]
+        d._mm = None
+        assert same(d._read_chunked(np.array([36, 0, 17])), exp["filtered/cutouts"][[36, 0, 17]])       # without the cache
+
+
 def check_fits(folder, exp):
     hdu = fits_lite.read_image_hdu(os.path.join(folder, "astropy_f4.fits"), hdu=1)
     assert hdu.bitpix == -32 and hdu.raw.dtype == np.dtype(">f4")
@@ -186,6 +207,11 @@ def test_committed_h5py_files_read_bit_exactly(tmp_path):
     check_h5(IO, exp, tmp_path)
 
 
+def test_committed_h5py_filtered_file_reads_bit_exactly(tmp_path):
+    exp = np.load(os.path.join(IO, "io_expected.npz"))
+    check_h5_filtered(IO, exp, tmp_path)
+
+
 def test_committed_astropy_files_and_world_coordinates():
     exp = np.load(os.path.join(IO, "io_expected.npz"))
     assert "astropy 4.3.1" in list(exp["versions"])
@@ -216,5 +242,6 @@ def test_live_files_in_the_reference_geometry(tmp_path):
     exp = np.load(os.path.join(out, "io_expected.npz"))
     assert tuple(int(v) for v in exp["resizable/chunks"]) == (128, 1, 8, 16)
     check_h5(out, exp, tmp_path)
+    check_h5_filtered(out, exp, tmp_path)
     check_fits(out, exp)
     check_compressed_fits(out, exp)
